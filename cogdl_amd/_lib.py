@@ -1,0 +1,127 @@
+"""ctypes binding of the two C-ABI libraries (include/cogdl_hip.h, include/cogdl_host.h).
+
+Loading is strict: if libcogdl_hip.so is missing or fails to load, importing any GPU operator
+raises -- there is no CPU or PyTorch fallback behind the HIP entry points (the reference, by
+contrast, swallows build failures and silently drops to torch.scatter_add:
+cogdl/operators/spmm.py:30-31).
+"""
+import ctypes
+import os
+
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+HIP_LIB_PATH = os.path.join(_CSRC, "libcogdl_hip.so")
+HOST_LIB_PATH = os.path.join(_CSRC, "libcogdl_host.so")
+
+_vp, _i64, _i32, _f32, _sz, _u64 = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
+                                     ctypes.c_size_t, ctypes.c_uint64)
+
+# name -> (argtypes, restype): must list every symbol declared in include/cogdl_hip.h
+HIP_SIGNATURES = {
+    "cogdl_hip_abi_version": ([], _i32),
+    "cogdl_hip_strerror": ([_i32], ctypes.c_char_p),
+    "cogdl_hip_last_hip_error": ([], _i32),
+    "cogdl_hip_csr_spmm": ([_vp] * 5 + [_i64, _i64, _i32, _vp], _i32),
+    "cogdl_hip_csr_spmm_variant": ([_vp] * 5 + [_i64, _i64, _i32, _i32, _vp], _i32),
+    "cogdl_hip_csr2csc_workspace_bytes": ([_i64, _i64, _i64], _sz),
+    "cogdl_hip_csr2csc": ([_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp], _i32),
+    "cogdl_hip_gather_rows": ([_vp, _vp, _vp, _i64, _i64, _i32, _vp], _i32),
+    "cogdl_hip_csr_sddmm": ([_vp] * 5 + [_i64, _i64, _vp], _i32),
+    "cogdl_hip_edge_softmax_fwd": ([_vp] * 3 + [_i64, _i64, _i64, _vp], _i32),
+    "cogdl_hip_edge_softmax_bwd": ([_vp] * 4 + [_i64, _i64, _i64, _vp], _i32),
+    "cogdl_hip_mhspmm": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp], _i32),
+    "cogdl_hip_mhsddmm": ([_vp] * 5 + [_i64, _i64, _i64, _vp], _i32),
+    "cogdl_hip_scatter_max_fwd": ([_vp] * 5 + [_i64, _i64, _vp], _i32),
+    "cogdl_hip_scatter_max_bwd": ([_vp] * 3 + [_i64, _i64, _i64, _vp], _i32),
+    "cogdl_hip_csr_fingerprint": ([_vp, _vp, _i64, _i64, _vp, _vp], _i32),
+}
+
+HOST_SIGNATURES = {
+    "cogdl_host_strerror": ([_i32], ctypes.c_char_p),
+    "cogdl_host_coo2csr": ([_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp], _i32),
+    "cogdl_host_coo2csr_index": ([_vp, _i64, _i64, _vp, _vp], _i32),
+    "cogdl_host_sample_adj": ([_vp, _vp, _i64, _vp, _i64, _i64, _i32, _u64] + [_vp] * 4 + [_i64, _i64, _vp], _i32),
+    "cogdl_host_subgraph": ([_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp], _i32),
+    "cogdl_host_csr_spmm_f32": ([_vp] * 5 + [_i64, _i64, _i32], _i32),
+}
+
+DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+_hip = None
+_host = None
+
+
+class BackendError(RuntimeError):
+    """The HIP backend could not be loaded, or an entry point returned a non-zero status."""
+
+
+def _load(path, signatures, what):
+    if not os.path.exists(path):
+        raise BackendError(
+            "%s not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C cogdl_amd/csrc`). There is no fallback path." % (what, path))
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise BackendError("failed to load %s: %s" % (path, e)) from e
+    for name, (argtypes, restype) in signatures.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise BackendError("%s does not export %s (stale build?)" % (path, name)) from e
+        fn.argtypes, fn.restype = argtypes, restype
+    return lib
+
+
+def hip():
+    global _hip
+    if _hip is None:
+        _hip = _load(HIP_LIB_PATH, HIP_SIGNATURES, "libcogdl_hip.so (HIP kernels)")
+    return _hip
+
+
+def host():
+    global _host
+    if _host is None:
+        _host = _load(HOST_LIB_PATH, HOST_SIGNATURES, "libcogdl_host.so (host operators)")
+    return _host
+
+
+def ptr(t):
+    """Raw address of a tensor's first element (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t):
+    """The HIP stream torch would launch on for this tensor's device (current stream)."""
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def check(rc, what):
+    if rc != 0:
+        lib = hip()
+        msg = lib.cogdl_hip_strerror(rc).decode()
+        if rc == 4:
+            msg += " (hipError_t=%d)" % lib.cogdl_hip_last_hip_error()
+        raise BackendError("%s failed: %s" % (what, msg))
+
+
+def check_host(rc, what):
+    if rc != 0:
+        raise BackendError("%s failed: %s" % (what, host().cogdl_host_strerror(rc).decode()))
+
+
+def require_cuda(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise BackendError("cogdl_amd HIP operator called with a %s tensor; the HIP path has no CPU fallback"
+                               % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise BackendError("tensors on different devices: %s vs %s" % (dev, t.device))
+    return dev

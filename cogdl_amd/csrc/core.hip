@@ -1,0 +1,23 @@
+// core.hip -- status strings / ABI version of libcogdl_hip.
+#include "common.h"
+
+namespace cogdl {
+thread_local int g_last_hip_error = 0;
+}
+
+extern "C" int cogdl_hip_abi_version(void) { return COGDL_HIP_ABI_VERSION; }
+
+extern "C" int cogdl_hip_last_hip_error(void) { return cogdl::g_last_hip_error; }
+
+extern "C" const char *cogdl_hip_strerror(int status) {
+    switch (status) {
+        case COGDL_HIP_OK: return "ok";
+        case COGDL_HIP_EINVAL: return "invalid argument";
+        case COGDL_HIP_EDTYPE: return "unsupported dtype";
+        case COGDL_HIP_EALIGN: return "misaligned pointer";
+        case COGDL_HIP_ELAUNCH: return "HIP launch/runtime error";
+        case COGDL_HIP_EWORKSPACE: return "workspace too small";
+        case COGDL_HIP_ERANGE: return "size out of range for int32 CSR indices";
+        default: return "unknown status";
+    }
+}

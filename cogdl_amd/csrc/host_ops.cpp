@@ -1,0 +1,246 @@
+// host_ops.cpp -- libcogdl_host.so: HIP-free host operators of the message-passing path.
+// Replaces cogdl/operators/sample/sample.cpp (sample_adj, subgraph, coo2csr_cpu,
+// coo2csr_cpu_index) and cogdl/operators/spmm/spmm_cpu.cpp (csr_spmm_cpu) behind a C ABI
+// (include/cogdl_host.h).  Must stay free of any HIP/ROCm dependency: CogDL calls the sampler
+// from forked DataLoader workers (cogdl/data/sampler.py:82-116).
+//
+// Built with -ffp-contract=off and no -march: the CPU SpMM's `acc + v*b` is a rounded
+// multiply then a rounded add, as in the reference's own x86-64 build.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/cogdl_host.h"
+
+namespace {
+
+// ---------------------------------------------------------------- random numbers
+struct SplitMix64 {
+    uint64_t s;
+    explicit SplitMix64(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    }
+    // uniform in [0, n), n > 0 (multiply-high; bias < n / 2^64)
+    int64_t below(int64_t n) { return (int64_t)(((unsigned __int128)next() * (unsigned __int128)(uint64_t)n) >> 64); }
+};
+
+inline uint64_t stream_seed(uint64_t seed, uint64_t i) {
+    SplitMix64 g(seed ^ (0xd1342543de82ef95ull * (i + 1)));
+    return g.next();
+}
+
+// Choose `k` distinct positions out of [0, deg) uniformly; result ascending.
+void sample_without_replacement(int64_t deg, int64_t k, SplitMix64 &rng, std::vector<int64_t> &pick) {
+    pick.clear();
+    if (k >= deg) {
+        for (int64_t j = 0; j < deg; ++j) pick.push_back(j);
+        return;
+    }
+    if (k * 4 >= deg) {  // dense: partial Fisher-Yates over the row's positions
+        std::vector<int64_t> idx((size_t)deg);
+        for (int64_t j = 0; j < deg; ++j) idx[(size_t)j] = j;
+        for (int64_t j = 0; j < k; ++j) std::swap(idx[(size_t)j], idx[(size_t)(j + rng.below(deg - j))]);
+        pick.assign(idx.begin(), idx.begin() + k);
+    } else if (k <= 128) {  // sparse, small: Floyd with a linear membership scan
+        for (int64_t j = deg - k; j < deg; ++j) {
+            const int64_t t = rng.below(j + 1);
+            pick.push_back(std::find(pick.begin(), pick.end(), t) == pick.end() ? t : j);
+        }
+    } else {  // sparse, large: Floyd with a hash set
+        std::unordered_set<int64_t> seen;
+        seen.reserve((size_t)k * 2);
+        for (int64_t j = deg - k; j < deg; ++j) {
+            const int64_t t = rng.below(j + 1);
+            const int64_t v = seen.count(t) ? j : t;
+            seen.insert(v);
+            pick.push_back(v);
+        }
+    }
+    std::sort(pick.begin(), pick.end());
+}
+
+bool in_range(const int64_t *a, int64_t n, int64_t hi) {
+    for (int64_t i = 0; i < n; ++i)
+        if (a[i] < 0 || a[i] >= hi) return false;
+    return true;
+}
+
+// stable counting sort of edge positions by row; row_ptr gets the CSR offsets
+template <typename Emit>
+void counting_sort_by_row(const int64_t *row, int64_t nnz, int64_t num_nodes, int64_t *row_ptr, Emit emit) {
+    std::fill(row_ptr, row_ptr + num_nodes + 1, int64_t(0));
+    for (int64_t i = 0; i < nnz; ++i) ++row_ptr[row[i] + 1];
+    for (int64_t r = 0; r < num_nodes; ++r) row_ptr[r + 1] += row_ptr[r];
+    std::vector<int64_t> cursor(row_ptr, row_ptr + num_nodes);
+    for (int64_t i = 0; i < nnz; ++i) emit(cursor[(size_t)row[i]]++, i);
+}
+
+// ---------------------------------------------------------------- CPU SpMM rows
+__attribute__((target_clones("avx2", "default"))) void spmm_rows(const int32_t *rowptr, const int32_t *colind,
+                                                                  const float *val, const float *dense, float *out,
+                                                                  int64_t r0, int64_t r1, int64_t k) {
+    for (int64_t i = r0; i < r1; ++i) {
+        float *__restrict__ o = out + i * k;
+        for (int64_t t = 0; t < k; ++t) o[t] = 0.f;
+        for (int32_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+            const float *__restrict__ b = dense + (int64_t)colind[e] * k;
+            if (val) {
+                const float v = val[e];
+                for (int64_t t = 0; t < k; ++t) o[t] = o[t] + v * b[t];
+            } else {
+                for (int64_t t = 0; t < k; ++t) o[t] = o[t] + b[t];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *cogdl_host_strerror(int status) {
+    switch (status) {
+        case COGDL_HOST_OK: return "ok";
+        case COGDL_HOST_EINVAL: return "invalid argument";
+        case COGDL_HOST_ERANGE: return "index out of range";
+        case COGDL_HOST_ECAP: return "output capacity too small";
+        default: return "unknown status";
+    }
+}
+
+int cogdl_host_coo2csr(const int64_t *row, const int64_t *col, const float *val, int64_t nnz, int64_t num_nodes,
+                       int64_t *row_ptr, int64_t *col_ind, float *out_val) {
+    if (nnz < 0 || num_nodes < 0 || !row_ptr || (nnz > 0 && (!row || !col || !col_ind))) return COGDL_HOST_EINVAL;
+    if (!in_range(row, nnz, num_nodes)) return COGDL_HOST_ERANGE;
+    const bool with_val = val && out_val;
+    counting_sort_by_row(row, nnz, num_nodes, row_ptr, [&](int64_t dst, int64_t src) {
+        col_ind[dst] = col[src];
+        if (with_val) out_val[dst] = val[src];
+    });
+    return COGDL_HOST_OK;
+}
+
+int cogdl_host_coo2csr_index(const int64_t *row, int64_t nnz, int64_t num_nodes, int64_t *row_ptr, int64_t *perm) {
+    if (nnz < 0 || num_nodes < 0 || !row_ptr || (nnz > 0 && (!row || !perm))) return COGDL_HOST_EINVAL;
+    if (!in_range(row, nnz, num_nodes)) return COGDL_HOST_ERANGE;
+    counting_sort_by_row(row, nnz, num_nodes, row_ptr, [&](int64_t dst, int64_t src) { perm[dst] = src; });
+    return COGDL_HOST_OK;
+}
+
+int cogdl_host_sample_adj(const int64_t *indptr, const int64_t *indices, int64_t num_nodes, const int64_t *node_idx,
+                          int64_t batch, int64_t num_neighbors, int replace, uint64_t seed, int64_t *out_indptr,
+                          int64_t *out_indices, int64_t *out_nodes, int64_t *out_edges, int64_t cap_edges,
+                          int64_t cap_nodes, int64_t *out_counts) {
+    if (!indptr || !out_indptr || !out_counts || batch < 0 || num_nodes < 0 || (batch > 0 && !node_idx))
+        return COGDL_HOST_EINVAL;
+    if (!in_range(node_idx, batch, num_nodes)) return COGDL_HOST_ERANGE;
+    if (batch > cap_nodes) return COGDL_HOST_ECAP;
+
+    // local id of every global node: -1 = not seen yet
+    std::vector<int64_t> local((size_t)num_nodes, -1);
+    for (int64_t i = 0; i < batch; ++i) {
+        local[(size_t)node_idx[i]] = i;
+        out_nodes[i] = node_idx[i];
+    }
+    int64_t n_nodes = batch, n_edges = 0;
+    std::vector<int64_t> pick;
+    out_indptr[0] = 0;
+    for (int64_t i = 0; i < batch; ++i) {
+        const int64_t begin = indptr[node_idx[i]];
+        const int64_t deg = indptr[node_idx[i] + 1] - begin;
+        SplitMix64 rng(stream_seed(seed, (uint64_t)i));  // per-seed stream: result independent of batching
+        pick.clear();
+        if (num_neighbors < 0) {
+            for (int64_t j = 0; j < deg; ++j) pick.push_back(j);
+        } else if (replace) {
+            if (deg > 0)
+                for (int64_t j = 0; j < num_neighbors; ++j) pick.push_back(rng.below(deg));
+        } else {
+            sample_without_replacement(deg, num_neighbors, rng, pick);
+        }
+        if (n_edges + (int64_t)pick.size() > cap_edges) return COGDL_HOST_ECAP;
+        for (int64_t p : pick) {
+            const int64_t edge = begin + p;
+            const int64_t src = indices[edge];
+            if (src < 0 || src >= num_nodes) return COGDL_HOST_ERANGE;
+            int64_t &id = local[(size_t)src];
+            if (id < 0) {
+                if (n_nodes >= cap_nodes) return COGDL_HOST_ECAP;
+                id = n_nodes;
+                out_nodes[n_nodes++] = src;
+            }
+            out_indices[n_edges] = id;
+            out_edges[n_edges++] = edge;
+        }
+        out_indptr[i + 1] = n_edges;
+    }
+    out_counts[0] = n_nodes;
+    out_counts[1] = n_edges;
+    return COGDL_HOST_OK;
+}
+
+int cogdl_host_subgraph(const int64_t *indptr, const int64_t *indices, int64_t num_nodes, const int64_t *node_idx,
+                        int64_t batch, int64_t *out_indptr, int64_t *out_indices, int64_t *out_edges,
+                        int64_t cap_edges, int64_t *out_counts) {
+    if (!indptr || !out_indptr || !out_counts || batch < 0 || num_nodes < 0 || (batch > 0 && !node_idx))
+        return COGDL_HOST_EINVAL;
+    if (!in_range(node_idx, batch, num_nodes)) return COGDL_HOST_ERANGE;
+    std::vector<int64_t> local((size_t)num_nodes, -1);
+    for (int64_t i = 0; i < batch; ++i) local[(size_t)node_idx[i]] = i;
+    int64_t n_edges = 0;
+    out_indptr[0] = 0;
+    for (int64_t i = 0; i < batch; ++i) {
+        const int64_t node = node_idx[i];
+        for (int64_t e = indptr[node]; e < indptr[node + 1]; ++e) {
+            const int64_t id = local[(size_t)indices[e]];
+            if (id < 0) continue;
+            if (n_edges >= cap_edges) return COGDL_HOST_ECAP;
+            out_indices[n_edges] = id;
+            out_edges[n_edges++] = e;
+        }
+        out_indptr[i + 1] = n_edges;
+    }
+    out_counts[0] = n_edges;
+    return COGDL_HOST_OK;
+}
+
+int cogdl_host_csr_spmm_f32(const int32_t *rowptr, const int32_t *colind, const float *val, const float *dense,
+                            float *out, int64_t m, int64_t k, int nthreads) {
+    if (m < 0 || k < 0) return COGDL_HOST_EINVAL;
+    if (m == 0 || k == 0) return COGDL_HOST_OK;
+    if (!rowptr || !dense || !out) return COGDL_HOST_EINVAL;
+    const int64_t nnz = rowptr[m];
+    if (nthreads < 1) nthreads = 1;
+    // a thread per ~64k edge-columns of work at most; rows split at equal-nnz boundaries
+    const int64_t work = (nnz + m) * k;
+    int t = (int)std::min<int64_t>(nthreads, std::max<int64_t>(1, work / (1 << 16)));
+    if (t <= 1) {
+        spmm_rows(rowptr, colind, val, dense, out, 0, m, k);
+        return COGDL_HOST_OK;
+    }
+    std::vector<int64_t> cut((size_t)t + 1, 0);
+    cut[(size_t)t] = m;
+    for (int i = 1; i < t; ++i) {
+        const int64_t target = (nnz + m) * i / t;  // balance edges + rows
+        int64_t lo = 0, hi = m;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) / 2;
+            if ((int64_t)rowptr[mid] + mid < target) lo = mid + 1; else hi = mid;
+        }
+        cut[(size_t)i] = std::max(lo, cut[(size_t)i - 1]);
+    }
+    std::vector<std::thread> pool;
+    for (int i = 0; i < t; ++i)
+        pool.emplace_back(spmm_rows, rowptr, colind, val, dense, out, cut[(size_t)i], cut[(size_t)i + 1], k);
+    for (auto &th : pool) th.join();
+    return COGDL_HOST_OK;
+}
+
+}  // extern "C"

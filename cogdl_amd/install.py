@@ -1,0 +1,70 @@
+"""Hook the HIP operators underneath an unmodified CogDL.
+
+CogDL resolves its native operators by importing `cogdl.operators.<op>` lazily
+(cogdl/utils/spmm_utils.py:21-40,137-146,241-248; cogdl/layers/sage_layer.py:22-25;
+cogdl/data/data.py:18; cogdl/utils/graph_utils.py:7).  `install()` registers a meta-path finder
+that serves those module names from `cogdl_amd.operators.<op>`, so GCNLayer / GATLayer /
+SAGELayer and Graph pick the new path up without any source change.  Call it before
+`import cogdl` (modules CogDL already imported are also rebound, and the dispatcher's CONFIGS
+registry is reset so that it re-reads the names).
+
+The alternative, equivalent integration is to replace each cogdl/operators/<op>.py by a
+one-line shim (`from cogdl_amd.operators.<op> import *`) -- see INTEGRATION.md.
+"""
+import importlib
+import importlib.abc
+import importlib.util
+import sys
+
+REPLACED = ("spmm", "edge_softmax", "mhspmm", "scatter_max", "fused_gat", "sample")
+_PREFIX = "cogdl.operators."
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname.startswith(_PREFIX) and fullname[len(_PREFIX):] in REPLACED:
+            return importlib.util.spec_from_loader(fullname, self)
+        return None
+
+    def create_module(self, spec):
+        return importlib.import_module("cogdl_amd.operators." + spec.name[len(_PREFIX):])
+
+    def exec_module(self, module):
+        pass
+
+
+_finder = None
+
+
+def install():
+    """Idempotent.  Returns the list of cogdl module names that are now served by cogdl_amd."""
+    global _finder
+    if _finder is None:
+        _finder = _Finder()
+        sys.meta_path.insert(0, _finder)
+    for op in REPLACED:
+        name = _PREFIX + op
+        if name in sys.modules and not getattr(sys.modules[name], "__name__", "").startswith("cogdl_amd."):
+            mod = importlib.import_module("cogdl_amd.operators." + op)
+            sys.modules[name] = mod
+            pkg = sys.modules.get("cogdl.operators")
+            if pkg is not None:
+                setattr(pkg, op, mod)
+    su = sys.modules.get("cogdl.utils.spmm_utils")
+    if su is not None:  # force the dispatcher to re-resolve the callables
+        for k in ("spmm_flag", "mh_spmm_flag", "fused_gat_flag", "spmm_cpu_flag"):
+            su.CONFIGS[k] = False
+        for k in ("fast_spmm", "csrmhspmm", "csr_edge_softmax", "fused_gat_func", "fast_spmm_cpu"):
+            su.CONFIGS[k] = None
+    return [_PREFIX + op for op in REPLACED]
+
+
+def uninstall():
+    global _finder
+    if _finder is not None:
+        sys.meta_path.remove(_finder)
+        _finder = None
+    for op in REPLACED:
+        mod = sys.modules.get(_PREFIX + op)
+        if mod is not None and getattr(mod, "__name__", "").startswith("cogdl_amd."):
+            del sys.modules[_PREFIX + op]

@@ -1,0 +1,72 @@
+"""Drop-in for cogdl/operators/mhspmm.py: `csrmhspmm(rowptr, colind, feat[N,H,F], attention[E,H])`
+-> [N,H,F] (operators/mhspmm.py:34-64).
+
+Backward (same maths as MHSPMMFunction.backward, operators/mhspmm.py:52-64):
+    grad_feat = mhspmm(A^T, attention[perm], grad_out)      -- A^T/perm from the cached plan; the
+                reference transposes arange(nnz) through a float32 cuSPARSE call, which loses
+                edge ids above 2^24 (Reddit has 1.1e8 edges); here perm is int32 throughout.
+    grad_att  = mhsddmm(A, grad_out, feat)
+"""
+import torch
+
+from .. import _lib
+from ..plan import PLANS, Fingerprint, gather_rows
+
+_lib.hip()
+
+
+def mhspmm_raw(rowptr, colind, att, feat):
+    dev = _lib.require_cuda(rowptr, colind, att, feat)
+    if feat.dim() != 3:
+        raise _lib.BackendError("feat must be [N, H, F], got %s" % (tuple(feat.shape),))
+    if feat.dtype not in _lib.DTYPE_CODE:
+        raise _lib.BackendError("unsupported dtype %s" % feat.dtype)
+    feat = feat.contiguous()
+    att = att.contiguous().float()
+    v, (_, h, f) = rowptr.numel() - 1, feat.shape
+    if att.shape != (colind.numel(), h):
+        raise _lib.BackendError("attention must be [E, H] = %s, got %s" % ((colind.numel(), h), tuple(att.shape)))
+    out = torch.empty((v, h, f), dtype=feat.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.hip().cogdl_hip_mhspmm(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(att), _lib.ptr(feat),
+                                         _lib.ptr(out), v, h, f, _lib.DTYPE_CODE[feat.dtype], _lib.stream_of(feat))
+    _lib.check(rc, "mhspmm")
+    return out
+
+
+def mhsddmm_raw(rowptr, colind, grad, feat):
+    dev = _lib.require_cuda(rowptr, colind, grad, feat)
+    grad, feat = grad.contiguous().float(), feat.contiguous().float()
+    v, (_, h, f) = rowptr.numel() - 1, feat.shape
+    out = torch.empty((colind.numel(), h), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.hip().cogdl_hip_mhsddmm(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(grad), _lib.ptr(feat),
+                                          _lib.ptr(out), v, h, f, _lib.stream_of(feat))
+    _lib.check(rc, "mhsddmm")
+    return out
+
+
+class MHSPMMFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rowptr, colind, feat, attention):
+        out = mhspmm_raw(rowptr, colind, attention, feat)
+        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None
+        ctx.save_for_backward(rowptr, colind, feat, attention)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        rowptr, colind, feat, attention = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        grad_feat = grad_att = None
+        if ctx.needs_input_grad[2]:
+            plan = PLANS.get(ctx.fp, rowptr, colind, feat.shape[0])
+            att_t = gather_rows(plan.perm, attention.detach().float().contiguous())
+            grad_feat = mhspmm_raw(plan.colptr, plan.rowind, att_t, grad_out.to(feat.dtype))
+        if ctx.needs_input_grad[3]:
+            grad_att = mhsddmm_raw(rowptr, colind, grad_out, feat.detach()).to(attention.dtype)
+        return None, None, grad_feat, grad_att
+
+
+def csrmhspmm(rowptr, colind, feat, attention):
+    return MHSPMMFunction.apply(rowptr, colind, feat, attention)

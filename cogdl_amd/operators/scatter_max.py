@@ -1,0 +1,54 @@
+"""Drop-in for cogdl/operators/scatter_max.py: `scatter_max(rowptr, colind, feat)` -> [M, F]
+(operators/scatter_max.py:17-37), used by MaxAggregator (cogdl/layers/sage_layer.py:21-29)."""
+import torch
+
+from .. import _lib
+
+_lib.hip()
+
+
+def scatter_max_fp(rowptr, colind, feat):
+    dev = _lib.require_cuda(rowptr, colind, feat)
+    if rowptr.dtype != torch.int32 or colind.dtype != torch.int32:
+        raise _lib.BackendError("rowptr/colind must be int32")
+    if feat.dim() != 2 or feat.dtype != torch.float32:
+        raise _lib.BackendError("feat must be a float32 [N, F] tensor")
+    feat = feat.contiguous()
+    m, k = rowptr.numel() - 1, feat.shape[1]
+    out = torch.empty((m, k), dtype=torch.float32, device=dev)
+    max_id = torch.empty((m, k), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.hip().cogdl_hip_scatter_max_fwd(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(feat), _lib.ptr(out),
+                                                  _lib.ptr(max_id), m, k, _lib.stream_of(feat))
+    _lib.check(rc, "scatter_max_fwd")
+    return out, max_id
+
+
+def scatter_max_bp(grad, max_id, n_src):
+    dev = _lib.require_cuda(grad, max_id)
+    grad = grad.contiguous().float()
+    m, k = grad.shape
+    out = torch.empty((n_src, k), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.hip().cogdl_hip_scatter_max_bwd(_lib.ptr(grad), _lib.ptr(max_id), _lib.ptr(out), m, k, n_src,
+                                                  _lib.stream_of(grad))
+    _lib.check(rc, "scatter_max_bwd")
+    return out
+
+
+class ScatterMaxFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rowptr, colind, feat):
+        out, max_id = scatter_max_fp(rowptr, colind, feat)
+        ctx.save_for_backward(max_id)
+        ctx.n_src = feat.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (max_id,) = ctx.saved_tensors
+        return None, None, scatter_max_bp(grad, max_id, ctx.n_src)
+
+
+def scatter_max(rowptr, colind, feat):
+    return ScatterMaxFunction.apply(rowptr, colind, feat)

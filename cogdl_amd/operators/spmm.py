@@ -1,0 +1,119 @@
+"""Drop-in for cogdl/operators/spmm.py: exports `csrspmm` and `spmm_cpu` with the reference's
+call signatures (operators/spmm.py:24-27,35-40), backed by libcogdl_hip / libcogdl_host.
+
+    csrspmm(rowptr:int32[M+1], colind:int32[nnz], x:[N,F], csr_data:[nnz]|None, sym=False, actnn=False) -> [M,F]
+    spmm_cpu(rowptr, colind, csr_data, x) -> [M,F]          (CPU tensors; note the argument order)
+
+Differences from the reference, all deliberate (SURVEY.md section 7 "hard parts"):
+  * backward always uses the true transpose A^T (cached per structure, cogdl_amd/plan.py).  The
+    reference reuses A when `sym` is set (operators/spmm.py:61-62), which is only right for a
+    truly symmetric weighted graph -- for those both give the same operator.
+  * unweighted + not sym no longer calls csr2csc(None) (operators/spmm.py:75).
+  * failures raise BackendError instead of silently falling back to torch.scatter_add.
+  * actnn=True (activation quantisation, third_party/actnn absent) is rejected loudly.
+"""
+import os
+
+import torch
+
+from .. import _lib
+from ..plan import PLANS, Fingerprint, gather_rows
+
+_lib.hip()  # fail at import if the HIP library is missing (no silent `csrspmm = None`)
+
+
+def _check_csr(rowptr, colind, x):
+    if rowptr.dtype != torch.int32 or colind.dtype != torch.int32:
+        raise _lib.BackendError("rowptr/colind must be int32 (got %s/%s)" % (rowptr.dtype, colind.dtype))
+    if x.dim() != 2:
+        raise _lib.BackendError("dense operand must be 2-D, got shape %s" % (tuple(x.shape),))
+    if x.dtype not in _lib.DTYPE_CODE:
+        raise _lib.BackendError("unsupported dtype %s" % x.dtype)
+
+
+def csr_spmm_raw(rowptr, colind, val, x, variant=-1):
+    """One cogdl_hip_csr_spmm launch on the current stream (no autograd)."""
+    dev = _lib.require_cuda(rowptr, colind, val, x)
+    _check_csr(rowptr, colind, x)
+    x = x.contiguous()
+    rowptr, colind = rowptr.contiguous(), colind.contiguous()
+    if val is not None:
+        val = val.contiguous()
+        if val.dtype != x.dtype:
+            val = val.to(x.dtype)
+        if val.numel() != colind.numel():
+            raise _lib.BackendError("csr_data has %d entries for %d edges" % (val.numel(), colind.numel()))
+    m, k = rowptr.numel() - 1, x.shape[1]
+    out = torch.empty((m, k), dtype=x.dtype, device=dev)
+    lib = _lib.hip()
+    with torch.cuda.device(dev):
+        rc = lib.cogdl_hip_csr_spmm_variant(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(val), _lib.ptr(x),
+                                            _lib.ptr(out), m, k, _lib.DTYPE_CODE[x.dtype], variant,
+                                            _lib.stream_of(x))
+    _lib.check(rc, "csr_spmm")
+    return out
+
+
+def csr_sddmm_raw(rowptr, colind, d1, d2):
+    """out[e] = <d1[row(e)], d2[col[e]]>  (fp32)."""
+    dev = _lib.require_cuda(rowptr, colind, d1, d2)
+    d1, d2 = d1.contiguous().float(), d2.contiguous().float()
+    m, k = rowptr.numel() - 1, d1.shape[1]
+    out = torch.empty(colind.numel(), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.hip().cogdl_hip_csr_sddmm(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(d1), _lib.ptr(d2),
+                                            _lib.ptr(out), m, k, _lib.stream_of(d1))
+    _lib.check(rc, "csr_sddmm")
+    return out
+
+
+class SPMMFunction(torch.autograd.Function):
+    """Mirrors cogdl.operators.spmm.SPMMFunction (operators/spmm.py:43-80)."""
+
+    @staticmethod
+    def forward(ctx, rowptr, colind, feat, edge_weight_csr=None, sym=False):
+        out = csr_spmm_raw(rowptr, colind, edge_weight_csr, feat)
+        need_w = edge_weight_csr is not None and ctx.needs_input_grad[3]
+        ctx.n_src = feat.shape[0]
+        ctx.sym = sym
+        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None
+        ctx.save_for_backward(rowptr, colind, edge_weight_csr, feat if need_w else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        rowptr, colind, w, feat = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        grad_feat = grad_w = None
+        if ctx.needs_input_grad[2]:
+            plan = PLANS.get(ctx.fp, rowptr, colind, ctx.n_src)
+            w_t = gather_rows(plan.perm, w.detach()) if w is not None else None
+            grad_feat = csr_spmm_raw(plan.colptr, plan.rowind, w_t, grad_out)
+        if w is not None and ctx.needs_input_grad[3]:
+            grad_w = csr_sddmm_raw(rowptr, colind, grad_out, feat.detach()).to(w.dtype)
+        return None, None, grad_feat, grad_w, None
+
+
+def csrspmm(rowptr, colind, x, csr_data, sym=False, actnn=False):
+    if actnn:
+        raise _lib.BackendError("actnn=True needs the ActNN quantiser (third_party/actnn is an empty submodule "
+                                "in the reference); not supported by the HIP backend")
+    return SPMMFunction.apply(rowptr, colind, x, csr_data, sym)
+
+
+def spmm_cpu(rowptr, colind, csr_data, x):
+    """CogDL's CPU SpMM (csr_spmm_cpu, operators/spmm/spmm_cpu.cpp:39-58) on host threads."""
+    for name, t in (("rowptr", rowptr), ("colind", colind), ("csr_data", csr_data), ("x", x)):
+        if t is not None and t.device.type != "cpu":
+            raise _lib.BackendError("spmm_cpu: %s must be a CPU tensor" % name)
+    if rowptr.dtype != torch.int32 or colind.dtype != torch.int32 or x.dtype != torch.float32:
+        raise _lib.BackendError("spmm_cpu expects int32 indices and float32 features")
+    rowptr, colind, x = rowptr.contiguous(), colind.contiguous(), x.contiguous()
+    val = None if csr_data is None else csr_data.contiguous().float()
+    m, k = rowptr.numel() - 1, x.shape[1]
+    out = torch.empty((m, k), dtype=torch.float32)
+    nthreads = int(os.environ.get("COGDL_AMD_CPU_THREADS", torch.get_num_threads()))
+    rc = _lib.host().cogdl_host_csr_spmm_f32(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(val), _lib.ptr(x),
+                                             _lib.ptr(out), m, k, nthreads)
+    _lib.check_host(rc, "csr_spmm_cpu")
+    return out

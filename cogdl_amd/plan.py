@@ -1,0 +1,124 @@
+"""Graph plans: the cached CSC view (stable transpose) of a CSR structure.
+
+Why a cache keyed on *content*: CogDL's dispatcher hands the operators fresh int32 copies of
+the graph structure on every call (`graph.row_indptr.int()`, cogdl/utils/spmm_utils.py:106),
+so pointer identity never repeats across calls.  The reference re-runs cuSPARSE csr2csc in
+every backward (cogdl/operators/spmm.py:63-68) -- or skips the transpose when the caller
+says `sym`, which is wrong for sampled blocks that merely default to symmetric
+(cogdl/data/data.py:146).  Here the transpose is computed once per distinct structure:
+
+  forward : a 64-bit content fingerprint of (rowptr, colind) is computed on the stream and
+            copied to pinned host memory asynchronously (no stall);
+  backward: the fingerprint (long since landed) keys an LRU of (colptr, rowind, perm).
+
+perm[j] is the CSR position of CSC entry j, so per-call edge values are moved with one
+gather.  The cache holds 8 bytes per edge; eviction is by byte budget.
+"""
+import collections
+import os
+
+import torch
+
+from . import _lib
+
+
+class CscPlan:
+    __slots__ = ("colptr", "rowind", "perm", "m", "n_cols", "nnz")
+
+    def __init__(self, colptr, rowind, perm, m, n_cols, nnz):
+        self.colptr, self.rowind, self.perm = colptr, rowind, perm
+        self.m, self.n_cols, self.nnz = m, n_cols, nnz
+
+    def nbytes(self):
+        return 4 * (self.colptr.numel() + self.rowind.numel() + self.perm.numel())
+
+
+def csr2csc(rowptr, colind, n_cols=None):
+    """Stable transpose of the structure -> CscPlan (device tensors, int32)."""
+    dev = _lib.require_cuda(rowptr, colind)
+    m = rowptr.numel() - 1
+    nnz = colind.numel()
+    n_cols = m if n_cols is None else int(n_cols)
+    colptr = torch.empty(n_cols + 1, dtype=torch.int32, device=dev)
+    rowind = torch.empty(nnz, dtype=torch.int32, device=dev)
+    perm = torch.empty(nnz, dtype=torch.int32, device=dev)
+    lib = _lib.hip()
+    ws_bytes = lib.cogdl_hip_csr2csc_workspace_bytes(m, n_cols, nnz)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.cogdl_hip_csr2csc(_lib.ptr(rowptr), _lib.ptr(colind), m, n_cols, nnz, _lib.ptr(colptr),
+                                   _lib.ptr(rowind), _lib.ptr(perm), _lib.ptr(ws), ws_bytes, _lib.stream_of(rowptr))
+    _lib.check(rc, "csr2csc")
+    return CscPlan(colptr, rowind, perm, m, n_cols, nnz)
+
+
+def gather_rows(perm, src):
+    """out[i] = src[perm[i]] along dim 0 (src: [E] or [E,H], 2- or 4-byte elements)."""
+    dev = _lib.require_cuda(perm, src)
+    src = src.contiguous()
+    out = torch.empty_like(src)
+    n = perm.numel()
+    h = src.numel() // max(n, 1) if n else 0
+    with torch.cuda.device(dev):
+        rc = _lib.hip().cogdl_hip_gather_rows(_lib.ptr(perm), _lib.ptr(src), _lib.ptr(out), n, h,
+                                              src.element_size(), _lib.stream_of(src))
+    _lib.check(rc, "gather_rows")
+    return out
+
+
+class Fingerprint:
+    """A structure hash in flight: device -> pinned host copy plus the event that guards it."""
+    __slots__ = ("host", "event", "meta")
+
+    def __init__(self, rowptr, colind, n_cols):
+        dev = rowptr.device
+        m, nnz = rowptr.numel() - 1, colind.numel()
+        d = torch.empty(1, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.hip().cogdl_hip_csr_fingerprint(_lib.ptr(rowptr), _lib.ptr(colind), m, nnz, _lib.ptr(d),
+                                                      _lib.stream_of(rowptr))
+        _lib.check(rc, "csr_fingerprint")
+        self.host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+        self.host.copy_(d, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(dev))
+        self.meta = (dev.index, m, nnz, int(n_cols))
+
+    def key(self):
+        self.event.synchronize()
+        return self.meta + (int(self.host[0]),)
+
+
+class PlanCache:
+    def __init__(self, budget_bytes=None):
+        if budget_bytes is None:
+            budget_bytes = int(os.environ.get("COGDL_AMD_PLAN_CACHE_MB", "4096")) << 20
+        self.budget = budget_bytes
+        self.bytes = 0
+        self.lru = collections.OrderedDict()
+        self.hits = 0
+        self.misses = 0
+
+    def get(self, fingerprint, rowptr, colind, n_cols):
+        key = fingerprint.key()
+        plan = self.lru.get(key)
+        if plan is not None:
+            self.lru.move_to_end(key)
+            self.hits += 1
+            return plan
+        self.misses += 1
+        plan = csr2csc(rowptr, colind, n_cols)
+        if plan.nbytes() <= self.budget:
+            self.lru[key] = plan
+            self.bytes += plan.nbytes()
+            while self.bytes > self.budget:
+                _, old = self.lru.popitem(last=False)
+                self.bytes -= old.nbytes()
+        return plan
+
+    def clear(self):
+        self.lru.clear()
+        self.bytes = 0
+
+
+PLANS = PlanCache()

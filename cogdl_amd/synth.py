@@ -1,0 +1,134 @@
+"""Seeded synthetic graphs with the shapes of BASELINE.json's configs (no dataset is available
+offline).  Preprocessing mirrors what CogDL does before SpMM sees a graph:
+
+  symmetrise + coalesce           cogdl/datasets/ogb.py:50-55, planetoid_data.py:44-51
+  add_remaining_self_loops        cogdl/data/data.py:175-191 (loops appended after the edges)
+  stable COO->CSR                 cogdl/utils/graph_utils.py:133-142 -> sample.cpp:234-270
+  sym_norm: w = d^-1/2[row] * d^-1/2[col], d = row sums of the unit weights   data.py:260-274
+
+All generators are deterministic functions of `seed` (torch.Generator on CPU, so the same
+graph is produced on every machine) and return CPU tensors; callers move them to the GPU.
+"""
+import math
+
+import torch
+
+
+class CSRGraph:
+    """Plain container: int32 CSR (what reaches the operators) + fp32 weights."""
+
+    def __init__(self, rowptr, colind, weight, num_nodes, n_cols=None):
+        self.rowptr, self.colind, self.weight = rowptr, colind, weight
+        self.num_nodes = num_nodes
+        self.n_cols = num_nodes if n_cols is None else n_cols
+
+    @property
+    def nnz(self):
+        return int(self.colind.numel())
+
+    def to(self, device):
+        return CSRGraph(self.rowptr.to(device), self.colind.to(device),
+                        None if self.weight is None else self.weight.to(device), self.num_nodes, self.n_cols)
+
+    def degrees(self):
+        return (self.rowptr[1:] - self.rowptr[:-1]).long()
+
+
+def coo_to_csr_stable(row, col, num_nodes):
+    """Stable counting sort by row (edge order inside a row = COO order). -> rowptr(int64), perm."""
+    perm = torch.sort(row, stable=True).indices
+    counts = torch.bincount(row, minlength=num_nodes)
+    rowptr = torch.zeros(num_nodes + 1, dtype=torch.long, device=row.device)
+    torch.cumsum(counts, 0, out=rowptr[1:])
+    return rowptr, perm
+
+
+def finalize(src, dst, num_nodes, symmetrise=True, self_loops=True, norm="sym"):
+    """Directed pairs -> CogDL-preprocessed CSR graph (row = destination of aggregation)."""
+    src, dst = src.long(), dst.long()
+    if symmetrise:
+        src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+    key = torch.unique(src * num_nodes + dst)  # coalesce: sorted by (row, col), duplicates removed
+    row, col = key // num_nodes, key % num_nodes
+    if self_loops:  # add_remaining_self_loops: keep existing loops, append the missing ones
+        has_loop = torch.zeros(num_nodes, dtype=torch.bool, device=row.device)
+        has_loop[row[row == col]] = True
+        missing = torch.nonzero(~has_loop).flatten()
+        row, col = torch.cat([row, missing]), torch.cat([col, missing])
+    rowptr, perm = coo_to_csr_stable(row, col, num_nodes)
+    row, col = row[perm], col[perm]
+    w = torch.ones(row.numel(), dtype=torch.float32, device=row.device)
+    if norm == "sym":
+        deg = torch.zeros(num_nodes, dtype=torch.float32, device=row.device).scatter_add_(0, row, w)
+        dinv = deg.pow(-0.5)
+        dinv[torch.isinf(dinv)] = 0
+        w = dinv[row] * w * dinv[col]
+    elif norm == "row":
+        deg = torch.zeros(num_nodes, dtype=torch.float32, device=row.device).scatter_add_(0, row, w)
+        w = w / deg[row]
+    elif norm is None:
+        w = None
+    return CSRGraph(rowptr.int(), col.int(), w, num_nodes)
+
+
+def uniform_pairs(num_nodes, num_pairs, seed):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, num_nodes, (num_pairs,), generator=g)
+    dst = torch.randint(0, num_nodes, (num_pairs,), generator=g)
+    return src, dst
+
+
+def rmat_pairs(num_nodes, num_pairs, seed, a=0.57, b=0.19, c=0.19):
+    """R-MAT (Chakrabarti et al.) edge list; ids outside [0, num_nodes) are folded back by modulo."""
+    g = torch.Generator().manual_seed(seed)
+    scale = max(1, math.ceil(math.log2(num_nodes)))
+    src = torch.zeros(num_pairs, dtype=torch.long)
+    dst = torch.zeros(num_pairs, dtype=torch.long)
+    for _ in range(scale):
+        r = torch.rand(num_pairs, generator=g)
+        src_bit = (r >= a + b).long()
+        dst_bit = ((r >= a) & (r < a + b) | (r >= a + b + c)).long()
+        src = src * 2 + src_bit
+        dst = dst * 2 + dst_bit
+    return src % num_nodes, dst % num_nodes
+
+
+# ----------------------------------------------------------------------------------------------
+# Named workloads
+def arxiv_like(seed=0, topology="uniform"):
+    """ogbn-arxiv shape: N=169,343, 1,166,243 directed pairs -> symmetrise + loops + sym_norm
+    (nnz ~ 2.50 M).  topology='uniform' is the worst-case-locality stand-in BASELINE.md measured;
+    'rmat' is a power-law variant."""
+    n, pairs = 169_343, 1_166_243
+    src, dst = uniform_pairs(n, pairs, seed) if topology == "uniform" else rmat_pairs(n, pairs, seed)
+    return finalize(src, dst, n)
+
+
+def cora_like(seed=0):
+    """Cora shape: N=2,708, 5,278 undirected pairs -> 10,556 directed + 2,708 loops."""
+    n = 2_708
+    src, dst = uniform_pairs(n, 5_400, seed)
+    keep = src != dst
+    return finalize(src[keep], dst[keep], n)
+
+
+def scaled(num_nodes, avg_degree, seed=0, topology="uniform", **kw):
+    pairs = int(num_nodes * avg_degree / 2)
+    src, dst = uniform_pairs(num_nodes, pairs, seed) if topology == "uniform" else rmat_pairs(num_nodes, pairs, seed)
+    return finalize(src, dst, num_nodes, **kw)
+
+
+def random_csr(m, n_cols, nnz_per_row, seed=0, weighted=True, ragged=True):
+    """Rectangular CSR with ragged rows (some empty, duplicates allowed): operator unit tests."""
+    g = torch.Generator().manual_seed(seed)
+    if ragged:
+        deg = torch.randint(0, 2 * nnz_per_row + 1, (m,), generator=g)
+        deg[torch.rand(m, generator=g) < 0.1] = 0
+    else:
+        deg = torch.full((m,), nnz_per_row, dtype=torch.long)
+    rowptr = torch.zeros(m + 1, dtype=torch.long)
+    torch.cumsum(deg, 0, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    colind = torch.randint(0, n_cols, (nnz,), generator=g)
+    w = torch.randn(nnz, generator=g) if weighted else None
+    return CSRGraph(rowptr.int(), colind.int(), w, m, n_cols)

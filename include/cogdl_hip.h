@@ -1,0 +1,158 @@
+/*
+ * cogdl_hip.h -- C ABI of libcogdl_hip.so: the MI355X (gfx950) sparse message-passing
+ * backend that sits underneath CogDL's `cogdl.operators` API.
+ *
+ * Every entry point replaces one function of the reference's per-op pybind11/CUDA
+ * extensions (cited as file:line under /root/reference/).  The reference binds those with
+ * torch::Tensor arguments; this ABI is torch-free: raw device pointers, sizes, a dtype
+ * enum and the hipStream_t (as void*) to launch on.  Ownership: all buffers are
+ * caller-allocated and borrowed for the duration of the enqueued work; nothing is
+ * allocated, freed or synchronised inside (so calls are hipGraph-capturable), except the
+ * *_workspace_bytes queries which are pure host functions.
+ *
+ * Error convention: 0 = COGDL_HIP_OK, otherwise a COGDL_HIP_E* code (the reference
+ * assert()s / exit()s instead: operators/spmm/computeUtil.h:13-27).  cogdl_hip_strerror
+ * maps a code to text.  Launch errors are reported from hipGetLastError() right after the
+ * launch; asynchronous faults surface at the caller's next synchronisation as usual.
+ *
+ * Conventions: CSR index arrays are int32 (what the callers pass: rowptr.int(),
+ * colind.int(), cogdl/utils/spmm_utils.py:106); all row*width offset arithmetic inside
+ * the kernels is 64-bit.  Dense matrices are row-major contiguous.
+ */
+#ifndef COGDL_HIP_H
+#define COGDL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COGDL_HIP_ABI_VERSION 1
+
+/* Exported with default visibility (the library is built -fvisibility=hidden). */
+#if defined(COGDL_HIP_BUILD)
+#define COGDL_API __attribute__((visibility("default")))
+#else
+#define COGDL_API
+#endif
+
+enum cogdl_hip_status {
+    COGDL_HIP_OK = 0,
+    COGDL_HIP_EINVAL = 1,      /* bad argument (null pointer, negative size, ...) */
+    COGDL_HIP_EDTYPE = 2,      /* unsupported dtype for this entry point */
+    COGDL_HIP_EALIGN = 3,      /* pointer not aligned to the element size */
+    COGDL_HIP_ELAUNCH = 4,     /* hipLaunchKernel / runtime error (see cogdl_hip_last_hip_error) */
+    COGDL_HIP_EWORKSPACE = 5,  /* workspace too small */
+    COGDL_HIP_ERANGE = 6       /* size exceeds what int32 CSR indices can address */
+};
+
+enum cogdl_hip_dtype {
+    COGDL_HIP_F32 = 0,
+    COGDL_HIP_F16 = 1,
+    COGDL_HIP_BF16 = 2
+};
+
+COGDL_API int cogdl_hip_abi_version(void);
+COGDL_API const char *cogdl_hip_strerror(int status);
+/* hipError_t of the most recent COGDL_HIP_ELAUNCH on this thread (0 if none). */
+COGDL_API int cogdl_hip_last_hip_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * csr_spmm:  out[i,:] = sum_{e in row i, CSR order} val[e] * x[colind[e],:]
+ * Replaces spmm.csr_spmm (operators/spmm/spmm.cpp:22-45 -> spmm_cuda, spmm_kernel.cu:534-594)
+ * and, with val == NULL, spmm.csr_spmm_no_edge_value (spmm.cpp:47-65, spmm_kernel.cu:155-190).
+ * CPU twin / oracle: csr_spmm_cpu (operators/spmm/spmm_cpu.cpp:6-58).
+ * f32: each output element is accumulated sequentially in CSR edge order with a separate
+ * fp32 multiply and add -- bit-identical to the reference CPU path as CogDL builds it.
+ * f16/bf16: val has the dtype of x; products and sums are fp32, rounded once on store.
+ * x: [n_src, k], out: [m, k]; rowptr: [m+1]; colind/val: [rowptr[m]].
+ * ------------------------------------------------------------------------------------- */
+COGDL_API int cogdl_hip_csr_spmm(const int32_t *rowptr, const int32_t *colind, const void *val,
+                       const void *x, void *out, int64_t m, int64_t k, int dtype, void *stream);
+
+/* Tuning hook (benchmarks only): force a kernel variant for csr_spmm; <0 = automatic. */
+COGDL_API int cogdl_hip_csr_spmm_variant(const int32_t *rowptr, const int32_t *colind, const void *val,
+                               const void *x, void *out, int64_t m, int64_t k, int dtype,
+                               int variant, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * csr2csc: stable transpose of the CSR structure.
+ * Replaces spmm.csr2csc (operators/spmm/spmm.cpp:72-90 -> cusparseCsr2cscEx2 ALG1,
+ * spmm_kernel.cu:514-532,596-614) and mhtranspose.csr2csc (mhTranspose.cu:51-111).
+ * Outputs colptr [n_cols+1], rowind [nnz] and perm [nnz] (perm[j] = CSR position of CSC
+ * entry j; within a column entries keep ascending CSR position, i.e. ascending row).
+ * Values are moved with cogdl_hip_gather_rows(perm, val, ...) -- one gather serves both
+ * the scalar weights of csr2csc and the [E,H] attention of mhtranspose.
+ * workspace: device scratch of at least cogdl_hip_csr2csc_workspace_bytes(...) bytes.
+ * ------------------------------------------------------------------------------------- */
+COGDL_API size_t cogdl_hip_csr2csc_workspace_bytes(int64_t m, int64_t n_cols, int64_t nnz);
+COGDL_API int cogdl_hip_csr2csc(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols,
+                      int64_t nnz, int32_t *colptr, int32_t *rowind, int32_t *perm,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* out[i, 0:h] = src[perm[i], 0:h]  (elem_bytes in {2,4}).
+ * Replaces mhtranspose.mhtranspose (operators/spmm/mhTranspose.cu:6-49) and the value leg
+ * of csr2csc. */
+COGDL_API int cogdl_hip_gather_rows(const int32_t *perm, const void *src, void *out, int64_t n, int64_t h,
+                          int elem_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * csr_sddmm: out[e] = < d1[row(e),:], d2[colind[e],:] >      (gradient of edge weights)
+ * Replaces sddmm.csr_sddmm (operators/spmm/sddmm.cpp:47-70, sddmm_kernel.cu:249-417,451-476).
+ * ------------------------------------------------------------------------------------- */
+COGDL_API int cogdl_hip_csr_sddmm(const int32_t *rowptr, const int32_t *colind, const float *d1,
+                        const float *d2, float *out, int64_t m, int64_t k, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * edge_softmax: per (destination row, head) softmax over the row's edges; values [E,H].
+ * Replaces edge_softmax.edge_softmax / edge_softmax_backward
+ * (operators/edge_softmax/edge_softmax.cc:16-49, edge_softmax.cu:7-60,63-98).
+ * Any H >= 1 (the reference's block (32,H) caps H at 32).
+ * ------------------------------------------------------------------------------------- */
+COGDL_API int cogdl_hip_edge_softmax_fwd(const int32_t *rowptr, const float *values, float *out, int64_t m,
+                               int64_t nnz, int64_t h, void *stream);
+COGDL_API int cogdl_hip_edge_softmax_bwd(const int32_t *rowptr, const float *softmax, const float *grad,
+                               float *grad_in, int64_t m, int64_t nnz, int64_t h, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * mhspmm:  out[v,h,:] = sum_e att[e,h] * feat[colind[e],h,:]     feat [n_src,H,F]
+ * Replaces mhspmm.mhspmm (operators/spmm/multiheadSpmm.cpp, multiheadSpmm.cu:6-77).
+ * att is always f32; feat/out have `dtype` (f32: sequential fp32 mul+add per element).
+ * mhsddmm: out[e,h] = < grad[row(e),h,:], feat[colind[e],h,:] >
+ * Replaces mhsddmm.mhsddmm (operators/spmm/multiheadSddmm.cu:6-113).
+ * ------------------------------------------------------------------------------------- */
+COGDL_API int cogdl_hip_mhspmm(const int32_t *rowptr, const int32_t *colind, const float *att,
+                     const void *feat, void *out, int64_t v, int64_t h, int64_t f, int dtype,
+                     void *stream);
+COGDL_API int cogdl_hip_mhsddmm(const int32_t *rowptr, const int32_t *colind, const float *grad,
+                      const float *feat, float *out, int64_t v, int64_t h, int64_t f,
+                      void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * scatter_max: out[r,c] = max_{e in row r} feat[colind[e],c]; max_id[r,c] = the colind of
+ * the FIRST maximum in CSR order (-1 and 0.0 for an empty row).
+ * Replaces scatter_max.scatter_max_fp / scatter_max_bp
+ * (operators/scatter_max/scatter_max.cc:19-38, scatter_max.cu:5-75) -- without its
+ * FLT_MIN initial value, uninitialised argmax and uninitialised gradient buffer.
+ * Backward: grad_src[max_id[r,c], c] += grad[r,c]; grad_src [n_src,k] is zeroed inside.
+ * ------------------------------------------------------------------------------------- */
+COGDL_API int cogdl_hip_scatter_max_fwd(const int32_t *rowptr, const int32_t *colind, const float *feat,
+                              float *out, int32_t *max_id, int64_t m, int64_t k, void *stream);
+COGDL_API int cogdl_hip_scatter_max_bwd(const float *grad, const int32_t *max_id, float *grad_src, int64_t m,
+                              int64_t k, int64_t n_src, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Helpers used by the graph-plan cache and the vertex-sharded (multi-GPU) SpMM.
+ * fingerprint: 64-bit content hash of (rowptr[0..m], colind[0..nnz)) written to *out_hash
+ * (device or host-mapped pinned pointer).  Not part of the reference.
+ * gather_feature_rows: out[i,:] = x[idx[i],:] for the halo send buffers (idx int32).
+ * ------------------------------------------------------------------------------------- */
+COGDL_API int cogdl_hip_csr_fingerprint(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t nnz,
+                              uint64_t *out_hash, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COGDL_HIP_H */
