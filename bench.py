@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's benchmark contract for the sparse message-passing hot path.
+
+N = 1 : BASELINE.json configs[1] -- "GCN on ogbn-arxiv (170k nodes, 1.2M edges, 128-dim feat), full-graph
+        csr_spmm fwd+bwd on 1 MI355X, fp32".  A step = one csrspmm forward + its backward (grad wrt the
+        features) through the autograd operator a CogDL layer would call, on the arxiv-shaped synthetic graph
+        (uniform-random topology = worst-case locality; no dataset is available offline), inputs resident in HBM.
+        value = GEdges/s = 2 * nnz * steps / time.
+N > 1 : configs[4] -- vertex-sharded csr_spmm (1-D row partition, halo rows exchanged with an RCCL all-to-all
+        overlapped with the local-column SpMM), weak scaling: a fixed papers100M-like shard per GPU.
+        value = global nnz * 2 * steps / time (max over ranks).
+
+One JSON line on stdout (rank 0).  Extra objects: roofline (dominant kernel, HIP-event timed inside the timed
+region) and cpu_baseline (the reference's own csr_spmm_cpu, built from /root/reference by oracle/Makefile, timed on
+this host's cores; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+
+
+def b_alg(nnz, m, f, s=4, s_w=4):
+    """Algorithmic bytes of one csr_spmm launch: per edge colind + weight + one gathered row,
+    per row rowptr + one output row."""
+    return nnz * (4 + s_w + f * s) + m * (4 + f * s)
+
+
+def cpu_baseline(g, x, budget_s=10.0):
+    """Reference csr_spmm_cpu on the host cores (oracle/_ref, -O3 build; as-shipped -O0 build timed once)."""
+    from oracle import oracle
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    res = {"unit": "GEdges/s", "cores": cores}
+    if oracle.ref_available("O3"):
+        fn = oracle.ref_spmm_cpu("O3")
+        res["kind"] = "reference"
+        run = lambda: fn(g.rowptr, g.colind, g.weight, x)  # noqa: E731
+        flavour = "cogdl/operators/spmm/spmm_cpu.cpp built -fopenmp -O3 -mavx2 -mfma"
+    else:
+        res["kind"] = "port"
+        run = lambda: oracle.csr_spmm(g.rowptr, g.colind, g.weight, x, nthreads=cores)  # noqa: E731
+        flavour = "oracle/cogdl_oracle.c (OpenMP port)"
+    run()
+    t0 = time.perf_counter()
+    run()
+    t1 = time.perf_counter() - t0
+    reps = int(max(3, min(400, budget_s / max(t1, 1e-4))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    dt = (time.perf_counter() - t0) / reps
+    res["value"] = g.nnz / dt / 1e9
+    res["ms_per_call"] = dt * 1e3
+    res["sample"] = "%d forward csr_spmm calls on the full arxiv-like graph (nnz=%d, F=%d), %s, %d threads" % (
+        reps, g.nnz, x.shape[1], flavour, cores)
+    if oracle.ref_available("asshipped"):
+        fn0 = oracle.ref_spmm_cpu("asshipped")
+        fn0(g.rowptr, g.colind, g.weight, x)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn0(g.rowptr, g.colind, g.weight, x)
+        res["as_shipped_O0_GEdges_s"] = g.nnz / ((time.perf_counter() - t0) / 3) / 1e9
+    return res
+
+
+def load_pmc_traffic(tag):
+    """HBM bytes per launch from a committed rocprofv3 --pmc summary (profiles/pmc_*.json), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_spmm_arxiv.json")
+    if os.path.exists(path):
+        try:
+            return json.load(open(path)).get(tag)
+        except Exception:
+            return None
+    return None
+
+
+def bench_single(args):
+    from cogdl_amd import synth
+    from cogdl_amd.operators import spmm as spmm_mod
+    from cogdl_amd.operators.spmm import csrspmm
+
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(dev)
+    f = args.feat
+    g = synth.arxiv_like(seed=0, topology=args.topology)
+    x_cpu = torch.randn(g.num_nodes, f, generator=torch.Generator().manual_seed(0))
+    gd = g.to(dev)
+    x = x_cpu.to(dev).requires_grad_()
+    gout = torch.randn(g.num_nodes, f, device=dev)
+
+    def step():
+        # fresh int32 copies of the structure every call, as CogDL's dispatcher does (spmm_utils.py:106)
+        out = csrspmm(gd.rowptr.long().int(), gd.colind.long().int(), x, gd.weight, True)
+        x.grad = None
+        out.backward(gout)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    spmm_mod.KERNEL_EVENTS = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    events, spmm_mod.KERNEL_EVENTS = spmm_mod.KERNEL_EVENTS, None
+    kern_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
+
+    # the dominant kernel alone (no autograd, no per-call index casts), HIP-event timed
+    with torch.no_grad():
+        xs = x.detach()
+        for _ in range(5):
+            spmm_mod.csr_spmm_raw(gd.rowptr, gd.colind, gd.weight, xs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            spmm_mod.csr_spmm_raw(gd.rowptr, gd.colind, gd.weight, xs)
+        e1.record()
+        torch.cuda.synchronize()
+        fwd_ms = e0.elapsed_time(e1) / 50
+
+    bytes_alg = b_alg(g.nnz, g.num_nodes, f)
+    achieved = bytes_alg / (kern_ms * 1e-3) / 1e9
+    result = {
+        "metric": "SpMM GEdges/s (csr_spmm fwd+bwd, ogbn-arxiv-shaped GCN aggregation) @1 GPU",
+        "value": 2 * g.nnz * args.steps / dt / 1e9,
+        "unit": "GEdges/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ogbn-arxiv-like full-graph csr_spmm fwd+bwd (configs[1])", "nodes": g.num_nodes,
+                   "nnz": g.nnz, "feat": f, "topology": args.topology, "weighted": True,
+                   "parallelism": "single GPU"},
+        "roofline": {"bound": "hbm", "kernel": "csr_spmm_rowgroup_kernel<float,4,32,8,weighted>",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": load_pmc_traffic("hbm_bytes_per_launch"),
+                     "algorithmic_bytes_per_launch": bytes_alg,
+                     "compulsory_bytes_per_launch": g.nnz * 8 + 4 * (g.num_nodes + 1) + 2 * g.num_nodes * f * 4,
+                     "kernel_ms_in_step": kern_ms, "kernel_ms_fwd_alone": fwd_ms,
+                     "GEdges_s_fwd_alone": g.nnz / (fwd_ms * 1e-3) / 1e9},
+    }
+    if not args.no_cpu:
+        result["cpu_baseline"] = cpu_baseline(g, x_cpu)
+    return result
+
+
+def bench_sharded(args):
+    from cogdl_amd.dist import bench_sharded_spmm
+
+    return bench_sharded_spmm(args)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--feat", type=int, default=128)
+    ap.add_argument("--topology", default="uniform", choices=["uniform", "rmat"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--shard-nodes", type=int, default=0, help="N>1: nodes per GPU (default: papers100M/8)")
+    ap.add_argument("--shard-degree", type=float, default=0.0, help="N>1: mean in-degree (default 28.8)")
+    args = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        result = bench_sharded(args)
+    else:
+        result = bench_single(args)
+    if result is not None:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -21,6 +21,10 @@ from ..plan import PLANS, Fingerprint, gather_rows
 
 _lib.hip()  # fail at import if the HIP library is missing (no silent `csrspmm = None`)
 
+# bench.py sets this to a list to get (start, end) HIP events around every csr_spmm kernel launch,
+# recorded on the stream the kernel is launched on.
+KERNEL_EVENTS = None
+
 
 def _check_csr(rowptr, colind, x):
     if rowptr.dtype != torch.int32 or colind.dtype != torch.int32:
@@ -47,9 +51,15 @@ def csr_spmm_raw(rowptr, colind, val, x, variant=-1):
     out = torch.empty((m, k), dtype=x.dtype, device=dev)
     lib = _lib.hip()
     with torch.cuda.device(dev):
+        if KERNEL_EVENTS is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         rc = lib.cogdl_hip_csr_spmm_variant(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(val), _lib.ptr(x),
                                             _lib.ptr(out), m, k, _lib.DTYPE_CODE[x.dtype], variant,
                                             _lib.stream_of(x))
+        if KERNEL_EVENTS is not None:
+            ev1.record()
+            KERNEL_EVENTS.append((ev0, ev1))
     _lib.check(rc, "csr_spmm")
     return out
 
@@ -87,7 +97,7 @@ class SPMMFunction(torch.autograd.Function):
         grad_feat = grad_w = None
         if ctx.needs_input_grad[2]:
             plan = PLANS.get(ctx.fp, rowptr, colind, ctx.n_src)
-            w_t = gather_rows(plan.perm, w.detach()) if w is not None else None
+            w_t = plan.transposed_values(w) if w is not None else None
             grad_feat = csr_spmm_raw(plan.colptr, plan.rowind, w_t, grad_out)
         if w is not None and ctx.needs_input_grad[3]:
             grad_w = csr_sddmm_raw(rowptr, colind, grad_out, feat.detach()).to(w.dtype)

@@ -23,11 +23,21 @@ from . import _lib
 
 
 class CscPlan:
-    __slots__ = ("colptr", "rowind", "perm", "m", "n_cols", "nnz")
+    __slots__ = ("colptr", "rowind", "perm", "m", "n_cols", "nnz", "_val_key", "_val_t")
 
     def __init__(self, colptr, rowind, perm, m, n_cols, nnz):
         self.colptr, self.rowind, self.perm = colptr, rowind, perm
         self.m, self.n_cols, self.nnz = m, n_cols, nnz
+        self._val_key, self._val_t = None, None
+
+    def transposed_values(self, w):
+        """w[perm], memoised on the identity+version of `w` (CogDL passes the same
+        graph.raw_edge_weight tensor every call, cogdl/utils/spmm_utils.py:102)."""
+        key = (w.data_ptr(), w._version, w.dtype, w.numel())
+        if key != self._val_key:
+            self._val_t = gather_rows(self.perm, w.detach())
+            self._val_key = key
+        return self._val_t
 
     def nbytes(self):
         return 4 * (self.colptr.numel() + self.rowind.numel() + self.perm.numel())

@@ -1,0 +1,173 @@
+"""csr_spmm parity on the GPU, through the C ABI (ctypes) and the autograd operator.
+fp32: BIT-EXACT against the reference's CPU operator (golden vectors) and the oracle.
+fp16/bf16: within 2^-8 relative of an fp64 accumulation of the same rounded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from cogdl_amd import synth
+from cogdl_amd.operators.spmm import csr_spmm_raw, csrspmm
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a, dev=DEV):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def hip_spmm(rowptr, colind, val, x, variant=-1):
+    val = None if val is None else T(val) if isinstance(val, np.ndarray) else val.to(DEV)
+    rowptr = T(rowptr) if isinstance(rowptr, np.ndarray) else rowptr.to(DEV)
+    colind = T(colind) if isinstance(colind, np.ndarray) else colind.to(DEV)
+    x = T(x) if isinstance(x, np.ndarray) else x.to(DEV)
+    return csr_spmm_raw(rowptr, colind, val, x, variant).cpu().numpy()
+
+
+def test_reference_golden_vectors_bit_exact(golden):
+    z = golden("spmm_cpu")
+    for c in sorted({k.split("_")[0] for k in z}):
+        out = hip_spmm(z[c + "_rowptr"], z[c + "_colind"], z[c + "_val"], z[c + "_x"])
+        assert out.tobytes() == z[c + "_out"].tobytes(), c
+
+
+@pytest.mark.parametrize("k", [1, 2, 7, 16, 40, 41, 47, 64, 100, 128, 256, 602])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_widths_bit_exact_vs_oracle(oracle, k, weighted):
+    g = synth.random_csr(301, 257, 9, seed=k, weighted=weighted)
+    x = torch.randn(257, k, generator=torch.Generator().manual_seed(k))
+    want = oracle.csr_spmm(g.rowptr, g.colind, g.weight, x)
+    got = hip_spmm(g.rowptr, g.colind, g.weight, x)
+    assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 1000, 5000])
+def test_wave64_row_length_edges(oracle, deg):
+    """rows of exactly `deg` edges next to empty rows: chunk/unroll tails of the 64-wide design."""
+    m, n, k = 13, 97, 128
+    degs = torch.tensor([deg, 0, deg, 1, 0, deg, 64, 0, 0, deg, 3, 65, deg])
+    rowptr = torch.zeros(m + 1, dtype=torch.int32)
+    rowptr[1:] = torch.cumsum(degs, 0)
+    gen = torch.Generator().manual_seed(deg)
+    colind = torch.randint(0, n, (int(rowptr[-1]),), generator=gen, dtype=torch.int32)
+    val = torch.randn(int(rowptr[-1]), generator=gen)
+    x = torch.randn(n, k, generator=gen)
+    for kk in (128, 40, 7):
+        want = oracle.csr_spmm(rowptr, colind, val, x[:, :kk].contiguous())
+        got = hip_spmm(rowptr, colind, val, x[:, :kk].contiguous())
+        assert got.tobytes() == want.tobytes(), (deg, kk)
+
+
+def test_empty_and_degenerate_shapes():
+    rowptr = torch.zeros(6, dtype=torch.int32)
+    out = hip_spmm(rowptr, torch.zeros(0, dtype=torch.int32), torch.zeros(0), torch.randn(4, 8))
+    assert out.shape == (5, 8) and not out.any()
+    out = hip_spmm(torch.zeros(1, dtype=torch.int32), torch.zeros(0, dtype=torch.int32), None, torch.randn(4, 8))
+    assert out.shape == (0, 8)
+
+
+def test_non_finite_features_propagate_like_the_reference(oracle):
+    g = synth.random_csr(64, 64, 5, seed=11)
+    x = torch.randn(64, 32, generator=torch.Generator().manual_seed(1))
+    x[3, 5] = float("inf")
+    x[10, :] = float("nan")
+    x[20, 0] = -float("inf")
+    want = oracle.csr_spmm(g.rowptr, g.colind, g.weight, x)
+    got = hip_spmm(g.rowptr, g.colind, g.weight, x)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.array_equal(got[ok], want[ok])
+
+
+@pytest.mark.parametrize("variant", list(range(11)))
+def test_every_kernel_variant(oracle, variant):
+    g = synth.scaled(3000, 14, seed=5)
+    x = torch.randn(g.num_nodes, 128, generator=torch.Generator().manual_seed(3))
+    want = oracle.csr_spmm(g.rowptr, g.colind, g.weight, x)
+    got = hip_spmm(g.rowptr, g.colind, g.weight, x, variant)
+    if variant == 5:  # the FMA-contracted arithmetic variant: close, not bitwise
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    else:
+        assert got.tobytes() == want.tobytes()
+
+
+def test_full_size_arxiv_bit_exact(oracle):
+    """BASELINE.json configs[1] at full size: N=169,343, nnz~2.5M, F=128 fp32."""
+    g = synth.arxiv_like(seed=0)
+    x = torch.randn(g.num_nodes, 128, generator=torch.Generator().manual_seed(0))
+    want = oracle.csr_spmm(g.rowptr, g.colind, g.weight, x, nthreads=oracle.num_threads())
+    got = hip_spmm(g.rowptr, g.colind, g.weight, x)
+    assert got.tobytes() == want.tobytes()
+    # size-independent property: linearity in x (exactly, for power-of-two scaling)
+    got2 = hip_spmm(g.rowptr, g.colind, g.weight, 2.0 * x)
+    assert (2.0 * got).tobytes() == got2.tobytes()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_half_precision_inputs(oracle, dtype):
+    g = synth.scaled(2000, 10, seed=8)
+    x = torch.randn(g.num_nodes, 64, generator=torch.Generator().manual_seed(2)).to(dtype)
+    w = g.weight.to(dtype)
+    want = oracle.csr_spmm_f64(g.rowptr, g.colind, w.float(), x.float())
+    scale = oracle.csr_spmm_abs(g.rowptr, g.colind, w.float(), x.float())
+    got = csr_spmm_raw(g.rowptr.to(DEV), g.colind.to(DEV), w.to(DEV), x.to(DEV)).float().cpu().numpy()
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7  # one output rounding + fp32 accumulation
+    assert np.all(np.abs(got - want) <= eps * np.abs(want) + 1e-5 * scale + 1e-6)
+
+
+def test_backward_matches_reference_cpu_autograd(golden):
+    """Gradients vs the reference's CPU training path (spmm_scatter + autograd), golden vectors:
+    grad wrt features bit-exact (stable transpose => same accumulation order), grad wrt weights 1e-5."""
+    z = golden("spmm_scatter")
+    n = z["b"].shape[0]
+    from cogdl_amd.operators.sample import coo2csr_cpu_index
+
+    rp, perm = coo2csr_cpu_index(torch.from_numpy(z["row"]), torch.from_numpy(z["col"]), n)
+    rowptr, colind = rp.int().to(DEV), torch.from_numpy(z["col"])[perm].int().to(DEV)
+    w = T(z["w"])[perm.to(DEV)].clone().requires_grad_()
+    b = T(z["b"]).requires_grad_()
+    out = csrspmm(rowptr, colind, b, w, False)
+    assert out.detach().cpu().numpy().tobytes() == z["out"].tobytes()
+    out.backward(T(z["gout"]))
+    assert b.grad.cpu().numpy().tobytes() == z["grad_b"].tobytes()
+    np.testing.assert_allclose(w.grad.cpu().numpy(), z["grad_w"][perm.numpy()], rtol=1e-5, atol=1e-6)
+
+
+def test_backward_rectangular_block_and_sym_flag(oracle):
+    """A sampled-block-shaped operand (m != n_src, not symmetric) with sym=True passed, as CogDL does:
+    the gradient must still be A^T g (the reference's GPU path would use A here)."""
+    g = synth.random_csr(50, 80, 6, seed=21)
+    x = torch.randn(80, 24, generator=torch.Generator().manual_seed(4))
+    gout = torch.randn(50, 24, generator=torch.Generator().manual_seed(5))
+    xg = x.to(DEV).requires_grad_()
+    out = csrspmm(g.rowptr.to(DEV), g.colind.to(DEV), xg, g.weight.to(DEV), True)
+    out.backward(gout.to(DEV))
+    colptr, rowind, w_t, _ = oracle.csr2csc(g.rowptr, g.colind, g.weight, n_cols=80)
+    want = oracle.csr_spmm(colptr, rowind, w_t, gout)
+    assert xg.grad.cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_plan_cache_hits_across_calls():
+    from cogdl_amd.plan import PLANS
+
+    PLANS.clear()
+    g = synth.scaled(1000, 8, seed=1).to(DEV)
+    h0, m0 = PLANS.hits, PLANS.misses
+    for _ in range(3):
+        x = torch.randn(1000, 16, device=DEV, requires_grad=True)
+        # fresh int32 copies every call, exactly like spmm_utils.py:106
+        csrspmm(g.rowptr.long().int(), g.colind.long().int(), x, g.weight, True).sum().backward()
+    assert PLANS.misses - m0 == 1 and PLANS.hits - h0 == 2
+
+
+def test_runs_on_the_current_stream():
+    g = synth.scaled(5000, 10, seed=2).to(DEV)
+    x = torch.randn(5000, 64, device=DEV)
+    ref = csr_spmm_raw(g.rowptr, g.colind, g.weight, x)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        y = x * 2.0  # produced on the side stream; the op must be ordered after it on that stream
+        out = csr_spmm_raw(g.rowptr, g.colind, g.weight, y)
+    s.synchronize()
+    assert torch.equal(out, 2.0 * ref)
