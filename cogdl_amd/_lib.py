@@ -22,15 +22,18 @@ HIP_SIGNATURES = {
     "cogdl_hip_abi_version": ([], _i32),
     "cogdl_hip_strerror": ([_i32], ctypes.c_char_p),
     "cogdl_hip_last_hip_error": ([], _i32),
-    "cogdl_hip_csr_spmm": ([_vp] * 5 + [_i64, _i64, _i32, _vp], _i32),
-    "cogdl_hip_csr_spmm_variant": ([_vp] * 5 + [_i64, _i64, _i32, _i32, _vp], _i32),
+    "cogdl_hip_csr_spmm_workspace_bytes": ([_i64, _i64], _sz),
+    "cogdl_hip_csr_spmm_long_row_threshold": ([_i64], _i32),
+    "cogdl_hip_csr_spmm": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
+    "cogdl_hip_csr_spmm_acc": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
+    "cogdl_hip_csr_spmm_variant": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_csr2csc_workspace_bytes": ([_i64, _i64, _i64], _sz),
     "cogdl_hip_csr2csc": ([_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp], _i32),
     "cogdl_hip_gather_rows": ([_vp, _vp, _vp, _i64, _i64, _i32, _vp], _i32),
     "cogdl_hip_csr_sddmm": ([_vp] * 5 + [_i64, _i64, _vp], _i32),
     "cogdl_hip_edge_softmax_fwd": ([_vp] * 3 + [_i64, _i64, _i64, _vp], _i32),
     "cogdl_hip_edge_softmax_bwd": ([_vp] * 4 + [_i64, _i64, _i64, _vp], _i32),
-    "cogdl_hip_mhspmm": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp], _i32),
+    "cogdl_hip_mhspmm": ([_vp] * 5 + [_i64, _i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_mhsddmm": ([_vp] * 5 + [_i64, _i64, _i64, _vp], _i32),
     "cogdl_hip_scatter_max_fwd": ([_vp] * 5 + [_i64, _i64, _vp], _i32),
     "cogdl_hip_scatter_max_bwd": ([_vp] * 3 + [_i64, _i64, _i64, _vp], _i32),
@@ -86,6 +89,14 @@ def host():
     if _host is None:
         _host = _load(HOST_LIB_PATH, HOST_SIGNATURES, "libcogdl_host.so (host operators)")
     return _host
+
+
+def spmm_workspace(nnz, k, device):
+    """Scratch for the long-row path of csr_spmm / mhspmm (torch caching allocator: no hipMalloc per call)."""
+    nbytes = hip().cogdl_hip_csr_spmm_workspace_bytes(int(nnz), int(k))
+    if nbytes == 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
 
 def ptr(t):

@@ -27,9 +27,11 @@ def mhspmm_raw(rowptr, colind, att, feat):
     if att.shape != (colind.numel(), h):
         raise _lib.BackendError("attention must be [E, H] = %s, got %s" % ((colind.numel(), h), tuple(att.shape)))
     out = torch.empty((v, h, f), dtype=feat.dtype, device=dev)
+    ws, ws_bytes = _lib.spmm_workspace(colind.numel(), h * f, dev)
     with torch.cuda.device(dev):
         rc = _lib.hip().cogdl_hip_mhspmm(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(att), _lib.ptr(feat),
-                                         _lib.ptr(out), v, h, f, _lib.DTYPE_CODE[feat.dtype], _lib.stream_of(feat))
+                                         _lib.ptr(out), v, h, f, colind.numel(), _lib.DTYPE_CODE[feat.dtype],
+                                         _lib.ptr(ws), ws_bytes, _lib.stream_of(feat))
     _lib.check(rc, "mhspmm")
     return out
 

@@ -35,8 +35,9 @@ def _check_csr(rowptr, colind, x):
         raise _lib.BackendError("unsupported dtype %s" % x.dtype)
 
 
-def csr_spmm_raw(rowptr, colind, val, x, variant=-1):
-    """One cogdl_hip_csr_spmm launch on the current stream (no autograd)."""
+def csr_spmm_raw(rowptr, colind, val, x, variant=-1, out=None, split_long_rows=True):
+    """One cogdl_hip_csr_spmm launch on the current stream (no autograd).  With `out` given the result is
+    accumulated into it (out += A x, cogdl_hip_csr_spmm_acc)."""
     dev = _lib.require_cuda(rowptr, colind, val, x)
     _check_csr(rowptr, colind, x)
     x = x.contiguous()
@@ -47,16 +48,28 @@ def csr_spmm_raw(rowptr, colind, val, x, variant=-1):
             val = val.to(x.dtype)
         if val.numel() != colind.numel():
             raise _lib.BackendError("csr_data has %d entries for %d edges" % (val.numel(), colind.numel()))
-    m, k = rowptr.numel() - 1, x.shape[1]
-    out = torch.empty((m, k), dtype=x.dtype, device=dev)
+    m, k, nnz = rowptr.numel() - 1, x.shape[1], colind.numel()
+    acc = out is not None
+    if acc:
+        if out.shape != (m, k) or out.dtype != x.dtype or not out.is_contiguous():
+            raise _lib.BackendError("accumulation target must be a contiguous [%d, %d] %s tensor" % (m, k, x.dtype))
+    else:
+        out = torch.empty((m, k), dtype=x.dtype, device=dev)
     lib = _lib.hip()
+    ws, ws_bytes = _lib.spmm_workspace(nnz, k, dev) if split_long_rows else (None, 0)
+    code = _lib.DTYPE_CODE[x.dtype]
     with torch.cuda.device(dev):
         if KERNEL_EVENTS is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        rc = lib.cogdl_hip_csr_spmm_variant(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(val), _lib.ptr(x),
-                                            _lib.ptr(out), m, k, _lib.DTYPE_CODE[x.dtype], variant,
+        if acc:
+            rc = lib.cogdl_hip_csr_spmm_acc(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(val), _lib.ptr(x),
+                                            _lib.ptr(out), m, k, nnz, code, _lib.ptr(ws), ws_bytes,
                                             _lib.stream_of(x))
+        else:
+            rc = lib.cogdl_hip_csr_spmm_variant(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(val), _lib.ptr(x),
+                                                _lib.ptr(out), m, k, nnz, code, variant, _lib.ptr(ws), ws_bytes,
+                                                _lib.stream_of(x))
         if KERNEL_EVENTS is not None:
             ev1.record()
             KERNEL_EVENTS.append((ev0, ev1))

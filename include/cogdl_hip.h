@@ -67,15 +67,30 @@ COGDL_API int cogdl_hip_last_hip_error(void);
  * f32: each output element is accumulated sequentially in CSR edge order with a separate
  * fp32 multiply and add -- bit-identical to the reference CPU path as CogDL builds it.
  * f16/bf16: val has the dtype of x; products and sums are fp32, rounded once on store.
- * x: [n_src, k], out: [m, k]; rowptr: [m+1]; colind/val: [rowptr[m]].
+ * x: [n_src, k], out: [m, k]; rowptr: [m+1]; colind/val: [nnz], nnz == rowptr[m].
+ * workspace (optional, device, 256-B aligned, >= cogdl_hip_csr_spmm_workspace_bytes(nnz, k)):
+ * enables the chunk-parallel treatment of rows longer than
+ * cogdl_hip_csr_spmm_long_row_threshold(nnz) edges (power-law graphs); such rows are summed
+ * as fixed-order partial sums (deterministic, re-associated).  With workspace == NULL every
+ * row is summed strictly sequentially.
  * ------------------------------------------------------------------------------------- */
+COGDL_API size_t cogdl_hip_csr_spmm_workspace_bytes(int64_t nnz, int64_t k);
+COGDL_API int cogdl_hip_csr_spmm_long_row_threshold(int64_t nnz);
 COGDL_API int cogdl_hip_csr_spmm(const int32_t *rowptr, const int32_t *colind, const void *val,
-                       const void *x, void *out, int64_t m, int64_t k, int dtype, void *stream);
+                       const void *x, void *out, int64_t m, int64_t k, int64_t nnz, int dtype,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* out += A x: same kernels, the per-element accumulator starts from the existing out[i,:] (then the
+ * row's edges are added in CSR order).  Used by the vertex-sharded SpMM, where the remote-column
+ * block is applied after the local-column block (no reference counterpart). */
+COGDL_API int cogdl_hip_csr_spmm_acc(const int32_t *rowptr, const int32_t *colind, const void *val,
+                           const void *x, void *out, int64_t m, int64_t k, int64_t nnz, int dtype,
+                           void *workspace, size_t workspace_bytes, void *stream);
 
 /* Tuning hook (benchmarks only): force a kernel variant for csr_spmm; <0 = automatic. */
 COGDL_API int cogdl_hip_csr_spmm_variant(const int32_t *rowptr, const int32_t *colind, const void *val,
-                               const void *x, void *out, int64_t m, int64_t k, int dtype,
-                               int variant, void *stream);
+                               const void *x, void *out, int64_t m, int64_t k, int64_t nnz, int dtype,
+                               int variant, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * csr2csc: stable transpose of the CSR structure.
@@ -120,12 +135,13 @@ COGDL_API int cogdl_hip_edge_softmax_bwd(const int32_t *rowptr, const float *sof
  * mhspmm:  out[v,h,:] = sum_e att[e,h] * feat[colind[e],h,:]     feat [n_src,H,F]
  * Replaces mhspmm.mhspmm (operators/spmm/multiheadSpmm.cpp, multiheadSpmm.cu:6-77).
  * att is always f32; feat/out have `dtype` (f32: sequential fp32 mul+add per element).
+ * workspace: as for csr_spmm with k = H*F (cogdl_hip_csr_spmm_workspace_bytes(nnz, H*F)).
  * mhsddmm: out[e,h] = < grad[row(e),h,:], feat[colind[e],h,:] >
  * Replaces mhsddmm.mhsddmm (operators/spmm/multiheadSddmm.cu:6-113).
  * ------------------------------------------------------------------------------------- */
 COGDL_API int cogdl_hip_mhspmm(const int32_t *rowptr, const int32_t *colind, const float *att,
-                     const void *feat, void *out, int64_t v, int64_t h, int64_t f, int dtype,
-                     void *stream);
+                     const void *feat, void *out, int64_t v, int64_t h, int64_t f, int64_t nnz, int dtype,
+                     void *workspace, size_t workspace_bytes, void *stream);
 COGDL_API int cogdl_hip_mhsddmm(const int32_t *rowptr, const int32_t *colind, const float *grad,
                       const float *feat, float *out, int64_t v, int64_t h, int64_t f,
                       void *stream);

@@ -1,0 +1,37 @@
+#!/bin/bash
+# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+STAGES="${@:-smoke tests variants bench prof}"
+has() { [[ " $STAGES " == *" $1 "* ]]; }
+(lscpu | grep -E "Model name|^CPU\(s\)|Thread|Socket"; free -g | head -2; rocminfo | grep -E "gfx|Compute Unit" | head -6) > gpurun_out/host.txt 2>&1
+if has smoke; then
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
+  tail -2 gpurun_out/smoke.log
+fi
+if has tests; then
+  timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+  tail -15 gpurun_out/pytest_gpu.log
+fi
+if has variants; then
+  timeout 900 python tools/spmm_variants.py > gpurun_out/variants.txt 2>&1
+  tail -5 gpurun_out/variants.txt
+fi
+if has bench; then
+  timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err
+  cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err
+fi
+if has prof; then
+  rm -rf gpurun_out/prof_kt
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_kt" -o kt -- python "$GRAFT_REPO_ROOT/bench.py" --steps 50 --no-cpu) > gpurun_out/bench_prof.log 2>&1
+  find gpurun_out/prof_kt -name "*stats*" | head; 
+fi
+if has pmc; then
+  for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+    tag=$(echo $c | tr ' ' '_')
+    rm -rf gpurun_out/pmc_$tag
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag" -o pmc -- python "$GRAFT_REPO_ROOT/tools/pmc_probe.py") > gpurun_out/pmc_$tag.log 2>&1
+  done
+  python tools/pmc_summarize.py gpurun_out > gpurun_out/pmc_summary.json 2> gpurun_out/pmc_summary.err; cat gpurun_out/pmc_summary.json | head -50
+fi
