@@ -96,12 +96,13 @@ def bench_single(args):
     g = synth.arxiv_like(seed=0, topology=args.topology)
     x_cpu = torch.randn(g.num_nodes, f, generator=torch.Generator().manual_seed(0))
     gd = g.to(dev)
+    rowptr64, colind64 = gd.rowptr.long(), gd.colind.long()  # CogDL's Graph keeps int64 indices
     x = x_cpu.to(dev).requires_grad_()
     gout = torch.randn(g.num_nodes, f, device=dev)
 
     def step():
         # fresh int32 copies of the structure every call, as CogDL's dispatcher does (spmm_utils.py:106)
-        out = csrspmm(gd.rowptr.long().int(), gd.colind.long().int(), x, gd.weight, True)
+        out = csrspmm(rowptr64.int(), colind64.int(), x, gd.weight, True)
         x.grad = None
         out.backward(gout)
 
@@ -143,7 +144,7 @@ def bench_single(args):
         "config": {"workload": "ogbn-arxiv-like full-graph csr_spmm fwd+bwd (configs[1])", "nodes": g.num_nodes,
                    "nnz": g.nnz, "feat": f, "topology": args.topology, "weighted": True,
                    "parallelism": "single GPU"},
-        "roofline": {"bound": "hbm", "kernel": "csr_spmm_rowgroup_kernel<float,4,32,8,weighted>",
+        "roofline": {"bound": "hbm", "kernel": "csr_spmm_rowgroup_kernel<float,VEC=2,LPR=64,UNROLL=8,weighted>",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": load_pmc_traffic("hbm_bytes_per_launch"),
                      "algorithmic_bytes_per_launch": bytes_alg,

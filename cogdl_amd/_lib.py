@@ -22,6 +22,7 @@ HIP_SIGNATURES = {
     "cogdl_hip_abi_version": ([], _i32),
     "cogdl_hip_strerror": ([_i32], ctypes.c_char_p),
     "cogdl_hip_last_hip_error": ([], _i32),
+    "cogdl_hip_set_tuning": ([_i32, _i32], _i32),
     "cogdl_hip_csr_spmm_workspace_bytes": ([_i64, _i64], _sz),
     "cogdl_hip_csr_spmm_long_row_threshold": ([_i64], _i32),
     "cogdl_hip_csr_spmm": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
@@ -37,6 +38,9 @@ HIP_SIGNATURES = {
     "cogdl_hip_mhsddmm": ([_vp] * 5 + [_i64, _i64, _i64, _vp], _i32),
     "cogdl_hip_scatter_max_fwd": ([_vp] * 5 + [_i64, _i64, _vp], _i32),
     "cogdl_hip_scatter_max_bwd": ([_vp] * 3 + [_i64, _i64, _i64, _vp], _i32),
+    "cogdl_hip_gat_fwd": ([_vp] * 5 + [_f32] + [_vp] * 3 + [_i64, _i64, _i64, _i32, _vp], _i32),
+    "cogdl_hip_gat_bwd_workspace_bytes": ([_i64, _i64], _sz),
+    "cogdl_hip_gat_bwd": ([_vp] * 7 + [_f32] + [_vp] * 8 + [_sz, _i64, _i64, _i64, _i64, _vp], _i32),
     "cogdl_hip_csr_fingerprint": ([_vp, _vp, _i64, _i64, _vp, _vp], _i32),
 }
 

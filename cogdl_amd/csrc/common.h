@@ -25,17 +25,35 @@ inline int launch_status() {
 
 inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed,
-// speed-only).  Remap so that each XCD walks one contiguous 1/8th of the logical blocks:
-// consecutive row-blocks then share an L2, which is where the gathered feature rows of
-// graphs with id-locality get re-used.  Grid must be launched with xcd_grid(n) blocks;
-// returns -1 for the padding blocks.
-__host__ __device__ inline int64_t xcd_chunk(int64_t n_logical) { return (n_logical + kXcds - 1) / kXcds; }
-inline unsigned xcd_grid(int64_t n_logical) { return (unsigned)(xcd_chunk(n_logical) * kXcds); }
-__device__ __forceinline__ int64_t xcd_remap(unsigned bid, int64_t n_logical) {
-    const int64_t chunk = xcd_chunk(n_logical);
-    const int64_t logical = (int64_t)(bid % kXcds) * chunk + (bid / kXcds);
-    return logical < n_logical ? logical : -1;
+// Run-time tuning knobs (cogdl_hip_set_tuning): experiments without recompiling.
+enum Tuning { kTuneXcdStripe = 0, kTuneLongThresh = 1, kTuneCount = 8 };
+extern int g_tuning[kTuneCount];
+
+// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8; observed, used for
+// speed only).  Consecutive row-blocks gather overlapping neighbour rows on graphs with id-locality,
+// so they should share an XCD's private L2 -- but handing each XCD one contiguous 1/8th of the rows
+// unbalances the XCDs whenever degree correlates with node id (citation graphs: old papers are hubs).
+// Compromise: logical blocks are dealt to the XCDs in stripes of `stripe` consecutive blocks.
+// The grid is padded to a multiple of 8*stripe; xcd_remap returns -1 for the padding blocks.
+struct XcdMap {
+    int64_t n_logical;
+    int stripe;  // 0: identity (hardware round-robin)
+};
+inline XcdMap make_xcd_map(int64_t n_logical) {
+    int stripe = g_tuning[kTuneXcdStripe];
+    if (stripe < 0) stripe = 0;
+    return {n_logical, stripe};
+}
+inline unsigned xcd_grid(const XcdMap &m) {
+    if (m.stripe == 0) return (unsigned)m.n_logical;
+    const int64_t per = (int64_t)kXcds * m.stripe;
+    return (unsigned)((m.n_logical + per - 1) / per * per);
+}
+__device__ __forceinline__ int64_t xcd_remap(unsigned bid, const XcdMap &m) {
+    if (m.stripe == 0) return bid;
+    const int64_t idx = bid / kXcds, xcd = bid % kXcds;
+    const int64_t logical = (idx / m.stripe) * ((int64_t)kXcds * m.stripe) + xcd * m.stripe + idx % m.stripe;
+    return logical < m.n_logical ? logical : -1;
 }
 
 // ---- 16/8/4-byte vector access of T[VEC] -------------------------------------------------

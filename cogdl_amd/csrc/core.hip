@@ -3,6 +3,13 @@
 
 namespace cogdl {
 thread_local int g_last_hip_error = 0;
+int g_tuning[kTuneCount] = {/*xcd stripe*/ 32, /*long-row threshold override (0 = automatic)*/ 0, 0, 0, 0, 0, 0, 0};
+}
+
+extern "C" int cogdl_hip_set_tuning(int key, int value) {
+    if (key < 0 || key >= cogdl::kTuneCount) return COGDL_HIP_EINVAL;
+    cogdl::g_tuning[key] = value;
+    return COGDL_HIP_OK;
 }
 
 extern "C" int cogdl_hip_abi_version(void) { return COGDL_HIP_ABI_VERSION; }

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void edge_softmax_pow2_kernel(const int32_t *_
                                                                 const float *__restrict__ a,  // values | softmax
                                                                 const float *__restrict__ g,  // unused | grad
                                                                 float *__restrict__ out, int64_t m, int h,
-                                                                int64_t n_rowblocks) {
+                                                                XcdMap n_rowblocks) {
     constexpr int RPW = kWave / LPR;
     constexpr int RPB = RPW * 4;
     const int64_t rb = xcd_remap(blockIdx.x, n_rowblocks);
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void edge_softmax_generic_kernel(const int32_t
                                                                    const float *__restrict__ a,
                                                                    const float *__restrict__ g,
                                                                    float *__restrict__ out, int64_t m, int h,
-                                                                   int64_t n_rowblocks) {
+                                                                   XcdMap n_rowblocks) {
     const int64_t rb = xcd_remap(blockIdx.x, n_rowblocks);
     if (rb < 0) return;
     const int lane = threadIdx.x & (kWave - 1);
@@ -120,8 +120,8 @@ static int launch_pow2(const int32_t *rowptr, const float *a, const float *g, fl
     constexpr int RPB = (kWave / LPR) * 4;
     const int64_t nrb = (m + RPB - 1) / RPB;
     if (nrb > 0x7fffffff / kXcds) return COGDL_HIP_ERANGE;
-    hipLaunchKernelGGL((edge_softmax_pow2_kernel<LPR, BACKWARD>), dim3(xcd_grid(nrb)), dim3(256), 0, s, rowptr, a, g,
-                       out, m, h, nrb);
+    hipLaunchKernelGGL((edge_softmax_pow2_kernel<LPR, BACKWARD>), dim3(xcd_grid(make_xcd_map(nrb))), dim3(256), 0, s, rowptr, a, g,
+                       out, m, h, make_xcd_map(nrb));
     return launch_status();
 }
 
@@ -136,8 +136,8 @@ static int edge_softmax_dispatch(const int32_t *rowptr, const float *a, const fl
     if (!pow2) {
         const int64_t nrb = (m + 3) / 4;
         if (nrb > 0x7fffffff / kXcds) return COGDL_HIP_ERANGE;
-        hipLaunchKernelGGL((edge_softmax_generic_kernel<BACKWARD>), dim3(xcd_grid(nrb)), dim3(256), 0, s, rowptr, a,
-                           g, out, m, (int)h, nrb);
+        hipLaunchKernelGGL((edge_softmax_generic_kernel<BACKWARD>), dim3(xcd_grid(make_xcd_map(nrb))), dim3(256), 0, s, rowptr, a,
+                           g, out, m, (int)h, make_xcd_map(nrb));
         return launch_status();
     }
     // lanes per row ~ mean run length (deg*H), at least H and 8, at most 64

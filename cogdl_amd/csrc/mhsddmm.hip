@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void mhsddmm_kernel(const int32_t *__restrict_
                                                       const float *__restrict__ grad,
                                                       const float *__restrict__ feat, float *__restrict__ out,
                                                       int64_t m, int heads, int fdim, int lph /* lanes per head */,
-                                                      int64_t n_rowblocks) {
+                                                      XcdMap n_rowblocks) {
     constexpr int RPW = kWave / LPR;
     constexpr int RPB = RPW * 4;
     const int64_t rb = xcd_remap(blockIdx.x, n_rowblocks);
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void mhsddmm_generic_kernel(const int32_t *__r
                                                               const float *__restrict__ grad,
                                                               const float *__restrict__ feat,
                                                               float *__restrict__ out, int64_t m, int heads,
-                                                              int fdim, int64_t n_rowblocks) {
+                                                              int fdim, XcdMap n_rowblocks) {
     const int64_t rb = xcd_remap(blockIdx.x, n_rowblocks);
     if (rb < 0) return;
     const int lane = threadIdx.x & (kWave - 1);
@@ -92,8 +92,8 @@ static int launch_mhsddmm(const int32_t *rowptr, const int32_t *colind, const fl
     constexpr int RPB = (kWave / LPR) * 4;
     const int64_t nrb = (m + RPB - 1) / RPB;
     if (nrb > 0x7fffffff / kXcds) return COGDL_HIP_ERANGE;
-    hipLaunchKernelGGL((mhsddmm_kernel<VEC, LPR, 4>), dim3(xcd_grid(nrb)), dim3(256), 0, s, rowptr, colind, grad,
-                       feat, out, m, (int)h, (int)f, (int)(f / VEC), nrb);
+    hipLaunchKernelGGL((mhsddmm_kernel<VEC, LPR, 4>), dim3(xcd_grid(make_xcd_map(nrb))), dim3(256), 0, s, rowptr, colind, grad,
+                       feat, out, m, (int)h, (int)f, (int)(f / VEC), make_xcd_map(nrb));
     return launch_status();
 }
 
@@ -130,7 +130,7 @@ extern "C" int cogdl_hip_mhsddmm(const int32_t *rowptr, const int32_t *colind, c
     if (is_pow2(f) && h * f <= kWave) return dispatch_mhsddmm<1>(rowptr, colind, grad, feat, out, v, h, f, s);
     const int64_t nrb = (v + 3) / 4;
     if (nrb > 0x7fffffff / kXcds) return COGDL_HIP_ERANGE;
-    hipLaunchKernelGGL(mhsddmm_generic_kernel, dim3(xcd_grid(nrb)), dim3(256), 0, s, rowptr, colind, grad, feat, out,
-                       v, (int)h, (int)f, nrb);
+    hipLaunchKernelGGL(mhsddmm_generic_kernel, dim3(xcd_grid(make_xcd_map(nrb))), dim3(256), 0, s, rowptr, colind, grad, feat, out,
+                       v, (int)h, (int)f, make_xcd_map(nrb));
     return launch_status();
 }

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void scatter_max_fwd_kernel(const int32_t *__r
                                                               const int32_t *__restrict__ colind,
                                                               const float *__restrict__ x, float *__restrict__ out,
                                                               int32_t *__restrict__ max_id, int64_t m, int k,
-                                                              int64_t n_rowblocks) {
+                                                              XcdMap n_rowblocks) {
     constexpr int RPW = kWave / LPR;
     constexpr int RPB = RPW * 4;
     const int64_t rb = xcd_remap(blockIdx.x, n_rowblocks);
@@ -88,8 +88,8 @@ static int launch_smax(const int32_t *rowptr, const int32_t *colind, const float
     const int64_t nrb = (m + RPB - 1) / RPB;
     const int64_t tiles = (k + (int64_t)LPR * VEC - 1) / ((int64_t)LPR * VEC);
     if (nrb > 0x7fffffff / kXcds || tiles > 65535) return COGDL_HIP_ERANGE;
-    hipLaunchKernelGGL((scatter_max_fwd_kernel<VEC, LPR, 8>), dim3(xcd_grid(nrb), (unsigned)tiles), dim3(256), 0, s,
-                       rowptr, colind, x, out, max_id, m, (int)k, nrb);
+    hipLaunchKernelGGL((scatter_max_fwd_kernel<VEC, LPR, 8>), dim3(xcd_grid(make_xcd_map(nrb)), (unsigned)tiles), dim3(256), 0, s,
+                       rowptr, colind, x, out, max_id, m, (int)k, make_xcd_map(nrb));
     return launch_status();
 }
 

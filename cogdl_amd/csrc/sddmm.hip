@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void csr_sddmm_kernel(const int32_t *__restric
                                                         const int32_t *__restrict__ colind,
                                                         const float *__restrict__ d1,
                                                         const float *__restrict__ d2, float *__restrict__ out,
-                                                        int64_t m, int k, int64_t n_rowblocks) {
+                                                        int64_t m, int k, XcdMap n_rowblocks) {
     constexpr int RPW = kWave / LPR;
     constexpr int RPB = RPW * 4;
     const int64_t rb = xcd_remap(blockIdx.x, n_rowblocks);
@@ -88,13 +88,13 @@ static int launch_sddmm(const int32_t *rowptr, const int32_t *colind, const floa
     const int64_t n_rowblocks = (m + RPB - 1) / RPB;
     if (n_rowblocks == 0) return COGDL_HIP_OK;
     if (n_rowblocks > 0x7fffffff / kXcds) return COGDL_HIP_ERANGE;
-    dim3 grid(xcd_grid(n_rowblocks));
+    dim3 grid(xcd_grid(make_xcd_map(n_rowblocks)));
     if (k <= (int64_t)LPR * VEC)
         hipLaunchKernelGGL((csr_sddmm_kernel<VEC, LPR, UNROLL, true>), grid, dim3(256), 0, s, rowptr, colind, d1, d2,
-                           out, m, (int)k, n_rowblocks);
+                           out, m, (int)k, make_xcd_map(n_rowblocks));
     else
         hipLaunchKernelGGL((csr_sddmm_kernel<VEC, LPR, UNROLL, false>), grid, dim3(256), 0, s, rowptr, colind, d1,
-                           d2, out, m, (int)k, n_rowblocks);
+                           d2, out, m, (int)k, make_xcd_map(n_rowblocks));
     return launch_status();
 }
 

@@ -52,12 +52,13 @@ struct SpmmArgs {
     int64_t m;
     int k;               // feature width (heads * fdim for WMODE 2)
     int fdim;
-    int64_t n_rowblocks;
+    XcdMap rowblocks;
     int long_thresh;     // rows with more edges take the chunk-parallel path (INT_MAX: disabled)
     int acc_mode;        // != 0: out += A x
-    int32_t *chunk_row;  // [n_chunks][2]: long row intersecting the chunk (slot 0: the row that contains the
-                         //   chunk's first edge; slot 1: a row that starts inside the chunk), -1 = none
-    float *partial;      // [n_chunks][2][k] fp32 partial sums
+    int32_t *chunk_row;  // [n_chunks]: the LONG row that contains edge c*ch (the chunk's first edge), else -1.
+                         //   Every entry is (re)written by the main kernel on every launch: no memset needed.
+    float *partial;      // [n_chunks][2][k] fp32 partial sums (slot 0: the row owning the chunk's first edge,
+                         //   slot 1: the head of a long row that starts inside the chunk)
     int64_t nnz;
 };
 
@@ -115,7 +116,7 @@ template <typename T, int VEC, int LPR, int UNROLL, int WMODE, bool EXACT>
 __global__ __launch_bounds__(256) void csr_spmm_rowgroup_kernel(const SpmmArgs<T> a) {
     constexpr int RPW = kWave / LPR;  // rows per wave
     constexpr int RPB = RPW * 4;      // rows per 256-thread workgroup
-    const int64_t rb = xcd_remap(blockIdx.x, a.n_rowblocks);
+    const int64_t rb = xcd_remap(blockIdx.x, a.rowblocks);
     if (rb < 0) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
@@ -134,16 +135,13 @@ __global__ __launch_bounds__(256) void csr_spmm_rowgroup_kernel(const SpmmArgs<T
         start = __builtin_amdgcn_readfirstlane(start);
         end = __builtin_amdgcn_readfirstlane(end);
     }
-    if (end - start > a.long_thresh) {
-        // Long row: leave it to the chunk-parallel kernels, just record which chunks it touches.
-        if (blockIdx.y == 0) {
-            const int ch = a.long_thresh;  // chunk length == threshold
-            const int c_first = start / ch, c_last = (end - 1) / ch;
-            for (int c = c_first + l; c <= c_last; c += LPR)
-                a.chunk_row[2 * c + ((c == c_first && start != c * ch) ? 1 : 0)] = (int32_t)row;
-        }
-        return;
+    if (a.chunk_row && blockIdx.y == 0 && end > start) {
+        // Own the chunk_row entries of the chunks whose first edge lies in this row: c*ch in [start, end).
+        const int ch = a.long_thresh;
+        const int32_t mark = (end - start > ch) ? (int32_t)row : -1;
+        for (int c = (start + ch - 1) / ch + l; (int64_t)c * ch < end; c += LPR) a.chunk_row[c] = mark;
     }
+    if (end - start > a.long_thresh) return;  // long row: the chunk-parallel kernels compute it
     float acc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
@@ -155,13 +153,25 @@ __global__ __launch_bounds__(256) void csr_spmm_rowgroup_kernel(const SpmmArgs<T
     if (row < a.m && col_ok) store_vec<T, VEC>(a.out + row * (int64_t)a.k + col0, acc);
 }
 
-// One workgroup per edge chunk [c*ch, (c+1)*ch): for each long row intersecting the chunk the
-// 256/LPR groups take contiguous slices of the intersection, then group partials are summed in
-// group order through LDS and written to partial[c][slot][:].
+// Chunk c = edges [c*ch, (c+1)*ch).  A long row (> ch edges) intersecting it is either the row owning the
+// chunk's first edge (chunk_row[c], slot 0) or a row that starts inside the chunk -- which then owns the
+// NEXT chunk's first edge (chunk_row[c+1], slot 1).  For each piece the 256/LPR groups of the workgroup take
+// contiguous slices, group partials are summed in group order through LDS and written to partial[c][slot][:].
+// Workgroups own contiguous runs of chunks and skip runs without long rows after one coalesced look.
 template <typename T, int VEC, int LPR, int UNROLL, int WMODE>
-__global__ __launch_bounds__(256) void csr_spmm_longrow_partial_kernel(const SpmmArgs<T> a, int64_t n_chunks) {
+__global__ __launch_bounds__(256) void csr_spmm_longrow_partial_kernel(const SpmmArgs<T> a, int64_t n_chunks,
+                                                                       int chunks_per_block) {
     constexpr int G = 256 / LPR;  // groups per workgroup
     __shared__ float red[G][LPR * VEC];
+    __shared__ int any_long;
+    const int64_t c_begin = (int64_t)blockIdx.x * chunks_per_block;
+    const int64_t c_end = min(c_begin + chunks_per_block, n_chunks);
+    if (threadIdx.x == 0) any_long = 0;
+    __syncthreads();
+    for (int64_t c = c_begin + threadIdx.x; c <= c_end && c < n_chunks; c += blockDim.x)  // includes c_end: slot 1
+        if (a.chunk_row[c] >= 0) any_long = 1;
+    __syncthreads();
+    if (!any_long) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int sub = lane / LPR;
     const int l = lane % LPR;
@@ -172,9 +182,14 @@ __global__ __launch_bounds__(256) void csr_spmm_longrow_partial_kernel(const Spm
     const int heads = (WMODE == 2) ? a.k / a.fdim : 1;
     const int hd = (WMODE == 2) ? cc / a.fdim : 0;
     const int ch = a.long_thresh;
-    for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    for (int64_t c = c_begin; c < c_end; ++c) {
         for (int slot = 0; slot < 2; ++slot) {
-            const int32_t row = a.chunk_row[2 * c + slot];  // workgroup-uniform
+            int32_t row = -1;  // workgroup-uniform
+            if (slot == 0) row = a.chunk_row[c];
+            else if (c + 1 < n_chunks) {
+                row = a.chunk_row[c + 1];
+                if (row >= 0 && (int64_t)a.rowptr[row] <= c * ch) row = -1;  // same row as slot 0, not a new head
+            }
             if (row < 0) continue;
             const int lo = max(a.rowptr[row], (int)(c * ch));
             const int hi = (int)min((int64_t)a.rowptr[row + 1], (c + 1) * ch);
@@ -205,24 +220,35 @@ __global__ __launch_bounds__(256) void csr_spmm_longrow_partial_kernel(const Spm
     }
 }
 
-// For every long row (found through the chunk in which it starts) add its per-chunk partials in
-// chunk order and write (or accumulate into) the output row.  One wave per chunk.
+// For every long row add its per-chunk partials in chunk order and write (or accumulate into) the output
+// row.  The row is combined by the wave that finds it at its FIRST full chunk (the row's head piece, if any,
+// sits in slot 1 of the chunk before).
 template <typename T>
-__global__ __launch_bounds__(64) void csr_spmm_longrow_combine_kernel(const SpmmArgs<T> a, int64_t n_chunks) {
+__global__ __launch_bounds__(256) void csr_spmm_longrow_combine_kernel(const SpmmArgs<T> a, int64_t n_chunks,
+                                                                       int chunks_per_block) {
+    __shared__ int any_long;
+    const int64_t c_begin = (int64_t)blockIdx.x * chunks_per_block;
+    const int64_t c_end = min(c_begin + chunks_per_block, n_chunks);
+    if (threadIdx.x == 0) any_long = 0;
+    __syncthreads();
+    for (int64_t c = c_begin + threadIdx.x; c < c_end; c += blockDim.x)
+        if (a.chunk_row[c] >= 0) any_long = 1;
+    __syncthreads();
+    if (!any_long) return;
     const int ch = a.long_thresh;
-    for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        for (int slot = 0; slot < 2; ++slot) {
-            const int32_t row = a.chunk_row[2 * c + slot];
-            if (row < 0) continue;
-            const int start = a.rowptr[row], end = a.rowptr[row + 1];
-            if (start < c * ch) continue;  // the row started in an earlier chunk: that chunk owns the combine
-            const int64_t c_last = (end - 1) / ch;
-            for (int col = threadIdx.x; col < a.k; col += kWave) {
-                float acc = a.acc_mode ? to_f32<T>(a.out[(int64_t)row * a.k + col]) : 0.f;
-                acc += a.partial[(2 * c + slot) * (int64_t)a.k + col];
-                for (int64_t cc = c + 1; cc <= c_last; ++cc) acc += a.partial[(2 * cc) * (int64_t)a.k + col];
-                a.out[(int64_t)row * a.k + col] = from_f32<T>(acc);
-            }
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int64_t c = c_begin + (threadIdx.x >> 6); c < c_end; c += 4) {  // one wave per chunk
+        const int32_t row = a.chunk_row[c];
+        if (row < 0) continue;
+        const int start = a.rowptr[row], end = a.rowptr[row + 1];
+        if ((int64_t)(start + ch - 1) / ch != c) continue;  // not the row's first owned chunk
+        const int64_t c_last = (end - 1) / ch;
+        const bool head = (int64_t)start != c * ch;          // a head piece lives in chunk c-1, slot 1
+        for (int col = lane; col < a.k; col += kWave) {
+            float acc = a.acc_mode ? to_f32<T>(a.out[(int64_t)row * a.k + col]) : 0.f;
+            if (head) acc += a.partial[(2 * (c - 1) + 1) * (int64_t)a.k + col];
+            for (int64_t q = c; q <= c_last; ++q) acc += a.partial[(2 * q) * (int64_t)a.k + col];
+            a.out[(int64_t)row * a.k + col] = from_f32<T>(acc);
         }
     }
 }
@@ -232,43 +258,44 @@ static inline int64_t n_chunks_for(int64_t nnz, int thresh) { return (nnz + thre
 // Threshold above which a row is split: the sequential time of a row of T edges (~T/UNROLL gather
 // round trips) should stay a small fraction of the whole launch (~nnz / 13 GEdges/s).
 static inline int pick_long_thresh(int64_t nnz) {
-    int t = 128;
+    if (g_tuning[kTuneLongThresh] > 0) return g_tuning[kTuneLongThresh];
+    int t = 256;
     while (t < 4096 && (int64_t)t * 16384 < nnz) t <<= 1;
     return t;
 }
 
+static inline size_t chunk_row_bytes(int64_t n_chunks) { return ((size_t)(n_chunks + 1) * sizeof(int32_t) + 255) / 256 * 256; }
+
 template <typename T, int VEC, int LPR, int UNROLL, int WMODE, bool EXACT>
 static int launch_rowgroup(SpmmArgs<T> a, void *workspace, size_t workspace_bytes, hipStream_t stream) {
     constexpr int RPB = (kWave / LPR) * 4;
-    a.n_rowblocks = (a.m + RPB - 1) / RPB;
+    const int64_t n_rowblocks = (a.m + RPB - 1) / RPB;
     const int64_t tiles = ((int64_t)a.k + (int64_t)LPR * VEC - 1) / ((int64_t)LPR * VEC);
-    if (a.n_rowblocks == 0) return COGDL_HIP_OK;
-    if (a.n_rowblocks > 0x7fffffff / kXcds || tiles > 65535) return COGDL_HIP_ERANGE;
+    if (n_rowblocks == 0) return COGDL_HIP_OK;
+    if (n_rowblocks > 0x7fffffff / (kXcds * 64) || tiles > 65535) return COGDL_HIP_ERANGE;
+    a.rowblocks = make_xcd_map(n_rowblocks);
     a.long_thresh = INT_MAX;
+    a.chunk_row = nullptr;
     int64_t n_chunks = 0;
     if (workspace && a.nnz > 0) {
         const int t = pick_long_thresh(a.nnz);
         n_chunks = n_chunks_for(a.nnz, t);
-        const size_t need = (size_t)n_chunks * 2 * sizeof(int32_t) + 256 + (size_t)n_chunks * 2 * a.k * sizeof(float);
+        const size_t need = chunk_row_bytes(n_chunks) + (size_t)n_chunks * 2 * a.k * sizeof(float);
         if (workspace_bytes < need) return COGDL_HIP_EWORKSPACE;
         if (!aligned_to(workspace, 256)) return COGDL_HIP_EALIGN;
         a.long_thresh = t;
         a.chunk_row = (int32_t *)workspace;
-        const size_t off = ((size_t)n_chunks * 2 * sizeof(int32_t) + 255) / 256 * 256;
-        a.partial = (float *)((char *)workspace + off);
-        hipError_t e = hipMemsetAsync(a.chunk_row, 0xff, (size_t)n_chunks * 2 * sizeof(int32_t), stream);
-        if (e != hipSuccess) {
-            g_last_hip_error = (int)e;
-            return COGDL_HIP_ELAUNCH;
-        }
+        a.partial = (float *)((char *)workspace + chunk_row_bytes(n_chunks));
     }
-    dim3 grid(xcd_grid(a.n_rowblocks), (unsigned)tiles);
+    dim3 grid(xcd_grid(a.rowblocks), (unsigned)tiles);
     hipLaunchKernelGGL((csr_spmm_rowgroup_kernel<T, VEC, LPR, UNROLL, WMODE, EXACT>), grid, dim3(256), 0, stream, a);
     if (n_chunks > 0) {
-        const unsigned gx = (unsigned)std::min<int64_t>(n_chunks, 4096);
+        // <= 2048 workgroups, each owning a contiguous run of chunks (cheap to skip when no row is long)
+        const int cpb = (int)((n_chunks + 2047) / 2048);
+        const unsigned gx = (unsigned)((n_chunks + cpb - 1) / cpb);
         hipLaunchKernelGGL((csr_spmm_longrow_partial_kernel<T, VEC, LPR, UNROLL, WMODE>), dim3(gx, (unsigned)tiles),
-                           dim3(256), 0, stream, a, n_chunks);
-        hipLaunchKernelGGL((csr_spmm_longrow_combine_kernel<T>), dim3(gx), dim3(64), 0, stream, a, n_chunks);
+                           dim3(256), 0, stream, a, n_chunks, cpb);
+        hipLaunchKernelGGL((csr_spmm_longrow_combine_kernel<T>), dim3(gx), dim3(256), 0, stream, a, n_chunks, cpb);
     }
     return launch_status();
 }
@@ -285,9 +312,11 @@ static int dispatch_lpr(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t 
     return launch_rowgroup<T, VEC, 64, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
 }
 
-// Vector width: every lane's VEC columns must stay inside one row (k % VEC == 0), inside one head for
-// mhspmm (fdim % VEC == 0), and naturally aligned.  Among the legal widths take the SMALLEST that
-// still lets one group of <= 64 lanes cover the row (k / VEC <= 64), else the widest.
+// Vector width and lanes per row.  Every lane's VEC columns must stay inside one row (k % VEC == 0), inside
+// one head for mhspmm (fdim % VEC == 0), and be naturally aligned.  Measured on MI355X (arxiv-shaped graph):
+// narrow rows (k/4 <= 16 lanes) are fastest with 16-byte lanes and several rows per wave (less per-row
+// overhead); from 64 columns up a whole wave per row wins (scalar column broadcast, no intra-wave length
+// divergence), so the vector is narrowed until the row fills 64 lanes.
 template <typename T, int WMODE>
 static int spmm_auto(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) {
     constexpr int MAXV = 16 / sizeof(T);
@@ -296,11 +325,8 @@ static int spmm_auto(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) 
         return v <= MAXV && unit % v == 0 && aligned_to(a.x, v * sizeof(T)) && aligned_to(a.out, v * sizeof(T));
     };
     int vec = 1;
-    for (int v = 1; v <= MAXV; v <<= 1) {
-        if (!legal(v)) break;
-        vec = v;
-        if (v * sizeof(T) >= 4 && (int64_t)a.k <= (int64_t)v * kWave) break;  // at least 4 B per lane
-    }
+    while (vec * 2 <= MAXV && legal(vec * 2)) vec *= 2;                                   // widest legal
+    while (vec > 1 && (vec / 2) * sizeof(T) >= 4 && (int64_t)a.k / vec > 16 && (int64_t)a.k / (vec / 2) <= kWave) vec /= 2;
     switch (vec) {
         case 8:
             if constexpr (MAXV >= 8) return dispatch_lpr<T, 8, WMODE>(a, ws, wsb, s);
@@ -360,7 +386,7 @@ using namespace cogdl;
 extern "C" size_t cogdl_hip_csr_spmm_workspace_bytes(int64_t nnz, int64_t k) {
     if (nnz <= 0 || k <= 0) return 0;
     const int64_t n_chunks = n_chunks_for(nnz, pick_long_thresh(nnz));
-    return (size_t)n_chunks * 2 * sizeof(int32_t) + 256 + (size_t)n_chunks * 2 * (size_t)k * sizeof(float);
+    return chunk_row_bytes(n_chunks) + (size_t)n_chunks * 2 * (size_t)k * sizeof(float);
 }
 
 extern "C" int cogdl_hip_csr_spmm_long_row_threshold(int64_t nnz) { return pick_long_thresh(nnz); }

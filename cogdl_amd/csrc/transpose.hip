@@ -83,13 +83,16 @@ __global__ void csr_fingerprint_kernel(const int32_t *__restrict__ rowptr, const
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t i = tid; i <= m; i += stride) acc += mix64(((uint64_t)i << 32) ^ (uint32_t)rowptr[i] ^ 0xa5a5a5a500000000ull);
     for (int64_t i = tid; i < nnz; i += stride) acc += mix64(((uint64_t)i << 32) ^ (uint32_t)colind[i]);
-    // wave reduce then one atomic per wave (integer add: order independent)
+    // wave reduce, block reduce, then ONE atomic per workgroup (integer add: order independent)
 #pragma unroll
     for (int s = kWave / 2; s > 0; s >>= 1) {
         const uint32_t lo = __shfl_xor((uint32_t)acc, s, kWave), hi = __shfl_xor((uint32_t)(acc >> 32), s, kWave);
         acc += ((uint64_t)hi << 32) | lo;
     }
-    if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(out, (unsigned long long)acc);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
 }  // namespace cogdl
@@ -162,7 +165,7 @@ extern "C" int cogdl_hip_csr_fingerprint(const int32_t *rowptr, const int32_t *c
         g_last_hip_error = (int)e;
         return COGDL_HIP_ELAUNCH;
     }
-    const unsigned blocks = (unsigned)std::min<int64_t>((std::max(m + 1, nnz) + 255) / 256, 1024);
+    const unsigned blocks = (unsigned)std::min<int64_t>((std::max(m + 1, nnz) + 255) / 256, 512);
     hipLaunchKernelGGL(csr_fingerprint_kernel, dim3(blocks), dim3(256), 0, s, rowptr, colind, m, nnz,
                        (unsigned long long *)out_hash);
     return launch_status();

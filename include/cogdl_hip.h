@@ -58,6 +58,9 @@ COGDL_API int cogdl_hip_abi_version(void);
 COGDL_API const char *cogdl_hip_strerror(int status);
 /* hipError_t of the most recent COGDL_HIP_ELAUNCH on this thread (0 if none). */
 COGDL_API int cogdl_hip_last_hip_error(void);
+/* Run-time tuning knobs for experiments: key 0 = XCD stripe of the row-block -> workgroup map (0 = hardware
+ * round-robin, default 32), key 1 = long-row threshold override (0 = automatic). */
+COGDL_API int cogdl_hip_set_tuning(int key, int value);
 
 /* ---------------------------------------------------------------------------------------
  * csr_spmm:  out[i,:] = sum_{e in row i, CSR order} val[e] * x[colind[e],:]
@@ -158,6 +161,33 @@ COGDL_API int cogdl_hip_scatter_max_fwd(const int32_t *rowptr, const int32_t *co
                               float *out, int32_t *max_id, int64_t m, int64_t k, void *stream);
 COGDL_API int cogdl_hip_scatter_max_bwd(const float *grad, const int32_t *max_id, float *grad_src, int64_t m,
                               int64_t k, int64_t n_src, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused GAT attention + aggregation (no [E,H] tensor is materialised in forward):
+ *   s[e,h] = LeakyReLU(attn_row[row(e),h] + attn_col[colind[e],h]);  a = softmax_row(s)
+ *   out[v,h,:] = sum_e a[e,h] * feat[colind[e],h,:]
+ * Replaces fused_gatconv.gat_forward / gat_backward as bound by
+ * operators/fused_gat.py:14-41 (dgNN; source absent from the reference tree -- semantics
+ * are those of the unfused path, layers/gat_layer.py:73-77).
+ * Forward also emits edge_max/edge_sum [v,H] (row max of s and sum exp(s-max)), which the
+ * backward consumes like the reference's ctx.save_for_backward does (fused_gat.py:20).
+ * Backward (fp32) needs the CSC view (colptr,rowind from cogdl_hip_csr2csc), the forward
+ * output and a workspace of cogdl_hip_gat_bwd_workspace_bytes(v, h) bytes.  It returns
+ * COGDL_HIP_EINVAL for shapes it does not cover (H*F must fit 64 lanes x 4 columns and
+ * F/vec must be a power of two unless H == 1); callers then compose the unfused operators.
+ * ------------------------------------------------------------------------------------- */
+COGDL_API int cogdl_hip_gat_fwd(const int32_t *rowptr, const int32_t *colind, const float *attn_row,
+                      const float *attn_col, const void *feat, float negative_slope, void *out,
+                      float *edge_max, float *edge_sum, int64_t v, int64_t h, int64_t f,
+                      int dtype, void *stream);
+COGDL_API size_t cogdl_hip_gat_bwd_workspace_bytes(int64_t v, int64_t h);
+COGDL_API int cogdl_hip_gat_bwd(const int32_t *rowptr, const int32_t *colind, const int32_t *colptr,
+                      const int32_t *rowind, const float *attn_row, const float *attn_col,
+                      const float *feat, float negative_slope, const float *edge_max,
+                      const float *edge_sum, const float *out, const float *grad_out,
+                      float *grad_feat, float *grad_attn_row, float *grad_attn_col,
+                      void *workspace, size_t workspace_bytes, int64_t v, int64_t n_src, int64_t h,
+                      int64_t f, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Helpers used by the graph-plan cache and the vertex-sharded (multi-GPU) SpMM.

@@ -15,7 +15,7 @@ if has tests; then
   tail -15 gpurun_out/pytest_gpu.log
 fi
 if has variants; then
-  timeout 900 python tools/spmm_variants.py > gpurun_out/variants.txt 2>&1
+  timeout 900 python tools/spmm_variants.py > gpurun_out/variants.txt 2>&1; timeout 600 python tools/spmm_variants.py big >> gpurun_out/variants.txt 2>&1
   tail -5 gpurun_out/variants.txt
 fi
 if has bench; then

@@ -19,7 +19,7 @@ def family(name):
         return "csr_spmm_longrow_partial_kernel"
     if "longrow_combine" in name:
         return "csr_spmm_longrow_combine_kernel"
-    if "elementwise" in name and "copy" in name.lower():
+    if "copyBuffer" in name:
         return "torch_copy_1GiB"
     if "reduce_kernel" in name:
         return "torch_sum_1GiB"

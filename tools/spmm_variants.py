@@ -29,6 +29,12 @@ def timeit(fn, reps=30, warm=5):
     return ts[len(ts) // 2], ts[0]
 
 
+def tune(key, value):
+    from cogdl_amd import _lib
+
+    _lib.hip().cogdl_hip_set_tuning(key, value)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--feat", type=int, default=128)
@@ -54,6 +60,18 @@ def main():
                 v, med * 1e3, mn * 1e3, g.nnz / med / 1e6, balg / med / 1e6, balg / med / 1e6 / 80))
         med, _ = timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, None, x))
         print("unweighted auto: %.1f us" % (med * 1e3))
+        med, _ = timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x, split_long_rows=False))
+        print("auto, no long-row workspace (single launch): %.1f us" % (med * 1e3))
+        for stripe in (0, 1, 8, 32, 128, 100000):
+            tune(0, stripe)
+            r = [timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x, v), reps=15)[0] for v in (-1, 0)]
+            print("xcd stripe %6d: auto %.1f us, V4L32 %.1f us" % (stripe, r[0] * 1e3, r[1] * 1e3))
+        tune(0, 32)
+        for thr in (128, 256, 512, 1024, 4096):
+            tune(1, thr)
+            r = [timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x, v), reps=15)[0] for v in (-1, 0)]
+            print("long-row threshold %5d: auto %.1f us, V4L32 %.1f us" % (thr, r[0] * 1e3, r[1] * 1e3))
+        tune(1, 0)
         # roofs
         y = torch.empty_like(x)
         med, _ = timeit(lambda: y.copy_(x))
@@ -79,5 +97,20 @@ def main():
             print("auto F=%d: %.1f us -> %.2f GEdges/s, %.0f GB/s alg" % (ff, med * 1e3, g.nnz / med / 1e6, ba / med / 1e6))
 
 
+def big():
+    """Beyond the Infinity Cache: X = 2 GiB."""
+    dev = "cuda:0"
+    g = synth.scaled(4_000_000, 15, seed=1).to(dev)
+    for f in (128, 64):
+        x = torch.randn(g.num_nodes, f, device=dev)
+        med, _ = timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x), reps=8, warm=2)
+        balg = g.nnz * (8 + f * 4) + g.num_nodes * (4 + f * 4)
+        print("BIG N=%d nnz=%d F=%d: %.2f ms -> %.2f GEdges/s, %.0f GB/s alg" % (g.num_nodes, g.nnz, f, med, g.nnz / med / 1e6, balg / med / 1e6))
+        del x
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        big()
+        sys.exit(0)
     main()
