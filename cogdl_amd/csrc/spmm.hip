@@ -55,6 +55,7 @@ struct SpmmArgs {
     XcdMap rowblocks;
     int long_thresh;     // rows with more edges take the chunk-parallel path (INT_MAX: disabled)
     int acc_mode;        // != 0: out += A x
+    int rows_seq;        // consecutive rows walked one after the other by each lane group
     int32_t *chunk_row;  // [n_chunks]: the LONG row that contains edge c*ch (the chunk's first edge), else -1.
                          //   Every entry is (re)written by the main kernel on every launch: no memset needed.
     float *partial;      // [n_chunks][2][k] fp32 partial sums (slot 0: the row owning the chunk's first edge,
@@ -114,43 +115,46 @@ __device__ __forceinline__ void accumulate_edges(const SpmmArgs<T> &a, int start
 
 template <typename T, int VEC, int LPR, int UNROLL, int WMODE, bool EXACT>
 __global__ __launch_bounds__(256) void csr_spmm_rowgroup_kernel(const SpmmArgs<T> a) {
-    constexpr int RPW = kWave / LPR;  // rows per wave
-    constexpr int RPB = RPW * 4;      // rows per 256-thread workgroup
+    constexpr int RPW = kWave / LPR;  // row groups per wave
+    constexpr int GPB = RPW * 4;      // row groups per 256-thread workgroup
     const int64_t rb = xcd_remap(blockIdx.x, a.rowblocks);
     if (rb < 0) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int sub = lane / LPR;
     const int l = lane % LPR;
-    const int64_t row = rb * RPB + wave * RPW + sub;
     const int col0 = ((int)blockIdx.y * LPR + l) * VEC;
     const bool col_ok = col0 < a.k;
-
-    int start = 0, end = 0;
-    if (row < a.m) {
-        start = a.rowptr[row];
-        end = a.rowptr[row + 1];
-    }
-    if constexpr (LPR == kWave) {  // whole wave on one row: make the loop bounds scalar
-        start = __builtin_amdgcn_readfirstlane(start);
-        end = __builtin_amdgcn_readfirstlane(end);
-    }
-    if (a.chunk_row && blockIdx.y == 0 && end > start) {
-        // Own the chunk_row entries of the chunks whose first edge lies in this row: c*ch in [start, end).
-        const int ch = a.long_thresh;
-        const int32_t mark = (end - start > ch) ? (int32_t)row : -1;
-        for (int c = (start + ch - 1) / ch + l; (int64_t)c * ch < end; c += LPR) a.chunk_row[c] = mark;
-    }
-    if (end - start > a.long_thresh) return;  // long row: the chunk-parallel kernels compute it
-    float acc[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-    if (a.acc_mode && row < a.m && col_ok) load_vec<T, VEC>(a.out + row * (int64_t)a.k + col0, acc);
     const int cc = col_ok ? col0 : 0;  // lanes past the last column read column 0 and never store
     const int heads = (WMODE == 2) ? a.k / a.fdim : 1;
-    accumulate_edges<T, VEC, LPR, UNROLL, WMODE, EXACT>(a, start, end, sub, l, a.x + cc, heads,
-                                                        (WMODE == 2) ? cc / a.fdim : 0, acc);
-    if (row < a.m && col_ok) store_vec<T, VEC>(a.out + row * (int64_t)a.k + col0, acc);
+    const int hd = (WMODE == 2) ? cc / a.fdim : 0;
+    const int64_t row0 = (rb * GPB + wave * RPW + sub) * a.rows_seq;
+
+    for (int rs = 0; rs < a.rows_seq; ++rs) {
+        const int64_t row = row0 + rs;
+        int start = 0, end = 0;
+        if (row < a.m) {
+            start = a.rowptr[row];
+            end = a.rowptr[row + 1];
+        }
+        if constexpr (LPR == kWave) {  // whole wave on one row: make the loop bounds scalar
+            start = __builtin_amdgcn_readfirstlane(start);
+            end = __builtin_amdgcn_readfirstlane(end);
+        }
+        if (a.chunk_row && blockIdx.y == 0 && end > start) {
+            // Own the chunk_row entries of the chunks whose first edge lies in this row: c*ch in [start, end).
+            const int ch = a.long_thresh;
+            const int32_t mark = (end - start > ch) ? (int32_t)row : -1;
+            for (int c = (start + ch - 1) / ch + l; (int64_t)c * ch < end; c += LPR) a.chunk_row[c] = mark;
+        }
+        if (end - start > a.long_thresh) continue;  // long row: the chunk-parallel kernels compute it
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        if (a.acc_mode && row < a.m && col_ok) load_vec<T, VEC>(a.out + row * (int64_t)a.k + col0, acc);
+        accumulate_edges<T, VEC, LPR, UNROLL, WMODE, EXACT>(a, start, end, sub, l, a.x + cc, heads, hd, acc);
+        if (row < a.m && col_ok) store_vec<T, VEC>(a.out + row * (int64_t)a.k + col0, acc);
+    }
 }
 
 // Chunk c = edges [c*ch, (c+1)*ch).  A long row (> ch edges) intersecting it is either the row owning the
@@ -268,7 +272,8 @@ static inline size_t chunk_row_bytes(int64_t n_chunks) { return ((size_t)(n_chun
 
 template <typename T, int VEC, int LPR, int UNROLL, int WMODE, bool EXACT>
 static int launch_rowgroup(SpmmArgs<T> a, void *workspace, size_t workspace_bytes, hipStream_t stream) {
-    constexpr int RPB = (kWave / LPR) * 4;
+    a.rows_seq = std::max(1, std::min(64, g_tuning[kTuneRowsSeq]));
+    const int64_t RPB = (kWave / LPR) * 4 * a.rows_seq;
     const int64_t n_rowblocks = (a.m + RPB - 1) / RPB;
     const int64_t tiles = ((int64_t)a.k + (int64_t)LPR * VEC - 1) / ((int64_t)LPR * VEC);
     if (n_rowblocks == 0) return COGDL_HIP_OK;
@@ -290,8 +295,9 @@ static int launch_rowgroup(SpmmArgs<T> a, void *workspace, size_t workspace_byte
     dim3 grid(xcd_grid(a.rowblocks), (unsigned)tiles);
     hipLaunchKernelGGL((csr_spmm_rowgroup_kernel<T, VEC, LPR, UNROLL, WMODE, EXACT>), grid, dim3(256), 0, stream, a);
     if (n_chunks > 0) {
-        // <= 2048 workgroups, each owning a contiguous run of chunks (cheap to skip when no row is long)
-        const int cpb = (int)((n_chunks + 2047) / 2048);
+        // a bounded number of workgroups, each owning a contiguous run of chunks (cheap to skip when no row is long)
+        const int64_t max_wg = std::max(64, g_tuning[kTuneLongGrid]);
+        const int cpb = (int)((n_chunks + max_wg - 1) / max_wg);
         const unsigned gx = (unsigned)((n_chunks + cpb - 1) / cpb);
         hipLaunchKernelGGL((csr_spmm_longrow_partial_kernel<T, VEC, LPR, UNROLL, WMODE>), dim3(gx, (unsigned)tiles),
                            dim3(256), 0, stream, a, n_chunks, cpb);

@@ -76,13 +76,22 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
+// One strong mix per 4 consecutive int32 values (position-keyed): ~1/4 of the 64-bit multiplies.
+__device__ __forceinline__ uint64_t hash4(const int32_t *p, int64_t i, int64_t n, uint64_t salt) {
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (i + j < n) ? (uint32_t)p[i + j] : 0x5bd1e995u;
+    const uint64_t a = ((uint64_t)v[1] << 32) | v[0], b = ((uint64_t)v[3] << 32) | v[2];
+    return mix64(a * 0x9e3779b97f4a7c15ull + (b ^ salt) * 0xc2b2ae3d27d4eb4full + (uint64_t)i);
+}
+
 __global__ void csr_fingerprint_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
                                        int64_t m, int64_t nnz, unsigned long long *out) {
     uint64_t acc = 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (int64_t i = tid; i <= m; i += stride) acc += mix64(((uint64_t)i << 32) ^ (uint32_t)rowptr[i] ^ 0xa5a5a5a500000000ull);
-    for (int64_t i = tid; i < nnz; i += stride) acc += mix64(((uint64_t)i << 32) ^ (uint32_t)colind[i]);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    const int64_t tid4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    for (int64_t i = tid4; i <= m; i += stride) acc += hash4(rowptr, i, m + 1, 0xa5a5a5a5a5a5a5a5ull);
+    for (int64_t i = tid4; i < nnz; i += stride) acc += hash4(colind, i, nnz, 0);
     // wave reduce, block reduce, then ONE atomic per workgroup (integer add: order independent)
 #pragma unroll
     for (int s = kWave / 2; s > 0; s >>= 1) {

@@ -62,16 +62,19 @@ def main():
         print("unweighted auto: %.1f us" % (med * 1e3))
         med, _ = timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x, split_long_rows=False))
         print("auto, no long-row workspace (single launch): %.1f us" % (med * 1e3))
-        for stripe in (0, 1, 8, 32, 128, 100000):
-            tune(0, stripe)
-            r = [timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x, v), reps=15)[0] for v in (-1, 0)]
-            print("xcd stripe %6d: auto %.1f us, V4L32 %.1f us" % (stripe, r[0] * 1e3, r[1] * 1e3))
-        tune(0, 32)
-        for thr in (128, 256, 512, 1024, 4096):
-            tune(1, thr)
-            r = [timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x, v), reps=15)[0] for v in (-1, 0)]
-            print("long-row threshold %5d: auto %.1f us, V4L32 %.1f us" % (thr, r[0] * 1e3, r[1] * 1e3))
+        for rs in (1, 2, 4):
+            tune(2, rs)
+            for thr in (32, 64, 128, 256):
+                tune(1, thr)
+                r = [timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x, v), reps=15)[0] for v in (-1, 0)]
+                print("rows_seq %d long-thresh %4d: auto(V2L64) %.1f us, V4L32 %.1f us" % (rs, thr, r[0] * 1e3, r[1] * 1e3))
+        tune(2, 1)
         tune(1, 0)
+        for lg in (128, 512, 1024, 2048):
+            tune(3, lg)
+            r = timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x), reps=15)[0]
+            print("long-row grid cap %5d: auto %.1f us" % (lg, r * 1e3))
+        tune(3, 1024)
         # roofs
         y = torch.empty_like(x)
         med, _ = timeit(lambda: y.copy_(x))
