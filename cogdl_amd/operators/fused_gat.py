@@ -55,8 +55,8 @@ def _unfused_backward(negative_slope, row_ptr, col_ind, in_feat, attn_row, attn_
 class FusedGATFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, negative_slope, in_feat):
+        ctx.fp = Fingerprint(row_ptr, col_ind, in_feat.shape[0])  # before the kernel: lands early for backward
         out, edge_max, edge_sum = gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat)
-        ctx.fp = Fingerprint(row_ptr, col_ind, in_feat.shape[0])
         ctx.save_for_backward(row_ptr, col_ind, edge_max, edge_sum, in_feat, attn_row, attn_col, out)
         ctx.negative_slope = float(negative_slope)
         return out

@@ -51,8 +51,8 @@ def mhsddmm_raw(rowptr, colind, grad, feat):
 class MHSPMMFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rowptr, colind, feat, attention):
+        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None  # before the kernel
         out = mhspmm_raw(rowptr, colind, attention, feat)
-        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None
         ctx.save_for_backward(rowptr, colind, feat, attention)
         return out
 

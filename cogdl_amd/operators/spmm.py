@@ -95,11 +95,14 @@ class SPMMFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rowptr, colind, feat, edge_weight_csr=None, sym=False):
+        # The structure hash is enqueued BEFORE the SpMM so that it has landed in pinned host memory long
+        # before backward asks for it (Fingerprint.key() waits on an event recorded right behind the hash
+        # kernel, not behind the SpMM).
+        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None
         out = csr_spmm_raw(rowptr, colind, edge_weight_csr, feat)
         need_w = edge_weight_csr is not None and ctx.needs_input_grad[3]
         ctx.n_src = feat.shape[0]
         ctx.sym = sym
-        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None
         ctx.save_for_backward(rowptr, colind, edge_weight_csr, feat if need_w else None)
         return out
 

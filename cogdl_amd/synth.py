@@ -71,21 +71,22 @@ def finalize(src, dst, num_nodes, symmetrise=True, self_loops=True, norm="sym"):
     return CSRGraph(rowptr.int(), col.int(), w, num_nodes)
 
 
-def uniform_pairs(num_nodes, num_pairs, seed):
-    g = torch.Generator().manual_seed(seed)
-    src = torch.randint(0, num_nodes, (num_pairs,), generator=g)
-    dst = torch.randint(0, num_nodes, (num_pairs,), generator=g)
+def uniform_pairs(num_nodes, num_pairs, seed, device="cpu"):
+    """device='cpu' (default) gives the same pairs on every machine; a GPU device is only for large benches."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    src = torch.randint(0, num_nodes, (num_pairs,), generator=g, device=device)
+    dst = torch.randint(0, num_nodes, (num_pairs,), generator=g, device=device)
     return src, dst
 
 
-def rmat_pairs(num_nodes, num_pairs, seed, a=0.57, b=0.19, c=0.19):
+def rmat_pairs(num_nodes, num_pairs, seed, a=0.57, b=0.19, c=0.19, device="cpu"):
     """R-MAT (Chakrabarti et al.) edge list; ids outside [0, num_nodes) are folded back by modulo."""
-    g = torch.Generator().manual_seed(seed)
+    g = torch.Generator(device=device).manual_seed(seed)
     scale = max(1, math.ceil(math.log2(num_nodes)))
-    src = torch.zeros(num_pairs, dtype=torch.long)
-    dst = torch.zeros(num_pairs, dtype=torch.long)
+    src = torch.zeros(num_pairs, dtype=torch.long, device=device)
+    dst = torch.zeros(num_pairs, dtype=torch.long, device=device)
     for _ in range(scale):
-        r = torch.rand(num_pairs, generator=g)
+        r = torch.rand(num_pairs, generator=g, device=device)
         src_bit = (r >= a + b).long()
         dst_bit = ((r >= a) & (r < a + b) | (r >= a + b + c)).long()
         src = src * 2 + src_bit

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc
+# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc ops
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -24,8 +24,12 @@ if has bench; then
 fi
 if has prof; then
   rm -rf gpurun_out/prof_kt
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_kt" -o kt -- python "$GRAFT_REPO_ROOT/bench.py" --steps 50 --no-cpu) > gpurun_out/bench_prof.log 2>&1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_kt" -o kt -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu) > gpurun_out/bench_prof.log 2>&1
   find gpurun_out/prof_kt -name "*stats*" | head; 
+fi
+if has ops; then
+  timeout 1500 python tools/ops_bench.py --json gpurun_out/ops_bench.json > gpurun_out/ops_bench.txt 2>&1; echo "ops rc=$?" >> gpurun_out/ops_bench.txt
+  tail -60 gpurun_out/ops_bench.txt
 fi
 if has pmc; then
   for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do

@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Per-operator roofline table on the GPU box (not part of the product): every entry point of
+include/cogdl_hip.h timed with HIP events on the workloads of SURVEY.md section 8 and priced with that
+section's ALGORITHMIC bytes.  Usage:  python tools/ops_bench.py [arxiv] [reddit] [--json out.json]"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cogdl_amd import synth  # noqa: E402
+from cogdl_amd.operators.edge_softmax import _launch as es_launch  # noqa: E402
+from cogdl_amd.operators.fused_gat import FusedGATFunction, gat_forward  # noqa: E402
+from cogdl_amd.operators.mhspmm import mhsddmm_raw, mhspmm_raw  # noqa: E402
+from cogdl_amd.operators.scatter_max import scatter_max_bp, scatter_max_fp  # noqa: E402
+from cogdl_amd.operators.spmm import csr_sddmm_raw, csr_spmm_raw  # noqa: E402
+from cogdl_amd.plan import csr2csc, gather_rows  # noqa: E402
+
+DEV = "cuda:0"
+PEAK = 8000.0
+ROWS = []
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def report(op, cfg, ms, nbytes, nnz):
+    gbs = nbytes / ms / 1e6
+    row = {"op": op, "config": cfg, "us": ms * 1e3, "alg_GB": nbytes / 1e9, "GBs": gbs, "frac": gbs / PEAK,
+           "GEdges_s": nnz / ms / 1e6}
+    ROWS.append(row)
+    print("%-28s %-34s %10.1f us  %8.3f GB  %7.0f GB/s  %5.1f%%  %7.2f GEdges/s" % (
+        op, cfg, row["us"], row["alg_GB"], gbs, 100 * row["frac"], row["GEdges_s"]), flush=True)
+
+
+def arxiv():
+    for topo in ("uniform", "rmat"):
+        g = synth.arxiv_like(seed=0, topology=topo).to(DEV)
+        n, nnz = g.num_nodes, g.nnz
+        for f in (40, 64, 128, 256):
+            x = torch.randn(n, f, device=DEV)
+            cfg = "arxiv-%s F=%d f32" % (topo, f)
+            report("csr_spmm", cfg, timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x)),
+                   nnz * (8 + f * 4) + n * (4 + f * 4), nnz)
+            if f in (64, 128):
+                report("csr_spmm(unweighted)", cfg, timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, None, x)),
+                       nnz * (4 + f * 4) + n * (4 + f * 4), nnz)
+                xb = x.bfloat16()
+                wb = g.weight.bfloat16()
+                report("csr_spmm", "arxiv-%s F=%d bf16" % (topo, f),
+                       timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, wb, xb)),
+                       nnz * (6 + f * 2) + n * (4 + f * 2), nnz)
+                y = torch.randn(n, f, device=DEV)
+                report("csr_sddmm", cfg, timeit(lambda: csr_sddmm_raw(g.rowptr, g.colind, y, x)),
+                       nnz * (4 + 4 + 2 * f * 4 + 4), nnz)
+                report("scatter_max_fwd", cfg, timeit(lambda: scatter_max_fp(g.rowptr, g.colind, x)),
+                       nnz * (4 + f * 4) + n * (4 + f * 4 + f * 4), nnz)
+                _, mid = scatter_max_fp(g.rowptr, g.colind, x)
+                report("scatter_max_bwd", cfg, timeit(lambda: scatter_max_bp(y, mid, n)), n * f * (4 + 4 + 4 + 4), nnz)
+        report("csr2csc", "arxiv-%s" % topo, timeit(lambda: csr2csc(g.rowptr, g.colind, n), reps=10),
+               nnz * (4 + 4) * 2 + 8 * (n + 1), nnz)
+        plan = csr2csc(g.rowptr, g.colind, n)
+        report("gather_rows(weights)", "arxiv-%s" % topo, timeit(lambda: gather_rows(plan.perm, g.weight)),
+               nnz * 12, nnz)
+        for h in (1, 8):
+            a = torch.randn(nnz, h, device=DEV)
+            cfg = "arxiv-%s H=%d" % (topo, h)
+            report("edge_softmax_fwd", cfg, timeit(lambda: es_launch("cogdl_hip_edge_softmax_fwd", g.rowptr, a)),
+                   nnz * h * 8 + 4 * (n + 1), nnz)
+            s = es_launch("cogdl_hip_edge_softmax_fwd", g.rowptr, a)
+            report("edge_softmax_bwd", cfg, timeit(lambda: es_launch("cogdl_hip_edge_softmax_bwd", g.rowptr, s, a)),
+                   nnz * h * 12, nnz)
+
+
+def gat_suite(g, tag, h, f, dtypes=(torch.float32, torch.bfloat16), reps=10):
+    n, nnz = g.num_nodes, g.nnz
+    att = torch.randn(nnz, h, device=DEV)
+    ar, ac = torch.randn(n, h, device=DEV), torch.randn(n, h, device=DEV)
+    cfg0 = "%s H=%d F=%d" % (tag, h, f)
+    report("edge_softmax_fwd", cfg0, timeit(lambda: es_launch("cogdl_hip_edge_softmax_fwd", g.rowptr, att), reps),
+           nnz * h * 8 + 4 * (n + 1), nnz)
+    sm = es_launch("cogdl_hip_edge_softmax_fwd", g.rowptr, att)
+    report("edge_softmax_bwd", cfg0, timeit(lambda: es_launch("cogdl_hip_edge_softmax_bwd", g.rowptr, sm, att), reps),
+           nnz * h * 12, nnz)
+    for dt in dtypes:
+        s = 4 if dt == torch.float32 else 2
+        name = "f32" if dt == torch.float32 else "bf16"
+        feat = torch.randn(n, h, f, device=DEV).to(dt)
+        cfg = "%s %s" % (cfg0, name)
+        report("mhspmm", cfg, timeit(lambda: mhspmm_raw(g.rowptr, g.colind, sm, feat), reps),
+               nnz * (4 + h * 4 + h * f * s) + n * (4 + h * f * s), nnz)
+        report("gat_fwd(fused)", cfg, timeit(lambda: gat_forward(ar, ac, g.rowptr, g.colind, 0.2, feat), reps),
+               nnz * (4 + h * 4 + h * f * s) + n * (4 + 2 * h * 4 + h * f * s), nnz)
+    feat = torch.randn(n, h, f, device=DEV)
+    grad = torch.randn(n, h, f, device=DEV)
+    report("mhsddmm", cfg0 + " f32", timeit(lambda: mhsddmm_raw(g.rowptr, g.colind, grad, feat), reps),
+           nnz * (4 + h * 4 + 2 * h * f * 4), nnz)
+    report("csr2csc", tag, timeit(lambda: csr2csc(g.rowptr, g.colind, n), reps=3, warm=1), nnz * 16 + 8 * (n + 1), nnz)
+    plan = csr2csc(g.rowptr, g.colind, n)
+    report("gather_rows(att[E,H])", cfg0, timeit(lambda: gather_rows(plan.perm, sm), reps), nnz * (4 + 8 * h), nnz)
+    # fused backward through the autograd function (plan cached after the first call)
+    ar_g, ac_g, ft_g = ar.clone().requires_grad_(), ac.clone().requires_grad_(), feat.clone().requires_grad_()
+
+    def fwd_bwd():
+        out = FusedGATFunction.apply(ar_g, ac_g, g.rowptr, g.colind, g.rowptr, g.colind, 0.2, ft_g)
+        torch.autograd.grad(out, (ar_g, ac_g, ft_g), grad)
+
+    t_fb = timeit(fwd_bwd, reps)
+    t_f = timeit(lambda: gat_forward(ar, ac, g.rowptr, g.colind, 0.2, feat), reps)
+    # backward: two passes over the edges (CSR pass for grad_attn_row, CSC pass for grad_feat/grad_attn_col)
+    report("gat_bwd(fused, fwd+bwd - fwd)", cfg0 + " f32", t_fb - t_f,
+           2 * nnz * (4 + 2 * h * f * 4 + h * 4) + 4 * n * h * f * 4, nnz)
+
+
+def reddit():
+    """Reddit-shaped GAT workload (config 3): N=232,965, ~114.6 M edges (RMAT), H=8 x F=8; generated on the GPU."""
+    n = 232_965
+    src, dst = synth.rmat_pairs(n, 57_300_000, seed=0, device=DEV)
+    g = synth.finalize(src, dst, n, norm=None)
+    del src, dst
+    print("reddit-like: N=%d nnz=%d max_deg=%d" % (n, g.nnz, int(g.degrees().max())), flush=True)
+    gat_suite(g, "reddit-rmat", 8, 8)
+    gat_suite(g, "reddit-rmat", 1, 41, dtypes=(torch.float32,))
+    x = torch.randn(n, 128, device=DEV)
+    w = torch.rand(g.nnz, device=DEV)
+    report("csr_spmm", "reddit-rmat F=128 f32", timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, w, x), 10),
+           g.nnz * (8 + 512) + n * 516, g.nnz)
+    xb, wb = x.bfloat16(), w.bfloat16()
+    report("csr_spmm", "reddit-rmat F=128 bf16", timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, wb, xb), 10),
+           g.nnz * (6 + 256) + n * 260, g.nnz)
+
+
+def main():
+    argv = sys.argv[1:]
+    json_path = None
+    if "--json" in argv:
+        i = argv.index("--json")
+        json_path = argv[i + 1]
+        del argv[i:i + 2]
+    args = argv
+    print(torch.cuda.get_device_name(0))
+    if not args or "arxiv" in args:
+        arxiv()
+        g = synth.arxiv_like(seed=0, topology="rmat").to(DEV)
+        gat_suite(g, "arxiv-rmat", 8, 8)
+        gat_suite(g, "arxiv-rmat", 4, 32, dtypes=(torch.float32,))
+    if not args or "reddit" in args:
+        reddit()
+    if json_path:
+        json.dump(ROWS, open(json_path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
