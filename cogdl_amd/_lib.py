@@ -23,24 +23,29 @@ HIP_SIGNATURES = {
     "cogdl_hip_strerror": ([_i32], ctypes.c_char_p),
     "cogdl_hip_last_hip_error": ([], _i32),
     "cogdl_hip_set_tuning": ([_i32, _i32], _i32),
-    "cogdl_hip_csr_spmm_workspace_bytes": ([_i64, _i64], _sz),
-    "cogdl_hip_csr_spmm_long_row_threshold": ([_i64], _i32),
+    "cogdl_hip_csr_spmm_workspace_bytes": ([_i64, _i64, _i32], _sz),
+    "cogdl_hip_long_row_threshold": ([_i64], _i32),
     "cogdl_hip_csr_spmm": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_csr_spmm_acc": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_csr_spmm_variant": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_csr2csc_workspace_bytes": ([_i64, _i64, _i64], _sz),
     "cogdl_hip_csr2csc": ([_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp], _i32),
     "cogdl_hip_gather_rows": ([_vp, _vp, _vp, _i64, _i64, _i32, _vp], _i32),
-    "cogdl_hip_csr_sddmm": ([_vp] * 5 + [_i64, _i64, _vp], _i32),
-    "cogdl_hip_edge_softmax_fwd": ([_vp] * 3 + [_i64, _i64, _i64, _vp], _i32),
-    "cogdl_hip_edge_softmax_bwd": ([_vp] * 4 + [_i64, _i64, _i64, _vp], _i32),
+    "cogdl_hip_edge_op_workspace_bytes": ([_i64], _sz),
+    "cogdl_hip_csr_sddmm": ([_vp] * 5 + [_i64, _i64, _i64, _vp, _sz, _vp], _i32),
+    "cogdl_hip_edge_softmax_workspace_bytes": ([_i64, _i64], _sz),
+    "cogdl_hip_edge_softmax_fwd": ([_vp] * 3 + [_i64, _i64, _i64, _vp, _sz, _vp], _i32),
+    "cogdl_hip_edge_softmax_bwd": ([_vp] * 4 + [_i64, _i64, _i64, _vp, _sz, _vp], _i32),
+    "cogdl_hip_mhspmm_workspace_bytes": ([_i64, _i64, _i64, _i32], _sz),
     "cogdl_hip_mhspmm": ([_vp] * 5 + [_i64, _i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
-    "cogdl_hip_mhsddmm": ([_vp] * 5 + [_i64, _i64, _i64, _vp], _i32),
-    "cogdl_hip_scatter_max_fwd": ([_vp] * 5 + [_i64, _i64, _vp], _i32),
+    "cogdl_hip_mhsddmm": ([_vp] * 5 + [_i64, _i64, _i64, _i64, _vp, _sz, _vp], _i32),
+    "cogdl_hip_scatter_max_workspace_bytes": ([_i64, _i64], _sz),
+    "cogdl_hip_scatter_max_fwd": ([_vp] * 5 + [_i64, _i64, _i64, _vp, _sz, _vp], _i32),
     "cogdl_hip_scatter_max_bwd": ([_vp] * 3 + [_i64, _i64, _i64, _vp], _i32),
-    "cogdl_hip_gat_fwd": ([_vp] * 5 + [_f32] + [_vp] * 3 + [_i64, _i64, _i64, _i32, _vp], _i32),
-    "cogdl_hip_gat_bwd_workspace_bytes": ([_i64, _i64], _sz),
-    "cogdl_hip_gat_bwd": ([_vp] * 7 + [_f32] + [_vp] * 8 + [_sz, _i64, _i64, _i64, _i64, _vp], _i32),
+    "cogdl_hip_gat_fwd_workspace_bytes": ([_i64, _i64, _i64, _i32], _sz),
+    "cogdl_hip_gat_fwd": ([_vp] * 5 + [_f32] + [_vp] * 3 + [_i64, _i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
+    "cogdl_hip_gat_bwd_workspace_bytes": ([_i64, _i64, _i64, _i64], _sz),
+    "cogdl_hip_gat_bwd": ([_vp] * 7 + [_f32] + [_vp] * 8 + [_sz, _i64, _i64, _i64, _i64, _i64, _vp], _i32),
     "cogdl_hip_csr_fingerprint": ([_vp, _vp, _i64, _i64, _vp, _vp], _i32),
 }
 
@@ -95,9 +100,10 @@ def host():
     return _host
 
 
-def spmm_workspace(nnz, k, device):
-    """Scratch for the long-row path of csr_spmm / mhspmm (torch caching allocator: no hipMalloc per call)."""
-    nbytes = hip().cogdl_hip_csr_spmm_workspace_bytes(int(nnz), int(k))
+def workspace(query, device, *args):
+    """Long-row scratch of a row-wise operator: `query` names its *_workspace_bytes function (torch caching
+    allocator: no hipMalloc per call).  Returns (tensor | None, nbytes)."""
+    nbytes = getattr(hip(), query)(*[int(a) for a in args])
     if nbytes == 0:
         return None, 0
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes

@@ -6,8 +6,10 @@
 //     out[v,h,:] = sum_e a[e,h] * feat[col[e],h,:]
 // Forward: ONE pass over the edges with an online softmax (running max / rescaled sum, flash-attention style),
 // so the [E,H] score/attention tensors are never materialised: algorithmic bytes per edge =
-// 4 (colind) + 4H (attn_col row) + H*F*s (feature row); per node 2*4H + H*F*s.  Row-group decomposition of
-// spmm.hip: a group of LPR lanes owns one destination row, each lane VEC columns inside one head.
+// 4 (colind) + 4H (attn_col row) + H*F*s (feature row); per node 2*4H + H*F*s.  Row-group decomposition and
+// long-row (chunk-parallel) path of rowreduce.h: a group of LPR lanes owns one destination row, each lane VEC
+// columns inside one head; the state (max, sum, acc[VEC]) of two edge ranges merges like two flash-attention
+// blocks, so hub rows are split over whole workgroups.
 // Backward (fp32): with D[v,h] = <g[v,h,:], out[v,h,:]>,
 //     dL/ds[e,h]      = a[e,h] * (<g[row,h,:], feat[col,h,:]> - D[row,h]) * LeakyReLU'(.)
 //     grad_attn_row[v,h] = sum over the row's edges            (row pass over the CSR, gathers feat)
@@ -15,7 +17,7 @@
 //     grad_feat[u,h,:]   = sum over the column's edges a * g[row,h,:]        (same column pass)
 // a[e,h] is recomputed from the saved row max / row sum (edge_max, edge_sum), exactly what the reference's
 // FusedGATFunction keeps in ctx (operators/fused_gat.py:20).  No atomics anywhere: deterministic.
-#include "common.h"
+#include "rowreduce.h"
 
 namespace cogdl {
 
@@ -30,267 +32,350 @@ __device__ __forceinline__ float head_sum(float v, int lph) {
     return v;
 }
 
-template <typename T, int VEC, int LPR, int UNROLL>
-__global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t *__restrict__ rowptr,
-                                                      const int32_t *__restrict__ colind,
-                                                      const float *__restrict__ attn_row,
-                                                      const float *__restrict__ attn_col, const T *__restrict__ feat,
-                                                      float slope, T *__restrict__ out, float *__restrict__ edge_max,
-                                                      float *__restrict__ edge_sum, int64_t m, int heads, int fdim,
-                                                      XcdMap n_rowblocks) {
-    constexpr int RPW = kWave / LPR;
-    constexpr int RPB = RPW * 4;
-    const int64_t rb = xcd_remap(blockIdx.x, n_rowblocks);
-    if (rb < 0) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int sub = lane / LPR;
-    const int l = lane % LPR;
-    const int64_t row = rb * RPB + (threadIdx.x >> 6) * RPW + sub;
-    const int k = heads * fdim;
-    const int col0 = ((int)blockIdx.y * LPR + l) * VEC;
-    const bool col_ok = col0 < k;
-    const int cc = col_ok ? col0 : 0;
-    const int hd = cc / fdim;
-    int start = 0, end = 0;
-    if (row < m) {
-        start = rowptr[row];
-        end = rowptr[row + 1];
-    }
-    const float ar = (row < m) ? attn_row[row * heads + hd] : 0.f;
-    float mx = -INFINITY, lsum = 0.f;
-    float acc[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+// ------------------------------------------------------------------------------------------ forward
+template <typename T, int VEC_, int LPR_, int UNROLL_>
+struct GatFwdOp {
+    static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_ + 2;
+    static constexpr bool kReduce = true;
+    const float *attn_row, *attn_col;
+    const T *feat;
+    T *out;
+    float *edge_max, *edge_sum;
+    float slope;
+    int heads, fdim;
 
-    for (int base = start; base < end; base += LPR) {
-        const int cnt = min(LPR, end - base);
-        const int my_c = (l < cnt) ? colind[base + l] : 0;
-        for (int j = 0; j < cnt; j += UNROLL) {
-            float v[UNROLL][VEC];
-            float ac[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int c = __shfl(my_c, sub * LPR + min(j + u, cnt - 1), kWave);
-                ac[u] = attn_col[(int64_t)c * heads + hd];
-                load_vec<T, VEC>(feat + (int64_t)c * k + cc, v[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                if (j + u < cnt) {
-                    const float s = leaky(ar + ac[u], slope);
-                    const float mn = fmaxf(mx, s);
-                    const float scale = (lsum == 0.f) ? 0.f : expf(mx - mn);
-                    const float p = expf(s - mn);
-                    lsum = lsum * scale + p;
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[i] = fmaf(p, v[u][i], acc[i] * scale);
-                    mx = mn;
-                }
-            }
-        }
-    }
-    if (row < m && col_ok) {
-        const float inv = (lsum > 0.f) ? 1.f / lsum : 0.f;  // empty row -> zeros
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] *= inv;
-        store_vec<T, VEC>(out + row * (int64_t)k + col0, acc);
-        if (col0 % fdim == 0) {
-            edge_max[row * heads + hd] = mx;
-            edge_sum[row * heads + hd] = lsum;
-        }
-    }
-}
+    struct Ctx {
+        int col0, cc, hd;
+        bool col_ok;
+        float ar;
+    };
+    struct State {
+        float acc[VEC];
+        float mx, lsum;
+    };
+    struct LaneVals {};
+    struct Batch {
+        float v[UNROLL][VEC];
+        float ac[UNROLL];
+    };
 
-// Row pass of the backward: D[v,h] and grad_attn_row[v,h].  The whole [H*F] row must fit one group.
-template <int VEC, int LPR, int UNROLL>
-__global__ __launch_bounds__(256) void gat_bwd_row_kernel(
-    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind, const float *__restrict__ attn_row,
-    const float *__restrict__ attn_col, const float *__restrict__ feat, float slope,
-    const float *__restrict__ edge_max, const float *__restrict__ edge_sum, const float *__restrict__ out,
-    const float *__restrict__ grad_out, float *__restrict__ dvec, float *__restrict__ grad_attn_row, int64_t m,
-    int heads, int fdim, int lph, XcdMap n_rowblocks) {
-    constexpr int RPW = kWave / LPR;
-    constexpr int RPB = RPW * 4;
-    const int64_t rb = xcd_remap(blockIdx.x, n_rowblocks);
-    if (rb < 0) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int sub = lane / LPR;
-    const int l = lane % LPR;
-    const int64_t row = rb * RPB + (threadIdx.x >> 6) * RPW + sub;
-    const int k = heads * fdim;
-    const bool col_ok = l * VEC < k;
-    const int cc = col_ok ? l * VEC : 0;
-    const int hd = cc / fdim;
-    int start = 0, end = 0;
-    if (row < m) {
-        start = rowptr[row];
-        end = rowptr[row + 1];
+    __device__ __forceinline__ Ctx make_ctx(int l, int tile) const {
+        Ctx c;
+        c.col0 = (tile * LPR + l) * VEC;
+        c.col_ok = c.col0 < heads * fdim;
+        c.cc = c.col_ok ? c.col0 : 0;
+        c.hd = c.cc / fdim;
+        c.ar = 0.f;
+        return c;
     }
-    float g[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) g[i] = 0.f;
-    float d = 0.f, ar = 0.f, mx = 0.f, inv = 0.f;
-    if (row < m && col_ok) {
-        load_vec<float, VEC>(grad_out + row * (int64_t)k + cc, g);
-        float o[VEC];
-        load_vec<float, VEC>(out + row * (int64_t)k + cc, o);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) d = fmaf(g[i], o[i], d);
-        ar = attn_row[row * heads + hd];
-        mx = edge_max[row * heads + hd];
-        const float ls = edge_sum[row * heads + hd];
-        inv = ls > 0.f ? 1.f / ls : 0.f;
+    __device__ __forceinline__ void row_load(Ctx &c, int64_t row, bool ok) const {
+        c.ar = ok ? attn_row[row * heads + c.hd] : 0.f;
     }
-    d = head_sum<LPR>(d, lph);
-    float gacc = 0.f;
-    for (int base = start; base < end; base += LPR) {
-        const int cnt = min(LPR, end - base);
-        const int my_c = (l < cnt) ? colind[base + l] : 0;
-        for (int j = 0; j < cnt; j += UNROLL) {
-            float v[UNROLL][VEC];
-            float ac[UNROLL];
+    __device__ __forceinline__ void init_zero(State &s) const {
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int c = __shfl(my_c, sub * LPR + min(j + u, cnt - 1), kWave);
-                ac[u] = attn_col[(int64_t)c * heads + hd];
-                load_vec<float, VEC>(feat + (int64_t)c * k + cc, v[u]);
-            }
+        for (int i = 0; i < VEC; ++i) s.acc[i] = 0.f;
+        s.mx = -INFINITY;
+        s.lsum = 0.f;
+    }
+    __device__ __forceinline__ void init(const Ctx &, State &s, int64_t, bool) const { init_zero(s); }
+    __device__ __forceinline__ void lane_load(const Ctx &, LaneVals &, int64_t) const {}
+    __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t, const LaneVals &, int,
+                                          int) const {
+        b.ac[u] = attn_col[(int64_t)col * heads + c.hd];
+        load_vec<T, VEC>(feat + (int64_t)col * (heads * fdim) + c.cc, b.v[u]);
+    }
+    __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
+                                          int) const {
+        if (valid) {
+            const float sc = leaky(c.ar + b.ac[u], slope);
+            const float mn = fmaxf(s.mx, sc);
+            const float scale = (s.lsum == 0.f) ? 0.f : expf(s.mx - mn);
+            const float p = expf(sc - mn);
+            s.lsum = s.lsum * scale + p;
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                float dot = 0.f;
+            for (int i = 0; i < VEC; ++i) s.acc[i] = fmaf(p, b.v[u][i], s.acc[i] * scale);
+            s.mx = mn;
+        }
+    }
+    __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
+    __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
+        if (ok && c.col_ok) {
+            const float inv = (s.lsum > 0.f) ? 1.f / s.lsum : 0.f;  // empty row -> zeros
+            float r[VEC];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) dot = fmaf(g[i], col_ok ? v[u][i] : 0.f, dot);
-                dot = head_sum<LPR>(dot, lph);
-                if (j + u < cnt) {
-                    const float pre = ar + ac[u];
-                    const float a = expf(leaky(pre, slope) - mx) * inv;
-                    gacc += a * (dot - d) * (pre > 0.f ? 1.f : slope);
-                }
+            for (int i = 0; i < VEC; ++i) r[i] = s.acc[i] * inv;
+            store_vec<T, VEC>(out + row * (int64_t)(heads * fdim) + c.col0, r);
+            if (c.col0 % fdim == 0) {
+                edge_max[row * heads + c.hd] = s.mx;
+                edge_sum[row * heads + c.hd] = s.lsum;
             }
         }
     }
-    if (row < m && col_ok && cc % fdim == 0) {
-        dvec[row * heads + hd] = d;
-        grad_attn_row[row * heads + hd] = gacc;
+    __device__ __forceinline__ void pack(const State &s, float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) rec[i] = s.acc[i];
+        rec[VEC] = s.mx;
+        rec[VEC + 1] = s.lsum;
     }
-}
+    __device__ __forceinline__ void unpack(State &s, const float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.acc[i] = rec[i];
+        s.mx = rec[VEC];
+        s.lsum = rec[VEC + 1];
+    }
+    // Two flash-attention blocks: rescale both to the common maximum (an empty block has lsum == 0, mx == -inf).
+    __device__ __forceinline__ void merge(State &a, const State &b) const {
+        const float mn = fmaxf(a.mx, b.mx);
+        const float sa = (a.lsum == 0.f) ? 0.f : expf(a.mx - mn);
+        const float sb = (b.lsum == 0.f) ? 0.f : expf(b.mx - mn);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) a.acc[i] = a.acc[i] * sa + b.acc[i] * sb;
+        a.lsum = a.lsum * sa + b.lsum * sb;
+        a.mx = mn;
+    }
+};
 
-// Column pass of the backward over the CSC (colptr, rowind): grad_feat[u,h,:] and grad_attn_col[u,h].
-template <int VEC, int LPR, int UNROLL>
-__global__ __launch_bounds__(256) void gat_bwd_col_kernel(
-    const int32_t *__restrict__ colptr, const int32_t *__restrict__ rowind, const float *__restrict__ attn_row,
-    const float *__restrict__ attn_col, const float *__restrict__ feat, float slope,
-    const float *__restrict__ edge_max, const float *__restrict__ edge_sum, const float *__restrict__ dvec,
-    const float *__restrict__ grad_out, float *__restrict__ grad_feat, float *__restrict__ grad_attn_col,
-    int64_t n_src, int heads, int fdim, int lph, XcdMap n_rowblocks) {
-    constexpr int RPW = kWave / LPR;
-    constexpr int RPB = RPW * 4;
-    const int64_t rb = xcd_remap(blockIdx.x, n_rowblocks);
-    if (rb < 0) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int sub = lane / LPR;
-    const int l = lane % LPR;
-    const int64_t u_node = rb * RPB + (threadIdx.x >> 6) * RPW + sub;
-    const int k = heads * fdim;
-    const bool col_ok = l * VEC < k;
-    const int cc = col_ok ? l * VEC : 0;
-    const int hd = cc / fdim;
-    int start = 0, end = 0;
-    if (u_node < n_src) {
-        start = colptr[u_node];
-        end = colptr[u_node + 1];
+// ------------------------------------------------------------------------------------------ backward
+// Row pass: D[v,h] and grad_attn_row[v,h].  The whole [H*F] row must fit one group.
+template <int VEC_, int LPR_, int UNROLL_>
+struct GatBwdRowOp {
+    static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = 1;
+    static constexpr bool kReduce = true;
+    const float *attn_row, *attn_col, *feat, *edge_max, *edge_sum, *out, *grad_out;
+    float *dvec, *grad_attn_row;
+    float slope;
+    int heads, fdim, lph;
+
+    struct Ctx {
+        int cc, hd;
+        bool col_ok, head_lane;
+        float g[VEC];
+        float d, ar, mx, inv;
+    };
+    struct State { float gacc; };
+    struct LaneVals {};
+    struct Batch {
+        float v[UNROLL][VEC];
+        float ac[UNROLL];
+    };
+
+    __device__ __forceinline__ Ctx make_ctx(int l, int) const {
+        Ctx c;
+        c.col_ok = l * VEC < heads * fdim;
+        c.cc = c.col_ok ? l * VEC : 0;
+        c.hd = c.cc / fdim;
+        c.head_lane = c.col_ok && (c.cc % fdim == 0);
+        return c;
     }
-    float f[VEC], acc[VEC];
+    __device__ __forceinline__ void row_load(Ctx &c, int64_t row, bool ok) const {
+        const int k = heads * fdim;
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) f[i] = acc[i] = 0.f;
-    float ac = 0.f;
-    if (u_node < n_src && col_ok) {
-        load_vec<float, VEC>(feat + u_node * (int64_t)k + cc, f);
-        ac = attn_col[u_node * heads + hd];
+        for (int i = 0; i < VEC; ++i) c.g[i] = 0.f;
+        float d = 0.f;
+        c.ar = c.mx = c.inv = 0.f;
+        if (ok && c.col_ok) {
+            load_vec<float, VEC>(grad_out + row * (int64_t)k + c.cc, c.g);
+            float o[VEC];
+            load_vec<float, VEC>(out + row * (int64_t)k + c.cc, o);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) d = fmaf(c.g[i], o[i], d);
+            c.ar = attn_row[row * heads + c.hd];
+            c.mx = edge_max[row * heads + c.hd];
+            const float ls = edge_sum[row * heads + c.hd];
+            c.inv = ls > 0.f ? 1.f / ls : 0.f;
+        }
+        c.d = head_sum<LPR>(d, lph);
     }
-    float gacc = 0.f;
-    for (int base = start; base < end; base += LPR) {
-        const int cnt = min(LPR, end - base);
-        const int my_r = (l < cnt) ? rowind[base + l] : 0;
-        for (int j = 0; j < cnt; j += UNROLL) {
-            float g[UNROLL][VEC];
-            float ar[UNROLL], mx[UNROLL], ls[UNROLL], dd[UNROLL];
+    __device__ __forceinline__ void init_zero(State &s) const { s.gacc = 0.f; }
+    __device__ __forceinline__ void init(const Ctx &, State &s, int64_t, bool) const { s.gacc = 0.f; }
+    __device__ __forceinline__ void lane_load(const Ctx &, LaneVals &, int64_t) const {}
+    __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t, const LaneVals &, int,
+                                          int) const {
+        b.ac[u] = attn_col[(int64_t)col * heads + c.hd];
+        load_vec<float, VEC>(feat + (int64_t)col * (heads * fdim) + c.cc, b.v[u]);
+    }
+    __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
+                                          int) const {
+        float dot = 0.f;
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int r = __shfl(my_r, sub * LPR + min(j + u, cnt - 1), kWave);
-                const int64_t rh = (int64_t)r * heads + hd;
-                ar[u] = attn_row[rh];
-                mx[u] = edge_max[rh];
-                ls[u] = edge_sum[rh];
-                dd[u] = dvec[rh];
-                load_vec<float, VEC>(grad_out + (int64_t)r * k + cc, g[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                float dot = 0.f;
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) dot = fmaf(f[i], col_ok ? g[u][i] : 0.f, dot);
-                dot = head_sum<LPR>(dot, lph);
-                if (j + u < cnt) {
-                    const float pre = ar[u] + ac;
-                    const float a = expf(leaky(pre, slope) - mx[u]) / ls[u];
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[i] = fmaf(a, g[u][i], acc[i]);
-                    gacc += a * (dot - dd[u]) * (pre > 0.f ? 1.f : slope);
-                }
-            }
+        for (int i = 0; i < VEC; ++i) dot = fmaf(c.g[i], c.col_ok ? b.v[u][i] : 0.f, dot);
+        dot = head_sum<LPR>(dot, lph);
+        if (valid) {
+            const float pre = c.ar + b.ac[u];
+            const float a = expf(leaky(pre, slope) - c.mx) * c.inv;
+            s.gacc += a * (dot - c.d) * (pre > 0.f ? 1.f : slope);
         }
     }
-    if (u_node < n_src && col_ok) {
-        store_vec<float, VEC>(grad_feat + u_node * (int64_t)k + cc, acc);
-        if (cc % fdim == 0) grad_attn_col[u_node * heads + hd] = gacc;
+    __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
+    __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
+        if (ok && c.head_lane) {
+            dvec[row * heads + c.hd] = c.d;
+            grad_attn_row[row * heads + c.hd] = s.gacc;
+        }
     }
-}
+    __device__ __forceinline__ void pack(const State &s, float (&rec)[kRec]) const { rec[0] = s.gacc; }
+    __device__ __forceinline__ void unpack(State &s, const float (&rec)[kRec]) const { s.gacc = rec[0]; }
+    __device__ __forceinline__ void merge(State &a, const State &b) const { a.gacc += b.gacc; }
+};
+
+// Column pass over the CSC (colptr, rowind): grad_feat[u,h,:] and grad_attn_col[u,h].
+template <int VEC_, int LPR_, int UNROLL_>
+struct GatBwdColOp {
+    static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_ + 1;
+    static constexpr bool kReduce = true;
+    const float *attn_row, *attn_col, *feat, *edge_max, *edge_sum, *dvec, *grad_out;
+    float *grad_feat, *grad_attn_col;
+    float slope;
+    int heads, fdim, lph;
+
+    struct Ctx {
+        int cc, hd;
+        bool col_ok, head_lane;
+        float f[VEC];
+        float ac;
+    };
+    struct State {
+        float acc[VEC];
+        float gacc;
+    };
+    struct LaneVals {};
+    struct Batch {
+        float g[UNROLL][VEC];
+        float ar[UNROLL], mx[UNROLL], ls[UNROLL], dd[UNROLL];
+    };
+
+    __device__ __forceinline__ Ctx make_ctx(int l, int) const {
+        Ctx c;
+        c.col_ok = l * VEC < heads * fdim;
+        c.cc = c.col_ok ? l * VEC : 0;
+        c.hd = c.cc / fdim;
+        c.head_lane = c.col_ok && (c.cc % fdim == 0);
+        return c;
+    }
+    __device__ __forceinline__ void row_load(Ctx &c, int64_t u_node, bool ok) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) c.f[i] = 0.f;
+        c.ac = 0.f;
+        if (ok && c.col_ok) {
+            load_vec<float, VEC>(feat + u_node * (int64_t)(heads * fdim) + c.cc, c.f);
+            c.ac = attn_col[u_node * heads + c.hd];
+        }
+    }
+    __device__ __forceinline__ void init_zero(State &s) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.acc[i] = 0.f;
+        s.gacc = 0.f;
+    }
+    __device__ __forceinline__ void init(const Ctx &, State &s, int64_t, bool) const { init_zero(s); }
+    __device__ __forceinline__ void lane_load(const Ctx &, LaneVals &, int64_t) const {}
+    __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int r, int64_t, const LaneVals &, int,
+                                          int) const {
+        const int64_t rh = (int64_t)r * heads + c.hd;
+        b.ar[u] = attn_row[rh];
+        b.mx[u] = edge_max[rh];
+        b.ls[u] = edge_sum[rh];
+        b.dd[u] = dvec[rh];
+        load_vec<float, VEC>(grad_out + (int64_t)r * (heads * fdim) + c.cc, b.g[u]);
+    }
+    __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
+                                          int) const {
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) dot = fmaf(c.f[i], c.col_ok ? b.g[u][i] : 0.f, dot);
+        dot = head_sum<LPR>(dot, lph);
+        if (valid) {
+            const float pre = b.ar[u] + c.ac;
+            const float a = expf(leaky(pre, slope) - b.mx[u]) / b.ls[u];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) s.acc[i] = fmaf(a, b.g[u][i], s.acc[i]);
+            s.gacc += a * (dot - b.dd[u]) * (pre > 0.f ? 1.f : slope);
+        }
+    }
+    __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
+    __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t u_node, bool ok) const {
+        if (ok && c.col_ok) {
+            store_vec<float, VEC>(grad_feat + u_node * (int64_t)(heads * fdim) + c.cc, s.acc);
+            if (c.head_lane) grad_attn_col[u_node * heads + c.hd] = s.gacc;
+        }
+    }
+    __device__ __forceinline__ void pack(const State &s, float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) rec[i] = s.acc[i];
+        rec[VEC] = s.gacc;
+    }
+    __device__ __forceinline__ void unpack(State &s, const float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.acc[i] = rec[i];
+        s.gacc = rec[VEC];
+    }
+    __device__ __forceinline__ void merge(State &a, const State &b) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) a.acc[i] += b.acc[i];
+        a.gacc += b.gacc;
+    }
+};
 
 static bool pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// Forward geometry: the widest legal vector, narrowed until the [H*F] row fills 64 lanes (as csr_spmm), but
+// every lane's columns stay inside one head.
+static RowGeometry gat_fwd_geometry(int64_t h, int64_t f, int elem_bytes, int align) {
+    const int maxv = 16 / elem_bytes;
+    int vec = 1;
+    for (int w = 1; w <= maxv; w <<= 1) {
+        if (f % w != 0 || align % (w * elem_bytes) != 0) break;
+        vec = w;
+        if (w * elem_bytes >= 4 && h * f <= (int64_t)w * kWave) break;
+    }
+    const int64_t need = (h * f + vec - 1) / vec;
+    int lpr = 8;
+    while (lpr < kWave && lpr < need) lpr <<= 1;
+    RowGeometry g;
+    g.vec = vec;
+    g.lpr = lpr;
+    g.tiles = (h * f + (int64_t)lpr * vec - 1) / ((int64_t)lpr * vec);
+    return g;
+}
+
+struct FwdArgs {
+    const int32_t *rowptr, *colind;
+    const float *ar, *ac;
+    const void *feat;
+    float slope;
+    void *out;
+    float *emax, *esum;
+    int64_t v, h, f, nnz;
+};
+
 template <typename T, int VEC, int LPR>
-static int launch_fwd(const int32_t *rowptr, const int32_t *colind, const float *ar, const float *ac, const T *feat,
-                      float slope, T *out, float *emax, float *esum, int64_t v, int64_t h, int64_t f, hipStream_t s) {
-    constexpr int RPB = (kWave / LPR) * 4;
-    const int64_t nrb = (v + RPB - 1) / RPB;
-    const int64_t tiles = (h * f + (int64_t)LPR * VEC - 1) / ((int64_t)LPR * VEC);
-    if (nrb > 0x7fffffff / kXcds || tiles > 65535) return COGDL_HIP_ERANGE;
-    hipLaunchKernelGGL((gat_fwd_kernel<T, VEC, LPR, 8>), dim3(xcd_grid(make_xcd_map(nrb)), (unsigned)tiles), dim3(256), 0, s, rowptr,
-                       colind, ar, ac, feat, slope, out, emax, esum, v, (int)h, (int)f, make_xcd_map(nrb));
-    return launch_status();
+static int launch_fwd(const FwdArgs &a, int64_t tiles, void *ws, size_t wsb, hipStream_t s) {
+    GatFwdOp<T, VEC, LPR, 8> op{a.ar, a.ac, (const T *)a.feat, (T *)a.out, a.emax, a.esum, a.slope, (int)a.h, (int)a.f};
+    return launch_rowreduce(op, a.rowptr, a.colind, a.v, a.nnz, tiles, ws, wsb, s);
 }
 
 template <typename T, int VEC>
-static int dispatch_fwd(const int32_t *rowptr, const int32_t *colind, const float *ar, const float *ac, const T *feat,
-                        float slope, T *out, float *emax, float *esum, int64_t v, int64_t h, int64_t f,
-                        hipStream_t s) {
-    const int64_t need = (h * f + VEC - 1) / VEC;
-    if (need <= 8) return launch_fwd<T, VEC, 8>(rowptr, colind, ar, ac, feat, slope, out, emax, esum, v, h, f, s);
-    if (need <= 16) return launch_fwd<T, VEC, 16>(rowptr, colind, ar, ac, feat, slope, out, emax, esum, v, h, f, s);
-    if (need <= 32) return launch_fwd<T, VEC, 32>(rowptr, colind, ar, ac, feat, slope, out, emax, esum, v, h, f, s);
-    return launch_fwd<T, VEC, 64>(rowptr, colind, ar, ac, feat, slope, out, emax, esum, v, h, f, s);
+static int dispatch_fwd(const FwdArgs &a, const RowGeometry &g, void *ws, size_t wsb, hipStream_t s) {
+    switch (g.lpr) {
+        case 8: return launch_fwd<T, VEC, 8>(a, g.tiles, ws, wsb, s);
+        case 16: return launch_fwd<T, VEC, 16>(a, g.tiles, ws, wsb, s);
+        case 32: return launch_fwd<T, VEC, 32>(a, g.tiles, ws, wsb, s);
+        default: return launch_fwd<T, VEC, 64>(a, g.tiles, ws, wsb, s);
+    }
 }
 
 template <typename T>
-static int gat_fwd_typed(const int32_t *rowptr, const int32_t *colind, const float *ar, const float *ac,
-                         const void *feat_, float slope, void *out_, float *emax, float *esum, int64_t v, int64_t h,
-                         int64_t f, hipStream_t s) {
-    const T *feat = (const T *)feat_;
-    T *out = (T *)out_;
+static int gat_fwd_typed(const FwdArgs &a, void *ws, size_t wsb, hipStream_t s) {
     constexpr int MAXV = 16 / sizeof(T);
-    int vec = 1;
-    for (int w = 1; w <= MAXV; w <<= 1) {
-        if (f % w != 0 || !aligned_to(feat, w * sizeof(T)) || !aligned_to(out, w * sizeof(T))) break;
-        vec = w;
-        if (w * sizeof(T) >= 4 && h * f <= (int64_t)w * kWave) break;
-    }
-    switch (vec) {
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(a.feat) | reinterpret_cast<uintptr_t>(a.out);
+    const int align = (bits % 16 == 0) ? 16 : (bits % 8 == 0) ? 8 : (bits % 4 == 0) ? 4 : 2;
+    if (align < (int)sizeof(T)) return COGDL_HIP_EALIGN;
+    const RowGeometry g = gat_fwd_geometry(a.h, a.f, (int)sizeof(T), align);
+    switch (g.vec) {
         case 8:
-            if constexpr (MAXV >= 8) return dispatch_fwd<T, 8>(rowptr, colind, ar, ac, feat, slope, out, emax, esum, v, h, f, s);
-        case 4: return dispatch_fwd<T, 4>(rowptr, colind, ar, ac, feat, slope, out, emax, esum, v, h, f, s);
-        case 2: return dispatch_fwd<T, 2>(rowptr, colind, ar, ac, feat, slope, out, emax, esum, v, h, f, s);
-        default: return dispatch_fwd<T, 1>(rowptr, colind, ar, ac, feat, slope, out, emax, esum, v, h, f, s);
+            if constexpr (MAXV >= 8) return dispatch_fwd<T, 8>(a, g, ws, wsb, s);
+        case 4: return dispatch_fwd<T, 4>(a, g, ws, wsb, s);
+        case 2: return dispatch_fwd<T, 2>(a, g, ws, wsb, s);
+        default: return dispatch_fwd<T, 1>(a, g, ws, wsb, s);
     }
 }
 
@@ -299,64 +384,89 @@ struct BwdArgs {
     const float *ar, *ac, *feat, *emax, *esum, *out, *gout;
     float slope;
     float *gfeat, *gar, *gac, *dvec;
-    int64_t v, n_src, h, f;
+    int64_t v, n_src, h, f, nnz;
+    void *ws_row, *ws_col;  // long-row scratch of the two passes (either both or none)
+    size_t wsb_row, wsb_col;
 };
+
+// Backward geometry: the whole [H*F] row in ONE group (the per-head dot products are reduced with shuffles):
+// vec in {1,2,4} with F % vec == 0, H*F/vec <= 64 lanes and F/vec a power of two (unless H == 1).
+static int gat_bwd_vec(int64_t h, int64_t f, int align) {
+    auto ok = [&](int vec) { return f % vec == 0 && h * f / vec <= kWave && (h == 1 || pow2(f / vec)); };
+    if (ok(1)) return 1;
+    if (ok(2) && align >= 8) return 2;
+    if (ok(4) && align >= 16) return 4;
+    return 0;
+}
+static int gat_bwd_lpr(int64_t h, int64_t f, int vec) {
+    const int64_t need = (h * f + vec - 1) / vec;
+    int lpr = 8;
+    while (lpr < kWave && lpr < need) lpr <<= 1;
+    return lpr;
+}
 
 template <int VEC, int LPR>
 static int launch_bwd(const BwdArgs &b, hipStream_t s) {
-    constexpr int RPB = (kWave / LPR) * 4;
     const int lph = (b.h == 1) ? LPR : (int)(b.f / VEC);  // one head: reduce over the whole (zero-padded) group
-    const int64_t nrb = (b.v + RPB - 1) / RPB, ncb = (b.n_src + RPB - 1) / RPB;
-    if (nrb > 0x7fffffff / kXcds || ncb > 0x7fffffff / kXcds) return COGDL_HIP_ERANGE;
-    if (nrb)
-        hipLaunchKernelGGL((gat_bwd_row_kernel<VEC, LPR, 4>), dim3(xcd_grid(make_xcd_map(nrb))), dim3(256), 0, s, b.rowptr, b.colind,
-                           b.ar, b.ac, b.feat, b.slope, b.emax, b.esum, b.out, b.gout, b.dvec, b.gar, b.v, (int)b.h,
-                           (int)b.f, lph, make_xcd_map(nrb));
-    if (ncb)
-        hipLaunchKernelGGL((gat_bwd_col_kernel<VEC, LPR, 4>), dim3(xcd_grid(make_xcd_map(ncb))), dim3(256), 0, s, b.colptr, b.rowind,
-                           b.ar, b.ac, b.feat, b.slope, b.emax, b.esum, b.dvec, b.gout, b.gfeat, b.gac, b.n_src,
-                           (int)b.h, (int)b.f, lph, make_xcd_map(ncb));
-    return launch_status();
+    GatBwdRowOp<VEC, LPR, 4> row_op{b.ar, b.ac, b.feat, b.emax, b.esum, b.out, b.gout, b.dvec, b.gar, b.slope,
+                                     (int)b.h, (int)b.f, lph};
+    int rc = launch_rowreduce(row_op, b.rowptr, b.colind, b.v, b.nnz, 1, b.ws_row, b.wsb_row, s);
+    if (rc != COGDL_HIP_OK) return rc;
+    GatBwdColOp<VEC, LPR, 4> col_op{b.ar, b.ac, b.feat, b.emax, b.esum, b.dvec, b.gout, b.gfeat, b.gac, b.slope,
+                                     (int)b.h, (int)b.f, lph};
+    return launch_rowreduce(col_op, b.colptr, b.rowind, b.n_src, b.nnz, 1, b.ws_col, b.wsb_col, s);
 }
 
 template <int VEC>
 static int dispatch_bwd(const BwdArgs &b, hipStream_t s) {
-    const int64_t need = (b.h * b.f + VEC - 1) / VEC;
-    if (need <= 8) return launch_bwd<VEC, 8>(b, s);
-    if (need <= 16) return launch_bwd<VEC, 16>(b, s);
-    if (need <= 32) return launch_bwd<VEC, 32>(b, s);
-    return launch_bwd<VEC, 64>(b, s);
+    switch (gat_bwd_lpr(b.h, b.f, VEC)) {
+        case 8: return launch_bwd<VEC, 8>(b, s);
+        case 16: return launch_bwd<VEC, 16>(b, s);
+        case 32: return launch_bwd<VEC, 32>(b, s);
+        default: return launch_bwd<VEC, 64>(b, s);
+    }
 }
+
+static size_t dvec_bytes(int64_t v, int64_t h) { return ((size_t)(v > 0 ? v : 0) * (size_t)(h > 0 ? h : 0) * sizeof(float) + 255) / 256 * 256; }
 
 }  // namespace cogdl
 
 using namespace cogdl;
 
+extern "C" size_t cogdl_hip_gat_fwd_workspace_bytes(int64_t nnz, int64_t h, int64_t f, int dtype) {
+    if (nnz <= 0 || h <= 0 || f <= 0) return 0;
+    const RowGeometry g = gat_fwd_geometry(h, f, dtype == COGDL_HIP_F32 ? 4 : 2, 16);
+    return rowreduce_workspace_bytes(nnz, g.tiles * (g.vec + 2) * g.lpr);
+}
+
 extern "C" int cogdl_hip_gat_fwd(const int32_t *rowptr, const int32_t *colind, const float *attn_row,
                                  const float *attn_col, const void *feat, float negative_slope, void *out,
-                                 float *edge_max, float *edge_sum, int64_t v, int64_t h, int64_t f, int dtype,
-                                 void *stream) {
-    if (v < 0 || h < 0 || f < 0) return COGDL_HIP_EINVAL;
+                                 float *edge_max, float *edge_sum, int64_t v, int64_t h, int64_t f, int64_t nnz,
+                                 int dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    if (v < 0 || h < 0 || f < 0 || nnz < 0) return COGDL_HIP_EINVAL;
     if (v == 0 || h == 0 || f == 0) return COGDL_HIP_OK;
     if (!rowptr || !attn_row || !attn_col || !feat || !out || !edge_max || !edge_sum) return COGDL_HIP_EINVAL;
-    if (h * f > 0x7fffffff) return COGDL_HIP_ERANGE;
+    if (h * f > 0x7fffffff || nnz > 0x7fffffff) return COGDL_HIP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
+    FwdArgs a{rowptr, colind, attn_row, attn_col, feat, negative_slope, out, edge_max, edge_sum, v, h, f, nnz};
     switch (dtype) {
-        case COGDL_HIP_F32:
-            return gat_fwd_typed<float>(rowptr, colind, attn_row, attn_col, feat, negative_slope, out, edge_max,
-                                        edge_sum, v, h, f, s);
-        case COGDL_HIP_F16:
-            return gat_fwd_typed<__half>(rowptr, colind, attn_row, attn_col, feat, negative_slope, out, edge_max,
-                                         edge_sum, v, h, f, s);
-        case COGDL_HIP_BF16:
-            return gat_fwd_typed<__hip_bfloat16>(rowptr, colind, attn_row, attn_col, feat, negative_slope, out,
-                                                 edge_max, edge_sum, v, h, f, s);
+        case COGDL_HIP_F32: return gat_fwd_typed<float>(a, workspace, workspace_bytes, s);
+        case COGDL_HIP_F16: return gat_fwd_typed<__half>(a, workspace, workspace_bytes, s);
+        case COGDL_HIP_BF16: return gat_fwd_typed<__hip_bfloat16>(a, workspace, workspace_bytes, s);
         default: return COGDL_HIP_EDTYPE;
     }
 }
 
-extern "C" size_t cogdl_hip_gat_bwd_workspace_bytes(int64_t v, int64_t h) {
-    return (size_t)(v > 0 ? v : 0) * (size_t)(h > 0 ? h : 0) * sizeof(float) + 256;
+// Layout of the backward workspace: [D: v*h floats][long-row scratch of the row pass][... of the column pass].
+extern "C" size_t cogdl_hip_gat_bwd_workspace_bytes(int64_t v, int64_t h, int64_t f, int64_t nnz) {
+    size_t total = dvec_bytes(v, h);
+    const int vec = gat_bwd_vec(h, f, 16);
+    if (vec > 0 && nnz > 0) {
+        const int lpr = gat_bwd_lpr(h, f, vec);
+        total += rowreduce_workspace_bytes(nnz, 1 * lpr);
+        total += rowreduce_workspace_bytes(nnz, (int64_t)(vec + 1) * lpr);
+    }
+    return total + 256;
 }
 
 // Returns COGDL_HIP_EINVAL for shapes the fused backward does not cover (the [H*F] row must fit one group of
@@ -367,21 +477,34 @@ extern "C" int cogdl_hip_gat_bwd(const int32_t *rowptr, const int32_t *colind, c
                                  const float *feat, float negative_slope, const float *edge_max,
                                  const float *edge_sum, const float *out, const float *grad_out, float *grad_feat,
                                  float *grad_attn_row, float *grad_attn_col, void *workspace, size_t workspace_bytes,
-                                 int64_t v, int64_t n_src, int64_t h, int64_t f, void *stream) {
-    if (v < 0 || n_src < 0 || h <= 0 || f <= 0) return COGDL_HIP_EINVAL;
+                                 int64_t v, int64_t n_src, int64_t h, int64_t f, int64_t nnz, void *stream) {
+    if (v < 0 || n_src < 0 || h <= 0 || f <= 0 || nnz < 0) return COGDL_HIP_EINVAL;
     if (!rowptr || !colptr || !attn_row || !attn_col || !feat || !edge_max || !edge_sum || !out || !grad_out ||
         !grad_feat || !grad_attn_row || !grad_attn_col || !workspace)
         return COGDL_HIP_EINVAL;
-    if (workspace_bytes < cogdl_hip_gat_bwd_workspace_bytes(v, h)) return COGDL_HIP_EWORKSPACE;
+    if (workspace_bytes < dvec_bytes(v, h) || !aligned_to(workspace, 256)) return COGDL_HIP_EWORKSPACE;
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out) |
+                           reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_feat);
+    const int align = (bits % 16 == 0) ? 16 : (bits % 8 == 0) ? 8 : 4;
+    const int vec = gat_bwd_vec(h, f, align);
+    if (vec == 0) return COGDL_HIP_EINVAL;
     BwdArgs b{rowptr, colind, colptr, rowind, attn_row, attn_col, feat, edge_max, edge_sum, out, grad_out,
-              negative_slope, grad_feat, grad_attn_row, grad_attn_col, (float *)workspace, v, n_src, h, f};
+              negative_slope, grad_feat, grad_attn_row, grad_attn_col, (float *)workspace, v, n_src, h, f, nnz,
+              nullptr, nullptr, 0, 0};
+    // the long-row scratch is used only when the caller's workspace covers all of it
+    const int lpr = gat_bwd_lpr(h, f, vec);
+    const size_t need_row = rowreduce_workspace_bytes(nnz, 1 * lpr);
+    const size_t need_col = rowreduce_workspace_bytes(nnz, (int64_t)(vec + 1) * lpr);
+    if (nnz > 0 && workspace_bytes >= dvec_bytes(v, h) + need_row + need_col) {
+        b.ws_row = (char *)workspace + dvec_bytes(v, h);
+        b.wsb_row = need_row;
+        b.ws_col = (char *)b.ws_row + need_row;
+        b.wsb_col = need_col;
+    }
     hipStream_t s = (hipStream_t)stream;
-    const int64_t k = h * f;
-    const bool al16 = aligned_to(feat, 16) && aligned_to(out, 16) && aligned_to(grad_out, 16) && aligned_to(grad_feat, 16);
-    const bool al8 = aligned_to(feat, 8) && aligned_to(out, 8) && aligned_to(grad_out, 8) && aligned_to(grad_feat, 8);
-    auto ok = [&](int vec) { return f % vec == 0 && k / vec <= kWave && (h == 1 || pow2(f / vec)); };
-    if (ok(1)) return dispatch_bwd<1>(b, s);
-    if (ok(2) && al8) return dispatch_bwd<2>(b, s);
-    if (ok(4) && al16) return dispatch_bwd<4>(b, s);
-    return COGDL_HIP_EINVAL;
+    switch (vec) {
+        case 1: return dispatch_bwd<1>(b, s);
+        case 2: return dispatch_bwd<2>(b, s);
+        default: return dispatch_bwd<4>(b, s);
+    }
 }

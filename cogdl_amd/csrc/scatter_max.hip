@@ -7,116 +7,172 @@
 //           as in the reference's `acc < B`.
 // backward: grad_src[max_id[r,c], c] += grad[r,c] into a buffer zeroed here (the reference
 //           accumulates into torch::empty memory).  fp32 hardware atomics, one per element.
-// Same row-group decomposition and coalesced row gathers as spmm.hip.
-#include "common.h"
+// Same row-group decomposition, coalesced row gathers and long-row path as spmm.hip (engine: rowreduce.h).
+#include "rowreduce.h"
 
 namespace cogdl {
 
-template <int VEC, int LPR, int UNROLL>
-__global__ __launch_bounds__(256) void scatter_max_fwd_kernel(const int32_t *__restrict__ rowptr,
-                                                              const int32_t *__restrict__ colind,
-                                                              const float *__restrict__ x, float *__restrict__ out,
-                                                              int32_t *__restrict__ max_id, int64_t m, int k,
-                                                              XcdMap n_rowblocks) {
-    constexpr int RPW = kWave / LPR;
-    constexpr int RPB = RPW * 4;
-    const int64_t rb = xcd_remap(blockIdx.x, n_rowblocks);
-    if (rb < 0) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int sub = lane / LPR;
-    const int l = lane % LPR;
-    const int64_t row = rb * RPB + (threadIdx.x >> 6) * RPW + sub;
-    const int col0 = ((int)blockIdx.y * LPR + l) * VEC;
-    const bool col_ok = col0 < k;
-    int start = 0, end = 0;
-    if (row < m) {
-        start = rowptr[row];
-        end = rowptr[row + 1];
+// State = (running max, colind of its first occurrence) per column; two edge ranges merge by keeping the
+// earlier range's entry on ties, so the chunk-parallel path returns the same argmax as the sequential walk.
+template <int VEC_, int LPR_, int UNROLL_>
+struct ScatterMaxOp {
+    static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = 2 * VEC_;
+    static constexpr bool kReduce = true;
+    const float *x;
+    float *out;
+    int32_t *max_id;
+    int k;
+
+    struct Ctx {
+        int col0;
+        bool col_ok;
+        const float *xcol;
+    };
+    struct State {
+        float acc[VEC];
+        int id[VEC];
+    };
+    struct LaneVals {};
+    struct Batch {
+        float v[UNROLL][VEC];
+        int c[UNROLL];
+    };
+
+    __device__ __forceinline__ Ctx make_ctx(int l, int tile) const {
+        Ctx c;
+        c.col0 = (tile * LPR + l) * VEC;
+        c.col_ok = c.col0 < k;
+        c.xcol = x + (c.col_ok ? c.col0 : 0);
+        return c;
     }
-    float acc[VEC];
-    int id[VEC];
+    __device__ __forceinline__ void row_load(Ctx &, int64_t, bool) const {}
+    __device__ __forceinline__ void init_zero(State &s) const {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        acc[i] = 0.f;
-        id[i] = -1;
+        for (int i = 0; i < VEC; ++i) {
+            s.acc[i] = 0.f;
+            s.id[i] = -1;
+        }
     }
-    const float *xcol = x + (col_ok ? col0 : 0);
-    for (int base = start; base < end; base += LPR) {
-        const int cnt = min(LPR, end - base);
-        const int my_c = (l < cnt) ? colind[base + l] : 0;
-        for (int j = 0; j < cnt; j += UNROLL) {
-            float v[UNROLL][VEC];
-            int c[UNROLL];
+    __device__ __forceinline__ void init(const Ctx &, State &s, int64_t, bool) const { init_zero(s); }
+    __device__ __forceinline__ void lane_load(const Ctx &, LaneVals &, int64_t) const {}
+    __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t, const LaneVals &, int,
+                                          int) const {
+        b.c[u] = col;
+        load_vec<float, VEC>(c.xcol + (int64_t)col * k, b.v[u]);
+    }
+    __device__ __forceinline__ void apply(const Ctx &, State &s, const Batch &b, int u, bool valid, int64_t,
+                                          int) const {
+        if (valid) {
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                c[u] = __shfl(my_c, sub * LPR + min(j + u, cnt - 1), kWave);
-                load_vec<float, VEC>(xcol + (int64_t)c[u] * k, v[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                if (j + u < cnt) {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) {
-                        const bool take = (id[i] < 0) || (v[u][i] > acc[i]);
-                        acc[i] = take ? v[u][i] : acc[i];
-                        id[i] = take ? c[u] : id[i];
-                    }
-                }
+            for (int i = 0; i < VEC; ++i) {
+                const bool take = (s.id[i] < 0) || (b.v[u][i] > s.acc[i]);
+                s.acc[i] = take ? b.v[u][i] : s.acc[i];
+                s.id[i] = take ? b.c[u] : s.id[i];
             }
         }
     }
-    if (row < m && col_ok) {
-        store_vec<float, VEC>(out + row * (int64_t)k + col0, acc);
+    __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
+    __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
+        if (ok && c.col_ok) {
+            store_vec<float, VEC>(out + row * (int64_t)k + c.col0, s.acc);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) max_id[row * (int64_t)k + col0 + i] = id[i];
+            for (int i = 0; i < VEC; ++i) max_id[row * (int64_t)k + c.col0 + i] = s.id[i];
+        }
     }
-}
+    __device__ __forceinline__ void pack(const State &s, float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            rec[i] = s.acc[i];
+            rec[VEC + i] = __int_as_float(s.id[i]);
+        }
+    }
+    __device__ __forceinline__ void unpack(State &s, const float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            s.acc[i] = rec[i];
+            s.id[i] = __float_as_int(rec[VEC + i]);
+        }
+    }
+    __device__ __forceinline__ void merge(State &a, const State &b) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const bool take = b.id[i] >= 0 && ((a.id[i] < 0) || (b.acc[i] > a.acc[i]));
+            a.acc[i] = take ? b.acc[i] : a.acc[i];
+            a.id[i] = take ? b.id[i] : a.id[i];
+        }
+    }
+};
 
 __global__ void scatter_max_bwd_kernel(const float *__restrict__ grad, const int32_t *__restrict__ max_id,
                                        float *__restrict__ grad_src, int64_t total, int k) {
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int32_t id = max_id[idx];
-        if (id >= 0) atomicAdd(grad_src + (int64_t)id * k + (idx % k), grad[idx]);
+        if (id >= 0) unsafeAtomicAdd(grad_src + (int64_t)id * k + (idx % k), grad[idx]);  // global_atomic_add_f32, no CAS loop
     }
 }
 
+static RowGeometry smax_geometry(int64_t k, int align) {
+    int vec = (k % 4 == 0 && align >= 16) ? 4 : (k % 2 == 0 && align >= 8) ? 2 : 1;
+    const int64_t need = (k + vec - 1) / vec;
+    int lpr = 8;
+    while (lpr < kWave && lpr < need) lpr <<= 1;
+    RowGeometry g;
+    g.vec = vec;
+    g.lpr = lpr;
+    g.tiles = (k + (int64_t)lpr * vec - 1) / ((int64_t)lpr * vec);
+    return g;
+}
+
+struct SmaxArgs {
+    const int32_t *rowptr, *colind;
+    const float *x;
+    float *out;
+    int32_t *max_id;
+    int64_t m, k, nnz;
+};
+
 template <int VEC, int LPR>
-static int launch_smax(const int32_t *rowptr, const int32_t *colind, const float *x, float *out, int32_t *max_id,
-                       int64_t m, int64_t k, hipStream_t s) {
-    constexpr int RPB = (kWave / LPR) * 4;
-    const int64_t nrb = (m + RPB - 1) / RPB;
-    const int64_t tiles = (k + (int64_t)LPR * VEC - 1) / ((int64_t)LPR * VEC);
-    if (nrb > 0x7fffffff / kXcds || tiles > 65535) return COGDL_HIP_ERANGE;
-    hipLaunchKernelGGL((scatter_max_fwd_kernel<VEC, LPR, 8>), dim3(xcd_grid(make_xcd_map(nrb)), (unsigned)tiles), dim3(256), 0, s,
-                       rowptr, colind, x, out, max_id, m, (int)k, make_xcd_map(nrb));
-    return launch_status();
+static int launch_smax(const SmaxArgs &a, int64_t tiles, void *ws, size_t wsb, hipStream_t s) {
+    ScatterMaxOp<VEC, LPR, 8> op{a.x, a.out, a.max_id, (int)a.k};
+    return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, tiles, ws, wsb, s);
 }
 
 template <int VEC>
-static int dispatch_smax(const int32_t *rowptr, const int32_t *colind, const float *x, float *out, int32_t *max_id,
-                         int64_t m, int64_t k, hipStream_t s) {
-    const int64_t need = (k + VEC - 1) / VEC;
-    if (need <= 8) return launch_smax<VEC, 8>(rowptr, colind, x, out, max_id, m, k, s);
-    if (need <= 16) return launch_smax<VEC, 16>(rowptr, colind, x, out, max_id, m, k, s);
-    if (need <= 32) return launch_smax<VEC, 32>(rowptr, colind, x, out, max_id, m, k, s);
-    return launch_smax<VEC, 64>(rowptr, colind, x, out, max_id, m, k, s);
+static int dispatch_smax(const SmaxArgs &a, const RowGeometry &g, void *ws, size_t wsb, hipStream_t s) {
+    switch (g.lpr) {
+        case 8: return launch_smax<VEC, 8>(a, g.tiles, ws, wsb, s);
+        case 16: return launch_smax<VEC, 16>(a, g.tiles, ws, wsb, s);
+        case 32: return launch_smax<VEC, 32>(a, g.tiles, ws, wsb, s);
+        default: return launch_smax<VEC, 64>(a, g.tiles, ws, wsb, s);
+    }
 }
-
 }  // namespace cogdl
 
 using namespace cogdl;
 
+extern "C" size_t cogdl_hip_scatter_max_workspace_bytes(int64_t nnz, int64_t k) {
+    if (nnz <= 0 || k <= 0) return 0;
+    const RowGeometry g = smax_geometry(k, 16);
+    return rowreduce_workspace_bytes(nnz, g.tiles * 2 * g.vec * g.lpr);
+}
+
 extern "C" int cogdl_hip_scatter_max_fwd(const int32_t *rowptr, const int32_t *colind, const float *feat,
-                                         float *out, int32_t *max_id, int64_t m, int64_t k, void *stream) {
-    if (m < 0 || k < 0) return COGDL_HIP_EINVAL;
+                                         float *out, int32_t *max_id, int64_t m, int64_t k, int64_t nnz,
+                                         void *workspace, size_t workspace_bytes, void *stream) {
+    if (m < 0 || k < 0 || nnz < 0) return COGDL_HIP_EINVAL;
     if (m == 0 || k == 0) return COGDL_HIP_OK;
     if (!rowptr || !feat || !out || !max_id) return COGDL_HIP_EINVAL;
-    if (k > 0x7fffffff) return COGDL_HIP_ERANGE;
+    if (k > 0x7fffffff || nnz > 0x7fffffff) return COGDL_HIP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
-    if (k % 4 == 0 && aligned_to(feat, 16) && aligned_to(out, 16)) return dispatch_smax<4>(rowptr, colind, feat, out, max_id, m, k, s);
-    if (k % 2 == 0 && aligned_to(feat, 8) && aligned_to(out, 8)) return dispatch_smax<2>(rowptr, colind, feat, out, max_id, m, k, s);
-    return dispatch_smax<1>(rowptr, colind, feat, out, max_id, m, k, s);
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out);
+    const RowGeometry g = smax_geometry(k, (bits % 16 == 0) ? 16 : (bits % 8 == 0) ? 8 : 4);
+    SmaxArgs a{rowptr, colind, feat, out, max_id, m, k, nnz};
+    switch (g.vec) {
+        case 4: return dispatch_smax<4>(a, g, workspace, workspace_bytes, s);
+        case 2: return dispatch_smax<2>(a, g, workspace, workspace_bytes, s);
+        default: return dispatch_smax<1>(a, g, workspace, workspace_bytes, s);
+    }
 }
 
 extern "C" int cogdl_hip_scatter_max_bwd(const float *grad, const int32_t *max_id, float *grad_src, int64_t m,

@@ -1,126 +1,132 @@
 // sddmm.hip -- csr_sddmm for gfx950: out[e] = < d1[row(e),:], d2[colind[e],:] >.
 // Replaces cogdl/operators/spmm/sddmm_kernel.cu:249-417 (16 edges per block, binary search
-// of the row per 4 edges, warp=32 shuffles).  Here the row-group decomposition of spmm.hip
-// is reused: a group of LPR lanes owns one CSR row, so row(e) is known without a search and
+// of the row per 4 edges, warp=32 shuffles).  Here the row-group engine of rowreduce.h is
+// reused: a group of LPR lanes owns one CSR row, so row(e) is known without a search and
 // d1[row,:] stays in registers for the whole row; each neighbour row of d2 is one coalesced
 // vector load; per-edge dot products are reduced with a wave64 butterfly inside the group
-// and written back as one coalesced store per chunk of LPR edges.
+// and written back as one coalesced store per chunk of LPR edges.  Rows longer than the
+// long-row threshold are cut into chunks processed by whole workgroups (per-edge outputs:
+// nothing to merge).
 // HBM-bound: algorithmic bytes per edge = 4 (colind) + F*s (d2 row) + 4 (out); d1 once per row.
-#include "common.h"
+#include "rowreduce.h"
 
 namespace cogdl {
 
-template <int VEC, int LPR, int UNROLL, bool SINGLE_TILE>
-__global__ __launch_bounds__(256) void csr_sddmm_kernel(const int32_t *__restrict__ rowptr,
-                                                        const int32_t *__restrict__ colind,
-                                                        const float *__restrict__ d1,
-                                                        const float *__restrict__ d2, float *__restrict__ out,
-                                                        int64_t m, int k, XcdMap n_rowblocks) {
-    constexpr int RPW = kWave / LPR;
-    constexpr int RPB = RPW * 4;
-    const int64_t rb = xcd_remap(blockIdx.x, n_rowblocks);
-    if (rb < 0) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-    const int sub = lane / LPR;
-    const int l = lane % LPR;
-    const int64_t row = rb * RPB + wave * RPW + sub;
-    int start = 0, end = 0;
-    if (row < m) {
-        start = rowptr[row];
-        end = rowptr[row + 1];
-    }
-    const float *a_row = d1 + (row < m ? row : 0) * (int64_t)k;
-    float a0[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) a0[i] = 0.f;
-    if (SINGLE_TILE && l * VEC < k) load_vec<float, VEC>(a_row + l * VEC, a0);
+template <int VEC_, int LPR_, int UNROLL_, bool SINGLE_TILE>
+struct SddmmOp {
+    static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = 1;
+    static constexpr bool kReduce = false;
+    const float *d1, *d2;
+    float *out;
+    int k;
 
-    for (int base = start; base < end; base += LPR) {
-        const int cnt = min(LPR, end - base);
-        const int my_c = (l < cnt) ? colind[base + l] : 0;
-        float my_out = 0.f;
-        for (int j = 0; j < cnt; j += UNROLL) {
-            float p[UNROLL];
-            int c[UNROLL];
+    struct Ctx {
+        int l, c0;
+        bool col_ok;
+        const float *a_row;
+        float a0[VEC];
+    };
+    struct State { float my_out; };
+    struct LaneVals {};
+    struct Batch {
+        float b[UNROLL][VEC];
+        int c[UNROLL];
+    };
+
+    __device__ __forceinline__ Ctx make_ctx(int l, int) const {
+        Ctx c;
+        c.l = l;
+        c.col_ok = l * VEC < k;
+        c.c0 = c.col_ok ? l * VEC : 0;
+        c.a_row = d1;
+        return c;
+    }
+    __device__ __forceinline__ void row_load(Ctx &c, int64_t row, bool ok) const {
+        c.a_row = d1 + (ok ? row : 0) * (int64_t)k;
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                p[u] = 0.f;
-                c[u] = __shfl(my_c, sub * LPR + min(j + u, cnt - 1), kWave);
-            }
-            if constexpr (SINGLE_TILE) {
-                float b[UNROLL][VEC];
-                const bool col_ok = l * VEC < k;
-                const int c0 = col_ok ? l * VEC : 0;
+        for (int i = 0; i < VEC; ++i) c.a0[i] = 0.f;
+        if (SINGLE_TILE && ok && c.col_ok) load_vec<float, VEC>(c.a_row + c.c0, c.a0);
+    }
+    __device__ __forceinline__ void init_zero(State &s) const { s.my_out = 0.f; }
+    __device__ __forceinline__ void init(const Ctx &, State &s, int64_t, bool) const { s.my_out = 0.f; }
+    __device__ __forceinline__ void lane_load(const Ctx &, LaneVals &, int64_t) const {}
+    __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t, const LaneVals &, int,
+                                          int) const {
+        b.c[u] = col;
+        if constexpr (SINGLE_TILE) load_vec<float, VEC>(d2 + (int64_t)col * k + c.c0, b.b[u]);
+    }
+    __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool, int64_t,
+                                          int jpos) const {
+        float p = 0.f;
+        if constexpr (SINGLE_TILE) {
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) load_vec<float, VEC>(d2 + (int64_t)c[u] * k + c0, b[u]);
+            for (int i = 0; i < VEC; ++i) p = fmaf(c.a0[i], c.col_ok ? b.b[u][i] : 0.f, p);
+        } else {  // wide rows: walk the column tiles (k > LPR*VEC)
+            for (int c0 = c.l * VEC; c0 < k; c0 += LPR * VEC) {
+                float a[VEC], v[VEC];
+                load_vec<float, VEC>(c.a_row + c0, a);
+                load_vec<float, VEC>(d2 + (int64_t)b.c[u] * k + c0, v);
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) p[u] = fmaf(a0[i], col_ok ? b[u][i] : 0.f, p[u]);
-            } else {
-                for (int c0 = l * VEC; c0 < k; c0 += LPR * VEC) {
-                    float a[VEC], b[UNROLL][VEC];
-                    load_vec<float, VEC>(a_row + c0, a);
-#pragma unroll
-                    for (int u = 0; u < UNROLL; ++u) load_vec<float, VEC>(d2 + (int64_t)c[u] * k + c0, b[u]);
-#pragma unroll
-                    for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) p[u] = fmaf(a[i], b[u][i], p[u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const float r = group_sum<LPR>(p[u]);
-                if (l == j + u) my_out = r;
+                for (int i = 0; i < VEC; ++i) p = fmaf(a[i], v[i], p);
             }
         }
-        if (l < cnt) out[base + l] = my_out;
+        const float r = group_sum<LPR>(p);
+        if (c.l == jpos) s.my_out = r;
     }
-}
+    __device__ __forceinline__ void chunk_end(const Ctx &c, State &s, int base, int cnt) const {
+        if (c.l < cnt) out[base + c.l] = s.my_out;
+    }
+    __device__ __forceinline__ void row_end(const Ctx &, const State &, int64_t, bool) const {}
+    __device__ __forceinline__ void pack(const State &, float (&)[kRec]) const {}
+    __device__ __forceinline__ void unpack(State &, const float (&)[kRec]) const {}
+    __device__ __forceinline__ void merge(State &, const State &) const {}
+};
+
+struct SddmmArgs {
+    const int32_t *rowptr, *colind;
+    const float *d1, *d2;
+    float *out;
+    int64_t m, k, nnz;
+};
 
 template <int VEC, int LPR>
-static int launch_sddmm(const int32_t *rowptr, const int32_t *colind, const float *d1, const float *d2,
-                        float *out, int64_t m, int64_t k, hipStream_t s) {
-    constexpr int RPB = (kWave / LPR) * 4;
+static int launch_sddmm(const SddmmArgs &a, void *ws, size_t wsb, hipStream_t s) {
     constexpr int UNROLL = 4;
-    const int64_t n_rowblocks = (m + RPB - 1) / RPB;
-    if (n_rowblocks == 0) return COGDL_HIP_OK;
-    if (n_rowblocks > 0x7fffffff / kXcds) return COGDL_HIP_ERANGE;
-    dim3 grid(xcd_grid(make_xcd_map(n_rowblocks)));
-    if (k <= (int64_t)LPR * VEC)
-        hipLaunchKernelGGL((csr_sddmm_kernel<VEC, LPR, UNROLL, true>), grid, dim3(256), 0, s, rowptr, colind, d1, d2,
-                           out, m, (int)k, make_xcd_map(n_rowblocks));
-    else
-        hipLaunchKernelGGL((csr_sddmm_kernel<VEC, LPR, UNROLL, false>), grid, dim3(256), 0, s, rowptr, colind, d1,
-                           d2, out, m, (int)k, make_xcd_map(n_rowblocks));
-    return launch_status();
+    if (a.k <= (int64_t)LPR * VEC) {
+        SddmmOp<VEC, LPR, UNROLL, true> op{a.d1, a.d2, a.out, (int)a.k};
+        return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, 1, ws, wsb, s);
+    }
+    SddmmOp<VEC, LPR, UNROLL, false> op{a.d1, a.d2, a.out, (int)a.k};
+    return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, 1, ws, wsb, s);
 }
 
 template <int VEC>
-static int dispatch_sddmm(const int32_t *rowptr, const int32_t *colind, const float *d1, const float *d2,
-                          float *out, int64_t m, int64_t k, hipStream_t s) {
-    const int64_t need = (k + VEC - 1) / VEC;
-    if (need <= 8) return launch_sddmm<VEC, 8>(rowptr, colind, d1, d2, out, m, k, s);
-    if (need <= 16) return launch_sddmm<VEC, 16>(rowptr, colind, d1, d2, out, m, k, s);
-    if (need <= 32) return launch_sddmm<VEC, 32>(rowptr, colind, d1, d2, out, m, k, s);
-    return launch_sddmm<VEC, 64>(rowptr, colind, d1, d2, out, m, k, s);
+static int dispatch_sddmm(const SddmmArgs &a, void *ws, size_t wsb, hipStream_t s) {
+    const int64_t need = (a.k + VEC - 1) / VEC;
+    if (need <= 8) return launch_sddmm<VEC, 8>(a, ws, wsb, s);
+    if (need <= 16) return launch_sddmm<VEC, 16>(a, ws, wsb, s);
+    if (need <= 32) return launch_sddmm<VEC, 32>(a, ws, wsb, s);
+    return launch_sddmm<VEC, 64>(a, ws, wsb, s);
 }
 
 }  // namespace cogdl
 
 using namespace cogdl;
 
+// Scratch of the operators with per-EDGE outputs (csr_sddmm, mhsddmm): only the long-row chunk table.
+extern "C" size_t cogdl_hip_edge_op_workspace_bytes(int64_t nnz) { return rowreduce_workspace_bytes(nnz, 0); }
+
 extern "C" int cogdl_hip_csr_sddmm(const int32_t *rowptr, const int32_t *colind, const float *d1,
-                                   const float *d2, float *out, int64_t m, int64_t k, void *stream) {
-    if (m < 0 || k < 0) return COGDL_HIP_EINVAL;
+                                   const float *d2, float *out, int64_t m, int64_t k, int64_t nnz, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+    if (m < 0 || k < 0 || nnz < 0) return COGDL_HIP_EINVAL;
     if (m == 0) return COGDL_HIP_OK;
     if (!rowptr || !d1 || !d2 || !out) return COGDL_HIP_EINVAL;
-    if (k > 0x7fffffff) return COGDL_HIP_ERANGE;
+    if (k > 0x7fffffff || nnz > 0x7fffffff) return COGDL_HIP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
     if (k == 0) return COGDL_HIP_EINVAL;
-    if (k % 4 == 0 && aligned_to(d1, 16) && aligned_to(d2, 16)) return dispatch_sddmm<4>(rowptr, colind, d1, d2, out, m, k, s);
-    if (k % 2 == 0 && aligned_to(d1, 8) && aligned_to(d2, 8)) return dispatch_sddmm<2>(rowptr, colind, d1, d2, out, m, k, s);
-    return dispatch_sddmm<1>(rowptr, colind, d1, d2, out, m, k, s);
+    SddmmArgs a{rowptr, colind, d1, d2, out, m, k, nnz};
+    if (k % 4 == 0 && aligned_to(d1, 16) && aligned_to(d2, 16)) return dispatch_sddmm<4>(a, workspace, workspace_bytes, s);
+    if (k % 2 == 0 && aligned_to(d1, 8) && aligned_to(d2, 8)) return dispatch_sddmm<2>(a, workspace, workspace_bytes, s);
+    return dispatch_sddmm<1>(a, workspace, workspace_bytes, s);
 }

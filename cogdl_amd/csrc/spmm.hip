@@ -3,7 +3,7 @@
 // shared-memory colind tiles) with a wave64 design; the arithmetic follows the reference CPU
 // operator (cogdl/operators/spmm/spmm_cpu.cpp:24-35) so fp32 results are bit-identical to it.
 //
-// Work decomposition ("row groups"):
+// Work decomposition ("row groups", engine in rowreduce.h):
 //   * a group of LPR lanes owns one CSR row and VEC consecutive feature columns per lane, so one
 //     gathered neighbour row x[col,:] is ONE fully coalesced vector load of LPR*VEC*sizeof(T)
 //     bytes (F=128 fp32: 64 lanes x float2 = 512 B);
@@ -15,19 +15,12 @@
 //   * the gather is issued UNROLL rows at a time (independent loads in flight); accumulation
 //     stays strictly in CSR edge order per output element: acc = acc + w*x with separate fp32
 //     multiply and add -- no cross-lane reduction over edges;
-//   * workgroups are remapped so each XCD (private L2) walks a contiguous range of rows.
-// Skewed degree distributions ("long rows"): a row longer than `long_thresh` edges would
-// serialise one lane group for longer than the rest of the launch takes.  Such rows are skipped
-// by the main kernel (it records them per edge-chunk), their edges are processed chunk-parallel
-// by a second kernel (every group of a workgroup takes a contiguous slice of the chunk, partial
-// sums are combined in a FIXED order through LDS and a small fp32 workspace) and a third kernel
-// adds the per-chunk partials in chunk order.  No atomics: results are deterministic; rows
-// <= long_thresh keep the reference's exact summation order, longer rows differ from it only by
-// re-association (<= 1e-6 relative).
+//   * workgroups are remapped so each XCD (private L2) walks contiguous stripes of rows.
+// Skewed degree distributions: rows longer than the long-row threshold take the engine's chunk-parallel
+// path (piece sums combined in a FIXED order: deterministic; such rows differ from the reference only by
+// re-association, <= 1e-6 relative).
 // HBM-bound: algorithmic bytes per edge = 4 (colind) + s_w + F*s, per row 4 + F*s.
-#include <climits>
-
-#include "common.h"
+#include "rowreduce.h"
 
 namespace cogdl {
 
@@ -41,281 +34,120 @@ __device__ __forceinline__ float mul_add(float acc, float w, float v) {
     else return fmaf(w, v, acc);
 }
 
+// WMODE: 0 = unweighted (csr_spmm_no_edge_value), 1 = one weight per edge (val, dtype T),
+//        2 = multi-head (mhspmm): x is [N, H, fdim], weight att[e, head] in fp32, head = column / fdim.
+template <typename T, int VEC_, int LPR_, int UNROLL_, int WMODE, bool EXACT>
+struct SpmmOp {
+    static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_;
+    static constexpr bool kReduce = true;
+    const T *val;      // WMODE 1
+    const float *att;  // WMODE 2: [E, heads]
+    const T *x;
+    T *out;
+    int k;       // feature width (heads * fdim for WMODE 2)
+    int fdim;
+    int acc_mode;  // != 0: out += A x
+
+    struct Ctx {
+        int col0, heads, hd;
+        bool col_ok;
+        const T *xcol;
+    };
+    struct State { float acc[VEC]; };
+    struct LaneVals { float w; };
+    struct Batch {
+        float v[UNROLL][VEC];
+        float w[UNROLL];
+    };
+
+    __device__ __forceinline__ Ctx make_ctx(int l, int tile) const {
+        Ctx c;
+        c.col0 = (tile * LPR + l) * VEC;
+        c.col_ok = c.col0 < k;
+        const int cc = c.col_ok ? c.col0 : 0;  // lanes past the last column read column 0 and never store
+        c.heads = (WMODE == 2) ? k / fdim : 1;
+        c.hd = (WMODE == 2) ? cc / fdim : 0;
+        c.xcol = x + cc;
+        return c;
+    }
+    __device__ __forceinline__ void row_load(Ctx &, int64_t, bool) const {}
+    __device__ __forceinline__ void init_zero(State &s) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.acc[i] = 0.f;
+    }
+    __device__ __forceinline__ void init(const Ctx &c, State &s, int64_t row, bool ok) const {
+        init_zero(s);
+        if (acc_mode && ok && c.col_ok) load_vec<T, VEC>(out + row * (int64_t)k + c.col0, s.acc);
+    }
+    __device__ __forceinline__ void lane_load(const Ctx &, LaneVals &lv, int64_t e) const {
+        if constexpr (WMODE == 1) lv.w = to_f32<T>(val[e]);
+    }
+    __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t e, const LaneVals &lv,
+                                          int sub, int jj) const {
+        if constexpr (WMODE == 1) b.w[u] = group_bcast<LPR>(lv.w, sub, jj);
+        else if constexpr (WMODE == 2) b.w[u] = att[e * c.heads + c.hd];  // 4*H-byte run per edge
+        else b.w[u] = 1.f;
+        load_vec<T, VEC>(c.xcol + (int64_t)col * k, b.v[u]);
+    }
+    // Strictly in CSR order.  acc + 0*0 == acc exactly (acc is never -0), so masked slots are no-ops;
+    // selecting v (not only w) to zero keeps inf/nan out.
+    __device__ __forceinline__ void apply(const Ctx &, State &s, const Batch &b, int u, bool valid, int64_t,
+                                          int) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float vv = valid ? b.v[u][i] : 0.f;
+            if constexpr (WMODE != 0) s.acc[i] = mul_add<EXACT>(s.acc[i], valid ? b.w[u] : 0.f, vv);
+            else s.acc[i] = s.acc[i] + vv;
+        }
+    }
+    __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
+    __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
+        if (ok && c.col_ok) store_vec<T, VEC>(out + row * (int64_t)k + c.col0, s.acc);
+    }
+    __device__ __forceinline__ void pack(const State &s, float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) rec[i] = s.acc[i];
+    }
+    __device__ __forceinline__ void unpack(State &s, const float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.acc[i] = rec[i];
+    }
+    __device__ __forceinline__ void merge(State &a, const State &b) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) a.acc[i] += b.acc[i];
+    }
+};
+
 template <typename T>
 struct SpmmArgs {
     const int32_t *rowptr;
     const int32_t *colind;
-    const T *val;        // WMODE 1: one weight per edge
-    const float *att;    // WMODE 2: [E, heads] fp32
+    const T *val;
+    const float *att;
     const T *x;
     T *out;
-    int64_t m;
-    int k;               // feature width (heads * fdim for WMODE 2)
-    int fdim;
-    XcdMap rowblocks;
-    int long_thresh;     // rows with more edges take the chunk-parallel path (INT_MAX: disabled)
-    int acc_mode;        // != 0: out += A x
-    int rows_seq;        // consecutive rows walked one after the other by each lane group
-    int32_t *chunk_row;  // [n_chunks]: the LONG row that contains edge c*ch (the chunk's first edge), else -1.
-                         //   Every entry is (re)written by the main kernel on every launch: no memset needed.
-    float *partial;      // [n_chunks][2][k] fp32 partial sums (slot 0: the row owning the chunk's first edge,
-                         //   slot 1: the head of a long row that starts inside the chunk)
-    int64_t nnz;
+    int64_t m, nnz;
+    int k, fdim, acc_mode;
 };
 
-// WMODE: 0 = unweighted (csr_spmm_no_edge_value), 1 = one weight per edge (val, dtype T),
-//        2 = multi-head (mhspmm): x is [N, H, fdim], weight att[e, head] in fp32, head = column / fdim.
-// Accumulate edges [start, end) of one row into acc, in order.  All lanes of the group execute it.
 template <typename T, int VEC, int LPR, int UNROLL, int WMODE, bool EXACT>
-__device__ __forceinline__ void accumulate_edges(const SpmmArgs<T> &a, int start, int end, int sub, int l,
-                                                 const T *xcol, int heads, int hd, float (&acc)[VEC]) {
-    constexpr bool WEIGHTED = WMODE != 0;
-    for (int base = start; base < end; base += LPR) {
-        const int cnt = min(LPR, end - base);
-        int my_c = 0;
-        float my_w = 0.f;
-        if (l < cnt) {
-            my_c = a.colind[base + l];
-            if constexpr (WMODE == 1) my_w = to_f32<T>(a.val[base + l]);
-        }
-        for (int j = 0; j < cnt; j += UNROLL) {
-            float v[UNROLL][VEC];
-            float w[UNROLL];
-            // Issue all UNROLL gathers back to back (no branches: a masked tail slot re-reads
-            // the row's last valid neighbour, an L1 hit, and is zeroed by the selects below).
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int jj = min(j + u, cnt - 1);
-                int c;
-                if constexpr (LPR == kWave) {
-                    c = __builtin_amdgcn_readlane(my_c, jj);
-                    w[u] = (WMODE == 1) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), jj)) : 1.f;
-                } else {
-                    c = __shfl(my_c, sub * LPR + jj, kWave);
-                    w[u] = (WMODE == 1) ? __shfl(my_w, sub * LPR + jj, kWave) : 1.f;
-                }
-                if constexpr (WMODE == 2) w[u] = a.att[(int64_t)(base + jj) * heads + hd];  // 4*H-byte run per edge
-                load_vec<T, VEC>(xcol + (int64_t)c * a.k, v[u]);
-            }
-            // Strictly in CSR order.  acc + 0*0 == acc exactly (acc is never -0), so masked
-            // slots are no-ops; selecting v (not only w) to zero keeps inf/nan out.
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const bool valid = (j + u) < cnt;
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    const float vv = valid ? v[u][i] : 0.f;
-                    if constexpr (WEIGHTED) acc[i] = mul_add<EXACT>(acc[i], valid ? w[u] : 0.f, vv);
-                    else acc[i] = acc[i] + vv;
-                }
-            }
-        }
-    }
-}
-
-template <typename T, int VEC, int LPR, int UNROLL, int WMODE, bool EXACT>
-__global__ __launch_bounds__(256) void csr_spmm_rowgroup_kernel(const SpmmArgs<T> a) {
-    constexpr int RPW = kWave / LPR;  // row groups per wave
-    constexpr int GPB = RPW * 4;      // row groups per 256-thread workgroup
-    const int64_t rb = xcd_remap(blockIdx.x, a.rowblocks);
-    if (rb < 0) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-    const int sub = lane / LPR;
-    const int l = lane % LPR;
-    const int col0 = ((int)blockIdx.y * LPR + l) * VEC;
-    const bool col_ok = col0 < a.k;
-    const int cc = col_ok ? col0 : 0;  // lanes past the last column read column 0 and never store
-    const int heads = (WMODE == 2) ? a.k / a.fdim : 1;
-    const int hd = (WMODE == 2) ? cc / a.fdim : 0;
-    const int64_t row0 = (rb * GPB + wave * RPW + sub) * a.rows_seq;
-
-    for (int rs = 0; rs < a.rows_seq; ++rs) {
-        const int64_t row = row0 + rs;
-        int start = 0, end = 0;
-        if (row < a.m) {
-            start = a.rowptr[row];
-            end = a.rowptr[row + 1];
-        }
-        if constexpr (LPR == kWave) {  // whole wave on one row: make the loop bounds scalar
-            start = __builtin_amdgcn_readfirstlane(start);
-            end = __builtin_amdgcn_readfirstlane(end);
-        }
-        if (a.chunk_row && blockIdx.y == 0 && end > start) {
-            // Own the chunk_row entries of the chunks whose first edge lies in this row: c*ch in [start, end).
-            const int ch = a.long_thresh;
-            const int32_t mark = (end - start > ch) ? (int32_t)row : -1;
-            for (int c = (start + ch - 1) / ch + l; (int64_t)c * ch < end; c += LPR) a.chunk_row[c] = mark;
-        }
-        if (end - start > a.long_thresh) continue;  // long row: the chunk-parallel kernels compute it
-        float acc[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-        if (a.acc_mode && row < a.m && col_ok) load_vec<T, VEC>(a.out + row * (int64_t)a.k + col0, acc);
-        accumulate_edges<T, VEC, LPR, UNROLL, WMODE, EXACT>(a, start, end, sub, l, a.x + cc, heads, hd, acc);
-        if (row < a.m && col_ok) store_vec<T, VEC>(a.out + row * (int64_t)a.k + col0, acc);
-    }
-}
-
-// Chunk c = edges [c*ch, (c+1)*ch).  A long row (> ch edges) intersecting it is either the row owning the
-// chunk's first edge (chunk_row[c], slot 0) or a row that starts inside the chunk -- which then owns the
-// NEXT chunk's first edge (chunk_row[c+1], slot 1).  For each piece the 256/LPR groups of the workgroup take
-// contiguous slices, group partials are summed in group order through LDS and written to partial[c][slot][:].
-// Workgroups own contiguous runs of chunks and skip runs without long rows after one coalesced look.
-template <typename T, int VEC, int LPR, int UNROLL, int WMODE>
-__global__ __launch_bounds__(256) void csr_spmm_longrow_partial_kernel(const SpmmArgs<T> a, int64_t n_chunks,
-                                                                       int chunks_per_block) {
-    constexpr int G = 256 / LPR;  // groups per workgroup
-    __shared__ float red[G][LPR * VEC];
-    __shared__ int any_long;
-    const int64_t c_begin = (int64_t)blockIdx.x * chunks_per_block;
-    const int64_t c_end = min(c_begin + chunks_per_block, n_chunks);
-    if (threadIdx.x == 0) any_long = 0;
-    __syncthreads();
-    for (int64_t c = c_begin + threadIdx.x; c <= c_end && c < n_chunks; c += blockDim.x)  // includes c_end: slot 1
-        if (a.chunk_row[c] >= 0) any_long = 1;
-    __syncthreads();
-    if (!any_long) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int sub = lane / LPR;
-    const int l = lane % LPR;
-    const int g = (threadIdx.x >> 6) * (kWave / LPR) + sub;
-    const int col0 = ((int)blockIdx.y * LPR + l) * VEC;
-    const bool col_ok = col0 < a.k;
-    const int cc = col_ok ? col0 : 0;
-    const int heads = (WMODE == 2) ? a.k / a.fdim : 1;
-    const int hd = (WMODE == 2) ? cc / a.fdim : 0;
-    const int ch = a.long_thresh;
-    for (int64_t c = c_begin; c < c_end; ++c) {
-        for (int slot = 0; slot < 2; ++slot) {
-            int32_t row = -1;  // workgroup-uniform
-            if (slot == 0) row = a.chunk_row[c];
-            else if (c + 1 < n_chunks) {
-                row = a.chunk_row[c + 1];
-                if (row >= 0 && (int64_t)a.rowptr[row] <= c * ch) row = -1;  // same row as slot 0, not a new head
-            }
-            if (row < 0) continue;
-            const int lo = max(a.rowptr[row], (int)(c * ch));
-            const int hi = (int)min((int64_t)a.rowptr[row + 1], (c + 1) * ch);
-            const int per = (hi - lo + G - 1) / G;
-            int s = min(lo + g * per, hi), e = min(s + per, hi);
-            if constexpr (LPR == kWave) {  // one wave per slice: keep the loop bounds scalar
-                s = __builtin_amdgcn_readfirstlane(s);
-                e = __builtin_amdgcn_readfirstlane(e);
-            }
-            float acc[VEC];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-            accumulate_edges<T, VEC, LPR, UNROLL, WMODE, true>(a, s, e, sub, l, a.x + cc, heads, hd, acc);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) red[g][l * VEC + i] = acc[i];
-            __syncthreads();
-            if (g == 0 && col_ok) {
-                float *dst = a.partial + ((int64_t)(2 * c + slot)) * a.k + col0;
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    float sum = red[0][l * VEC + i];
-                    for (int q = 1; q < G; ++q) sum += red[q][l * VEC + i];
-                    dst[i] = sum;
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// For every long row add its per-chunk partials in chunk order and write (or accumulate into) the output
-// row.  The row is combined by the wave that finds it at its FIRST full chunk (the row's head piece, if any,
-// sits in slot 1 of the chunk before).
-template <typename T>
-__global__ __launch_bounds__(256) void csr_spmm_longrow_combine_kernel(const SpmmArgs<T> a, int64_t n_chunks,
-                                                                       int chunks_per_block) {
-    __shared__ int any_long;
-    const int64_t c_begin = (int64_t)blockIdx.x * chunks_per_block;
-    const int64_t c_end = min(c_begin + chunks_per_block, n_chunks);
-    if (threadIdx.x == 0) any_long = 0;
-    __syncthreads();
-    for (int64_t c = c_begin + threadIdx.x; c < c_end; c += blockDim.x)
-        if (a.chunk_row[c] >= 0) any_long = 1;
-    __syncthreads();
-    if (!any_long) return;
-    const int ch = a.long_thresh;
-    const int lane = threadIdx.x & (kWave - 1);
-    for (int64_t c = c_begin + (threadIdx.x >> 6); c < c_end; c += 4) {  // one wave per chunk
-        const int32_t row = a.chunk_row[c];
-        if (row < 0) continue;
-        const int start = a.rowptr[row], end = a.rowptr[row + 1];
-        if ((int64_t)(start + ch - 1) / ch != c) continue;  // not the row's first owned chunk
-        const int64_t c_last = (end - 1) / ch;
-        const bool head = (int64_t)start != c * ch;          // a head piece lives in chunk c-1, slot 1
-        for (int col = lane; col < a.k; col += kWave) {
-            float acc = a.acc_mode ? to_f32<T>(a.out[(int64_t)row * a.k + col]) : 0.f;
-            if (head) acc += a.partial[(2 * (c - 1) + 1) * (int64_t)a.k + col];
-            for (int64_t q = c; q <= c_last; ++q) acc += a.partial[(2 * q) * (int64_t)a.k + col];
-            a.out[(int64_t)row * a.k + col] = from_f32<T>(acc);
-        }
-    }
-}
-
-static inline int64_t n_chunks_for(int64_t nnz, int thresh) { return (nnz + thresh - 1) / thresh; }
-
-// Threshold above which a row is split: the sequential time of a row of T edges (~T/UNROLL gather
-// round trips) should stay a small fraction of the whole launch (~nnz / 13 GEdges/s).
-static inline int pick_long_thresh(int64_t nnz) {
-    if (g_tuning[kTuneLongThresh] > 0) return g_tuning[kTuneLongThresh];
-    int t = 256;
-    while (t < 4096 && (int64_t)t * 16384 < nnz) t <<= 1;
-    return t;
-}
-
-static inline size_t chunk_row_bytes(int64_t n_chunks) { return ((size_t)(n_chunks + 1) * sizeof(int32_t) + 255) / 256 * 256; }
-
-template <typename T, int VEC, int LPR, int UNROLL, int WMODE, bool EXACT>
-static int launch_rowgroup(SpmmArgs<T> a, void *workspace, size_t workspace_bytes, hipStream_t stream) {
-    a.rows_seq = std::max(1, std::min(64, g_tuning[kTuneRowsSeq]));
-    const int64_t RPB = (kWave / LPR) * 4 * a.rows_seq;
-    const int64_t n_rowblocks = (a.m + RPB - 1) / RPB;
+static int launch_spmm(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) {
+    SpmmOp<T, VEC, LPR, UNROLL, WMODE, EXACT> op{a.val, a.att, a.x, a.out, a.k, a.fdim, a.acc_mode};
     const int64_t tiles = ((int64_t)a.k + (int64_t)LPR * VEC - 1) / ((int64_t)LPR * VEC);
-    if (n_rowblocks == 0) return COGDL_HIP_OK;
-    if (n_rowblocks > 0x7fffffff / (kXcds * 64) || tiles > 65535) return COGDL_HIP_ERANGE;
-    a.rowblocks = make_xcd_map(n_rowblocks);
-    a.long_thresh = INT_MAX;
-    a.chunk_row = nullptr;
-    int64_t n_chunks = 0;
-    if (workspace && a.nnz > 0) {
-        const int t = pick_long_thresh(a.nnz);
-        n_chunks = n_chunks_for(a.nnz, t);
-        const size_t need = chunk_row_bytes(n_chunks) + (size_t)n_chunks * 2 * a.k * sizeof(float);
-        if (workspace_bytes < need) return COGDL_HIP_EWORKSPACE;
-        if (!aligned_to(workspace, 256)) return COGDL_HIP_EALIGN;
-        a.long_thresh = t;
-        a.chunk_row = (int32_t *)workspace;
-        a.partial = (float *)((char *)workspace + chunk_row_bytes(n_chunks));
-    }
-    dim3 grid(xcd_grid(a.rowblocks), (unsigned)tiles);
-    hipLaunchKernelGGL((csr_spmm_rowgroup_kernel<T, VEC, LPR, UNROLL, WMODE, EXACT>), grid, dim3(256), 0, stream, a);
-    if (n_chunks > 0) {
-        // a bounded number of workgroups, each owning a contiguous run of chunks (cheap to skip when no row is long)
-        const int64_t max_wg = std::max(64, g_tuning[kTuneLongGrid]);
-        const int cpb = (int)((n_chunks + max_wg - 1) / max_wg);
-        const unsigned gx = (unsigned)((n_chunks + cpb - 1) / cpb);
-        hipLaunchKernelGGL((csr_spmm_longrow_partial_kernel<T, VEC, LPR, UNROLL, WMODE>), dim3(gx, (unsigned)tiles),
-                           dim3(256), 0, stream, a, n_chunks, cpb);
-        hipLaunchKernelGGL((csr_spmm_longrow_combine_kernel<T>), dim3(gx), dim3(256), 0, stream, a, n_chunks, cpb);
-    }
-    return launch_status();
+    return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, tiles, ws, wsb, s);
 }
 
 // (VEC, LPR) choice: as many lanes per row as the row has VEC-wide columns (whole-wave rows are the
 // fastest: scalar column broadcast, no inter-row divergence inside a wave), VEC as small as that allows.
 template <typename T, int VEC, int WMODE>
-static int dispatch_lpr(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) {
-    const int64_t need = ((int64_t)a.k + VEC - 1) / VEC;
-    if (need <= 4) return launch_rowgroup<T, VEC, 4, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
-    if (need <= 8) return launch_rowgroup<T, VEC, 8, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
-    if (need <= 16) return launch_rowgroup<T, VEC, 16, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
-    if (need <= 32) return launch_rowgroup<T, VEC, 32, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
-    return launch_rowgroup<T, VEC, 64, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
+static int dispatch_lpr(const SpmmArgs<T> &a, int lpr, void *ws, size_t wsb, hipStream_t s) {
+    switch (lpr) {
+        case 4: return launch_spmm<T, VEC, 4, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
+        case 8: return launch_spmm<T, VEC, 8, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
+        case 16: return launch_spmm<T, VEC, 16, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
+        case 32: return launch_spmm<T, VEC, 32, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
+        default: return launch_spmm<T, VEC, 64, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
+    }
 }
 
 // Vector width and lanes per row.  Every lane's VEC columns must stay inside one row (k % VEC == 0), inside
@@ -323,22 +155,38 @@ static int dispatch_lpr(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t 
 // narrow rows (k/4 <= 16 lanes) are fastest with 16-byte lanes and several rows per wave (less per-row
 // overhead); from 64 columns up a whole wave per row wins (scalar column broadcast, no intra-wave length
 // divergence), so the vector is narrowed until the row fills 64 lanes.
+// `align` = guaranteed alignment in bytes of x and out (the workspace query assumes 16: allocator memory).
+RowGeometry spmm_geometry(int64_t k, int64_t unit, int elem_bytes, int align) {
+    const int maxv = 16 / elem_bytes;
+    auto legal = [&](int v) { return v <= maxv && unit % v == 0 && align % (v * elem_bytes) == 0; };
+    int vec = 1;
+    while (vec * 2 <= maxv && legal(vec * 2)) vec *= 2;  // widest legal
+    while (vec > 1 && (vec / 2) * elem_bytes >= 4 && k / vec > 16 && k / (vec / 2) <= kWave) vec /= 2;
+    const int64_t need = (k + vec - 1) / vec;
+    int lpr = 4;
+    while (lpr < kWave && lpr < need) lpr <<= 1;
+    RowGeometry g;
+    g.vec = vec;
+    g.lpr = lpr;
+    g.tiles = (k + (int64_t)lpr * vec - 1) / ((int64_t)lpr * vec);
+    return g;
+}
+
+static int pointer_alignment(const void *a, const void *b) {
+    const uintptr_t v = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b);
+    return (v % 16 == 0) ? 16 : (v % 8 == 0) ? 8 : (v % 4 == 0) ? 4 : 2;
+}
+
 template <typename T, int WMODE>
 static int spmm_auto(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) {
     constexpr int MAXV = 16 / sizeof(T);
-    const int64_t unit = (WMODE == 2) ? a.fdim : a.k;
-    auto legal = [&](int v) {
-        return v <= MAXV && unit % v == 0 && aligned_to(a.x, v * sizeof(T)) && aligned_to(a.out, v * sizeof(T));
-    };
-    int vec = 1;
-    while (vec * 2 <= MAXV && legal(vec * 2)) vec *= 2;                                   // widest legal
-    while (vec > 1 && (vec / 2) * sizeof(T) >= 4 && (int64_t)a.k / vec > 16 && (int64_t)a.k / (vec / 2) <= kWave) vec /= 2;
-    switch (vec) {
+    const RowGeometry g = spmm_geometry(a.k, (WMODE == 2) ? a.fdim : a.k, (int)sizeof(T), pointer_alignment(a.x, a.out));
+    switch (g.vec) {
         case 8:
-            if constexpr (MAXV >= 8) return dispatch_lpr<T, 8, WMODE>(a, ws, wsb, s);
-        case 4: return dispatch_lpr<T, 4, WMODE>(a, ws, wsb, s);
-        case 2: return dispatch_lpr<T, 2, WMODE>(a, ws, wsb, s);
-        default: return dispatch_lpr<T, 1, WMODE>(a, ws, wsb, s);
+            if constexpr (MAXV >= 8) return dispatch_lpr<T, 8, WMODE>(a, g.lpr, ws, wsb, s);
+        case 4: return dispatch_lpr<T, 4, WMODE>(a, g.lpr, ws, wsb, s);
+        case 2: return dispatch_lpr<T, 2, WMODE>(a, g.lpr, ws, wsb, s);
+        default: return dispatch_lpr<T, 1, WMODE>(a, g.lpr, ws, wsb, s);
     }
 }
 
@@ -346,9 +194,7 @@ template <typename T>
 static int spmm_typed(const int32_t *rowptr, const int32_t *colind, const void *val, const void *x, void *out,
                       int64_t m, int64_t k, int64_t nnz, int acc_mode, void *ws, size_t wsb, hipStream_t s) {
     if (!aligned_to(x, sizeof(T)) || !aligned_to(out, sizeof(T))) return COGDL_HIP_EALIGN;
-    SpmmArgs<T> a{};
-    a.rowptr = rowptr; a.colind = colind; a.val = (const T *)val; a.att = nullptr;
-    a.x = (const T *)x; a.out = (T *)out; a.m = m; a.k = (int)k; a.fdim = (int)k; a.nnz = nnz; a.acc_mode = acc_mode;
+    SpmmArgs<T> a{rowptr, colind, (const T *)val, nullptr, (const T *)x, (T *)out, m, nnz, (int)k, (int)k, acc_mode};
     return val ? spmm_auto<T, 1>(a, ws, wsb, s) : spmm_auto<T, 0>(a, ws, wsb, s);
 }
 
@@ -379,23 +225,29 @@ template <typename T>
 static int mhspmm_typed(const int32_t *rowptr, const int32_t *colind, const float *att, const void *feat, void *out,
                         int64_t v, int64_t h, int64_t f, int64_t nnz, void *ws, size_t wsb, hipStream_t s) {
     if (!aligned_to(feat, sizeof(T)) || !aligned_to(out, sizeof(T))) return COGDL_HIP_EALIGN;
-    SpmmArgs<T> a{};
-    a.rowptr = rowptr; a.colind = colind; a.val = nullptr; a.att = att;
-    a.x = (const T *)feat; a.out = (T *)out; a.m = v; a.k = (int)(h * f); a.fdim = (int)f; a.nnz = nnz; a.acc_mode = 0;
+    SpmmArgs<T> a{rowptr, colind, nullptr, att, (const T *)feat, (T *)out, v, nnz, (int)(h * f), (int)f, 0};
     return spmm_auto<T, 2>(a, ws, wsb, s);
 }
+
+static int elem_bytes_of(int dtype) { return dtype == COGDL_HIP_F32 ? 4 : 2; }
 
 }  // namespace cogdl
 
 using namespace cogdl;
 
-extern "C" size_t cogdl_hip_csr_spmm_workspace_bytes(int64_t nnz, int64_t k) {
+extern "C" size_t cogdl_hip_csr_spmm_workspace_bytes(int64_t nnz, int64_t k, int dtype) {
     if (nnz <= 0 || k <= 0) return 0;
-    const int64_t n_chunks = n_chunks_for(nnz, pick_long_thresh(nnz));
-    return chunk_row_bytes(n_chunks) + (size_t)n_chunks * 2 * (size_t)k * sizeof(float);
+    const RowGeometry g = spmm_geometry(k, k, elem_bytes_of(dtype), 16);
+    return rowreduce_workspace_bytes(nnz, g.tiles * g.vec * g.lpr);
 }
 
-extern "C" int cogdl_hip_csr_spmm_long_row_threshold(int64_t nnz) { return pick_long_thresh(nnz); }
+extern "C" size_t cogdl_hip_mhspmm_workspace_bytes(int64_t nnz, int64_t h, int64_t f, int dtype) {
+    if (nnz <= 0 || h <= 0 || f <= 0) return 0;
+    const RowGeometry g = spmm_geometry(h * f, f, elem_bytes_of(dtype), 16);
+    return rowreduce_workspace_bytes(nnz, g.tiles * g.vec * g.lpr);
+}
+
+extern "C" int cogdl_hip_long_row_threshold(int64_t nnz) { return pick_long_thresh(nnz); }
 
 extern "C" int cogdl_hip_csr_spmm(const int32_t *rowptr, const int32_t *colind, const void *val, const void *x,
                                   void *out, int64_t m, int64_t k, int64_t nnz, int dtype, void *workspace,
@@ -440,11 +292,14 @@ extern "C" int cogdl_hip_csr_spmm_variant(const int32_t *rowptr, const int32_t *
     if (dtype != COGDL_HIP_F32 || !val) return COGDL_HIP_EDTYPE;
     if (k % 4 != 0 || !aligned_to(x, 16) || !aligned_to(out, 16)) return COGDL_HIP_EALIGN;
     hipStream_t s = (hipStream_t)stream;
-    SpmmArgs<float> a{};
-    a.rowptr = rowptr; a.colind = colind; a.val = (const float *)val; a.x = (const float *)x; a.out = (float *)out;
-    a.m = m; a.k = (int)k; a.fdim = (int)k; a.nnz = nnz;
-#define V(id, VEC, LPR, UNR, EX) \
-    case id: return launch_rowgroup<float, VEC, LPR, UNR, 1, EX>(a, workspace, workspace_bytes, s);
+    SpmmArgs<float> a{rowptr, colind, (const float *)val, nullptr, (const float *)x, (float *)out, m, nnz, (int)k, (int)k, 0};
+    // The variants may need more workspace than the automatic geometry: only pass it on when it is big enough.
+#define V(id, VEC, LPR, UNR, EX)                                                                                   \
+    case id: {                                                                                                     \
+        const int64_t tiles = (k + (int64_t)LPR * VEC - 1) / ((int64_t)LPR * VEC);                                  \
+        const bool fits = workspace && workspace_bytes >= rowreduce_workspace_bytes(nnz, tiles * VEC * LPR);        \
+        return launch_spmm<float, VEC, LPR, UNR, 1, EX>(a, fits ? workspace : nullptr, fits ? workspace_bytes : 0, s); \
+    }
     switch (variant) {
         V(0, 4, 32, 8, true)
         V(1, 4, 32, 4, true)

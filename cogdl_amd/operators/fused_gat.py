@@ -28,11 +28,13 @@ def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat):
     out = torch.empty((v, h, f), dtype=feat.dtype, device=dev)
     edge_max = torch.empty((v, h), dtype=torch.float32, device=dev)
     edge_sum = torch.empty((v, h), dtype=torch.float32, device=dev)
+    nnz, code = col_ind.numel(), _lib.DTYPE_CODE[feat.dtype]
+    ws, ws_bytes = _lib.workspace("cogdl_hip_gat_fwd_workspace_bytes", dev, nnz, h, f, code)
     with torch.cuda.device(dev):
         rc = _lib.hip().cogdl_hip_gat_fwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(attn_row),
                                           _lib.ptr(attn_col), _lib.ptr(feat), float(negative_slope), _lib.ptr(out),
-                                          _lib.ptr(edge_max), _lib.ptr(edge_sum), v, h, f,
-                                          _lib.DTYPE_CODE[feat.dtype], _lib.stream_of(feat))
+                                          _lib.ptr(edge_max), _lib.ptr(edge_sum), v, h, f, nnz, code,
+                                          _lib.ptr(ws), ws_bytes, _lib.stream_of(feat))
     _lib.check(rc, "gat_fwd")
     return out, edge_max, edge_sum
 
@@ -74,14 +76,15 @@ class FusedGATFunction(torch.autograd.Function):
         grad_ar = torch.empty((v, h), dtype=torch.float32, device=dev)
         grad_ac = torch.empty((n_src, h), dtype=torch.float32, device=dev)
         lib = _lib.hip()
-        ws_bytes = lib.cogdl_hip_gat_bwd_workspace_bytes(v, h)
+        nnz = col_ind.numel()
+        ws_bytes = lib.cogdl_hip_gat_bwd_workspace_bytes(v, h, f, nnz)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             rc = lib.cogdl_hip_gat_bwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(plan.colptr),
                                        _lib.ptr(plan.rowind), _lib.ptr(ar), _lib.ptr(ac), _lib.ptr(feat),
                                        ctx.negative_slope, _lib.ptr(edge_max), _lib.ptr(edge_sum), _lib.ptr(o),
                                        _lib.ptr(g), _lib.ptr(grad_feat), _lib.ptr(grad_ar), _lib.ptr(grad_ac),
-                                       _lib.ptr(ws), ws_bytes, v, n_src, h, f, _lib.stream_of(g))
+                                       _lib.ptr(ws), ws_bytes, v, n_src, h, f, nnz, _lib.stream_of(g))
         if rc == 1:  # COGDL_HIP_EINVAL: shape outside the fused backward's coverage
             grad_feat, grad_ar, grad_ac = _unfused_backward(ctx.negative_slope, row_ptr, col_ind, in_feat, attn_row,
                                                             attn_col, grad_out)

@@ -27,7 +27,8 @@ def mhspmm_raw(rowptr, colind, att, feat):
     if att.shape != (colind.numel(), h):
         raise _lib.BackendError("attention must be [E, H] = %s, got %s" % ((colind.numel(), h), tuple(att.shape)))
     out = torch.empty((v, h, f), dtype=feat.dtype, device=dev)
-    ws, ws_bytes = _lib.spmm_workspace(colind.numel(), h * f, dev)
+    ws, ws_bytes = _lib.workspace("cogdl_hip_mhspmm_workspace_bytes", dev, colind.numel(), h, f,
+                                  _lib.DTYPE_CODE[feat.dtype])
     with torch.cuda.device(dev):
         rc = _lib.hip().cogdl_hip_mhspmm(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(att), _lib.ptr(feat),
                                          _lib.ptr(out), v, h, f, colind.numel(), _lib.DTYPE_CODE[feat.dtype],
@@ -40,10 +41,12 @@ def mhsddmm_raw(rowptr, colind, grad, feat):
     dev = _lib.require_cuda(rowptr, colind, grad, feat)
     grad, feat = grad.contiguous().float(), feat.contiguous().float()
     v, (_, h, f) = rowptr.numel() - 1, feat.shape
-    out = torch.empty((colind.numel(), h), dtype=torch.float32, device=dev)
+    nnz = colind.numel()
+    out = torch.empty((nnz, h), dtype=torch.float32, device=dev)
+    ws, ws_bytes = _lib.workspace("cogdl_hip_edge_op_workspace_bytes", dev, nnz)
     with torch.cuda.device(dev):
         rc = _lib.hip().cogdl_hip_mhsddmm(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(grad), _lib.ptr(feat),
-                                          _lib.ptr(out), v, h, f, _lib.stream_of(feat))
+                                          _lib.ptr(out), v, h, f, nnz, _lib.ptr(ws), ws_bytes, _lib.stream_of(feat))
     _lib.check(rc, "mhsddmm")
     return out
 

@@ -17,9 +17,12 @@ def scatter_max_fp(rowptr, colind, feat):
     m, k = rowptr.numel() - 1, feat.shape[1]
     out = torch.empty((m, k), dtype=torch.float32, device=dev)
     max_id = torch.empty((m, k), dtype=torch.int32, device=dev)
+    nnz = colind.numel()
+    ws, ws_bytes = _lib.workspace("cogdl_hip_scatter_max_workspace_bytes", dev, nnz, k)
     with torch.cuda.device(dev):
         rc = _lib.hip().cogdl_hip_scatter_max_fwd(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(feat), _lib.ptr(out),
-                                                  _lib.ptr(max_id), m, k, _lib.stream_of(feat))
+                                                  _lib.ptr(max_id), m, k, nnz, _lib.ptr(ws), ws_bytes,
+                                                  _lib.stream_of(feat))
     _lib.check(rc, "scatter_max_fwd")
     return out, max_id
 

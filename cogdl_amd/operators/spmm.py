@@ -56,8 +56,9 @@ def csr_spmm_raw(rowptr, colind, val, x, variant=-1, out=None, split_long_rows=T
     else:
         out = torch.empty((m, k), dtype=x.dtype, device=dev)
     lib = _lib.hip()
-    ws, ws_bytes = _lib.spmm_workspace(nnz, k, dev) if split_long_rows else (None, 0)
     code = _lib.DTYPE_CODE[x.dtype]
+    ws, ws_bytes = (_lib.workspace("cogdl_hip_csr_spmm_workspace_bytes", dev, nnz, k, code) if split_long_rows
+                    else (None, 0))
     with torch.cuda.device(dev):
         if KERNEL_EVENTS is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -82,10 +83,12 @@ def csr_sddmm_raw(rowptr, colind, d1, d2):
     dev = _lib.require_cuda(rowptr, colind, d1, d2)
     d1, d2 = d1.contiguous().float(), d2.contiguous().float()
     m, k = rowptr.numel() - 1, d1.shape[1]
-    out = torch.empty(colind.numel(), dtype=torch.float32, device=dev)
+    nnz = colind.numel()
+    out = torch.empty(nnz, dtype=torch.float32, device=dev)
+    ws, ws_bytes = _lib.workspace("cogdl_hip_edge_op_workspace_bytes", dev, nnz)
     with torch.cuda.device(dev):
         rc = _lib.hip().cogdl_hip_csr_sddmm(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(d1), _lib.ptr(d2),
-                                            _lib.ptr(out), m, k, _lib.stream_of(d1))
+                                            _lib.ptr(out), m, k, nnz, _lib.ptr(ws), ws_bytes, _lib.stream_of(d1))
     _lib.check(rc, "csr_sddmm")
     return out
 

@@ -133,3 +133,19 @@ def random_csr(m, n_cols, nnz_per_row, seed=0, weighted=True, ragged=True):
     colind = torch.randint(0, n_cols, (nnz,), generator=g)
     w = torch.randn(nnz, generator=g) if weighted else None
     return CSRGraph(rowptr.int(), colind.int(), w, m, n_cols)
+
+
+def hub_csr(m, n_cols, base_deg=5, hubs=((3, 129), (4, 1000), (17, 5000), (18, 257), (40, 128)), seed=0, weighted=True):
+    """Short ragged rows plus a few hub rows of given lengths (row id, degree): exercises the chunk-parallel
+    long-row path (hubs longer than the threshold, next to each other, aligned or not with chunk borders)."""
+    g = torch.Generator().manual_seed(seed)
+    deg = torch.randint(0, 2 * base_deg + 1, (m,), generator=g)
+    for r, d in hubs:
+        if r < m:
+            deg[r] = d
+    rowptr = torch.zeros(m + 1, dtype=torch.long)
+    torch.cumsum(deg, 0, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    colind = torch.randint(0, n_cols, (nnz,), generator=g)
+    w = torch.randn(nnz, generator=g) if weighted else None
+    return CSRGraph(rowptr.int(), colind.int(), w, m, n_cols)

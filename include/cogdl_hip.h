@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define COGDL_HIP_ABI_VERSION 1
+#define COGDL_HIP_ABI_VERSION 2
 
 /* Exported with default visibility (the library is built -fvisibility=hidden). */
 #if defined(COGDL_HIP_BUILD)
@@ -71,14 +71,16 @@ COGDL_API int cogdl_hip_set_tuning(int key, int value);
  * fp32 multiply and add -- bit-identical to the reference CPU path as CogDL builds it.
  * f16/bf16: val has the dtype of x; products and sums are fp32, rounded once on store.
  * x: [n_src, k], out: [m, k]; rowptr: [m+1]; colind/val: [nnz], nnz == rowptr[m].
- * workspace (optional, device, 256-B aligned, >= cogdl_hip_csr_spmm_workspace_bytes(nnz, k)):
- * enables the chunk-parallel treatment of rows longer than
- * cogdl_hip_csr_spmm_long_row_threshold(nnz) edges (power-law graphs); such rows are summed
- * as fixed-order partial sums (deterministic, re-associated).  With workspace == NULL every
- * row is summed strictly sequentially.
+ * workspace (optional, device, 256-B aligned, >= cogdl_hip_csr_spmm_workspace_bytes(nnz, k, dtype)):
+ * enables the chunk-parallel treatment of rows longer than cogdl_hip_long_row_threshold(nnz)
+ * edges (power-law graphs); such rows are summed as fixed-order partial sums (deterministic,
+ * re-associated).  With workspace == NULL every row is summed strictly sequentially.
+ * The same convention holds for every row-wise operator below: `workspace` is optional scratch
+ * for the long-row path (csrc/rowreduce.h), sized by the operator's *_workspace_bytes query
+ * (pure host functions; they assume 16-byte aligned operands, as every allocator provides).
  * ------------------------------------------------------------------------------------- */
-COGDL_API size_t cogdl_hip_csr_spmm_workspace_bytes(int64_t nnz, int64_t k);
-COGDL_API int cogdl_hip_csr_spmm_long_row_threshold(int64_t nnz);
+COGDL_API size_t cogdl_hip_csr_spmm_workspace_bytes(int64_t nnz, int64_t k, int dtype);
+COGDL_API int cogdl_hip_long_row_threshold(int64_t nnz);
 COGDL_API int cogdl_hip_csr_spmm(const int32_t *rowptr, const int32_t *colind, const void *val,
                        const void *x, void *out, int64_t m, int64_t k, int64_t nnz, int dtype,
                        void *workspace, size_t workspace_bytes, void *stream);
@@ -120,8 +122,11 @@ COGDL_API int cogdl_hip_gather_rows(const int32_t *perm, const void *src, void *
  * csr_sddmm: out[e] = < d1[row(e),:], d2[colind[e],:] >      (gradient of edge weights)
  * Replaces sddmm.csr_sddmm (operators/spmm/sddmm.cpp:47-70, sddmm_kernel.cu:249-417,451-476).
  * ------------------------------------------------------------------------------------- */
+/* Scratch of the operators with per-EDGE outputs (csr_sddmm, mhsddmm): the long-row chunk table only. */
+COGDL_API size_t cogdl_hip_edge_op_workspace_bytes(int64_t nnz);
 COGDL_API int cogdl_hip_csr_sddmm(const int32_t *rowptr, const int32_t *colind, const float *d1,
-                        const float *d2, float *out, int64_t m, int64_t k, void *stream);
+                        const float *d2, float *out, int64_t m, int64_t k, int64_t nnz, void *workspace,
+                        size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * edge_softmax: per (destination row, head) softmax over the row's edges; values [E,H].
@@ -129,25 +134,28 @@ COGDL_API int cogdl_hip_csr_sddmm(const int32_t *rowptr, const int32_t *colind, 
  * (operators/edge_softmax/edge_softmax.cc:16-49, edge_softmax.cu:7-60,63-98).
  * Any H >= 1 (the reference's block (32,H) caps H at 32).
  * ------------------------------------------------------------------------------------- */
+COGDL_API size_t cogdl_hip_edge_softmax_workspace_bytes(int64_t nnz, int64_t h);
 COGDL_API int cogdl_hip_edge_softmax_fwd(const int32_t *rowptr, const float *values, float *out, int64_t m,
-                               int64_t nnz, int64_t h, void *stream);
+                               int64_t nnz, int64_t h, void *workspace, size_t workspace_bytes, void *stream);
 COGDL_API int cogdl_hip_edge_softmax_bwd(const int32_t *rowptr, const float *softmax, const float *grad,
-                               float *grad_in, int64_t m, int64_t nnz, int64_t h, void *stream);
+                               float *grad_in, int64_t m, int64_t nnz, int64_t h, void *workspace,
+                               size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * mhspmm:  out[v,h,:] = sum_e att[e,h] * feat[colind[e],h,:]     feat [n_src,H,F]
  * Replaces mhspmm.mhspmm (operators/spmm/multiheadSpmm.cpp, multiheadSpmm.cu:6-77).
  * att is always f32; feat/out have `dtype` (f32: sequential fp32 mul+add per element).
- * workspace: as for csr_spmm with k = H*F (cogdl_hip_csr_spmm_workspace_bytes(nnz, H*F)).
+ * workspace: cogdl_hip_mhspmm_workspace_bytes(nnz, H, F, dtype) (mhsddmm: cogdl_hip_edge_op_workspace_bytes).
  * mhsddmm: out[e,h] = < grad[row(e),h,:], feat[colind[e],h,:] >
  * Replaces mhsddmm.mhsddmm (operators/spmm/multiheadSddmm.cu:6-113).
  * ------------------------------------------------------------------------------------- */
+COGDL_API size_t cogdl_hip_mhspmm_workspace_bytes(int64_t nnz, int64_t h, int64_t f, int dtype);
 COGDL_API int cogdl_hip_mhspmm(const int32_t *rowptr, const int32_t *colind, const float *att,
                      const void *feat, void *out, int64_t v, int64_t h, int64_t f, int64_t nnz, int dtype,
                      void *workspace, size_t workspace_bytes, void *stream);
 COGDL_API int cogdl_hip_mhsddmm(const int32_t *rowptr, const int32_t *colind, const float *grad,
-                      const float *feat, float *out, int64_t v, int64_t h, int64_t f,
-                      void *stream);
+                      const float *feat, float *out, int64_t v, int64_t h, int64_t f, int64_t nnz,
+                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * scatter_max: out[r,c] = max_{e in row r} feat[colind[e],c]; max_id[r,c] = the colind of
@@ -157,8 +165,10 @@ COGDL_API int cogdl_hip_mhsddmm(const int32_t *rowptr, const int32_t *colind, co
  * FLT_MIN initial value, uninitialised argmax and uninitialised gradient buffer.
  * Backward: grad_src[max_id[r,c], c] += grad[r,c]; grad_src [n_src,k] is zeroed inside.
  * ------------------------------------------------------------------------------------- */
+COGDL_API size_t cogdl_hip_scatter_max_workspace_bytes(int64_t nnz, int64_t k);
 COGDL_API int cogdl_hip_scatter_max_fwd(const int32_t *rowptr, const int32_t *colind, const float *feat,
-                              float *out, int32_t *max_id, int64_t m, int64_t k, void *stream);
+                              float *out, int32_t *max_id, int64_t m, int64_t k, int64_t nnz,
+                              void *workspace, size_t workspace_bytes, void *stream);
 COGDL_API int cogdl_hip_scatter_max_bwd(const float *grad, const int32_t *max_id, float *grad_src, int64_t m,
                               int64_t k, int64_t n_src, void *stream);
 
@@ -171,23 +181,27 @@ COGDL_API int cogdl_hip_scatter_max_bwd(const float *grad, const int32_t *max_id
  * are those of the unfused path, layers/gat_layer.py:73-77).
  * Forward also emits edge_max/edge_sum [v,H] (row max of s and sum exp(s-max)), which the
  * backward consumes like the reference's ctx.save_for_backward does (fused_gat.py:20).
+ * Forward workspace (optional): cogdl_hip_gat_fwd_workspace_bytes -- hub rows are then split over whole
+ * workgroups and their (max, sum, acc) states merged like flash-attention blocks.
  * Backward (fp32) needs the CSC view (colptr,rowind from cogdl_hip_csr2csc), the forward
- * output and a workspace of cogdl_hip_gat_bwd_workspace_bytes(v, h) bytes.  It returns
+ * output and a workspace of cogdl_hip_gat_bwd_workspace_bytes(v, h, f, nnz) bytes (D[v,h] plus the
+ * long-row scratch of its two passes; a workspace of only v*h floats disables the long-row path).  It returns
  * COGDL_HIP_EINVAL for shapes it does not cover (H*F must fit 64 lanes x 4 columns and
  * F/vec must be a power of two unless H == 1); callers then compose the unfused operators.
  * ------------------------------------------------------------------------------------- */
+COGDL_API size_t cogdl_hip_gat_fwd_workspace_bytes(int64_t nnz, int64_t h, int64_t f, int dtype);
 COGDL_API int cogdl_hip_gat_fwd(const int32_t *rowptr, const int32_t *colind, const float *attn_row,
                       const float *attn_col, const void *feat, float negative_slope, void *out,
-                      float *edge_max, float *edge_sum, int64_t v, int64_t h, int64_t f,
-                      int dtype, void *stream);
-COGDL_API size_t cogdl_hip_gat_bwd_workspace_bytes(int64_t v, int64_t h);
+                      float *edge_max, float *edge_sum, int64_t v, int64_t h, int64_t f, int64_t nnz,
+                      int dtype, void *workspace, size_t workspace_bytes, void *stream);
+COGDL_API size_t cogdl_hip_gat_bwd_workspace_bytes(int64_t v, int64_t h, int64_t f, int64_t nnz);
 COGDL_API int cogdl_hip_gat_bwd(const int32_t *rowptr, const int32_t *colind, const int32_t *colptr,
                       const int32_t *rowind, const float *attn_row, const float *attn_col,
                       const float *feat, float negative_slope, const float *edge_max,
                       const float *edge_sum, const float *out, const float *grad_out,
                       float *grad_feat, float *grad_attn_row, float *grad_attn_col,
                       void *workspace, size_t workspace_bytes, int64_t v, int64_t n_src, int64_t h,
-                      int64_t f, void *stream);
+                      int64_t f, int64_t nnz, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Helpers used by the graph-plan cache and the vertex-sharded (multi-GPU) SpMM.

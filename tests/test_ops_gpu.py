@@ -234,3 +234,77 @@ def test_fused_gat_bf16(oracle):
     want = oracle.gat_fwd(g.rowptr, g.colind, a_row, a_col, featb.float(), 0.2)
     out, _, _ = gat_forward(a_row.to(DEV), a_col.to(DEV), g.rowptr.to(DEV), g.colind.to(DEV), 0.2, featb.to(DEV))
     np.testing.assert_allclose(out.float().cpu().numpy(), want, rtol=2.0 ** -7, atol=1e-2)
+
+
+# ------------------------------------------------------------------ hub rows (chunk-parallel long-row path)
+HUBS = [((3, 129), (4, 1000), (17, 5000), (18, 257), (40, 128)), ((0, 4000),), ((59, 3000), (58, 131))]
+
+
+@pytest.mark.parametrize("hubs", HUBS)
+@pytest.mark.parametrize("k", [8, 64, 100])
+def test_hub_rows_sddmm_scatter_max(oracle, hubs, k):
+    g = synth.hub_csr(60, 90, hubs=hubs, seed=k, weighted=False)
+    rp, ci = g.rowptr.to(DEV), g.colind.to(DEV)
+    d1, d2 = rand(60, k, seed=1), rand(90, k, seed=2)
+    want = oracle.csr_sddmm(g.rowptr, g.colind, d1, d2)
+    got = csr_sddmm_raw(rp, ci, d1.to(DEV), d2.to(DEV)).cpu().numpy()
+    scale = (d1.abs().numpy()[np.repeat(np.arange(60), np.diff(g.rowptr.numpy()))] *
+             d2.abs().numpy()[g.colind.numpy()]).sum(1)
+    assert np.all(np.abs(got - want) <= 1e-5 * scale + 1e-7)
+    d2[5] = d2[6]  # ties across chunk borders: still the FIRST maximum in CSR order
+    want, want_id = oracle.scatter_max_fwd(g.rowptr, g.colind, d2, quirk=False)
+    out, idx = scatter_max_fp(rp, ci, d2.to(DEV))
+    assert out.cpu().numpy().tobytes() == want.tobytes()
+    assert np.array_equal(idx.cpu().numpy(), want_id)
+
+
+@pytest.mark.parametrize("hubs", HUBS)
+@pytest.mark.parametrize("h", [1, 8, 5, 100])
+def test_hub_rows_edge_softmax(oracle, hubs, h):
+    g = synth.hub_csr(60, 60, hubs=hubs, seed=h)
+    v = rand(g.nnz, h, seed=3, scale=4.0)
+    gr = rand(g.nnz, h, seed=4)
+    vd = v.to(DEV).requires_grad_()
+    out = csr_edge_softmax(g.rowptr.to(DEV), vd)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), oracle.edge_softmax_fwd(g.rowptr, v), rtol=1e-5, atol=1e-9)
+    out.backward(gr.to(DEV))
+    sm = out.detach().cpu()
+    want_g = oracle.edge_softmax_bwd(g.rowptr, sm, gr)
+    rows_ = torch.repeat_interleave(torch.arange(60), g.degrees())
+    dot_abs = torch.zeros(60, h).index_add_(0, rows_, (sm * gr).abs())
+    scale_g = (sm * (gr.abs() + dot_abs[rows_])).numpy()
+    assert np.all(np.abs(vd.grad.cpu().numpy() - want_g) <= 1e-5 * scale_g + 1e-12)
+
+
+@pytest.mark.parametrize("hubs", HUBS)
+@pytest.mark.parametrize("h,f", [(8, 8), (1, 41), (4, 16)])
+def test_hub_rows_mhspmm_mhsddmm_gat(oracle, hubs, h, f):
+    from cogdl_amd.operators.fused_gat import fused_gat_func
+
+    g = synth.hub_csr(60, 60, hubs=hubs, seed=h * f, weighted=False)
+    rp, ci = g.rowptr.to(DEV), g.colind.to(DEV)
+    att, feat, gout = rand(g.nnz, h, seed=1), rand(60, h, f, seed=2), rand(60, h, f, seed=3)
+    want = oracle.mhspmm(g.rowptr, g.colind, att, feat)
+    got = mhspmm_raw(rp, ci, att.to(DEV), feat.to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-3)  # long rows are re-associated
+    want_ga = oracle.mhsddmm(g.rowptr, g.colind, gout, feat)
+    np.testing.assert_allclose(mhsddmm_raw(rp, ci, gout.to(DEV), feat.to(DEV)).cpu().numpy(), want_ga, rtol=1e-5, atol=1e-5)
+    # fused GAT forward + backward against float64 autograd of the unfused composition
+    a_row, a_col = rand(60, h, seed=7), rand(60, h, seed=8)
+    ar, ac, ft = (t.to(DEV).requires_grad_() for t in (a_row, a_col, feat))
+    out = fused_gat_func(ar, ac, rp, ci, rp, ci, 0.2, ft)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), oracle.gat_fwd(g.rowptr, g.colind, a_row, a_col, feat, 0.2),
+                               rtol=2e-5, atol=2e-6)
+    out.backward(gout.to(DEV))
+    dd = torch.float64
+    ar64, ac64, ft64 = (t.to(dd).requires_grad_() for t in (a_row, a_col, feat))
+    row = torch.repeat_interleave(torch.arange(60), g.degrees())
+    col = g.colind.long()
+    s = torch.nn.functional.leaky_relu(ar64[row] + ac64[col], 0.2)
+    mx = torch.full((60, h), -1e30, dtype=dd).scatter_reduce(0, row.view(-1, 1).expand_as(s), s, "amax")
+    e = torch.exp(s - mx[row])
+    a64 = e / torch.zeros(60, h, dtype=dd).index_add_(0, row, e)[row]
+    o64 = torch.zeros(60, h, f, dtype=dd).index_add_(0, row, a64.unsqueeze(-1) * ft64[col])
+    o64.backward(gout.to(dd))
+    for got_g, ref, name in ((ar.grad, ar64.grad, "attn_row"), (ac.grad, ac64.grad, "attn_col"), (ft.grad, ft64.grad, "feat")):
+        np.testing.assert_allclose(got_g.cpu().numpy(), ref.numpy(), rtol=5e-4, atol=5e-5, err_msg=name)
