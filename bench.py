@@ -97,6 +97,49 @@ def load_pmc_traffic(phase="arxiv_uniform_F128"):
         return None
 
 
+def gcn_epoch_ms(gd, rowptr64, colind64, x, reps=20, warmup=5):
+    """The 'GNN epoch time' half of BASELINE.json's metric: one full-graph training step (= one epoch) of CogDL's
+    default `gcn` model (cogdl/models/nn/gcn.py:26-29: 2 GCNLayers, hidden 64, relu, dropout 0.5; GCNLayer.forward
+    = spmm(graph, linear(x)), cogdl/layers/gcn_layer.py:51-53) on the arxiv-shaped graph, 40 classes, Adam(lr 0.01,
+    wd 5e-4) -- the aggregation goes through the csrspmm operator exactly as spmm_utils.spmm calls it (fresh .int()
+    index copies per call), the dense X.W stays on torch/hipBLASLt.  Median of `reps` steps, fenced."""
+    from cogdl_amd.operators.spmm import csrspmm
+
+    dev = x.device
+    torch.manual_seed(0)
+    n, f_in, hidden, classes = x.shape[0], x.shape[1], 64, 40
+    lin1, lin2 = torch.nn.Linear(f_in, hidden).to(dev), torch.nn.Linear(hidden, classes).to(dev)
+    drop = torch.nn.Dropout(0.5)
+    params = list(lin1.parameters()) + list(lin2.parameters())
+    opt = torch.optim.Adam(params, lr=0.01, weight_decay=5e-4)
+    y = torch.randint(0, classes, (n,), device=dev)
+    train_mask = torch.rand(n, device=dev) < 0.537  # ogbn-arxiv: 90,941 of 169,343 nodes train
+    feats = x.detach()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        h = csrspmm(rowptr64.int(), colind64.int(), lin1(feats), gd.weight, True)
+        h = drop(torch.relu_(h))
+        out = csrspmm(rowptr64.int(), colind64.int(), lin2(h), gd.weight, True)
+        loss = torch.nn.functional.cross_entropy(out[train_mask], y[train_mask])
+        loss.backward()
+        opt.step()
+
+    for _ in range(warmup):
+        step()
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    return {"model": "CogDL gcn default: 2 x GCNLayer, hidden 64, relu, dropout 0.5, Adam; full-graph step = 1 epoch",
+            "ms": ts[len(ts) // 2], "min_ms": ts[0], "reps": reps,
+            "spmm_calls_per_epoch": 4, "spmm_widths": [hidden, classes]}
+
+
 def bench_single(args):
     from cogdl_amd import synth
     from cogdl_amd.operators import spmm as spmm_mod
@@ -164,6 +207,7 @@ def bench_single(args):
                      "kernel_ms_in_step": kern_ms, "kernel_ms_fwd_alone": fwd_ms,
                      "GEdges_s_fwd_alone": g.nnz / (fwd_ms * 1e-3) / 1e9},
     }
+    result["gnn_epoch"] = gcn_epoch_ms(gd, rowptr64, colind64, x)
     if not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(g, x_cpu)
     return result

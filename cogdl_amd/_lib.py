@@ -31,14 +31,13 @@ HIP_SIGNATURES = {
     "cogdl_hip_csr2csc_workspace_bytes": ([_i64, _i64, _i64], _sz),
     "cogdl_hip_csr2csc": ([_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp], _i32),
     "cogdl_hip_gather_rows": ([_vp, _vp, _vp, _i64, _i64, _i32, _vp], _i32),
-    "cogdl_hip_edge_op_workspace_bytes": ([_i64], _sz),
-    "cogdl_hip_csr_sddmm": ([_vp] * 5 + [_i64, _i64, _i64, _vp, _sz, _vp], _i32),
+    "cogdl_hip_csr_sddmm": ([_vp] * 5 + [_i64, _i64, _i64, _vp], _i32),
     "cogdl_hip_edge_softmax_workspace_bytes": ([_i64, _i64], _sz),
     "cogdl_hip_edge_softmax_fwd": ([_vp] * 3 + [_i64, _i64, _i64, _vp, _sz, _vp], _i32),
     "cogdl_hip_edge_softmax_bwd": ([_vp] * 4 + [_i64, _i64, _i64, _vp, _sz, _vp], _i32),
     "cogdl_hip_mhspmm_workspace_bytes": ([_i64, _i64, _i64, _i32], _sz),
     "cogdl_hip_mhspmm": ([_vp] * 5 + [_i64, _i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
-    "cogdl_hip_mhsddmm": ([_vp] * 5 + [_i64, _i64, _i64, _i64, _vp, _sz, _vp], _i32),
+    "cogdl_hip_mhsddmm": ([_vp] * 5 + [_i64, _i64, _i64, _i64, _vp], _i32),
     "cogdl_hip_scatter_max_workspace_bytes": ([_i64, _i64], _sz),
     "cogdl_hip_scatter_max_fwd": ([_vp] * 5 + [_i64, _i64, _i64, _vp, _sz, _vp], _i32),
     "cogdl_hip_scatter_max_bwd": ([_vp] * 3 + [_i64, _i64, _i64, _vp], _i32),

@@ -11,10 +11,10 @@
 // = E*H*4 read + E*H*4 written + rowptr.  Rows are packed 64/LPR per wave so short rows
 // (arxiv: deg 15) do not idle most of a wave; LPR is chosen from the mean run length.
 // Any other H (not a power of two, or > 64) takes the generic kernel: lanes own heads.
-// Rows longer than the long-row threshold (hub nodes: Reddit has rows of 10^4..10^5 edges) are skipped by both
-// kernels and recorded in the chunk table of rowreduce.h; three small kernels then treat them chunk-parallel, for
-// any H: per-piece statistics ((max, sum) forward, <softmax, grad> backward) by a whole workgroup, a per-row merge
-// in chunk order, and the normalising write of every piece.
+// Rows longer than the long-row threshold (hub nodes: Reddit has rows of 10^4..10^5 edges) are skipped by the row
+// blocks; the LEADING workgroups of the same launch treat them chunk-parallel (rowreduce.h bookkeeping), for any H:
+// per-piece statistics ((max, sum) forward, <softmax, grad> backward) by a whole workgroup; a second kernel merges a
+// row's piece records in chunk order (each piece workgroup redoes that tiny merge itself) and writes the piece.
 #include "rowreduce.h"
 
 namespace cogdl {
@@ -34,14 +34,16 @@ __device__ __forceinline__ MaxSum combine(MaxSum a, MaxSum b) {
 // Reduce over the lanes of a group that share the same head: strides LPR/2 ... H.
 template <int LPR>
 __device__ __forceinline__ MaxSum head_reduce_maxsum(MaxSum v, int h) {
+    // butterfly of the maxima first, ONE rescale of the lane's sum to the common maximum, then plain sums
+    float m = v.m;
 #pragma unroll
-    for (int s = LPR / 2; s > 0; s >>= 1) {
-        if (s >= h) {
-            MaxSum o{__shfl_xor(v.m, s, kWave), __shfl_xor(v.s, s, kWave)};
-            v = combine(v, o);
-        }
-    }
-    return v;
+    for (int s = LPR / 2; s > 0; s >>= 1)
+        if (s >= h) m = fmaxf(m, __shfl_xor(m, s, kWave));
+    float sum = (v.s == 0.f) ? 0.f : v.s * expf(v.m - m);
+#pragma unroll
+    for (int s = LPR / 2; s > 0; s >>= 1)
+        if (s >= h) sum += __shfl_xor(sum, s, kWave);
+    return {m, sum};
 }
 template <int LPR>
 __device__ __forceinline__ float head_reduce_sum(float v, int h) {
@@ -51,72 +53,78 @@ __device__ __forceinline__ float head_reduce_sum(float v, int h) {
     return v;
 }
 
-template <int LPR, bool BACKWARD>
-__global__ __launch_bounds__(256) void edge_softmax_pow2_kernel(const int32_t *__restrict__ rowptr,
-                                                                const float *__restrict__ a,  // values | softmax
-                                                                const float *__restrict__ g,  // unused | grad
-                                                                float *__restrict__ out, int64_t m, int h,
-                                                                XcdMap n_rowblocks, LongRows lr) {
-    constexpr int RPW = kWave / LPR;
-    constexpr int RPB = RPW * 4;
-    const int64_t rb = xcd_remap(blockIdx.x, n_rowblocks);
-    if (rb < 0) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int l = lane % LPR;
-    const int64_t row = rb * RPB + (threadIdx.x >> 6) * RPW + lane / LPR;
-    int64_t lo = 0, hi = 0;
-    if (row < m) {
-        const int start = rowptr[row], end = rowptr[row + 1];
-        if (mark_long_chunks<LPR>(lr, row, start, end, l)) return;  // long row: chunk-parallel kernels
-        lo = (int64_t)start * h;
-        hi = (int64_t)end * h;
+// ---- strided element walks, kEsUnroll independent loads in flight -------------------------------------------------
+// Every kernel below walks elements idx = i0, i0 + stride, ... < end of `a` (and `g`).  The loads of a batch are
+// issued back to back; the forward statistic takes ONE rescale per batch (batch max first), i.e. U+1 exps per U
+// elements instead of the 2U of an element-wise online softmax.
+constexpr int kEsUnroll = 4;
+
+__device__ __forceinline__ MaxSum maxsum_strided(const float *__restrict__ a, int64_t i0, int64_t end, int64_t stride) {
+    if (i0 + stride >= end) {  // at most one element for this lane (short rows: the common case on small graphs)
+        if (i0 < end) return {a[i0], 1.f};
+        return {-INFINITY, 0.f};
     }
-    if constexpr (!BACKWARD) {
-        MaxSum acc{-INFINITY, 0.f};
-        for (int64_t i = lo + l; i < hi; i += LPR) {
-            const float v = a[i];
-            const float mn = fmaxf(acc.m, v);
-            acc.s = ((acc.s == 0.f) ? 0.f : acc.s * expf(acc.m - mn)) + expf(v - mn);
-            acc.m = mn;
+    MaxSum acc{-INFINITY, 0.f};
+    for (; i0 < end; i0 += stride * kEsUnroll) {
+        float v[kEsUnroll];
+#pragma unroll
+        for (int u = 0; u < kEsUnroll; ++u) {
+            const int64_t idx = i0 + u * stride;
+            v[u] = (idx < end) ? a[idx] : -INFINITY;
         }
-        acc = head_reduce_maxsum<LPR>(acc, h);
-        const float inv = 1.f / acc.s;
-        for (int64_t i = lo + l; i < hi; i += LPR) out[i] = expf(a[i] - acc.m) * inv;
-    } else {
-        float dot = 0.f;
-        for (int64_t i = lo + l; i < hi; i += LPR) dot = fmaf(a[i], g[i], dot);
-        dot = head_reduce_sum<LPR>(dot, h);
-        for (int64_t i = lo + l; i < hi; i += LPR) out[i] = a[i] * (g[i] - dot);
+        float bm = v[0];
+#pragma unroll
+        for (int u = 1; u < kEsUnroll; ++u) bm = fmaxf(bm, v[u]);
+        const float mn = fmaxf(acc.m, bm);
+        float ssum = 0.f;
+#pragma unroll
+        for (int u = 0; u < kEsUnroll; ++u) ssum += expf(v[u] - mn);  // masked slots: exp(-inf) == 0
+        acc.s = ((acc.s == 0.f) ? 0.f : acc.s * expf(acc.m - mn)) + ssum;
+        acc.m = mn;
     }
+    return acc;
 }
 
-// Generic H: one wave per row, lane owns heads lane, lane+64, ...; edges walked sequentially
-// (loads are coalesced across heads).
+__device__ __forceinline__ float dot_strided(const float *__restrict__ a, const float *__restrict__ g, int64_t i0,
+                                             int64_t end, int64_t stride) {
+    float dot = 0.f;
+    for (; i0 < end; i0 += stride * kEsUnroll) {
+        float v[kEsUnroll], w[kEsUnroll];
+#pragma unroll
+        for (int u = 0; u < kEsUnroll; ++u) {
+            const int64_t idx = i0 + u * stride;
+            const bool ok = idx < end;
+            v[u] = ok ? a[idx] : 0.f;
+            w[u] = ok ? g[idx] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kEsUnroll; ++u) dot = fmaf(v[u], w[u], dot);
+    }
+    return dot;
+}
+
+// out = exp(a - mx) * inv   (forward)      out = a * (g - dot)   (backward; mx carries dot)
 template <bool BACKWARD>
-__global__ __launch_bounds__(256) void edge_softmax_generic_kernel(const int32_t *__restrict__ rowptr,
-                                                                   const float *__restrict__ a,
-                                                                   const float *__restrict__ g,
-                                                                   float *__restrict__ out, int64_t m, int h,
-                                                                   XcdMap n_rowblocks, LongRows lr) {
-    const int64_t rb = xcd_remap(blockIdx.x, n_rowblocks);
-    if (rb < 0) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t row = rb * 4 + (threadIdx.x >> 6);
-    if (row >= m) return;
-    const int64_t lo = rowptr[row], hi = rowptr[row + 1];
-    if (mark_long_chunks<kWave>(lr, row, (int)lo, (int)hi, lane)) return;
-    for (int hd = lane; hd < h; hd += kWave) {
-        if constexpr (!BACKWARD) {
-            float mx = -INFINITY;
-            for (int64_t e = lo; e < hi; ++e) mx = fmaxf(mx, a[e * h + hd]);
-            float s = 0.f;
-            for (int64_t e = lo; e < hi; ++e) s += expf(a[e * h + hd] - mx);
-            const float inv = 1.f / s;
-            for (int64_t e = lo; e < hi; ++e) out[e * h + hd] = expf(a[e * h + hd] - mx) * inv;
-        } else {
-            float dot = 0.f;
-            for (int64_t e = lo; e < hi; ++e) dot = fmaf(a[e * h + hd], g[e * h + hd], dot);
-            for (int64_t e = lo; e < hi; ++e) out[e * h + hd] = a[e * h + hd] * (g[e * h + hd] - dot);
+__device__ __forceinline__ void write_strided(const float *__restrict__ a, const float *__restrict__ g,
+                                              float *__restrict__ out, int64_t i0, int64_t end, int64_t stride,
+                                              float mx, float inv) {
+    if (i0 + stride >= end) {
+        if (i0 < end) out[i0] = BACKWARD ? a[i0] * (g[i0] - mx) : expf(a[i0] - mx) * inv;
+        return;
+    }
+    for (; i0 < end; i0 += stride * kEsUnroll) {
+        float v[kEsUnroll], w[kEsUnroll];
+#pragma unroll
+        for (int u = 0; u < kEsUnroll; ++u) {
+            const int64_t idx = i0 + u * stride;
+            const bool ok = idx < end;
+            v[u] = ok ? a[idx] : 0.f;
+            if constexpr (BACKWARD) w[u] = ok ? g[idx] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kEsUnroll; ++u) {
+            const int64_t idx = i0 + u * stride;
+            if (idx < end) out[idx] = BACKWARD ? v[u] * (w[u] - mx) : expf(v[u] - mx) * inv;
         }
     }
 }
@@ -132,49 +140,68 @@ __device__ __forceinline__ int es_cols(int h) {
 }
 
 template <bool BACKWARD>
-__global__ __launch_bounds__(256) void edge_softmax_long_stats_kernel(const int32_t *__restrict__ rowptr,
-                                                                      const float *__restrict__ a,
-                                                                      const float *__restrict__ g, int h,
-                                                                      LongRows lr) {
+__device__ __forceinline__ void edge_softmax_long_stats_block(const int32_t *__restrict__ rowptr,
+                                                              const float *__restrict__ a,
+                                                              const float *__restrict__ g, int64_t m, int h,
+                                                              const LongRows &lr) {
     __shared__ float red_m[256], red_s[256];
-    __shared__ int any_long;
+    __shared__ int32_t tbl[kMaxChunksPerBlock + 1];
     const int64_t c_begin = (int64_t)blockIdx.x * lr.chunks_per_block;
-    const int64_t c_end = min(c_begin + lr.chunks_per_block, lr.n_chunks);
-    if (!run_has_long_rows(lr, c_begin, c_end, &any_long)) return;
+    if (c_begin >= lr.n_chunks) return;
+    const int n = (int)min((int64_t)lr.chunks_per_block, lr.n_chunks - c_begin);
+    if (!build_chunk_table(lr, rowptr, m, c_begin, n + 1, tbl)) return;
     const int C = es_cols(h), R = 256 / C;
     const int r = threadIdx.x / C, ci = threadIdx.x % C;
-    for (int64_t c = c_begin; c < c_end; ++c) {
+    for (int t = 0; t < n; ++t) {
+        const int64_t c = c_begin + t;
         for (int slot = 0; slot < 2; ++slot) {
             int32_t row;
             int lo, hi;
-            if (!decode_piece(lr, rowptr, c, slot, row, lo, hi)) continue;
+            if (!decode_piece(lr, rowptr, tbl, c, t, slot, row, lo, hi)) continue;
             float *rec = lr.partial + (2 * c + slot) * lr.rec_stride;
             for (int hd0 = 0; hd0 < h; hd0 += C) {
                 const int hd = hd0 + ci;
                 MaxSum acc{-INFINITY, 0.f};
                 float dot = 0.f;
                 if (hd < h) {
-                    for (int64_t e = lo + r; e < hi; e += R) {
-                        const float v = a[e * h + hd];
-                        if constexpr (!BACKWARD) {
-                            const float mn = fmaxf(acc.m, v);
-                            acc.s = ((acc.s == 0.f) ? 0.f : acc.s * expf(acc.m - mn)) + expf(v - mn);
-                            acc.m = mn;
-                        } else {
-                            dot = fmaf(v, g[e * h + hd], dot);
+                    const int64_t i0 = ((int64_t)lo + r) * h + hd, iend = (int64_t)hi * h, istr = (int64_t)R * h;
+                    if constexpr (!BACKWARD) acc = maxsum_strided(a, i0, iend, istr);
+                    else dot = dot_strided(a, g, i0, iend, istr);
+                }
+                // Reduce over the R threads that share head `hd`: a butterfly inside each wave over the lane strides
+                // >= C (lanes with equal ci), then the (at most 4) wave partials through LDS in wave order.
+                if (C < kWave) {
+#pragma unroll
+                    for (int sft = kWave / 2; sft > 0; sft >>= 1) {
+                        if (sft >= C) {
+                            if constexpr (!BACKWARD) {
+                                MaxSum o{__shfl_xor(acc.m, sft, kWave), __shfl_xor(acc.s, sft, kWave)};
+                                acc = combine(acc, o);
+                            } else {
+                                dot += __shfl_xor(dot, sft, kWave);
+                            }
                         }
                     }
                 }
-                red_m[threadIdx.x] = BACKWARD ? dot : acc.m;
-                red_s[threadIdx.x] = acc.s;
+                // after the butterfly every lane of a wave holds the wave's value for its ci
+                const int per_wave = (C < kWave) ? C : kWave;          // distinct ci values inside one wave
+                const int n_part = (C < kWave) ? 4 : R;                // partials per head to merge through LDS
+                const int part = (C < kWave) ? (threadIdx.x >> 6) : r;  // which partial this thread holds
+                const bool writer = (C < kWave) ? ((threadIdx.x & (kWave - 1)) < per_wave) : true;
+                if (writer) {
+                    red_m[part * C + ci] = BACKWARD ? dot : acc.m;
+                    red_s[part * C + ci] = acc.s;
+                }
                 __syncthreads();
-                if (r == 0 && hd < h) {  // fixed order over r
-                    for (int q = 1; q < R; ++q) {
-                        if constexpr (!BACKWARD) acc = combine(acc, MaxSum{red_m[q * C + ci], red_s[q * C + ci]});
-                        else dot += red_m[q * C + ci];
+                if (threadIdx.x < C && hd0 + (int)threadIdx.x < h) {  // thread ci finishes head hd0 + ci
+                    MaxSum tot{red_m[threadIdx.x], red_s[threadIdx.x]};
+                    float dsum = red_m[threadIdx.x];
+                    for (int q = 1; q < n_part; ++q) {
+                        if constexpr (!BACKWARD) tot = combine(tot, MaxSum{red_m[q * C + threadIdx.x], red_s[q * C + threadIdx.x]});
+                        else dsum += red_m[q * C + threadIdx.x];
                     }
-                    rec[2 * hd] = BACKWARD ? dot : acc.m;
-                    rec[2 * hd + 1] = acc.s;
+                    rec[2 * (hd0 + threadIdx.x)] = BACKWARD ? dsum : tot.m;
+                    rec[2 * (hd0 + threadIdx.x) + 1] = tot.s;
                 }
                 __syncthreads();
             }
@@ -182,82 +209,141 @@ __global__ __launch_bounds__(256) void edge_softmax_long_stats_kernel(const int3
     }
 }
 
-// Per long row (found at its first full chunk c0): merge the piece records in chunk order; the row's final
-// statistics replace the record of (c0, slot 0), where the apply kernel looks them up.
-template <bool BACKWARD>
-__global__ __launch_bounds__(256) void edge_softmax_long_merge_kernel(const int32_t *__restrict__ rowptr, int h,
-                                                                      LongRows lr) {
-    __shared__ int any_long;
-    const int64_t c_begin = (int64_t)blockIdx.x * lr.chunks_per_block;
-    const int64_t c_end = min(c_begin + lr.chunks_per_block, lr.n_chunks);
-    if (!run_has_long_rows(lr, c_begin, c_end - 1, &any_long)) return;
-    const int ch = lr.thresh;
-    for (int64_t c = c_begin; c < c_end; ++c) {
-        const int32_t row = lr.chunk_row[c];
-        if (row < 0) continue;
-        const int start = rowptr[row], end = rowptr[row + 1];
-        if ((int64_t)(start + ch - 1) / ch != c) continue;  // not the row's first owned chunk
-        const int64_t c_last = (end - 1) / ch;
-        const bool head = (int64_t)start != c * ch;
-        for (int hd = threadIdx.x; hd < h; hd += blockDim.x) {
-            MaxSum acc{-INFINITY, 0.f};
-            float dot = 0.f;
-            if (head) {
-                const float *p = lr.partial + (2 * (c - 1) + 1) * lr.rec_stride + 2 * hd;
-                if constexpr (!BACKWARD) acc = combine(acc, MaxSum{p[0], p[1]});
-                else dot += p[0];
-            }
-            for (int64_t q = c; q <= c_last; ++q) {
-                const float *p = lr.partial + (2 * q) * lr.rec_stride + 2 * hd;
-                if constexpr (!BACKWARD) acc = combine(acc, MaxSum{p[0], p[1]});
-                else dot += p[0];
-            }
-            float *dst = lr.partial + (2 * c) * lr.rec_stride + 2 * hd;
-            dst[0] = BACKWARD ? dot : acc.m;
-            dst[1] = BACKWARD ? 0.f : 1.f / acc.s;
-        }
-    }
-}
-
+// Second launch: every piece workgroup merges the records of ITS row in chunk order (a row of 10^5 edges has ~100
+// records of 2H floats: cheaper than a third launch) and writes the piece's outputs.
 template <bool BACKWARD>
 __global__ __launch_bounds__(256) void edge_softmax_long_apply_kernel(const int32_t *__restrict__ rowptr,
                                                                       const float *__restrict__ a,
                                                                       const float *__restrict__ g,
-                                                                      float *__restrict__ out, int h, LongRows lr) {
-    __shared__ int any_long;
+                                                                      float *__restrict__ out, int64_t m, int h,
+                                                                      LongRows lr) {
+    __shared__ int32_t tbl[kMaxChunksPerBlock + 1];
     const int64_t c_begin = (int64_t)blockIdx.x * lr.chunks_per_block;
-    const int64_t c_end = min(c_begin + lr.chunks_per_block, lr.n_chunks);
-    if (!run_has_long_rows(lr, c_begin, c_end, &any_long)) return;
+    if (c_begin >= lr.n_chunks) return;
+    const int n = (int)min((int64_t)lr.chunks_per_block, lr.n_chunks - c_begin);
+    if (!build_chunk_table(lr, rowptr, m, c_begin, n + 1, tbl)) return;
     const int C = es_cols(h), R = 256 / C;
     const int r = threadIdx.x / C, ci = threadIdx.x % C;
     const int ch = lr.thresh;
-    for (int64_t c = c_begin; c < c_end; ++c) {
+    // A hub row spans many consecutive chunks of this workgroup's run: its merged statistics are computed once (per
+    // head by one thread, records in chunk order) and kept in LDS while the pieces of the row are written.
+    constexpr int kStatCap = 1024;  // heads cached in LDS; beyond that every thread merges for itself
+    __shared__ float st_a[kStatCap], st_b[kStatCap];
+    int32_t cached_row = -1;
+    for (int t = 0; t < n; ++t) {
+        const int64_t c = c_begin + t;
         for (int slot = 0; slot < 2; ++slot) {
             int32_t row;
             int lo, hi;
-            if (!decode_piece(lr, rowptr, c, slot, row, lo, hi)) continue;
-            const int64_t c0 = ((int64_t)rowptr[row] + ch - 1) / ch;  // the row's first full chunk holds its statistics
-            const float *stat = lr.partial + (2 * c0) * lr.rec_stride;
-            for (int hd = ci; hd < h; hd += C) {
-                const float s0 = stat[2 * hd], s1 = stat[2 * hd + 1];
-                for (int64_t e = lo + r; e < hi; e += R) {
-                    const int64_t i = e * h + hd;
-                    if constexpr (!BACKWARD) out[i] = expf(a[i] - s0) * s1;
-                    else out[i] = a[i] * (g[i] - s0);
+            if (!decode_piece(lr, rowptr, tbl, c, t, slot, row, lo, hi)) continue;
+            const int start = rowptr[row], end = rowptr[row + 1];
+            const int64_t c0 = ((int64_t)start + ch - 1) / ch, c_last = ((int64_t)end - 1) / ch;
+            const bool head = (int64_t)start != c0 * ch;  // head piece: chunk c0-1, slot 1
+            auto merged = [&](int hd, float &sa, float &sb) {
+                MaxSum acc{-INFINITY, 0.f};
+                float dot = 0.f;
+                if (head) {
+                    const float *p = lr.partial + (2 * (c0 - 1) + 1) * lr.rec_stride + 2 * hd;
+                    if constexpr (!BACKWARD) acc = combine(acc, MaxSum{p[0], p[1]});
+                    else dot += p[0];
                 }
+                for (int64_t q = c0; q <= c_last; ++q) {
+                    const float *p = lr.partial + (2 * q) * lr.rec_stride + 2 * hd;
+                    if constexpr (!BACKWARD) acc = combine(acc, MaxSum{p[0], p[1]});
+                    else dot += p[0];
+                }
+                sa = BACKWARD ? dot : acc.m;
+                sb = BACKWARD ? 0.f : 1.f / acc.s;
+            };
+            if (row != cached_row && h <= kStatCap) {  // workgroup-uniform
+                __syncthreads();  // the previous row's readers are done
+                for (int hd = threadIdx.x; hd < h; hd += blockDim.x) merged(hd, st_a[hd], st_b[hd]);
+                __syncthreads();
+                cached_row = row;
+            }
+            for (int hd = ci; hd < h; hd += C) {
+                float sa, sb;
+                if (h <= kStatCap) {
+                    sa = st_a[hd];
+                    sb = st_b[hd];
+                } else {
+                    merged(hd, sa, sb);
+                }
+                write_strided<BACKWARD>(a, g, out, ((int64_t)lo + r) * h + hd, (int64_t)hi * h, (int64_t)R * h, sa, sb);
             }
         }
     }
 }
 
+template <int LPR, bool BACKWARD>
+__global__ __launch_bounds__(256) void edge_softmax_pow2_kernel(const int32_t *__restrict__ rowptr,
+                                                                const float *__restrict__ a,  // values | softmax
+                                                                const float *__restrict__ g,  // unused | grad
+                                                                float *__restrict__ out, int64_t m, int h,
+                                                                XcdMap n_rowblocks, LongRows lr) {
+    if (blockIdx.x < lr.n_long_blocks) {
+        edge_softmax_long_stats_block<BACKWARD>(rowptr, a, g, m, h, lr);
+        return;
+    }
+    constexpr int RPW = kWave / LPR;
+    constexpr int RPB = RPW * 4;
+    const int64_t rb = xcd_remap(blockIdx.x - lr.n_long_blocks, n_rowblocks);
+    if (rb < 0) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int l = lane % LPR;
+    const int64_t row = rb * RPB + (threadIdx.x >> 6) * RPW + lane / LPR;
+    int64_t lo = 0, hi = 0;
+    if (row < m) {
+        const int start = rowptr[row], end = rowptr[row + 1];
+        if (end - start > lr.thresh) return;  // long row: the long-row workgroups compute it
+        lo = (int64_t)start * h;
+        hi = (int64_t)end * h;
+    }
+    if constexpr (!BACKWARD) {
+        const MaxSum acc = head_reduce_maxsum<LPR>(maxsum_strided(a, lo + l, hi, LPR), h);
+        write_strided<false>(a, g, out, lo + l, hi, LPR, acc.m, 1.f / acc.s);
+    } else {
+        const float dot = head_reduce_sum<LPR>(dot_strided(a, g, lo + l, hi, LPR), h);
+        write_strided<true>(a, g, out, lo + l, hi, LPR, dot, 0.f);
+    }
+}
+
+// Generic H: one wave per row, lane owns heads lane, lane+64, ...; edges walked sequentially
+// (loads are coalesced across heads).
 template <bool BACKWARD>
-static void launch_long(const int32_t *rowptr, const float *a, const float *g, float *out, int h, const LongRows &lr,
-                        hipStream_t s) {
-    if (lr.n_chunks == 0) return;
-    const unsigned gx = (unsigned)((lr.n_chunks + lr.chunks_per_block - 1) / lr.chunks_per_block);
-    hipLaunchKernelGGL((edge_softmax_long_stats_kernel<BACKWARD>), dim3(gx), dim3(256), 0, s, rowptr, a, g, h, lr);
-    hipLaunchKernelGGL((edge_softmax_long_merge_kernel<BACKWARD>), dim3(gx), dim3(256), 0, s, rowptr, h, lr);
-    hipLaunchKernelGGL((edge_softmax_long_apply_kernel<BACKWARD>), dim3(gx), dim3(256), 0, s, rowptr, a, g, out, h, lr);
+__global__ __launch_bounds__(256) void edge_softmax_generic_kernel(const int32_t *__restrict__ rowptr,
+                                                                   const float *__restrict__ a,
+                                                                   const float *__restrict__ g,
+                                                                   float *__restrict__ out, int64_t m, int h,
+                                                                   XcdMap n_rowblocks, LongRows lr) {
+    if (blockIdx.x < lr.n_long_blocks) {
+        edge_softmax_long_stats_block<BACKWARD>(rowptr, a, g, m, h, lr);
+        return;
+    }
+    const int64_t rb = xcd_remap(blockIdx.x - lr.n_long_blocks, n_rowblocks);
+    if (rb < 0) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t row = rb * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    const int64_t lo = rowptr[row], hi = rowptr[row + 1];
+    if (hi - lo > lr.thresh) return;
+    for (int hd = lane; hd < h; hd += kWave) {
+        if constexpr (!BACKWARD) {
+            const MaxSum acc = maxsum_strided(a, lo * h + hd, hi * h, h);
+            write_strided<false>(a, g, out, lo * h + hd, hi * h, h, acc.m, 1.f / acc.s);
+        } else {
+            const float dot = dot_strided(a, g, lo * h + hd, hi * h, h);
+            write_strided<true>(a, g, out, lo * h + hd, hi * h, h, dot, 0.f);
+        }
+    }
+}
+
+template <bool BACKWARD>
+static void launch_long(const int32_t *rowptr, const float *a, const float *g, float *out, int64_t m, int h,
+                        const LongRows &lr, hipStream_t s) {
+    if (lr.n_long_blocks == 0) return;
+    hipLaunchKernelGGL((edge_softmax_long_apply_kernel<BACKWARD>), dim3(lr.n_long_blocks), dim3(256), 0, s, rowptr, a, g,
+                       out, m, h, lr);
 }
 
 template <int LPR, bool BACKWARD>
@@ -266,9 +352,9 @@ static int launch_pow2(const int32_t *rowptr, const float *a, const float *g, fl
     constexpr int RPB = (kWave / LPR) * 4;
     const int64_t nrb = (m + RPB - 1) / RPB;
     if (nrb > 0x7fffffff / kXcds) return COGDL_HIP_ERANGE;
-    hipLaunchKernelGGL((edge_softmax_pow2_kernel<LPR, BACKWARD>), dim3(xcd_grid(make_xcd_map(nrb))), dim3(256), 0, s, rowptr, a, g,
-                       out, m, h, make_xcd_map(nrb), lr);
-    launch_long<BACKWARD>(rowptr, a, g, out, h, lr, s);
+    hipLaunchKernelGGL((edge_softmax_pow2_kernel<LPR, BACKWARD>), dim3(lr.n_long_blocks + xcd_grid(make_xcd_map(nrb))), dim3(256),
+                       0, s, rowptr, a, g, out, m, h, make_xcd_map(nrb), lr);
+    launch_long<BACKWARD>(rowptr, a, g, out, m, h, lr, s);
     return launch_status();
 }
 
@@ -282,25 +368,19 @@ static int edge_softmax_dispatch(const int32_t *rowptr, const float *a, const fl
     LongRows lr{};
     lr.thresh = INT_MAX;
     if (ws) {
-        const int t = pick_long_thresh(nnz);
-        const int64_t n_chunks = n_chunks_for(nnz, t);
         if (wsb < rowreduce_workspace_bytes(nnz, 2 * h)) return COGDL_HIP_EWORKSPACE;
         if (!aligned_to(ws, 256)) return COGDL_HIP_EALIGN;
-        lr.thresh = t;
-        lr.chunk_row = (int32_t *)ws;
-        lr.partial = (float *)((char *)ws + chunk_row_bytes(n_chunks));
-        lr.n_chunks = n_chunks;
+        plan_long_rows(lr, nnz);
+        lr.partial = (float *)ws;
         lr.rec_stride = 2 * h;
-        const int64_t max_wg = std::max(64, g_tuning[kTuneLongGrid]);
-        lr.chunks_per_block = (int)((n_chunks + max_wg - 1) / max_wg);
     }
     const bool pow2 = (h & (h - 1)) == 0 && h <= kWave;
     if (!pow2) {
         const int64_t nrb = (m + 3) / 4;
         if (nrb > 0x7fffffff / kXcds) return COGDL_HIP_ERANGE;
-        hipLaunchKernelGGL((edge_softmax_generic_kernel<BACKWARD>), dim3(xcd_grid(make_xcd_map(nrb))), dim3(256), 0, s, rowptr, a,
-                           g, out, m, (int)h, make_xcd_map(nrb), lr);
-        launch_long<BACKWARD>(rowptr, a, g, out, (int)h, lr, s);
+        hipLaunchKernelGGL((edge_softmax_generic_kernel<BACKWARD>), dim3(lr.n_long_blocks + xcd_grid(make_xcd_map(nrb))), dim3(256),
+                           0, s, rowptr, a, g, out, m, (int)h, make_xcd_map(nrb), lr);
+        launch_long<BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s);
         return launch_status();
     }
     // lanes per row ~ mean run length (deg*H), at least H and 8, at most 64

@@ -97,13 +97,14 @@ struct MhsddmmArgs {
 
 template <int VEC, int LPR>
 static int launch_mhsddmm(const MhsddmmArgs &a, void *ws, size_t wsb, hipStream_t s) {
-    MhsddmmOp<VEC, LPR, 4> op{a.grad, a.feat, a.out, (int)a.h, (int)a.f, (int)(a.f / VEC)};
+    // one head: reduce over the whole (zero-padded) group, so F/VEC need not be a power of two
+    MhsddmmOp<VEC, LPR, 4> op{a.grad, a.feat, a.out, (int)a.h, (int)a.f, (a.h == 1) ? LPR : (int)(a.f / VEC)};
     return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, 1, ws, wsb, s);
 }
 
 template <int VEC>
 static int dispatch_mhsddmm(const MhsddmmArgs &a, void *ws, size_t wsb, hipStream_t s) {
-    const int64_t need = a.h * a.f / VEC;
+    const int64_t need = (a.h * a.f + VEC - 1) / VEC;
     if (need <= 8) return launch_mhsddmm<VEC, 8>(a, ws, wsb, s);
     if (need <= 16) return launch_mhsddmm<VEC, 16>(a, ws, wsb, s);
     if (need <= 32) return launch_mhsddmm<VEC, 32>(a, ws, wsb, s);
@@ -118,7 +119,7 @@ using namespace cogdl;
 
 extern "C" int cogdl_hip_mhsddmm(const int32_t *rowptr, const int32_t *colind, const float *grad,
                                  const float *feat, float *out, int64_t v, int64_t h, int64_t f, int64_t nnz,
-                                 void *workspace, size_t workspace_bytes, void *stream) {
+                                 void *stream) {
     if (v < 0 || h < 0 || f < 0 || nnz < 0) return COGDL_HIP_EINVAL;
     if (v == 0 || h == 0) return COGDL_HIP_OK;
     if (!rowptr || !grad || !feat || !out || f == 0) return COGDL_HIP_EINVAL;
@@ -127,12 +128,11 @@ extern "C" int cogdl_hip_mhsddmm(const int32_t *rowptr, const int32_t *colind, c
     const bool al16 = aligned_to(grad, 16) && aligned_to(feat, 16);
     const bool al8 = aligned_to(grad, 8) && aligned_to(feat, 8);
     MhsddmmArgs a{rowptr, colind, grad, feat, out, v, h, f, nnz};
-    // fast path: the whole [H*F] row fits one group of <= 64 lanes and F/VEC is a power of two
-    if (f % 4 == 0 && al16 && is_pow2(f / 4) && h * f / 4 <= kWave)
-        return dispatch_mhsddmm<4>(a, workspace, workspace_bytes, s);
-    if (f % 2 == 0 && al8 && is_pow2(f / 2) && h * f / 2 <= kWave)
-        return dispatch_mhsddmm<2>(a, workspace, workspace_bytes, s);
-    if (is_pow2(f) && h * f <= kWave) return dispatch_mhsddmm<1>(a, workspace, workspace_bytes, s);
+    // fast path: the whole [H*F] row fits one group of <= 64 lanes and F/VEC is a power of two (any F if H == 1)
+    auto fits = [&](int vec) { return f % vec == 0 && h * f / vec <= kWave && (h == 1 || is_pow2(f / vec)); };
+    if (fits(4) && al16) return dispatch_mhsddmm<4>(a, nullptr, 0, s);
+    if (fits(2) && al8) return dispatch_mhsddmm<2>(a, nullptr, 0, s);
+    if (fits(1)) return dispatch_mhsddmm<1>(a, nullptr, 0, s);
     const int64_t nrb = (v + 3) / 4;
     if (nrb > 0x7fffffff / kXcds) return COGDL_HIP_ERANGE;
     hipLaunchKernelGGL(mhsddmm_generic_kernel, dim3(xcd_grid(make_xcd_map(nrb))), dim3(256), 0, s, rowptr, colind, grad, feat, out,

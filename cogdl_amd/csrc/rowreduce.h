@@ -3,28 +3,25 @@
 //
 // Every one of those operators walks the edges of a CSR row, gathers one dense row per edge and folds it into a
 // small per-row state (or emits one value per edge).  The engine owns the traversal; an `Op` functor owns the
-// arithmetic.  Three kernels:
+// arithmetic.  Two launches (one for per-edge operators):
 //
-//   rowreduce_main_kernel      one group of Op::LPR lanes per row ("row group"), 64/LPR rows per wave, 4 waves per
+//   rowreduce_main_kernel      grid = [long-row workgroups | row-block workgroups] x column tiles.
+//     row blocks               one group of Op::LPR lanes per row ("row group"), 64/LPR rows per wave, 4 waves per
 //                              workgroup; colind (and per-edge scalars) are read in coalesced chunks of LPR edges and
 //                              broadcast lane-to-lane; gathers are issued Op::UNROLL at a time; the state is updated
-//                              strictly in CSR edge order.  Rows longer than `thresh` edges are skipped and recorded.
-//   rowreduce_long_kernel      power-law graphs: a row of 10^4..10^5 edges would serialise one lane group for longer
+//                              strictly in CSR edge order.  Rows longer than `thresh` edges are skipped.
+//     long-row workgroups      power-law graphs: a row of 10^4..10^5 edges would serialise one lane group for longer
 //                              than the rest of the launch takes.  Edges are cut into aligned chunks of `thresh` edges;
 //                              every piece (long row  x  chunk) is processed by a whole workgroup: its 256/LPR groups
 //                              take contiguous slices, group states are merged in group order through LDS and the
 //                              piece's state is written to a workspace record.  Ops without a per-row state (sddmm)
-//                              stop here.
+//                              stop here.  Each workgroup owns a run of chunks and FINDS its pieces itself by binary
+//                              searching rowptr (build_chunk_table) -- no pre-pass, no table in memory, no dependency
+//                              on the row blocks, hence the same launch.
 //   rowreduce_combine_kernel   per long row: merge the piece records in chunk order, finish the row.
 //
 // No atomics anywhere, every merge order is fixed => results are deterministic, and rows of at most `thresh` edges
 // are reduced in exactly the reference's (sequential CSR) order.
-//
-// Bookkeeping without a pre-pass or a memset: chunk c = edges [c*T, (c+1)*T).  A long row intersecting chunk c is
-// either the row that owns the chunk's FIRST edge (chunk_row[c], "slot 0") or a row that starts inside the chunk --
-// which, being longer than T, then owns the first edge of chunk c+1 ("slot 1" of c == chunk_row[c+1]).  The main
-// kernel writes chunk_row[c] (the long row's id, or -1) for every chunk whose first edge lies in one of its rows, so
-// every entry is rewritten on every launch.
 //
 // Op concept (all methods __device__, const; see spmm.hip for the canonical example):
 //   constants  LPR, UNROLL, kRec (floats per lane of a piece record), kReduce (has a per-row state to merge)
@@ -48,13 +45,15 @@
 namespace cogdl {
 
 struct LongRows {
-    int thresh;           // rows with more edges take the chunk-parallel path; also the chunk size (INT_MAX: off)
-    int32_t *chunk_row;   // [n_chunks + 1]
-    float *partial;       // [n_chunks][2][rec_stride] fp32 piece records (kReduce ops)
+    int thresh;              // rows with more edges take the chunk-parallel path; also the chunk size (INT_MAX: off)
+    float *partial;          // [n_chunks][2][rec_stride] fp32 piece records (kReduce ops)
     int64_t n_chunks;
-    int64_t rec_stride;   // tiles * kRec * LPR
-    int chunks_per_block; // the long/combine kernels give each workgroup a contiguous run of chunks
+    int64_t rec_stride;      // tiles * kRec * LPR
+    int chunks_per_block;    // a long-row workgroup owns a contiguous run of <= kMaxChunksPerBlock chunks
+    unsigned n_long_blocks;  // leading workgroups of the main grid that process long-row pieces (multiple of 8)
+    int64_t nnz;
 };
+constexpr int kMaxChunksPerBlock = 255;
 
 // Lanes per row / vector width / column tiles chosen for a row of k columns (see spmm.hip: spmm_geometry).
 struct RowGeometry {
@@ -69,6 +68,7 @@ struct RowSched {
     int64_t m;
     XcdMap rowblocks;
     LongRows lr;
+    int rows_per_group;  // > 1: streaming row blocks (each lane group walks that many consecutive rows as one stream)
 };
 
 // Threshold above which a row is split.  The sequential time of a row of T edges (~T/UNROLL gather round trips of
@@ -80,52 +80,63 @@ inline int pick_long_thresh(int64_t nnz) {
     return t;
 }
 inline int64_t n_chunks_for(int64_t nnz, int thresh) { return (nnz + thresh - 1) / thresh; }
-inline size_t chunk_row_bytes(int64_t n_chunks) { return ((size_t)(n_chunks + 1) * sizeof(int32_t) + 255) / 256 * 256; }
-// Workspace of an operator whose piece record holds `rec_stride` floats (0: no per-row state).
+// Workspace of an operator whose piece record holds `rec_stride` floats.
 inline size_t rowreduce_workspace_bytes(int64_t nnz, int64_t rec_stride) {
-    if (nnz <= 0) return 0;
+    if (nnz <= 0 || rec_stride <= 0) return 0;
     const int64_t n_chunks = n_chunks_for(nnz, pick_long_thresh(nnz));
-    const size_t b = chunk_row_bytes(n_chunks) + (size_t)n_chunks * 2 * (size_t)rec_stride * sizeof(float);
-    return (b + 255) / 256 * 256;
+    return ((size_t)n_chunks * 2 * (size_t)rec_stride * sizeof(float) + 255) / 256 * 256;
+}
+// Fill the scheduling fields of the long-row path (everything but `partial`/`rec_stride`).
+inline void plan_long_rows(LongRows &lr, int64_t nnz) {
+    lr.thresh = pick_long_thresh(nnz);
+    lr.n_chunks = n_chunks_for(nnz, lr.thresh);
+    lr.nnz = nnz;
+    const int64_t max_wg = std::max(64, g_tuning[kTuneLongGrid]);
+    lr.chunks_per_block = (int)std::min<int64_t>(kMaxChunksPerBlock, (lr.n_chunks + max_wg - 1) / max_wg);
+    const int64_t blocks = (lr.n_chunks + lr.chunks_per_block - 1) / lr.chunks_per_block;
+    lr.n_long_blocks = (unsigned)((blocks + kXcds - 1) / kXcds * kXcds);  // keeps block % 8 == XCD for the row blocks
 }
 
-// Main-kernel side of the bookkeeping: the group (lanes l = 0..LPR-1) that owns row `row` = edges [start, end)
-// writes chunk_row[c] for every chunk whose first edge lies in the row.  Returns true when the row is long.
-template <int LPR>
-__device__ __forceinline__ bool mark_long_chunks(const LongRows &lr, int64_t row, int start, int end, int l) {
-    const int ch = lr.thresh;
-    const bool is_long = end - start > ch;
-    if (lr.chunk_row && end > start) {
-        const int32_t mark = is_long ? (int32_t)row : -1;
-        for (int c = (start + ch - 1) / ch + l; (int64_t)c * ch < end; c += LPR) lr.chunk_row[c] = mark;
+// The row that contains edge e (0 <= e < nnz): rowptr[r] <= e < rowptr[r+1].
+__device__ __forceinline__ int row_of_edge(const int32_t *__restrict__ rowptr, int64_t m, int e) {
+    int lo = 0, hi = (int)m;  // invariant: rowptr[lo] <= e < rowptr[hi]
+    while (hi - lo > 1) {
+        const int mid = (int)(((int64_t)lo + hi) >> 1);
+        if (rowptr[mid] <= e) lo = mid;
+        else hi = mid;
     }
-    return is_long;
+    return lo;
 }
 
-// Piece (chunk c, slot) -> the long row it belongs to and its edge range [lo, hi); false if there is none.
-__device__ __forceinline__ bool decode_piece(const LongRows &lr, const int32_t *rowptr, int64_t c, int slot,
-                                             int32_t &row, int &lo, int &hi) {
-    const int ch = lr.thresh;
-    row = -1;
-    if (slot == 0) row = lr.chunk_row[c];
-    else if (c + 1 < lr.n_chunks) {
-        row = lr.chunk_row[c + 1];
-        if (row >= 0 && (int64_t)rowptr[row] <= c * ch) row = -1;  // same row as slot 0, not a new head
+// Bookkeeping without a pre-pass, a table in memory or a second launch: chunk c = edges [c*T, (c+1)*T).  A long row
+// (> T edges) intersecting chunk c is either the row that owns the chunk's FIRST edge ("slot 0") or a row that
+// starts inside the chunk -- which, being longer than T, then owns the first edge of chunk c+1 ("slot 1").  So a
+// workgroup that owns the chunks [c_begin, c_begin + n) finds all its pieces from n+1 binary searches of rowptr
+// (one per thread, concurrently): tbl[t] = the row containing edge (c_begin+t)*T if that row is long, else -1.
+// Returns (block-wide) whether any entry is a long row.
+__device__ __forceinline__ bool build_chunk_table(const LongRows &lr, const int32_t *__restrict__ rowptr, int64_t m,
+                                                  int64_t c_begin, int n_entries, int32_t *tbl) {
+    int32_t mine = -1;
+    if ((int)threadIdx.x < n_entries) {
+        const int64_t e = (c_begin + threadIdx.x) * lr.thresh;
+        if (e < lr.nnz) {
+            const int r = row_of_edge(rowptr, m, (int)e);
+            if (rowptr[r + 1] - rowptr[r] > lr.thresh) mine = r;
+        }
+        tbl[threadIdx.x] = mine;
     }
+    return __syncthreads_or(mine >= 0) != 0;
+}
+
+// Piece (t-th chunk of the block's run, slot) -> the long row it belongs to and its edge range [lo, hi).
+__device__ __forceinline__ bool decode_piece(const LongRows &lr, const int32_t *__restrict__ rowptr,
+                                             const int32_t *tbl, int64_t c, int t, int slot, int32_t &row, int &lo,
+                                             int &hi) {
+    row = (slot == 0) ? tbl[t] : ((tbl[t + 1] != tbl[t]) ? tbl[t + 1] : -1);
     if (row < 0) return false;
-    lo = max(rowptr[row], (int)(c * ch));
-    hi = (int)min((int64_t)rowptr[row + 1], (c + 1) * ch);
-    return true;
-}
-
-// Does the run of chunks [c_begin, c_end] (inclusive: slot 1 of the last chunk) contain any long row?  Block-wide.
-__device__ __forceinline__ bool run_has_long_rows(const LongRows &lr, int64_t c_begin, int64_t c_end_incl, int *flag) {
-    if (threadIdx.x == 0) *flag = 0;
-    __syncthreads();
-    for (int64_t c = c_begin + threadIdx.x; c <= c_end_incl && c < lr.n_chunks; c += blockDim.x)
-        if (lr.chunk_row[c] >= 0) *flag = 1;
-    __syncthreads();
-    return *flag != 0;
+    lo = max(rowptr[row], (int)(c * lr.thresh));
+    hi = (int)min((int64_t)rowptr[row + 1], (c + 1) * lr.thresh);
+    return lo < hi;
 }
 
 template <int LPR>
@@ -167,60 +178,30 @@ __device__ __forceinline__ void reduce_edges(const Op &op, const typename Op::Ct
     }
 }
 
+// One workgroup per run of `chunks_per_block` chunks: the leading blocks of the main grid.
 template <class Op>
-__global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const RowSched s) {
-    constexpr int LPR = Op::LPR;
-    constexpr int RPW = kWave / LPR;  // row groups per wave
-    constexpr int GPB = RPW * 4;      // row groups per 256-thread workgroup
-    const int64_t rb = xcd_remap(blockIdx.x, s.rowblocks);
-    if (rb < 0) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-    const int sub = lane / LPR;
-    const int l = lane % LPR;
-    const int64_t row = rb * GPB + wave * RPW + sub;
-    const bool ok = row < s.m;
-    int start = 0, end = 0;
-    if (ok) {
-        start = s.rowptr[row];
-        end = s.rowptr[row + 1];
-    }
-    if constexpr (LPR == kWave) {  // whole wave on one row: make the loop bounds scalar
-        start = __builtin_amdgcn_readfirstlane(start);
-        end = __builtin_amdgcn_readfirstlane(end);
-    }
-    if (blockIdx.y == 0) mark_long_chunks<LPR>(s.lr, row, start, end, l);
-    if (end - start > s.lr.thresh) return;  // long row: the chunk-parallel kernels compute it
-    typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
-    op.row_load(ctx, row, ok);
-    typename Op::State st;
-    op.init(ctx, st, row, ok);
-    reduce_edges<Op>(op, ctx, st, s.colind, start, end, sub, l);
-    op.row_end(ctx, st, row, ok);
-}
-
-// One workgroup per run of `chunks_per_block` chunks; runs without long rows are skipped after one coalesced look.
-template <class Op>
-__global__ __launch_bounds__(256) void rowreduce_long_kernel(const Op op, const RowSched s) {
+__device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSched &s) {
     constexpr int LPR = Op::LPR;
     constexpr int G = 256 / LPR;  // groups per workgroup
     constexpr int NREC = Op::kReduce ? Op::kRec : 1;
     __shared__ float red[Op::kReduce ? G : 1][NREC][LPR];
-    __shared__ int any_long;
+    __shared__ int32_t tbl[kMaxChunksPerBlock + 1];
     const LongRows &lr = s.lr;
     const int64_t c_begin = (int64_t)blockIdx.x * lr.chunks_per_block;
-    const int64_t c_end = min(c_begin + lr.chunks_per_block, lr.n_chunks);
-    if (!run_has_long_rows(lr, c_begin, c_end, &any_long)) return;
+    if (c_begin >= lr.n_chunks) return;
+    const int n = (int)min((int64_t)lr.chunks_per_block, lr.n_chunks - c_begin);
+    if (!build_chunk_table(lr, s.rowptr, s.m, c_begin, n + 1, tbl)) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int sub = lane / LPR;
     const int l = lane % LPR;
     const int g = (threadIdx.x >> 6) * (kWave / LPR) + sub;
     typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
-    for (int64_t c = c_begin; c < c_end; ++c) {
+    for (int t = 0; t < n; ++t) {
+        const int64_t c = c_begin + t;
         for (int slot = 0; slot < 2; ++slot) {
             int32_t row;  // workgroup-uniform
             int lo, hi;
-            if (!decode_piece(lr, s.rowptr, c, slot, row, lo, hi)) continue;
+            if (!decode_piece(lr, s.rowptr, tbl, c, t, slot, row, lo, hi)) continue;
             const int per = (hi - lo + G - 1) / G;  // contiguous slices
             int sb = min(lo + g * per, hi), se = min(sb + per, hi);
             if constexpr (LPR == kWave) {  // one wave per slice: keep the loop bounds scalar
@@ -256,6 +237,122 @@ __global__ __launch_bounds__(256) void rowreduce_long_kernel(const Op op, const 
     }
 }
 
+// Streaming row blocks (rows_per_group = R > 1): a lane group owns R consecutive rows and walks ALL their edges as one
+// stream -- index chunks of LPR edges and batches of UNROLL gathers run across row borders, so graphs whose rows are
+// mostly 1..3 edges long (citation / R-MAT graphs) keep UNROLL gathers in flight instead of one short dependent
+// round trip per row.  The per-row arithmetic and its order are unchanged (the state is finished and restarted at
+// every row border).  A group that meets a long row falls back to the row-at-a-time walk for its R rows.
+template <class Op>
+__device__ __forceinline__ void rowreduce_stream_rows(const Op &op, const RowSched &s, int64_t row0, int sub, int l) {
+    constexpr int LPR = Op::LPR, UNROLL = Op::UNROLL;
+    const int R = (int)min((int64_t)s.rows_per_group, s.m - row0);  // rows of this group (R <= LPR - 1)
+    if (R <= 0) return;
+    int my_rp = (l <= R) ? s.rowptr[row0 + l] : 0;  // lane i holds rowptr[row0 + i]
+    const int next_rp = group_bcast<LPR>(my_rp, sub, min(l + 1, R));
+    const bool mine_long = (l < R) && (next_rp - my_rp > s.lr.thresh);
+    unsigned long long vote = __ballot(mine_long);
+    if constexpr (LPR < kWave) vote = (vote >> (sub * LPR)) & ((1ull << LPR) - 1ull);
+    typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
+    typename Op::State st;
+    if (vote != 0ull) {  // group-uniform: a hub row among them -> one row at a time, the hub is skipped
+        for (int i = 0; i < R; ++i) {
+            const int start = group_bcast<LPR>(my_rp, sub, i), end = group_bcast<LPR>(my_rp, sub, i + 1);
+            if (end - start > s.lr.thresh) continue;
+            op.row_load(ctx, row0 + i, true);
+            op.init(ctx, st, row0 + i, true);
+            reduce_edges<Op>(op, ctx, st, s.colind, start, end, sub, l);
+            op.row_end(ctx, st, row0 + i, true);
+        }
+        return;
+    }
+    const int e_begin = group_bcast<LPR>(my_rp, sub, 0), e_end = group_bcast<LPR>(my_rp, sub, R);
+    int cur = 0;
+    int row_hi = group_bcast<LPR>(my_rp, sub, 1);
+    op.row_load(ctx, row0, true);
+    op.init(ctx, st, row0, true);
+    for (int base = e_begin; base < e_end; base += LPR) {
+        const int cnt = min(LPR, e_end - base);
+        int my_c = 0;
+        typename Op::LaneVals lv{};
+        if (l < cnt) {
+            my_c = s.colind[base + l];
+            op.lane_load(ctx, lv, base + l);
+        }
+        for (int j = 0; j < cnt; j += UNROLL) {
+            typename Op::Batch b;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int jj = min(j + u, cnt - 1);
+                op.fetch(ctx, b, u, group_bcast<LPR>(my_c, sub, jj), base + jj, lv, sub, jj);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int e = base + j + u;
+                const bool valid = (j + u) < cnt;
+                if (valid) {
+                    while (e >= row_hi) {  // group-uniform: finish the row(s) that end before edge e
+                        op.row_end(ctx, st, row0 + cur, true);
+                        ++cur;
+                        row_hi = group_bcast<LPR>(my_rp, sub, cur + 1);
+                        op.row_load(ctx, row0 + cur, true);
+                        op.init(ctx, st, row0 + cur, true);
+                    }
+                }
+                op.apply(ctx, st, b, u, valid, e, j + u);
+            }
+        }
+        op.chunk_end(ctx, st, base, cnt);
+    }
+    for (;;) {  // the current row and the empty rows behind it
+        op.row_end(ctx, st, row0 + cur, true);
+        if (++cur >= R) break;
+        op.row_load(ctx, row0 + cur, true);
+        op.init(ctx, st, row0 + cur, true);
+    }
+}
+
+// Grid: [ n_long_blocks long-row workgroups | row-block workgroups ]  x  column tiles.  The long-row workgroups come
+// first so that the (critical-path) hub rows start at once; they cost a graph without hub rows ~17 dependent
+// L2-resident loads in <= 1024 workgroups, overlapped with the row blocks.
+template <class Op>
+__global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const RowSched s) {
+    if (blockIdx.x < s.lr.n_long_blocks) {
+        rowreduce_long_block<Op>(op, s);
+        return;
+    }
+    constexpr int LPR = Op::LPR;
+    constexpr int RPW = kWave / LPR;  // row groups per wave
+    constexpr int GPB = RPW * 4;      // row groups per 256-thread workgroup
+    const int64_t rb = xcd_remap(blockIdx.x - s.lr.n_long_blocks, s.rowblocks);
+    if (rb < 0) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int sub = lane / LPR;
+    const int l = lane % LPR;
+    if (s.rows_per_group > 1) {
+        rowreduce_stream_rows<Op>(op, s, (rb * GPB + wave * RPW + sub) * s.rows_per_group, sub, l);
+        return;
+    }
+    const int64_t row = rb * GPB + wave * RPW + sub;
+    const bool ok = row < s.m;
+    int start = 0, end = 0;
+    if (ok) {
+        start = s.rowptr[row];
+        end = s.rowptr[row + 1];
+    }
+    if constexpr (LPR == kWave) {  // whole wave on one row: make the loop bounds scalar
+        start = __builtin_amdgcn_readfirstlane(start);
+        end = __builtin_amdgcn_readfirstlane(end);
+    }
+    if (end - start > s.lr.thresh) return;  // long row: the long-row workgroups compute it
+    typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
+    op.row_load(ctx, row, ok);
+    typename Op::State st;
+    op.init(ctx, st, row, ok);
+    reduce_edges<Op>(op, ctx, st, s.colind, start, end, sub, l);
+    op.row_end(ctx, st, row, ok);
+}
+
 // For every long row merge its piece records in chunk order and finish the row.  The row is combined by the lane
 // group that finds it at its FIRST full chunk (the row's head piece, if any, sits in slot 1 of the chunk before).
 template <class Op>
@@ -263,30 +360,30 @@ __global__ __launch_bounds__(256) void rowreduce_combine_kernel(const Op op, con
     constexpr int LPR = Op::LPR;
     constexpr int G = 256 / LPR;
     constexpr int NREC = Op::kRec;
-    __shared__ int any_long;
+    __shared__ int32_t tbl[kMaxChunksPerBlock + 1];
     const LongRows &lr = s.lr;
     const int64_t c_begin = (int64_t)blockIdx.x * lr.chunks_per_block;
-    const int64_t c_end = min(c_begin + lr.chunks_per_block, lr.n_chunks);
-    if (!run_has_long_rows(lr, c_begin, c_end - 1, &any_long)) return;
+    if (c_begin >= lr.n_chunks) return;
+    const int n = (int)min((int64_t)lr.chunks_per_block, lr.n_chunks - c_begin);
+    if (!build_chunk_table(lr, s.rowptr, s.m, c_begin, n, tbl)) return;
     const int ch = lr.thresh;
     const int lane = threadIdx.x & (kWave - 1);
     const int sub = lane / LPR;
     const int l = lane % LPR;
     const int g = (threadIdx.x >> 6) * (kWave / LPR) + sub;
     typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
-    // every group of a wave runs the same number of iterations (row_load may shuffle across the whole wave)
-    for (int64_t c0 = c_begin; c0 < c_end; c0 += G) {
-        const int64_t c = c0 + g;
-        int32_t row = (c < c_end) ? lr.chunk_row[c] : -1;
+    for (int t0 = 0; t0 < n; t0 += G) {
+        const int t = t0 + g;
+        const int64_t c = c_begin + t;
+        int32_t row = (t < n) ? tbl[t] : -1;
         int start = 0, end = 0;
         if (row >= 0) {
             start = s.rowptr[row];
             end = s.rowptr[row + 1];
             if ((int64_t)(start + ch - 1) / ch != c) row = -1;  // not the row's first owned chunk
         }
-        const bool ok = row >= 0;
-        op.row_load(ctx, ok ? row : 0, ok);
-        if (!ok) continue;
+        if (row < 0) continue;  // (group-uniform; the shuffles of row_load are group-local)
+        op.row_load(ctx, row, true);
         typename Op::State st;
         op.init(ctx, st, row, true);
         const int64_t c_last = (end - 1) / ch;
@@ -311,12 +408,14 @@ __global__ __launch_bounds__(256) void rowreduce_combine_kernel(const Op op, con
     }
 }
 
-// Launch the 1..3 kernels of one operator call.  `tiles` = column tiles (gridDim.y).  workspace == nullptr: every
-// row is reduced sequentially by its lane group (exact reference order for any length).
+// Launch the 1..2 kernels of one operator call.  `tiles` = column tiles (gridDim.y).  Operators with a per-row state
+// (kReduce) use the long-row path only when given a workspace; with workspace == nullptr every row is reduced
+// sequentially by its lane group (exact reference order for any length).  Per-edge operators need no scratch.
 template <class Op>
 static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t nnz,
                             int64_t tiles, void *workspace, size_t workspace_bytes, hipStream_t stream) {
-    constexpr int RPB = (kWave / Op::LPR) * 4;
+    const int rows_per_group = std::max(1, std::min(Op::LPR - 1, g_tuning[kTuneRowsSeq]));
+    const int64_t RPB = (kWave / Op::LPR) * 4 * rows_per_group;
     const int64_t n_rowblocks = (m + RPB - 1) / RPB;
     if (n_rowblocks == 0) return COGDL_HIP_OK;
     if (n_rowblocks > 0x7fffffff / (kXcds * 64) || tiles > 65535 || tiles < 1) return COGDL_HIP_ERANGE;
@@ -325,30 +424,23 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
     s.colind = colind;
     s.m = m;
     s.rowblocks = make_xcd_map(n_rowblocks);
+    s.rows_per_group = rows_per_group;
     s.lr.thresh = INT_MAX;
-    if (workspace && nnz > 0) {
-        const int t = pick_long_thresh(nnz);
-        const int64_t n_chunks = n_chunks_for(nnz, t);
-        const int64_t rec_stride = Op::kReduce ? tiles * Op::kRec * Op::LPR : 0;
-        const size_t need = chunk_row_bytes(n_chunks) + (size_t)n_chunks * 2 * (size_t)rec_stride * sizeof(float);
-        if (workspace_bytes < need) return COGDL_HIP_EWORKSPACE;
-        if (!aligned_to(workspace, 256)) return COGDL_HIP_EALIGN;
-        s.lr.thresh = t;
-        s.lr.chunk_row = (int32_t *)workspace;
-        s.lr.partial = (float *)((char *)workspace + chunk_row_bytes(n_chunks));
-        s.lr.n_chunks = n_chunks;
-        s.lr.rec_stride = rec_stride;
-        // a bounded number of workgroups, each owning a contiguous run of chunks (cheap to skip when no row is long)
-        const int64_t max_wg = std::max(64, g_tuning[kTuneLongGrid]);
-        s.lr.chunks_per_block = (int)((n_chunks + max_wg - 1) / max_wg);
+    if (nnz > 0 && (!Op::kReduce || workspace)) {
+        plan_long_rows(s.lr, nnz);
+        if constexpr (Op::kReduce) {
+            s.lr.rec_stride = tiles * Op::kRec * Op::LPR;
+            if (workspace_bytes < rowreduce_workspace_bytes(nnz, s.lr.rec_stride)) return COGDL_HIP_EWORKSPACE;
+            if (!aligned_to(workspace, 256)) return COGDL_HIP_EALIGN;
+            s.lr.partial = (float *)workspace;
+        }
     }
-    dim3 grid(xcd_grid(s.rowblocks), (unsigned)tiles);
+    dim3 grid(s.lr.n_long_blocks + xcd_grid(s.rowblocks), (unsigned)tiles);
     hipLaunchKernelGGL((rowreduce_main_kernel<Op>), grid, dim3(256), 0, stream, op, s);
-    if (s.lr.n_chunks > 0) {
-        const unsigned gx = (unsigned)((s.lr.n_chunks + s.lr.chunks_per_block - 1) / s.lr.chunks_per_block);
-        hipLaunchKernelGGL((rowreduce_long_kernel<Op>), dim3(gx, (unsigned)tiles), dim3(256), 0, stream, op, s);
-        if constexpr (Op::kReduce)
-            hipLaunchKernelGGL((rowreduce_combine_kernel<Op>), dim3(gx, (unsigned)tiles), dim3(256), 0, stream, op, s);
+    if constexpr (Op::kReduce) {
+        if (s.lr.n_long_blocks > 0)
+            hipLaunchKernelGGL((rowreduce_combine_kernel<Op>), dim3(s.lr.n_long_blocks, (unsigned)tiles), dim3(256), 0,
+                               stream, op, s);
     }
     return launch_status();
 }

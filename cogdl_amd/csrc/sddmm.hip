@@ -113,12 +113,8 @@ static int dispatch_sddmm(const SddmmArgs &a, void *ws, size_t wsb, hipStream_t 
 
 using namespace cogdl;
 
-// Scratch of the operators with per-EDGE outputs (csr_sddmm, mhsddmm): only the long-row chunk table.
-extern "C" size_t cogdl_hip_edge_op_workspace_bytes(int64_t nnz) { return rowreduce_workspace_bytes(nnz, 0); }
-
 extern "C" int cogdl_hip_csr_sddmm(const int32_t *rowptr, const int32_t *colind, const float *d1,
-                                   const float *d2, float *out, int64_t m, int64_t k, int64_t nnz, void *workspace,
-                                   size_t workspace_bytes, void *stream) {
+                                   const float *d2, float *out, int64_t m, int64_t k, int64_t nnz, void *stream) {
     if (m < 0 || k < 0 || nnz < 0) return COGDL_HIP_EINVAL;
     if (m == 0) return COGDL_HIP_OK;
     if (!rowptr || !d1 || !d2 || !out) return COGDL_HIP_EINVAL;
@@ -126,7 +122,7 @@ extern "C" int cogdl_hip_csr_sddmm(const int32_t *rowptr, const int32_t *colind,
     hipStream_t s = (hipStream_t)stream;
     if (k == 0) return COGDL_HIP_EINVAL;
     SddmmArgs a{rowptr, colind, d1, d2, out, m, k, nnz};
-    if (k % 4 == 0 && aligned_to(d1, 16) && aligned_to(d2, 16)) return dispatch_sddmm<4>(a, workspace, workspace_bytes, s);
-    if (k % 2 == 0 && aligned_to(d1, 8) && aligned_to(d2, 8)) return dispatch_sddmm<2>(a, workspace, workspace_bytes, s);
-    return dispatch_sddmm<1>(a, workspace, workspace_bytes, s);
+    if (k % 4 == 0 && aligned_to(d1, 16) && aligned_to(d2, 16)) return dispatch_sddmm<4>(a, nullptr, 0, s);
+    if (k % 2 == 0 && aligned_to(d1, 8) && aligned_to(d2, 8)) return dispatch_sddmm<2>(a, nullptr, 0, s);
+    return dispatch_sddmm<1>(a, nullptr, 0, s);
 }

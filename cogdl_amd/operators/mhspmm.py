@@ -43,10 +43,9 @@ def mhsddmm_raw(rowptr, colind, grad, feat):
     v, (_, h, f) = rowptr.numel() - 1, feat.shape
     nnz = colind.numel()
     out = torch.empty((nnz, h), dtype=torch.float32, device=dev)
-    ws, ws_bytes = _lib.workspace("cogdl_hip_edge_op_workspace_bytes", dev, nnz)
     with torch.cuda.device(dev):
         rc = _lib.hip().cogdl_hip_mhsddmm(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(grad), _lib.ptr(feat),
-                                          _lib.ptr(out), v, h, f, nnz, _lib.ptr(ws), ws_bytes, _lib.stream_of(feat))
+                                          _lib.ptr(out), v, h, f, nnz, _lib.stream_of(feat))
     _lib.check(rc, "mhsddmm")
     return out
 

@@ -85,10 +85,9 @@ def csr_sddmm_raw(rowptr, colind, d1, d2):
     m, k = rowptr.numel() - 1, d1.shape[1]
     nnz = colind.numel()
     out = torch.empty(nnz, dtype=torch.float32, device=dev)
-    ws, ws_bytes = _lib.workspace("cogdl_hip_edge_op_workspace_bytes", dev, nnz)
     with torch.cuda.device(dev):
         rc = _lib.hip().cogdl_hip_csr_sddmm(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(d1), _lib.ptr(d2),
-                                            _lib.ptr(out), m, k, nnz, _lib.ptr(ws), ws_bytes, _lib.stream_of(d1))
+                                            _lib.ptr(out), m, k, nnz, _lib.stream_of(d1))
     _lib.check(rc, "csr_sddmm")
     return out
 

@@ -122,11 +122,9 @@ COGDL_API int cogdl_hip_gather_rows(const int32_t *perm, const void *src, void *
  * csr_sddmm: out[e] = < d1[row(e),:], d2[colind[e],:] >      (gradient of edge weights)
  * Replaces sddmm.csr_sddmm (operators/spmm/sddmm.cpp:47-70, sddmm_kernel.cu:249-417,451-476).
  * ------------------------------------------------------------------------------------- */
-/* Scratch of the operators with per-EDGE outputs (csr_sddmm, mhsddmm): the long-row chunk table only. */
-COGDL_API size_t cogdl_hip_edge_op_workspace_bytes(int64_t nnz);
+/* Per-edge outputs: hub rows are split over whole workgroups without any scratch. */
 COGDL_API int cogdl_hip_csr_sddmm(const int32_t *rowptr, const int32_t *colind, const float *d1,
-                        const float *d2, float *out, int64_t m, int64_t k, int64_t nnz, void *workspace,
-                        size_t workspace_bytes, void *stream);
+                        const float *d2, float *out, int64_t m, int64_t k, int64_t nnz, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * edge_softmax: per (destination row, head) softmax over the row's edges; values [E,H].
@@ -145,7 +143,7 @@ COGDL_API int cogdl_hip_edge_softmax_bwd(const int32_t *rowptr, const float *sof
  * mhspmm:  out[v,h,:] = sum_e att[e,h] * feat[colind[e],h,:]     feat [n_src,H,F]
  * Replaces mhspmm.mhspmm (operators/spmm/multiheadSpmm.cpp, multiheadSpmm.cu:6-77).
  * att is always f32; feat/out have `dtype` (f32: sequential fp32 mul+add per element).
- * workspace: cogdl_hip_mhspmm_workspace_bytes(nnz, H, F, dtype) (mhsddmm: cogdl_hip_edge_op_workspace_bytes).
+ * workspace: cogdl_hip_mhspmm_workspace_bytes(nnz, H, F, dtype) (mhsddmm needs none).
  * mhsddmm: out[e,h] = < grad[row(e),h,:], feat[colind[e],h,:] >
  * Replaces mhsddmm.mhsddmm (operators/spmm/multiheadSddmm.cu:6-113).
  * ------------------------------------------------------------------------------------- */
@@ -155,7 +153,7 @@ COGDL_API int cogdl_hip_mhspmm(const int32_t *rowptr, const int32_t *colind, con
                      void *workspace, size_t workspace_bytes, void *stream);
 COGDL_API int cogdl_hip_mhsddmm(const int32_t *rowptr, const int32_t *colind, const float *grad,
                       const float *feat, float *out, int64_t v, int64_t h, int64_t f, int64_t nnz,
-                      void *workspace, size_t workspace_bytes, void *stream);
+                      void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * scatter_max: out[r,c] = max_{e in row r} feat[colind[e],c]; max_id[r,c] = the colind of
