@@ -371,7 +371,7 @@ static int edge_softmax_dispatch(const int32_t *rowptr, const float *a, const fl
         if (wsb < rowreduce_workspace_bytes(nnz, 2 * h)) return COGDL_HIP_EWORKSPACE;
         if (!aligned_to(ws, 256)) return COGDL_HIP_EALIGN;
         plan_long_rows(lr, nnz);
-        lr.partial = (float *)ws;
+        lr.partial = (float *)((char *)ws + kFoundBytes);
         lr.rec_stride = 2 * h;
     }
     const bool pow2 = (h & (h - 1)) == 0 && h <= kWave;

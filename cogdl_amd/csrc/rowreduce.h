@@ -47,6 +47,8 @@ namespace cogdl {
 struct LongRows {
     int thresh;              // rows with more edges take the chunk-parallel path; also the chunk size (INT_MAX: off)
     float *partial;          // [n_chunks][2][rec_stride] fp32 piece records (kReduce ops)
+    int32_t *found;          // [n_long_blocks]: did that long-row workgroup find a piece?  (written by every one of
+                             //   them on every launch; lets the combine kernel leave without searching)
     int64_t n_chunks;
     int64_t rec_stride;      // tiles * kRec * LPR
     int chunks_per_block;    // a long-row workgroup owns a contiguous run of <= kMaxChunksPerBlock chunks
@@ -68,7 +70,6 @@ struct RowSched {
     int64_t m;
     XcdMap rowblocks;
     LongRows lr;
-    int rows_per_group;  // > 1: streaming row blocks (each lane group walks that many consecutive rows as one stream)
 };
 
 // Threshold above which a row is split.  The sequential time of a row of T edges (~T/UNROLL gather round trips of
@@ -81,17 +82,18 @@ inline int pick_long_thresh(int64_t nnz) {
 }
 inline int64_t n_chunks_for(int64_t nnz, int thresh) { return (nnz + thresh - 1) / thresh; }
 // Workspace of an operator whose piece record holds `rec_stride` floats.
+constexpr size_t kFoundBytes = 8192;  // found[] of <= 2048 long-row workgroups, in front of the records
 inline size_t rowreduce_workspace_bytes(int64_t nnz, int64_t rec_stride) {
     if (nnz <= 0 || rec_stride <= 0) return 0;
     const int64_t n_chunks = n_chunks_for(nnz, pick_long_thresh(nnz));
-    return ((size_t)n_chunks * 2 * (size_t)rec_stride * sizeof(float) + 255) / 256 * 256;
+    return kFoundBytes + ((size_t)n_chunks * 2 * (size_t)rec_stride * sizeof(float) + 255) / 256 * 256;
 }
 // Fill the scheduling fields of the long-row path (everything but `partial`/`rec_stride`).
 inline void plan_long_rows(LongRows &lr, int64_t nnz) {
     lr.thresh = pick_long_thresh(nnz);
     lr.n_chunks = n_chunks_for(nnz, lr.thresh);
     lr.nnz = nnz;
-    const int64_t max_wg = std::max(64, g_tuning[kTuneLongGrid]);
+    const int64_t max_wg = std::min(2040, std::max(64, g_tuning[kTuneLongGrid]));
     lr.chunks_per_block = (int)std::min<int64_t>(kMaxChunksPerBlock, (lr.n_chunks + max_wg - 1) / max_wg);
     const int64_t blocks = (lr.n_chunks + lr.chunks_per_block - 1) / lr.chunks_per_block;
     lr.n_long_blocks = (unsigned)((blocks + kXcds - 1) / kXcds * kXcds);  // keeps block % 8 == XCD for the row blocks
@@ -190,7 +192,9 @@ __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSche
     const int64_t c_begin = (int64_t)blockIdx.x * lr.chunks_per_block;
     if (c_begin >= lr.n_chunks) return;
     const int n = (int)min((int64_t)lr.chunks_per_block, lr.n_chunks - c_begin);
-    if (!build_chunk_table(lr, s.rowptr, s.m, c_begin, n + 1, tbl)) return;
+    const bool any = build_chunk_table(lr, s.rowptr, s.m, c_begin, n + 1, tbl);
+    if (lr.found && threadIdx.x == 0 && blockIdx.y == 0) lr.found[blockIdx.x] = any ? 1 : 0;
+    if (!any) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int sub = lane / LPR;
     const int l = lane % LPR;
@@ -237,80 +241,6 @@ __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSche
     }
 }
 
-// Streaming row blocks (rows_per_group = R > 1): a lane group owns R consecutive rows and walks ALL their edges as one
-// stream -- index chunks of LPR edges and batches of UNROLL gathers run across row borders, so graphs whose rows are
-// mostly 1..3 edges long (citation / R-MAT graphs) keep UNROLL gathers in flight instead of one short dependent
-// round trip per row.  The per-row arithmetic and its order are unchanged (the state is finished and restarted at
-// every row border).  A group that meets a long row falls back to the row-at-a-time walk for its R rows.
-template <class Op>
-__device__ __forceinline__ void rowreduce_stream_rows(const Op &op, const RowSched &s, int64_t row0, int sub, int l) {
-    constexpr int LPR = Op::LPR, UNROLL = Op::UNROLL;
-    const int R = (int)min((int64_t)s.rows_per_group, s.m - row0);  // rows of this group (R <= LPR - 1)
-    if (R <= 0) return;
-    int my_rp = (l <= R) ? s.rowptr[row0 + l] : 0;  // lane i holds rowptr[row0 + i]
-    const int next_rp = group_bcast<LPR>(my_rp, sub, min(l + 1, R));
-    const bool mine_long = (l < R) && (next_rp - my_rp > s.lr.thresh);
-    unsigned long long vote = __ballot(mine_long);
-    if constexpr (LPR < kWave) vote = (vote >> (sub * LPR)) & ((1ull << LPR) - 1ull);
-    typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
-    typename Op::State st;
-    if (vote != 0ull) {  // group-uniform: a hub row among them -> one row at a time, the hub is skipped
-        for (int i = 0; i < R; ++i) {
-            const int start = group_bcast<LPR>(my_rp, sub, i), end = group_bcast<LPR>(my_rp, sub, i + 1);
-            if (end - start > s.lr.thresh) continue;
-            op.row_load(ctx, row0 + i, true);
-            op.init(ctx, st, row0 + i, true);
-            reduce_edges<Op>(op, ctx, st, s.colind, start, end, sub, l);
-            op.row_end(ctx, st, row0 + i, true);
-        }
-        return;
-    }
-    const int e_begin = group_bcast<LPR>(my_rp, sub, 0), e_end = group_bcast<LPR>(my_rp, sub, R);
-    int cur = 0;
-    int row_hi = group_bcast<LPR>(my_rp, sub, 1);
-    op.row_load(ctx, row0, true);
-    op.init(ctx, st, row0, true);
-    for (int base = e_begin; base < e_end; base += LPR) {
-        const int cnt = min(LPR, e_end - base);
-        int my_c = 0;
-        typename Op::LaneVals lv{};
-        if (l < cnt) {
-            my_c = s.colind[base + l];
-            op.lane_load(ctx, lv, base + l);
-        }
-        for (int j = 0; j < cnt; j += UNROLL) {
-            typename Op::Batch b;
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int jj = min(j + u, cnt - 1);
-                op.fetch(ctx, b, u, group_bcast<LPR>(my_c, sub, jj), base + jj, lv, sub, jj);
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int e = base + j + u;
-                const bool valid = (j + u) < cnt;
-                if (valid) {
-                    while (e >= row_hi) {  // group-uniform: finish the row(s) that end before edge e
-                        op.row_end(ctx, st, row0 + cur, true);
-                        ++cur;
-                        row_hi = group_bcast<LPR>(my_rp, sub, cur + 1);
-                        op.row_load(ctx, row0 + cur, true);
-                        op.init(ctx, st, row0 + cur, true);
-                    }
-                }
-                op.apply(ctx, st, b, u, valid, e, j + u);
-            }
-        }
-        op.chunk_end(ctx, st, base, cnt);
-    }
-    for (;;) {  // the current row and the empty rows behind it
-        op.row_end(ctx, st, row0 + cur, true);
-        if (++cur >= R) break;
-        op.row_load(ctx, row0 + cur, true);
-        op.init(ctx, st, row0 + cur, true);
-    }
-}
-
 // Grid: [ n_long_blocks long-row workgroups | row-block workgroups ]  x  column tiles.  The long-row workgroups come
 // first so that the (critical-path) hub rows start at once; they cost a graph without hub rows ~17 dependent
 // L2-resident loads in <= 1024 workgroups, overlapped with the row blocks.
@@ -329,10 +259,6 @@ __global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const 
     const int wave = threadIdx.x >> 6;
     const int sub = lane / LPR;
     const int l = lane % LPR;
-    if (s.rows_per_group > 1) {
-        rowreduce_stream_rows<Op>(op, s, (rb * GPB + wave * RPW + sub) * s.rows_per_group, sub, l);
-        return;
-    }
     const int64_t row = rb * GPB + wave * RPW + sub;
     const bool ok = row < s.m;
     int start = 0, end = 0;
@@ -364,6 +290,9 @@ __global__ __launch_bounds__(256) void rowreduce_combine_kernel(const Op op, con
     const LongRows &lr = s.lr;
     const int64_t c_begin = (int64_t)blockIdx.x * lr.chunks_per_block;
     if (c_begin >= lr.n_chunks) return;
+    // A row combined here owns the first edge of one of this run's chunks, so the long-row workgroup of the same run
+    // met it (slot 0): found[] == 0 means nothing to do -- one load instead of a search.
+    if (lr.found && lr.found[blockIdx.x] == 0) return;
     const int n = (int)min((int64_t)lr.chunks_per_block, lr.n_chunks - c_begin);
     if (!build_chunk_table(lr, s.rowptr, s.m, c_begin, n, tbl)) return;
     const int ch = lr.thresh;
@@ -414,8 +343,7 @@ __global__ __launch_bounds__(256) void rowreduce_combine_kernel(const Op op, con
 template <class Op>
 static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t nnz,
                             int64_t tiles, void *workspace, size_t workspace_bytes, hipStream_t stream) {
-    const int rows_per_group = std::max(1, std::min(Op::LPR - 1, g_tuning[kTuneRowsSeq]));
-    const int64_t RPB = (kWave / Op::LPR) * 4 * rows_per_group;
+    constexpr int64_t RPB = (kWave / Op::LPR) * 4;
     const int64_t n_rowblocks = (m + RPB - 1) / RPB;
     if (n_rowblocks == 0) return COGDL_HIP_OK;
     if (n_rowblocks > 0x7fffffff / (kXcds * 64) || tiles > 65535 || tiles < 1) return COGDL_HIP_ERANGE;
@@ -424,7 +352,6 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
     s.colind = colind;
     s.m = m;
     s.rowblocks = make_xcd_map(n_rowblocks);
-    s.rows_per_group = rows_per_group;
     s.lr.thresh = INT_MAX;
     if (nnz > 0 && (!Op::kReduce || workspace)) {
         plan_long_rows(s.lr, nnz);
@@ -432,7 +359,8 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
             s.lr.rec_stride = tiles * Op::kRec * Op::LPR;
             if (workspace_bytes < rowreduce_workspace_bytes(nnz, s.lr.rec_stride)) return COGDL_HIP_EWORKSPACE;
             if (!aligned_to(workspace, 256)) return COGDL_HIP_EALIGN;
-            s.lr.partial = (float *)workspace;
+            if (s.lr.n_long_blocks * sizeof(int32_t) <= kFoundBytes) s.lr.found = (int32_t *)workspace;
+            s.lr.partial = (float *)((char *)workspace + kFoundBytes);
         }
     }
     dim3 grid(s.lr.n_long_blocks + xcd_grid(s.rowblocks), (unsigned)tiles);

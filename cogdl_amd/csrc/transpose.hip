@@ -79,20 +79,28 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 // One strong mix per 4 consecutive int32 values (position-keyed): ~1/4 of the 64-bit multiplies.
 __device__ __forceinline__ uint64_t hash4(const int32_t *p, int64_t i, int64_t n, uint64_t salt) {
     uint32_t v[4];
+    if (i + 4 <= n && (reinterpret_cast<uintptr_t>(p + i) & 15) == 0) {  // one 16-byte load (the usual case)
+        const uint4 q = *reinterpret_cast<const uint4 *>(p + i);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (i + j < n) ? (uint32_t)p[i + j] : 0x5bd1e995u;
+        for (int j = 0; j < 4; ++j) v[j] = (i + j < n) ? (uint32_t)p[i + j] : 0x5bd1e995u;
+    }
     const uint64_t a = ((uint64_t)v[1] << 32) | v[0], b = ((uint64_t)v[3] << 32) | v[2];
     return mix64(a * 0x9e3779b97f4a7c15ull + (b ^ salt) * 0xc2b2ae3d27d4eb4full + (uint64_t)i);
 }
 
-__global__ void csr_fingerprint_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
-                                       int64_t m, int64_t nnz, unsigned long long *out) {
+// One partial per workgroup, written with a plain store (the target may be host-mapped pinned memory): no memset,
+// no atomics, no device-to-host copy behind it.  The fingerprint is the sum of the partials modulo 2^64.
+__global__ __launch_bounds__(256) void csr_fingerprint_kernel(const int32_t *__restrict__ rowptr,
+                                                              const int32_t *__restrict__ colind, int64_t m,
+                                                              int64_t nnz, unsigned long long *out) {
     uint64_t acc = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
     const int64_t tid4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     for (int64_t i = tid4; i <= m; i += stride) acc += hash4(rowptr, i, m + 1, 0xa5a5a5a5a5a5a5a5ull);
     for (int64_t i = tid4; i < nnz; i += stride) acc += hash4(colind, i, nnz, 0);
-    // wave reduce, block reduce, then ONE atomic per workgroup (integer add: order independent)
+    // wave reduce, block reduce (integer add: order independent)
 #pragma unroll
     for (int s = kWave / 2; s > 0; s >>= 1) {
         const uint32_t lo = __shfl_xor((uint32_t)acc, s, kWave), hi = __shfl_xor((uint32_t)(acc >> 32), s, kWave);
@@ -101,7 +109,7 @@ __global__ void csr_fingerprint_kernel(const int32_t *__restrict__ rowptr, const
     __shared__ unsigned long long part[4];
     if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
 }  // namespace cogdl
@@ -166,16 +174,9 @@ extern "C" int cogdl_hip_gather_rows(const int32_t *perm, const void *src, void 
 }
 
 extern "C" int cogdl_hip_csr_fingerprint(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t nnz,
-                                         uint64_t *out_hash, void *stream) {
-    if (m < 0 || nnz < 0 || !rowptr || !out_hash) return COGDL_HIP_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(out_hash, 0, sizeof(uint64_t), s);
-    if (e != hipSuccess) {
-        g_last_hip_error = (int)e;
-        return COGDL_HIP_ELAUNCH;
-    }
-    const unsigned blocks = (unsigned)std::min<int64_t>((std::max(m + 1, nnz) + 255) / 256, 512);
-    hipLaunchKernelGGL(csr_fingerprint_kernel, dim3(blocks), dim3(256), 0, s, rowptr, colind, m, nnz,
-                       (unsigned long long *)out_hash);
+                                         uint64_t *out_parts, void *stream) {
+    if (m < 0 || nnz < 0 || !rowptr || !out_parts) return COGDL_HIP_EINVAL;
+    hipLaunchKernelGGL(csr_fingerprint_kernel, dim3(COGDL_HIP_FINGERPRINT_PARTS), dim3(256), 0, (hipStream_t)stream,
+                       rowptr, colind, m, nnz, (unsigned long long *)out_parts);
     return launch_status();
 }

@@ -76,27 +76,29 @@ def gather_rows(perm, src):
     return out
 
 
+FINGERPRINT_PARTS = 256  # COGDL_HIP_FINGERPRINT_PARTS
+
+
 class Fingerprint:
-    """A structure hash in flight: device -> pinned host copy plus the event that guards it."""
+    """A structure hash in flight: the kernel writes its per-workgroup partials straight into pinned host memory
+    (device-visible on ROCm: no memset, no device-to-host copy kernel); an event guards them."""
     __slots__ = ("host", "event", "meta")
 
     def __init__(self, rowptr, colind, n_cols):
         dev = rowptr.device
         m, nnz = rowptr.numel() - 1, colind.numel()
-        d = torch.empty(1, dtype=torch.int64, device=dev)
+        self.host = torch.empty(FINGERPRINT_PARTS, dtype=torch.int64, pin_memory=True)
         with torch.cuda.device(dev):
-            rc = _lib.hip().cogdl_hip_csr_fingerprint(_lib.ptr(rowptr), _lib.ptr(colind), m, nnz, _lib.ptr(d),
-                                                      _lib.stream_of(rowptr))
+            rc = _lib.hip().cogdl_hip_csr_fingerprint(_lib.ptr(rowptr), _lib.ptr(colind), m, nnz,
+                                                      self.host.data_ptr(), _lib.stream_of(rowptr))
         _lib.check(rc, "csr_fingerprint")
-        self.host = torch.empty(1, dtype=torch.int64, pin_memory=True)
-        self.host.copy_(d, non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record(torch.cuda.current_stream(dev))
         self.meta = (dev.index, m, nnz, int(n_cols))
 
     def key(self):
         self.event.synchronize()
-        return self.meta + (int(self.host[0]),)
+        return self.meta + (int(self.host.sum()),)  # int64 sum wraps: the sum modulo 2^64
 
 
 class PlanCache:

@@ -203,12 +203,13 @@ COGDL_API int cogdl_hip_gat_bwd(const int32_t *rowptr, const int32_t *colind, co
 
 /* ---------------------------------------------------------------------------------------
  * Helpers used by the graph-plan cache and the vertex-sharded (multi-GPU) SpMM.
- * fingerprint: 64-bit content hash of (rowptr[0..m], colind[0..nnz)) written to *out_hash
- * (device or host-mapped pinned pointer).  Not part of the reference.
- * gather_feature_rows: out[i,:] = x[idx[i],:] for the halo send buffers (idx int32).
+ * fingerprint: 64-bit content hash of (rowptr[0..m], colind[0..nnz)) = the sum modulo 2^64 of the
+ * COGDL_HIP_FINGERPRINT_PARTS partials written to out_parts (device memory, or host-mapped pinned memory so that
+ * no device-to-host copy is needed; plain stores, no memset, no atomics).  Not part of the reference.
  * ------------------------------------------------------------------------------------- */
+#define COGDL_HIP_FINGERPRINT_PARTS 256
 COGDL_API int cogdl_hip_csr_fingerprint(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t nnz,
-                              uint64_t *out_hash, void *stream);
+                              uint64_t *out_parts, void *stream);
 
 #ifdef __cplusplus
 }

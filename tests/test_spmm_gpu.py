@@ -227,6 +227,31 @@ def test_plan_cache_hits_across_calls():
     assert PLANS.misses - m0 == 1 and PLANS.hits - h0 == 2
 
 
+def test_fingerprint_tracks_content_not_pointers():
+    """The plan-cache key: equal for fresh copies of one structure, different after any single change -- also for
+    unaligned views (scalar path of the hash) and odd sizes."""
+    from cogdl_amd.plan import Fingerprint
+
+    g = synth.scaled(3001, 9, seed=3).to(DEV)
+    k0 = Fingerprint(g.rowptr, g.colind, 3001).key()
+    assert Fingerprint(g.rowptr.clone(), g.colind.clone(), 3001).key() == k0
+    # an unaligned copy (offset by one element inside a bigger buffer) hashes the same content to the same key
+    buf = torch.empty(g.nnz + 1, dtype=torch.int32, device=DEV)
+    buf[1:] = g.colind
+    assert Fingerprint(g.rowptr, buf[1:], 3001).key() == k0
+    for pos in (0, 1, g.nnz // 2, g.nnz - 1):
+        c = g.colind.clone()
+        c[pos] = (c[pos] + 1) % 3001
+        assert Fingerprint(g.rowptr, c, 3001).key() != k0
+    c = g.colind.clone()
+    c[[5, 6]] = c[[6, 5]]  # swapping two different neighbours changes the key (position-keyed hash)
+    if int(g.colind[5]) != int(g.colind[6]):
+        assert Fingerprint(g.rowptr, c, 3001).key() != k0
+    r = g.rowptr.clone()
+    r[7] += 1
+    assert Fingerprint(r, g.colind, 3001).key() != k0
+
+
 def test_runs_on_the_current_stream():
     g = synth.scaled(5000, 10, seed=2).to(DEV)
     x = torch.randn(5000, 64, device=DEV)

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Fold the rocprofv3 --pmc CSVs under <dir>/pmc_*/ (one directory per counter pass, all running
+"""Kernel names: rowreduce_main_kernel<SpmmOp<...>> = the csr_spmm launch (row blocks + long-row workgroups),
+rowreduce_combine_kernel = the per-long-row merge.
+
+Fold the rocprofv3 --pmc CSVs under <dir>/pmc_*/ (one directory per counter pass, all running
 tools/pmc_probe.py) into one JSON: calibration of FETCH_SIZE / WRITE_SIZE on a 1 GiB copy, then per workload
 phase of the probe the mean counters per csr_spmm launch, the calibrated HBM-side bytes and the L2 hit rate.
 
@@ -16,7 +19,7 @@ root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 GIB = float(1 << 30)
 # (phase name, launches) -- must match tools/pmc_probe.py
 PHASES = [("arxiv_uniform_F128", 10), ("arxiv_rmat_F128", 10), ("scaled_4M_nodes_F128", 5)]
-KERNELS = {"csr_spmm_rowgroup_kernel": "main", "longrow_partial": "longrow_partial", "longrow_combine": "longrow_combine"}
+KERNELS = {"rowreduce_main_kernel": "main", "rowreduce_combine_kernel": "combine"}
 
 
 def phase_of(ordinal):
