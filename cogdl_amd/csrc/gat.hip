@@ -22,6 +22,7 @@
 namespace cogdl {
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+static bool pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // Sum over the `lph` lanes (power of two, aligned) that hold one head.
 template <int LPR>
@@ -37,6 +38,7 @@ template <typename T, int VEC_, int LPR_, int UNROLL_>
 struct GatFwdOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_ + 2;
     static constexpr bool kReduce = true;
+    static constexpr int kLds = 0;
     const float *attn_row, *attn_col;
     const T *feat;
     T *out;
@@ -96,6 +98,7 @@ struct GatFwdOp {
             s.mx = mn;
         }
     }
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
         if (ok && c.col_ok) {
@@ -123,12 +126,165 @@ struct GatFwdOp {
         s.lsum = rec[VEC + 1];
     }
     // Two flash-attention blocks: rescale both to the common maximum (an empty block has lsum == 0, mx == -inf).
-    __device__ __forceinline__ void merge(State &a, const State &b) const {
+    __device__ __forceinline__ void merge(const Ctx &, State &a, const State &b) const {
         const float mn = fmaxf(a.mx, b.mx);
         const float sa = (a.lsum == 0.f) ? 0.f : expf(a.mx - mn);
         const float sb = (b.lsum == 0.f) ? 0.f : expf(b.mx - mn);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) a.acc[i] = a.acc[i] * sa + b.acc[i] * sb;
+        a.lsum = a.lsum * sa + b.lsum * sb;
+        a.mx = mn;
+    }
+};
+
+// Chunk-wise softmax variant (H a power of two <= min(LPR, 16)): the flash-attention block structure.  For every
+// chunk of LPR edges the group first computes the chunk's softmax weights ONCE per (edge, head) -- lane l takes head
+// l % H of the edges l / H, l / H + LPR/H, ... (coalesced attn_col reads), the per-head chunk maximum and sum are
+// wave64 butterflies over the lanes of equal head, the weights go to LDS -- rescales its accumulator once, and only
+// then gathers the feature rows, folding each with the weight read back from LDS.  Versus the edge-wise online
+// softmax above: one exp per (edge, head) instead of two per (edge, lane), no dependent max/rescale chain per edge.
+template <typename T, int VEC_, int LPR_, int UNROLL_>
+struct GatFwdChunkOp {
+    static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_ + 2;
+    static constexpr bool kReduce = true;
+    static constexpr int kMaxHeads = 16;
+    static constexpr int kLds = kMaxHeads;  // LPR edges x H heads weights per group
+    const float *attn_row, *attn_col;
+    const T *feat;
+    T *out;
+    float *edge_max, *edge_sum;
+    float slope;
+    int heads, fdim;
+
+    struct Ctx {
+        int col0, cc, hd, hs, lane0, tile;  // hd: head of this lane's columns; hs = l % H: head of its softmax duty
+        bool col_ok;
+        float ar;                            // attn_row[row, hs]
+        const float *w;                      // the chunk's weights in LDS: w[edge_in_chunk * H + head]
+    };
+    struct State {
+        float acc[VEC];
+        float mx, lsum;  // running max / sum of head hs (identical in all lanes of equal hs)
+    };
+    struct LaneVals {};
+    struct Batch { float v[UNROLL][VEC]; };
+
+    __device__ __forceinline__ Ctx make_ctx(int l, int tile) const {
+        Ctx c;
+        c.col0 = (tile * LPR + l) * VEC;
+        c.col_ok = c.col0 < heads * fdim;
+        c.cc = c.col_ok ? c.col0 : 0;
+        c.hd = c.cc / fdim;
+        c.hs = l % heads;
+        c.lane0 = (int)(threadIdx.x & (kWave - 1)) - l;  // first lane of this group inside the wave
+        c.tile = tile;
+        c.ar = 0.f;
+        c.w = nullptr;
+        return c;
+    }
+    __device__ __forceinline__ void row_load(Ctx &c, int64_t row, bool ok) const {
+        c.ar = ok ? attn_row[row * heads + c.hs] : 0.f;
+    }
+    __device__ __forceinline__ void init_zero(State &s) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.acc[i] = 0.f;
+        s.mx = -INFINITY;
+        s.lsum = 0.f;
+    }
+    __device__ __forceinline__ void init(const Ctx &, State &s, int64_t, bool) const { init_zero(s); }
+    __device__ __forceinline__ void lane_load(const Ctx &, LaneVals &, int64_t) const {}
+    // reductions over the lanes of one group that share a softmax head: lane strides H, 2H, ... LPR/2
+    __device__ __forceinline__ float head_max(float v) const {
+#pragma unroll
+        for (int sft = LPR / 2; sft > 0; sft >>= 1)
+            if (sft >= heads) v = fmaxf(v, __shfl_xor(v, sft, kWave));
+        return v;
+    }
+    __device__ __forceinline__ float head_add(float v) const {
+#pragma unroll
+        for (int sft = LPR / 2; sft > 0; sft >>= 1)
+            if (sft >= heads) v += __shfl_xor(v, sft, kWave);
+        return v;
+    }
+    __device__ __forceinline__ void chunk_begin(Ctx &c, State &s, int, int cnt, int my_c, int, int l,
+                                                float *lds) const {
+        const int epr = LPR / heads;  // edges per round
+        const int eo = l / heads;
+        const int rounds = (cnt + epr - 1) / epr;
+        float lmax = -INFINITY;
+        for (int r = 0; r < rounds; ++r) {
+            const int je = r * epr + eo;
+            const int col = __shfl(my_c, c.lane0 + min(je, cnt - 1), kWave);
+            const float sc = (je < cnt) ? leaky(c.ar + attn_col[(int64_t)col * heads + c.hs], slope) : -INFINITY;
+            lds[r * LPR + l] = sc;  // == lds[je * H + hs]
+            lmax = fmaxf(lmax, sc);
+        }
+        lmax = head_max(lmax);
+        const float mn = fmaxf(s.mx, lmax);
+        const float scale = (s.lsum == 0.f) ? 0.f : expf(s.mx - mn);
+        float psum = 0.f;
+        for (int r = 0; r < rounds; ++r) {
+            const float p = expf(lds[r * LPR + l] - mn);  // exp(-inf) == 0 for the masked tail
+            lds[r * LPR + l] = p;
+            psum += p;
+        }
+        s.lsum = s.lsum * scale + head_add(psum);
+        s.mx = mn;
+        const float scale_col = __shfl(scale, c.lane0 + c.hd, kWave);  // lane hd of the group serves head hd
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.acc[i] *= scale_col;
+        c.w = lds;
+    }
+    __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t, const LaneVals &, int,
+                                          int) const {
+        load_vec<T, VEC>(feat + (int64_t)col * (heads * fdim) + c.cc, b.v[u]);
+    }
+    __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
+                                          int jpos) const {
+        if (valid) {
+            const float p = c.w[jpos * heads + c.hd];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) s.acc[i] = fmaf(p, b.v[u][i], s.acc[i]);
+        }
+    }
+    __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
+    __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
+        const float lsum_col = __shfl(s.lsum, c.lane0 + c.hd, kWave);  // (all lanes of the group take part)
+        if (!ok) return;
+        if (c.col_ok) {
+            const float inv = (lsum_col > 0.f) ? 1.f / lsum_col : 0.f;  // empty row -> zeros
+            float r[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) r[i] = s.acc[i] * inv;
+            store_vec<T, VEC>(out + row * (int64_t)(heads * fdim) + c.col0, r);
+        }
+        const int l = (int)(threadIdx.x & (kWave - 1)) - c.lane0;
+        if (c.tile == 0 && l < heads) {
+            edge_max[row * heads + l] = s.mx;
+            edge_sum[row * heads + l] = s.lsum;
+        }
+    }
+    __device__ __forceinline__ void pack(const State &s, float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) rec[i] = s.acc[i];
+        rec[VEC] = s.mx;
+        rec[VEC + 1] = s.lsum;
+    }
+    __device__ __forceinline__ void unpack(State &s, const float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.acc[i] = rec[i];
+        s.mx = rec[VEC];
+        s.lsum = rec[VEC + 1];
+    }
+    // b's edges follow a's.  The (max, sum) pair belongs to head hs, the accumulator to head hd: its two scale
+    // factors are fetched from lane hd of the group (all lanes of the group call merge together).
+    __device__ __forceinline__ void merge(const Ctx &c, State &a, const State &b) const {
+        const float mn = fmaxf(a.mx, b.mx);
+        const float sa = (a.lsum == 0.f) ? 0.f : expf(a.mx - mn);
+        const float sb = (b.lsum == 0.f) ? 0.f : expf(b.mx - mn);
+        const float sa_c = __shfl(sa, c.lane0 + c.hd, kWave), sb_c = __shfl(sb, c.lane0 + c.hd, kWave);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) a.acc[i] = a.acc[i] * sa_c + b.acc[i] * sb_c;
         a.lsum = a.lsum * sa + b.lsum * sb;
         a.mx = mn;
     }
@@ -140,6 +296,7 @@ template <int VEC_, int LPR_, int UNROLL_>
 struct GatBwdRowOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = 1;
     static constexpr bool kReduce = true;
+    static constexpr int kLds = 0;
     const float *attn_row, *attn_col, *feat, *edge_max, *edge_sum, *out, *grad_out;
     float *dvec, *grad_attn_row;
     float slope;
@@ -205,6 +362,7 @@ struct GatBwdRowOp {
             s.gacc += a * (dot - c.d) * (pre > 0.f ? 1.f : slope);
         }
     }
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
         if (ok && c.head_lane) {
@@ -214,7 +372,7 @@ struct GatBwdRowOp {
     }
     __device__ __forceinline__ void pack(const State &s, float (&rec)[kRec]) const { rec[0] = s.gacc; }
     __device__ __forceinline__ void unpack(State &s, const float (&rec)[kRec]) const { s.gacc = rec[0]; }
-    __device__ __forceinline__ void merge(State &a, const State &b) const { a.gacc += b.gacc; }
+    __device__ __forceinline__ void merge(const Ctx &, State &a, const State &b) const { a.gacc += b.gacc; }
 };
 
 // Column pass over the CSC (colptr, rowind): grad_feat[u,h,:] and grad_attn_col[u,h].
@@ -222,6 +380,7 @@ template <int VEC_, int LPR_, int UNROLL_>
 struct GatBwdColOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_ + 1;
     static constexpr bool kReduce = true;
+    static constexpr int kLds = 0;
     const float *attn_row, *attn_col, *feat, *edge_max, *edge_sum, *dvec, *grad_out;
     float *grad_feat, *grad_attn_col;
     float slope;
@@ -290,6 +449,7 @@ struct GatBwdColOp {
             s.gacc += a * (dot - b.dd[u]) * (pre > 0.f ? 1.f : slope);
         }
     }
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t u_node, bool ok) const {
         if (ok && c.col_ok) {
@@ -307,14 +467,12 @@ struct GatBwdColOp {
         for (int i = 0; i < VEC; ++i) s.acc[i] = rec[i];
         s.gacc = rec[VEC];
     }
-    __device__ __forceinline__ void merge(State &a, const State &b) const {
+    __device__ __forceinline__ void merge(const Ctx &, State &a, const State &b) const {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) a.acc[i] += b.acc[i];
         a.gacc += b.gacc;
     }
 };
-
-static bool pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // Forward geometry: the WIDEST legal vector (16-byte lanes) with every lane's columns inside one head.  Unlike
 // csr_spmm (which narrows the vector until a row fills 64 lanes) every lane here repeats the per-edge softmax
@@ -351,6 +509,16 @@ struct FwdArgs {
 
 template <typename T, int VEC, int LPR>
 static int launch_fwd(const FwdArgs &a, int64_t tiles, void *ws, size_t wsb, hipStream_t s) {
+    // Chunk-wise softmax pays once a round of the weight computation covers >= 8 edges (LPR/H) of a >= 16-edge chunk:
+    // measured on MI355X (reddit-shaped graph, f32) H=1,F=41: 7.3 -> 3.6 ms, H=1,F=64: 4.1 -> 2.8 ms, H=8,F=8
+    // (LPR 16, 2 edges per round): 4.2 -> 4.3 ms, bf16 H=8,F=8 (LPR 8): 2.9 -> 4.6 ms.  tuning key 5: 1 = never, 2 = always.
+    const bool can_chunk = pow2(a.h) && a.h <= LPR && a.h <= GatFwdChunkOp<T, VEC, LPR, 8>::kMaxHeads;
+    const bool want_chunk = g_tuning[kTuneGatOnline] == 2 || (g_tuning[kTuneGatOnline] == 0 && LPR >= 16 && a.h * 8 <= LPR);
+    if (can_chunk && want_chunk) {
+        GatFwdChunkOp<T, VEC, LPR, 8> op{a.ar, a.ac, (const T *)a.feat, (T *)a.out, a.emax, a.esum, a.slope, (int)a.h,
+                                         (int)a.f};
+        return launch_rowreduce(op, a.rowptr, a.colind, a.v, a.nnz, tiles, ws, wsb, s);
+    }
     GatFwdOp<T, VEC, LPR, 8> op{a.ar, a.ac, (const T *)a.feat, (T *)a.out, a.emax, a.esum, a.slope, (int)a.h, (int)a.f};
     return launch_rowreduce(op, a.rowptr, a.colind, a.v, a.nnz, tiles, ws, wsb, s);
 }

@@ -13,6 +13,7 @@ template <int VEC_, int LPR_, int UNROLL_>
 struct MhsddmmOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = 1;
     static constexpr bool kReduce = false;
+    static constexpr int kLds = 0;
     const float *grad, *feat;
     float *out;
     int heads, fdim, lph;  // lph = lanes per head
@@ -56,11 +57,12 @@ struct MhsddmmOp {
             if (s < lph) p += __shfl_xor(p, s, kWave);
         if (valid && c.head_lane) out[e * heads + c.hd] = p;
     }
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &, const State &, int64_t, bool) const {}
     __device__ __forceinline__ void pack(const State &, float (&)[kRec]) const {}
     __device__ __forceinline__ void unpack(State &, const float (&)[kRec]) const {}
-    __device__ __forceinline__ void merge(State &, const State &) const {}
+    __device__ __forceinline__ void merge(const Ctx &, State &, const State &) const {}
 };
 
 // Any shape: a group of 64 lanes per row; lane t walks (edge, head) pairs and dots F terms serially.

@@ -33,9 +33,13 @@
 //   void lane_load(Ctx, LaneVals&, e)            lane-parallel per-edge scalar of edge e (coalesced), e.g. the weight
 //   void fetch(Ctx, Batch&, u, col, e, LaneVals, sub, jj)   issue the loads of edge e (column col) into slot u
 //   void apply(Ctx, State&, Batch, u, valid, e, jpos)       fold slot u (edge e, position jpos in its LPR-chunk)
+//   constant   kLds: floats of LDS scratch per lane (0: none); the group's LPR*kLds floats are passed to chunk_begin
+//   void chunk_begin(Ctx&, State&, base, cnt, my_c, sub, l, lds)   before the gathers of each LPR-chunk of edges
+//                                                 (fused GAT: the chunk's softmax weights, once per (edge, head))
 //   void chunk_end(Ctx, State&, base, cnt)       after each LPR-chunk of edges (per-edge outputs: coalesced store)
 //   void row_end(Ctx, State, row, ok)            write the finished row
-//   void pack(State, float(&)[kRec]) / unpack / merge(State& a, State b)   (kReduce only; b's edges follow a's)
+//   void pack(State, float(&)[kRec]) / unpack / merge(Ctx, State& a, State b)   (kReduce only; b's edges follow a's;
+//                                                 called by all lanes of a group together: may shuffle)
 #pragma once
 #include <algorithm>
 #include <climits>
@@ -153,8 +157,9 @@ __device__ __forceinline__ float group_bcast(float v, int sub, int jj) {
 
 // Fold edges [start, end) of one row into st, in order.  All lanes of the group execute it.
 template <class Op>
-__device__ __forceinline__ void reduce_edges(const Op &op, const typename Op::Ctx &ctx, typename Op::State &st,
-                                             const int32_t *__restrict__ colind, int start, int end, int sub, int l) {
+__device__ __forceinline__ void reduce_edges(const Op &op, typename Op::Ctx &ctx, typename Op::State &st,
+                                             const int32_t *__restrict__ colind, int start, int end, int sub, int l,
+                                             float *lds) {
     constexpr int LPR = Op::LPR, UNROLL = Op::UNROLL;
     for (int base = start; base < end; base += LPR) {
         const int cnt = min(LPR, end - base);
@@ -164,6 +169,7 @@ __device__ __forceinline__ void reduce_edges(const Op &op, const typename Op::Ct
             my_c = colind[base + l];
             op.lane_load(ctx, lv, base + l);
         }
+        op.chunk_begin(ctx, st, base, cnt, my_c, sub, l, lds);
         for (int j = 0; j < cnt; j += UNROLL) {
             typename Op::Batch b;
             // Issue all UNROLL gathers back to back (no branches: a masked tail slot re-reads the row's last valid
@@ -182,7 +188,7 @@ __device__ __forceinline__ void reduce_edges(const Op &op, const typename Op::Ct
 
 // One workgroup per run of `chunks_per_block` chunks: the leading blocks of the main grid.
 template <class Op>
-__device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSched &s) {
+__device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSched &s, float *op_lds) {
     constexpr int LPR = Op::LPR;
     constexpr int G = 256 / LPR;  // groups per workgroup
     constexpr int NREC = Op::kReduce ? Op::kRec : 1;
@@ -215,7 +221,7 @@ __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSche
             op.row_load(ctx, row, true);
             typename Op::State st;
             op.init_zero(st);
-            reduce_edges<Op>(op, ctx, st, s.colind, sb, se, sub, l);
+            reduce_edges<Op>(op, ctx, st, s.colind, sb, se, sub, l, op_lds + (threadIdx.x / LPR) * LPR * Op::kLds);
             if constexpr (Op::kReduce) {
                 float rec[NREC];
                 op.pack(st, rec);
@@ -228,7 +234,7 @@ __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSche
                         for (int i = 0; i < NREC; ++i) rec[i] = red[q][i][l];
                         typename Op::State other;
                         op.unpack(other, rec);
-                        op.merge(st, other);
+                        op.merge(ctx, st, other);
                     }
                     op.pack(st, rec);
                     float *dst = lr.partial + (2 * c + slot) * lr.rec_stride + (int64_t)blockIdx.y * NREC * LPR;
@@ -246,8 +252,9 @@ __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSche
 // L2-resident loads in <= 1024 workgroups, overlapped with the row blocks.
 template <class Op>
 __global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const RowSched s) {
+    __shared__ float op_lds[Op::kLds > 0 ? 256 * Op::kLds : 1];  // one buffer for both kinds of workgroup
     if (blockIdx.x < s.lr.n_long_blocks) {
-        rowreduce_long_block<Op>(op, s);
+        rowreduce_long_block<Op>(op, s, op_lds);
         return;
     }
     constexpr int LPR = Op::LPR;
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const 
     op.row_load(ctx, row, ok);
     typename Op::State st;
     op.init(ctx, st, row, ok);
-    reduce_edges<Op>(op, ctx, st, s.colind, start, end, sub, l);
+    reduce_edges<Op>(op, ctx, st, s.colind, start, end, sub, l, op_lds + (threadIdx.x / LPR) * LPR * Op::kLds);
     op.row_end(ctx, st, row, ok);
 }
 
@@ -324,14 +331,14 @@ __global__ __launch_bounds__(256) void rowreduce_combine_kernel(const Op op, con
 #pragma unroll
             for (int i = 0; i < NREC; ++i) rec[i] = src[i * LPR];
             op.unpack(piece, rec);
-            op.merge(st, piece);
+            op.merge(ctx, st, piece);
         }
         for (int64_t q = c; q <= c_last; ++q) {
             const float *src = lr.partial + (2 * q) * lr.rec_stride + tile_off;
 #pragma unroll
             for (int i = 0; i < NREC; ++i) rec[i] = src[i * LPR];
             op.unpack(piece, rec);
-            op.merge(st, piece);
+            op.merge(ctx, st, piece);
         }
         op.row_end(ctx, st, row, true);
     }

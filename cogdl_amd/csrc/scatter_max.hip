@@ -18,6 +18,7 @@ template <int VEC_, int LPR_, int UNROLL_>
 struct ScatterMaxOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = 2 * VEC_;
     static constexpr bool kReduce = true;
+    static constexpr int kLds = 0;
     const float *x;
     float *out;
     int32_t *max_id;
@@ -71,6 +72,7 @@ struct ScatterMaxOp {
             }
         }
     }
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
         if (ok && c.col_ok) {
@@ -93,7 +95,7 @@ struct ScatterMaxOp {
             s.id[i] = __float_as_int(rec[VEC + i]);
         }
     }
-    __device__ __forceinline__ void merge(State &a, const State &b) const {
+    __device__ __forceinline__ void merge(const Ctx &, State &a, const State &b) const {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             const bool take = b.id[i] >= 0 && ((a.id[i] < 0) || (b.acc[i] > a.acc[i]));

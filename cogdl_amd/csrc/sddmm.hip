@@ -16,6 +16,7 @@ template <int VEC_, int LPR_, int UNROLL_, bool SINGLE_TILE>
 struct SddmmOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = 1;
     static constexpr bool kReduce = false;
+    static constexpr int kLds = 0;
     const float *d1, *d2;
     float *out;
     int k;
@@ -73,13 +74,14 @@ struct SddmmOp {
         const float r = group_sum<LPR>(p);
         if (c.l == jpos) s.my_out = r;
     }
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &c, State &s, int base, int cnt) const {
         if (c.l < cnt) out[base + c.l] = s.my_out;
     }
     __device__ __forceinline__ void row_end(const Ctx &, const State &, int64_t, bool) const {}
     __device__ __forceinline__ void pack(const State &, float (&)[kRec]) const {}
     __device__ __forceinline__ void unpack(State &, const float (&)[kRec]) const {}
-    __device__ __forceinline__ void merge(State &, const State &) const {}
+    __device__ __forceinline__ void merge(const Ctx &, State &, const State &) const {}
 };
 
 struct SddmmArgs {

@@ -40,6 +40,7 @@ template <typename T, int VEC_, int LPR_, int UNROLL_, int WMODE, bool EXACT>
 struct SpmmOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_;
     static constexpr bool kReduce = true;
+    static constexpr int kLds = 0;
     const T *val;      // WMODE 1
     const float *att;  // WMODE 2: [E, heads]
     const T *x;
@@ -100,6 +101,7 @@ struct SpmmOp {
             else s.acc[i] = s.acc[i] + vv;
         }
     }
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
         if (ok && c.col_ok) store_vec<T, VEC>(out + row * (int64_t)k + c.col0, s.acc);
@@ -112,7 +114,7 @@ struct SpmmOp {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) s.acc[i] = rec[i];
     }
-    __device__ __forceinline__ void merge(State &a, const State &b) const {
+    __device__ __forceinline__ void merge(const Ctx &, State &a, const State &b) const {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) a.acc[i] += b.acc[i];
     }

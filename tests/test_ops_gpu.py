@@ -176,13 +176,24 @@ def test_scatter_max_all_negative_rows_are_true_max(oracle):
 
 
 # ---------------------------------------------------------------------------------- fused GAT
+@pytest.fixture(params=[0, 1, 2], ids=["auto", "edgewise-softmax", "chunkwise-softmax"])
+def gat_kernel(request):
+    """The fused GAT forward has two kernels (edge-wise online softmax / chunk-wise softmax); the library picks one
+    per shape.  Tuning key 5 forces either, so that both are tested on every shape."""
+    from cogdl_amd import _lib
+
+    _lib.hip().cogdl_hip_set_tuning(5, request.param)
+    yield request.param
+    _lib.hip().cogdl_hip_set_tuning(5, 0)
+
+
 def _gat_inputs(g, n_src, h, f, seed):
     return (rand(g.num_nodes, h, seed=seed), rand(n_src, h, seed=seed + 1), rand(n_src, h, f, seed=seed + 2),
             rand(g.num_nodes, h, f, seed=seed + 3))
 
 
 @pytest.mark.parametrize("h,f", [(8, 8), (4, 8), (1, 41), (2, 16), (1, 64), (4, 16), (3, 5), (8, 32)])
-def test_fused_gat_forward_backward(oracle, h, f):
+def test_fused_gat_forward_backward(oracle, gat_kernel, h, f):
     """fused_gat_func == edge_softmax(LeakyReLU(attn_row[row] + attn_col[col])) -> mh_spmm  (the oracle's fp64
     composition, cogdl/layers/gat_layer.py:73-77); gradients against float64 autograd of the same maths.
     (3,5) and (8,32) fall outside the fused backward's shape coverage and exercise the unfused-composition path."""
@@ -225,7 +236,7 @@ def test_fused_gat_matches_unfused_ops_on_gpu():
     assert torch.allclose(fused, unfused, rtol=2e-5, atol=2e-6)
 
 
-def test_fused_gat_bf16(oracle):
+def test_fused_gat_bf16(oracle, gat_kernel):
     from cogdl_amd.operators.fused_gat import gat_forward
 
     g = synth.random_csr(200, 200, 9, seed=3, weighted=False)
@@ -278,7 +289,7 @@ def test_hub_rows_edge_softmax(oracle, hubs, h):
 
 @pytest.mark.parametrize("hubs", HUBS)
 @pytest.mark.parametrize("h,f", [(8, 8), (1, 41), (4, 16)])
-def test_hub_rows_mhspmm_mhsddmm_gat(oracle, hubs, h, f):
+def test_hub_rows_mhspmm_mhsddmm_gat(oracle, gat_kernel, hubs, h, f):
     from cogdl_amd.operators.fused_gat import fused_gat_func
 
     g = synth.hub_csr(60, 60, hubs=hubs, seed=h * f, weighted=False)
