@@ -7,7 +7,8 @@ N = 1 : BASELINE.json configs[1] -- "GCN on ogbn-arxiv (170k nodes, 1.2M edges, 
         (uniform-random topology = worst-case locality; no dataset is available offline), inputs resident in HBM.
         value = GEdges/s = 2 * nnz * steps / time.
 N > 1 : configs[4] -- vertex-sharded csr_spmm (1-D row partition, halo rows exchanged with an RCCL all-to-all
-        overlapped with the local-column SpMM), weak scaling: a fixed papers100M-like shard per GPU.
+        overlapped with the local-column SpMM), weak scaling: a fixed papers100M-like shard per GPU (10 % of a row's
+        sources in other shards = a locality-preserving partition; --remote-frac sets it).
         value = global nnz * 2 * steps / time (max over ranks).
 
 One JSON line on stdout (rank 0).  Extra objects: roofline (dominant kernel, HIP-event timed inside the timed
@@ -229,6 +230,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--shard-nodes", type=int, default=0, help="N>1: nodes per GPU (default: papers100M/8)")
     ap.add_argument("--shard-degree", type=float, default=0.0, help="N>1: mean in-degree (default 28.8)")
+    ap.add_argument("--remote-frac", type=float, default=-1.0,
+                    help="N>1: fraction of a row's sources owned by other ranks (default 0.1; (N-1)/N = random partition)")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")

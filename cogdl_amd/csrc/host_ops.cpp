@@ -66,6 +66,25 @@ void sample_without_replacement(int64_t deg, int64_t k, SplitMix64 &rng, std::ve
     std::sort(pick.begin(), pick.end());
 }
 
+// global id -> local id map of the samplers: a per-thread array that is all -1 between calls (only the entries a
+// call touched are reset), so a call costs O(batch + sampled edges) instead of the O(num_nodes) fill the reference
+// pays per mini-batch (sample.cpp:22: torch::full({N}, -1)).  Per thread => safe in DataLoader workers (threads or
+// forked processes).
+struct LocalIds {
+    std::vector<int64_t> &map;
+    const int64_t *touched;
+    int64_t n_touched = 0;
+    static std::vector<int64_t> &storage(int64_t num_nodes) {
+        thread_local std::vector<int64_t> v;
+        if ((int64_t)v.size() < num_nodes) v.resize((size_t)num_nodes, -1);
+        return v;
+    }
+    LocalIds(int64_t num_nodes, const int64_t *touched_list) : map(storage(num_nodes)), touched(touched_list) {}
+    ~LocalIds() {
+        for (int64_t i = 0; i < n_touched; ++i) map[(size_t)touched[i]] = -1;
+    }
+};
+
 bool in_range(const int64_t *a, int64_t n, int64_t hi) {
     for (int64_t i = 0; i < n; ++i)
         if (a[i] < 0 || a[i] >= hi) return false;
@@ -143,13 +162,15 @@ int cogdl_host_sample_adj(const int64_t *indptr, const int64_t *indices, int64_t
     if (!in_range(node_idx, batch, num_nodes)) return COGDL_HOST_ERANGE;
     if (batch > cap_nodes) return COGDL_HOST_ECAP;
 
-    // local id of every global node: -1 = not seen yet
-    std::vector<int64_t> local((size_t)num_nodes, -1);
+    // local id of every global node: -1 = not seen yet (out_nodes doubles as the list of touched entries)
+    LocalIds ids(num_nodes, out_nodes);
+    std::vector<int64_t> &local = ids.map;
     for (int64_t i = 0; i < batch; ++i) {
         local[(size_t)node_idx[i]] = i;
         out_nodes[i] = node_idx[i];
     }
     int64_t n_nodes = batch, n_edges = 0;
+    ids.n_touched = batch;
     std::vector<int64_t> pick;
     out_indptr[0] = 0;
     for (int64_t i = 0; i < batch; ++i) {
@@ -175,6 +196,7 @@ int cogdl_host_sample_adj(const int64_t *indptr, const int64_t *indices, int64_t
                 if (n_nodes >= cap_nodes) return COGDL_HOST_ECAP;
                 id = n_nodes;
                 out_nodes[n_nodes++] = src;
+                ids.n_touched = n_nodes;
             }
             out_indices[n_edges] = id;
             out_edges[n_edges++] = edge;
@@ -192,8 +214,10 @@ int cogdl_host_subgraph(const int64_t *indptr, const int64_t *indices, int64_t n
     if (!indptr || !out_indptr || !out_counts || batch < 0 || num_nodes < 0 || (batch > 0 && !node_idx))
         return COGDL_HOST_EINVAL;
     if (!in_range(node_idx, batch, num_nodes)) return COGDL_HOST_ERANGE;
-    std::vector<int64_t> local((size_t)num_nodes, -1);
+    LocalIds ids(num_nodes, node_idx);
+    std::vector<int64_t> &local = ids.map;
     for (int64_t i = 0; i < batch; ++i) local[(size_t)node_idx[i]] = i;
+    ids.n_touched = batch;
     int64_t n_edges = 0;
     out_indptr[0] = 0;
     for (int64_t i = 0; i < batch; ++i) {

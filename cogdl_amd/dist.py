@@ -193,16 +193,26 @@ def sharded_spmm(sh, x_local):
 
 
 # ------------------------------------------------------------------------------- bench (N > 1)
-def _papers_like_shard(rank, world, shard_nodes, degree, seed, device):
-    """This rank's rows of a papers100M-shaped graph: `shard_nodes` rows, Poisson-ish in-degree with mean
-    `degree`, source ids uniform over ALL world*shard_nodes nodes (worst case for a 1-D partition: a
-    fraction (world-1)/world of the edges is remote), self loop appended, row-normalised weights."""
+def _papers_like_shard(rank, world, shard_nodes, degree, remote_frac, seed, device):
+    """This rank's rows of a papers100M-shaped graph: `shard_nodes` rows, mean in-degree `degree`; a fraction
+    `remote_frac` of every row's sources lies in OTHER shards (uniform over them), the rest inside the own shard --
+    the shape a locality-preserving (METIS-like) 1-D partition of a citation graph has.  remote_frac = (world-1)/world
+    is a random partition of a structureless graph: the worst case for a 1-D partition.  Self loop appended,
+    row-normalised weights."""
     g = torch.Generator(device="cpu").manual_seed(seed * 1000003 + rank)
-    n_total = shard_nodes * world
     nnz = int(shard_nodes * degree)
-    rows = torch.randint(0, shard_nodes, (nnz,), generator=g).to(device)
-    cols = torch.randint(0, n_total, (nnz,), generator=g).to(device)
     lo = rank * shard_nodes
+    rows = torch.randint(0, shard_nodes, (nnz,), generator=g)
+    cols = torch.randint(0, shard_nodes, (nnz,), generator=g)  # offset inside a shard
+    if world > 1:
+        is_remote = torch.rand(nnz, generator=g) < remote_frac
+        other = torch.randint(0, world - 1, (nnz,), generator=g)
+        other = other + (other >= rank).long()  # uniform over the other shards
+        owner = torch.where(is_remote, other, torch.full_like(other, rank))
+    else:
+        owner = torch.zeros(nnz, dtype=torch.long)
+    cols = cols + owner * shard_nodes
+    rows, cols = rows.to(device), cols.to(device)
     rows = torch.cat([rows, torch.arange(shard_nodes, device=device)])
     cols = torch.cat([cols, torch.arange(lo, lo + shard_nodes, device=device)])
     order = torch.sort(rows, stable=True).indices
@@ -227,7 +237,8 @@ def bench_sharded_spmm(args):
     shard_nodes = args.shard_nodes or 111_059_956 // 8 // 8  # 1/8 of a papers100M 8-way shard per GPU
     degree = args.shard_degree or 28.8                         # 3.2e9 symmetrised edges / 111e6 nodes
     f = args.feat
-    rowptr, cols, w = _papers_like_shard(rank, world, shard_nodes, degree, 0, dev)
+    remote_frac = args.remote_frac if args.remote_frac >= 0 else 0.1
+    rowptr, cols, w = _papers_like_shard(rank, world, shard_nodes, degree, remote_frac, 0, dev)
     bounds = torch.arange(world + 1, dtype=torch.long) * shard_nodes
     sh = ShardedCSR(rowptr, cols, w, bounds)
     del cols
@@ -280,9 +291,10 @@ def bench_sharded_spmm(args):
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "papers100M-like 1-D vertex-sharded csr_spmm fwd+bwd (configs[4]), uniform-random "
-                                   "sources (worst-case halo)", "nodes_per_gpu": shard_nodes,
-                       "nnz_global": nnz_global, "feat": f,
+            "config": {"workload": "papers100M-like 1-D vertex-sharded csr_spmm fwd+bwd (configs[4]); %.0f%% of every "
+                                   "row's sources in other shards (locality-preserving partition; --remote-frac %.3f "
+                                   "= random partition, worst-case halo)" % (100 * remote_frac, (world - 1) / world),
+                       "nodes_per_gpu": shard_nodes, "nnz_global": nnz_global, "feat": f, "remote_frac": remote_frac,
                        "parallelism": "vertex-shard x%d, RCCL all-to-all halo exchange overlapped with local SpMM" % world},
             "halo_GB_per_step_all_ranks": float(halo_gb) * 2 / 1e9,
             "local_block_spmm_ms_rank0": loc_ms,
