@@ -44,11 +44,14 @@ inline XcdMap make_xcd_map(int64_t n_logical) {
     if (stripe < 0) stripe = 0;
     return {n_logical, stripe};
 }
-inline unsigned xcd_grid(const XcdMap &m) {
-    if (m.stripe == 0) return (unsigned)m.n_logical;
+inline int64_t xcd_grid64(const XcdMap &m) {
+    if (m.stripe == 0) return m.n_logical;
     const int64_t per = (int64_t)kXcds * m.stripe;
-    return (unsigned)((m.n_logical + per - 1) / per * per);
+    return (m.n_logical + per - 1) / per * per;
 }
+inline unsigned xcd_grid(const XcdMap &m) { return (unsigned)xcd_grid64(m); }
+// gridDim.x is a 31-bit quantity: `extra` leading workgroups + the padded row-block grid must fit.
+inline bool grid_fits(const XcdMap &m, int64_t extra = 0) { return xcd_grid64(m) + extra <= 0x7fffffff; }
 __device__ __forceinline__ int64_t xcd_remap(unsigned bid, const XcdMap &m) {
     if (m.stripe == 0) return bid;
     const int64_t idx = bid / kXcds, xcd = bid % kXcds;

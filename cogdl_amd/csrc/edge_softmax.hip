@@ -351,7 +351,7 @@ static int launch_pow2(const int32_t *rowptr, const float *a, const float *g, fl
                        const LongRows &lr, hipStream_t s) {
     constexpr int RPB = (kWave / LPR) * 4;
     const int64_t nrb = (m + RPB - 1) / RPB;
-    if (nrb > 0x7fffffff / kXcds) return COGDL_HIP_ERANGE;
+    if (!grid_fits(make_xcd_map(nrb), 4096)) return COGDL_HIP_ERANGE;
     hipLaunchKernelGGL((edge_softmax_pow2_kernel<LPR, BACKWARD>), dim3(lr.n_long_blocks + xcd_grid(make_xcd_map(nrb))), dim3(256),
                        0, s, rowptr, a, g, out, m, h, make_xcd_map(nrb), lr);
     launch_long<BACKWARD>(rowptr, a, g, out, m, h, lr, s);
@@ -377,7 +377,7 @@ static int edge_softmax_dispatch(const int32_t *rowptr, const float *a, const fl
     const bool pow2 = (h & (h - 1)) == 0 && h <= kWave;
     if (!pow2) {
         const int64_t nrb = (m + 3) / 4;
-        if (nrb > 0x7fffffff / kXcds) return COGDL_HIP_ERANGE;
+        if (!grid_fits(make_xcd_map(nrb), 4096)) return COGDL_HIP_ERANGE;
         hipLaunchKernelGGL((edge_softmax_generic_kernel<BACKWARD>), dim3(lr.n_long_blocks + xcd_grid(make_xcd_map(nrb))), dim3(256),
                            0, s, rowptr, a, g, out, m, (int)h, make_xcd_map(nrb), lr);
         launch_long<BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s);

@@ -136,7 +136,7 @@ extern "C" int cogdl_hip_mhsddmm(const int32_t *rowptr, const int32_t *colind, c
     if (fits(2) && al8) return dispatch_mhsddmm<2>(a, nullptr, 0, s);
     if (fits(1)) return dispatch_mhsddmm<1>(a, nullptr, 0, s);
     const int64_t nrb = (v + 3) / 4;
-    if (nrb > 0x7fffffff / kXcds) return COGDL_HIP_ERANGE;
+    if (!grid_fits(make_xcd_map(nrb), 4096)) return COGDL_HIP_ERANGE;
     hipLaunchKernelGGL(mhsddmm_generic_kernel, dim3(xcd_grid(make_xcd_map(nrb))), dim3(256), 0, s, rowptr, colind, grad, feat, out,
                        v, (int)h, (int)f, make_xcd_map(nrb));
     return launch_status();

@@ -353,7 +353,7 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
     constexpr int64_t RPB = (kWave / Op::LPR) * 4;
     const int64_t n_rowblocks = (m + RPB - 1) / RPB;
     if (n_rowblocks == 0) return COGDL_HIP_OK;
-    if (n_rowblocks > 0x7fffffff / (kXcds * 64) || tiles > 65535 || tiles < 1) return COGDL_HIP_ERANGE;
+    if (tiles > 65535 || tiles < 1) return COGDL_HIP_ERANGE;
     RowSched s{};
     s.rowptr = rowptr;
     s.colind = colind;
@@ -370,6 +370,7 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
             s.lr.partial = (float *)((char *)workspace + kFoundBytes);
         }
     }
+    if (!grid_fits(s.rowblocks, s.lr.n_long_blocks)) return COGDL_HIP_ERANGE;
     dim3 grid(s.lr.n_long_blocks + xcd_grid(s.rowblocks), (unsigned)tiles);
     hipLaunchKernelGGL((rowreduce_main_kernel<Op>), grid, dim3(256), 0, stream, op, s);
     if constexpr (Op::kReduce) {

@@ -57,6 +57,33 @@ __global__ void rowind_from_perm(const int32_t *__restrict__ rowptr, const int32
     rowind[j] = (int32_t)lo;
 }
 
+// ---- COO -> CSR on the GPU (coo2csr_index) ------------------------------------------------------------------------
+__global__ void keys_from_rows64(const int64_t *__restrict__ row, uint32_t *__restrict__ keys, int64_t nnz,
+                                 int64_t num_nodes, int *__restrict__ bad) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = row[i];
+        if (r < 0 || r >= num_nodes) *bad = 1;  // reported by the caller's next look at `bad`; key clamped
+        keys[i] = (uint32_t)(r < 0 ? 0 : (r >= num_nodes ? num_nodes - 1 : r));
+    }
+}
+
+// row_ptr[r] (int64) = number of sorted keys < r; perm widened to int64 in the same launch
+__global__ void rowptr64_and_perm64(const uint32_t *__restrict__ keys, const int32_t *__restrict__ perm32,
+                                    int64_t *__restrict__ row_ptr, int64_t *__restrict__ perm, int64_t nnz,
+                                    int64_t num_nodes) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t r = tid; r <= num_nodes; r += stride) {
+        int64_t lo = 0, hi = nnz;  // first position whose key >= r
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)keys[mid] < r) lo = mid + 1; else hi = mid;
+        }
+        row_ptr[r] = lo;
+    }
+    for (int64_t i = tid; i < nnz; i += stride) perm[i] = perm32[i];
+}
+
 template <typename E>
 __global__ void gather_rows_kernel(const int32_t *__restrict__ perm, const E *__restrict__ src,
                                    E *__restrict__ out, int64_t total, int64_t h) {
@@ -178,5 +205,51 @@ extern "C" int cogdl_hip_csr_fingerprint(const int32_t *rowptr, const int32_t *c
     if (m < 0 || nnz < 0 || !rowptr || !out_parts) return COGDL_HIP_EINVAL;
     hipLaunchKernelGGL(csr_fingerprint_kernel, dim3(COGDL_HIP_FINGERPRINT_PARTS), dim3(256), 0, (hipStream_t)stream,
                        rowptr, colind, m, nnz, (unsigned long long *)out_parts);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" size_t cogdl_hip_coo2csr_index_workspace_bytes(int64_t nnz, int64_t num_nodes) {
+    if (nnz <= 0) return 256;
+    size_t temp = 0;
+    (void)sort_pairs(nullptr, temp, nullptr, nullptr, nullptr, nnz, key_bits(num_nodes), nullptr);
+    return 2 * align_up((size_t)nnz * sizeof(uint32_t), 256) + align_up((size_t)nnz * sizeof(int32_t), 256) +
+           align_up(temp, 256) + 256;
+}
+
+extern "C" int cogdl_hip_coo2csr_index(const int64_t *row, int64_t nnz, int64_t num_nodes, int64_t *row_ptr,
+                                       int64_t *perm, int *bad_flag, void *workspace, size_t workspace_bytes,
+                                       void *stream) {
+    if (nnz < 0 || num_nodes < 0 || !row_ptr || !bad_flag) return COGDL_HIP_EINVAL;
+    if (nnz > 0x7fffffff || num_nodes > 0xffffffffll) return COGDL_HIP_ERANGE;
+    hipStream_t s = (hipStream_t)stream;
+    if (nnz > 0 && (!row || !perm || !workspace)) return COGDL_HIP_EINVAL;
+    if (workspace_bytes < cogdl_hip_coo2csr_index_workspace_bytes(nnz, num_nodes)) return COGDL_HIP_EWORKSPACE;
+    if (nnz > 0 && !aligned_to(workspace, 256)) return COGDL_HIP_EALIGN;
+    hipError_t e = hipMemsetAsync(bad_flag, 0, sizeof(int), s);
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return COGDL_HIP_ELAUNCH;
+    }
+    const size_t kb = align_up((size_t)nnz * sizeof(uint32_t), 256);
+    uint32_t *keys = (uint32_t *)workspace;
+    uint32_t *keys_sorted = (uint32_t *)((char *)workspace + kb);
+    int32_t *perm32 = (int32_t *)((char *)workspace + 2 * kb);
+    char *temp = (char *)workspace + 2 * kb + align_up((size_t)nnz * sizeof(int32_t), 256);
+    const unsigned eblocks = (unsigned)std::min<int64_t>((nnz + 255) / 256, 1 << 16);
+    if (nnz > 0) {
+        hipLaunchKernelGGL(keys_from_rows64, dim3(eblocks), dim3(256), 0, s, row, keys, nnz, num_nodes, bad_flag);
+        size_t temp_bytes = 0;
+        const unsigned bits = key_bits(num_nodes);
+        (void)sort_pairs(nullptr, temp_bytes, nullptr, nullptr, nullptr, nnz, bits, nullptr);
+        e = sort_pairs(temp, temp_bytes, keys, keys_sorted, perm32, nnz, bits, s);
+        if (e != hipSuccess) {
+            g_last_hip_error = (int)e;
+            return COGDL_HIP_ELAUNCH;
+        }
+    }
+    const unsigned blocks = (unsigned)std::min<int64_t>((std::max(nnz, num_nodes + 1) + 255) / 256, 1 << 16);
+    hipLaunchKernelGGL(rowptr64_and_perm64, dim3(blocks), dim3(256), 0, s, keys_sorted, perm32, row_ptr, perm, nnz,
+                       num_nodes);
     return launch_status();
 }

@@ -50,6 +50,7 @@ def install():
             pkg = sys.modules.get("cogdl.operators")
             if pkg is not None:
                 setattr(pkg, op, mod)
+    _rebind_graph_build()
     su = sys.modules.get("cogdl.utils.spmm_utils")
     if su is not None:  # force the dispatcher to re-resolve the callables
         for k in ("spmm_flag", "mh_spmm_flag", "fused_gat_flag", "spmm_cpu_flag"):
@@ -59,7 +60,29 @@ def install():
     return [_PREFIX + op for op in REPLACED]
 
 
+# modules that hold `coo2csr_index` by name (cogdl/utils/graph_utils.py:133 defines it; data.py:11 and utils.py:16 import it)
+_COO2CSR_HOLDERS = ("cogdl.utils.graph_utils", "cogdl.utils.utils", "cogdl.utils", "cogdl.data.data")
+
+
+def _rebind_graph_build():
+    """CSR construction stays on the GPU.  Effective for the CogDL modules already imported; call
+    install() again after `import cogdl` if it ran before (install() is idempotent)."""
+    from .graph_build import coo2csr_index
+
+    for name in _COO2CSR_HOLDERS:
+        mod = sys.modules.get(name)
+        if mod is not None and hasattr(mod, "coo2csr_index"):
+            if not hasattr(mod, "_cogdl_amd_orig_coo2csr_index"):
+                mod._cogdl_amd_orig_coo2csr_index = mod.coo2csr_index
+            mod.coo2csr_index = coo2csr_index
+
+
 def uninstall():
+    for name in _COO2CSR_HOLDERS:
+        mod = sys.modules.get(name)
+        if mod is not None and hasattr(mod, "_cogdl_amd_orig_coo2csr_index"):
+            mod.coo2csr_index = mod._cogdl_amd_orig_coo2csr_index
+            del mod._cogdl_amd_orig_coo2csr_index
     global _finder
     if _finder is not None:
         sys.meta_path.remove(_finder)

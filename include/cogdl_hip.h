@@ -213,6 +213,17 @@ COGDL_API int cogdl_hip_gat_bwd(const int32_t *rowptr, const int32_t *colind, co
 COGDL_API int cogdl_hip_csr_fingerprint(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t nnz,
                               uint64_t *out_parts, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * coo2csr_index on the GPU: stable sort of the edges by row -> (row_ptr[num_nodes+1], perm[nnz]), perm[j] = COO
+ * position of CSR entry j (edges of a row keep their COO order).  int64 in and out, like the reference's
+ * sampler.coo2csr_cpu_index (cogdl/operators/sample/sample.cpp:234-270), which cogdl/utils/graph_utils.py:133-142
+ * reaches through a GPU -> CPU -> GPU round trip and a single-threaded counting sort.  *bad_flag (device int) is set
+ * to 1 if a row id lies outside [0, num_nodes).  workspace: cogdl_hip_coo2csr_index_workspace_bytes.
+ * ------------------------------------------------------------------------------------- */
+COGDL_API size_t cogdl_hip_coo2csr_index_workspace_bytes(int64_t nnz, int64_t num_nodes);
+COGDL_API int cogdl_hip_coo2csr_index(const int64_t *row, int64_t nnz, int64_t num_nodes, int64_t *row_ptr,
+                            int64_t *perm, int *bad_flag, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

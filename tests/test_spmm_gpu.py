@@ -263,3 +263,28 @@ def test_runs_on_the_current_stream():
         out = csr_spmm_raw(g.rowptr, g.colind, g.weight, y)
     s.synchronize()
     assert torch.equal(out, 2.0 * ref)
+
+
+def test_hip_graph_capture_and_replay():
+    """The C-ABI entry points neither allocate nor synchronise: a csr_spmm call (main + combine launch) can be
+    captured into a HIP graph and replayed on new data in the same buffers."""
+    g = synth.arxiv_like(seed=0, topology="rmat").to(DEV)  # hub rows: both launches do real work
+    x = torch.randn(g.num_nodes, 64, device=DEV)
+    ref1 = csr_spmm_raw(g.rowptr, g.colind, g.weight, x)
+    static_x = x.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):  # warm-up on the side stream, as torch's capture rules ask
+        csr_spmm_raw(g.rowptr, g.colind, g.weight, static_x)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_out = csr_spmm_raw(g.rowptr, g.colind, g.weight, static_x)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, ref1)
+    x2 = torch.randn(g.num_nodes, 64, device=DEV)
+    static_x.copy_(x2)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, csr_spmm_raw(g.rowptr, g.colind, g.weight, x2))
