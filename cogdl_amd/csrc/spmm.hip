@@ -153,17 +153,30 @@ static int dispatch_lpr(const SpmmArgs<T> &a, int lpr, void *ws, size_t wsb, hip
 }
 
 // Vector width and lanes per row.  Every lane's VEC columns must stay inside one row (k % VEC == 0), inside
-// one head for mhspmm (fdim % VEC == 0), and be naturally aligned.  Measured on MI355X (arxiv-shaped graph):
-// narrow rows (k/4 <= 16 lanes) are fastest with 16-byte lanes and several rows per wave (less per-row
-// overhead); from 64 columns up a whole wave per row wins (scalar column broadcast, no intra-wave length
-// divergence), so the vector is narrowed until the row fills 64 lanes.
+// one head for mhspmm (fdim % VEC == 0), and be naturally aligned.  Measured on MI355X (arxiv-shaped uniform and
+// R-MAT graphs, profiles/r01_spmm_vector_width.txt):
+//   * at most 4 elements per lane (16 B fp32, 8 B bf16/fp16): 8 x bf16 lanes leave too few lanes per row
+//     (bf16 F=64 R-MAT: 164 -> 128 us, F=32: 167 -> 106 us);
+//   * a row group of at least 16 lanes where 4-byte lanes allow it (fp32 F=24 R-MAT: 128 -> 112 us), but not
+//     narrower lanes than that needs (fp32 F=40 R-MAT: 16-byte lanes 125 us vs 8-byte 150 us);
+//   * rows of >= 512 B (fp32 F >= 128) use 8-byte lanes so that a whole wave (or two) shares a row: scalar column
+//     broadcast, no intra-wave length divergence (fp32 F=256: 390 -> 359 us with two column tiles per row).
 // `align` = guaranteed alignment in bytes of x and out (the workspace query assumes 16: allocator memory).
 RowGeometry spmm_geometry(int64_t k, int64_t unit, int elem_bytes, int align) {
-    const int maxv = 16 / elem_bytes;
+    const int maxv = std::min(4, 16 / elem_bytes);
     auto legal = [&](int v) { return v <= maxv && unit % v == 0 && align % (v * elem_bytes) == 0; };
     int vec = 1;
     while (vec * 2 <= maxv && legal(vec * 2)) vec *= 2;  // widest legal
-    while (vec > 1 && (vec / 2) * elem_bytes >= 4 && k / vec > 16 && k / (vec / 2) <= kWave) vec /= 2;
+    auto lanes = [&](int v) {  // LPR for vector width v
+        int l = 4;
+        while (l < kWave && (int64_t)l * v < k) l <<= 1;
+        return l;
+    };
+    while (vec > 1 && (vec / 2) * elem_bytes >= 4 && lanes(vec) < 16) vec /= 2;  // >= 16 lanes per row
+    while (vec > 1 && (vec / 2) * elem_bytes >= 8 && k / vec >= 32) vec /= 2;  // wide rows: 8-byte lanes
+    if (g_tuning[kTuneSpmmVec] > 0)  // experiments: cap the vector width
+        while (vec > g_tuning[kTuneSpmmVec]) vec /= 2;
+    if (g_tuning[kTuneSpmmVec] < 0 && legal(-g_tuning[kTuneSpmmVec])) vec = -g_tuning[kTuneSpmmVec];  // ... or force it
     const int64_t need = (k + vec - 1) / vec;
     int lpr = 4;
     while (lpr < kWave && lpr < need) lpr <<= 1;
@@ -181,11 +194,8 @@ static int pointer_alignment(const void *a, const void *b) {
 
 template <typename T, int WMODE>
 static int spmm_auto(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) {
-    constexpr int MAXV = 16 / sizeof(T);
     const RowGeometry g = spmm_geometry(a.k, (WMODE == 2) ? a.fdim : a.k, (int)sizeof(T), pointer_alignment(a.x, a.out));
     switch (g.vec) {
-        case 8:
-            if constexpr (MAXV >= 8) return dispatch_lpr<T, 8, WMODE>(a, g.lpr, ws, wsb, s);
         case 4: return dispatch_lpr<T, 4, WMODE>(a, g.lpr, ws, wsb, s);
         case 2: return dispatch_lpr<T, 2, WMODE>(a, g.lpr, ws, wsb, s);
         default: return dispatch_lpr<T, 1, WMODE>(a, g.lpr, ws, wsb, s);

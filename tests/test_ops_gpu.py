@@ -349,3 +349,38 @@ def test_coo2csr_index_gpu_doc_example_and_errors():
     assert row_ptr.tolist() == [0, 2, 3, 4, 4, 5] and col[perm].tolist() == [1, 3, 3, 1, 2]
     with pytest.raises(_lib.BackendError):
         coo2csr_index(torch.tensor([0, 7], device=DEV), torch.tensor([0, 1], device=DEV), 5)
+
+
+# ------------------------------------------------------------- BASELINE configs[2] at full size (Reddit-shaped)
+def test_full_size_reddit_shaped_gat_properties():
+    """N = 232,965, ~79 M R-MAT edges (hub rows of ~10^5 edges), H = 8 x F = 8 -- too big for the CPU oracle, so
+    size-independent properties: fused == composition of the unfused HIP operators (f32 1e-4, bf16 inputs 2^-7);
+    softmax rows sum to one; the fused output is a convex combination of neighbour rows (bounded by their max);
+    the operator is deterministic run to run."""
+    from cogdl_amd.operators.fused_gat import gat_forward
+
+    n, h, f = 232_965, 8, 8
+    src, dst = synth.rmat_pairs(n, 57_300_000, seed=0, device=DEV)
+    g = synth.finalize(src, dst, n, norm=None)
+    del src, dst
+    assert int(g.degrees().max()) > 50_000
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    ar, ac = (torch.randn(n, h, device=DEV, generator=gen) for _ in range(2))
+    feat = torch.randn(n, h, f, device=DEV, generator=gen)
+    out, emax, esum = gat_forward(ar, ac, g.rowptr, g.colind, 0.2, feat)
+    again, _, _ = gat_forward(ar, ac, g.rowptr, g.colind, 0.2, feat)
+    assert torch.equal(out, again)
+    row = torch.repeat_interleave(torch.arange(n, device=DEV), g.degrees().to(DEV))
+    score = torch.nn.functional.leaky_relu(ar[row] + ac[g.colind.long()], 0.2)
+    att = csr_edge_softmax(g.rowptr, score)
+    sums = torch.zeros(n, h, device=DEV).index_add_(0, row, att)
+    assert torch.allclose(sums, torch.ones_like(sums), atol=2e-4)
+    unfused = mhspmm_raw(g.rowptr, g.colind, att, feat)
+    assert torch.allclose(out, unfused, rtol=1e-4, atol=1e-4)
+    assert float(out.abs().max()) <= float(feat.abs().max()) * (1 + 1e-5)
+    # saved statistics == the row max / sum of exp(score - max) the backward relies on
+    mx = torch.full((n, h), -float("inf"), device=DEV).scatter_reduce(0, row.view(-1, 1).expand_as(score), score, "amax")
+    assert torch.allclose(emax, mx, rtol=0, atol=1e-6)
+    del score, att, sums, unfused, mx
+    outb, _, _ = gat_forward(ar, ac, g.rowptr, g.colind, 0.2, feat.bfloat16())
+    assert torch.allclose(outb.float(), out, rtol=2.0 ** -6, atol=2e-2)
