@@ -62,13 +62,10 @@ def main():
         print("unweighted auto: %.1f us" % (med * 1e3))
         med, _ = timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x, split_long_rows=False))
         print("auto, no long-row workspace (single launch): %.1f us" % (med * 1e3))
-        for rs in (1, 2, 4):
-            tune(2, rs)
-            for thr in (32, 64, 128, 256):
-                tune(1, thr)
-                r = [timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x, v), reps=15)[0] for v in (-1, 0)]
-                print("rows_seq %d long-thresh %4d: auto(V2L64) %.1f us, V4L32 %.1f us" % (rs, thr, r[0] * 1e3, r[1] * 1e3))
-        tune(2, 1)
+        for thr in (64, 128, 256, 512):
+            tune(1, thr)
+            r = [timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x, v), reps=15)[0] for v in (-1, 0)]
+            print("long-thresh %4d: auto(V2L64) %.1f us, V4L32 %.1f us" % (thr, r[0] * 1e3, r[1] * 1e3))
         tune(1, 0)
         for lg in (128, 512, 1024, 2048):
             tune(3, lg)
