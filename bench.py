@@ -98,14 +98,17 @@ def load_pmc_traffic(phase="arxiv_uniform_F128"):
         return None
 
 
-def gcn_epoch_ms(gd, rowptr64, colind64, x, reps=20, warmup=5):
+def gcn_epoch_ms(gd, rowptr64, colind64, x, reps=20, warmup=5, mfma_linear=True):
     """The 'GNN epoch time' half of BASELINE.json's metric: one full-graph training step (= one epoch) of CogDL's
     default `gcn` model (cogdl/models/nn/gcn.py:26-29: 2 GCNLayers, hidden 64, relu, dropout 0.5; GCNLayer.forward
     = spmm(graph, linear(x)), cogdl/layers/gcn_layer.py:51-53) on the arxiv-shaped graph, 40 classes, Adam(lr 0.01,
     wd 5e-4) -- the aggregation goes through the csrspmm operator exactly as spmm_utils.spmm calls it (fresh .int()
     index copies per call), the dense X.W stays on torch/hipBLASLt.  Median of `reps` steps, fenced."""
+    from cogdl_amd import linear as cogdl_linear
     from cogdl_amd.operators.spmm import csrspmm
 
+    if mfma_linear:  # unchanged torch.nn.Linear modules pick the MFMA weight-gradient kernel up through F.linear
+        cogdl_linear.install()
     dev = x.device
     torch.manual_seed(0)
     n, f_in, hidden, classes = x.shape[0], x.shape[1], 64, 40
@@ -136,9 +139,11 @@ def gcn_epoch_ms(gd, rowptr64, colind64, x, reps=20, warmup=5):
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
     ts.sort()
+    cogdl_linear.uninstall()
     return {"model": "CogDL gcn default: 2 x GCNLayer, hidden 64, relu, dropout 0.5, Adam; full-graph step = 1 epoch",
             "ms": ts[len(ts) // 2], "min_ms": ts[0], "reps": reps,
-            "spmm_calls_per_epoch": 4, "spmm_widths": [hidden, classes]}
+            "spmm_calls_per_epoch": 4, "spmm_widths": [hidden, classes],
+            "linear_weight_grad": "cogdl_hip_linear_wgrad_f32 (MFMA split-K)" if mfma_linear else "torch / hipBLASLt"}
 
 
 def bench_single(args):
@@ -210,6 +215,7 @@ def bench_single(args):
                      "GEdges_s_fwd_alone": g.nnz / (fwd_ms * 1e-3) / 1e9},
     }
     result["gnn_epoch"] = gcn_epoch_ms(gd, rowptr64, colind64, x)
+    result["gnn_epoch"]["ms_with_torch_linear_backward"] = gcn_epoch_ms(gd, rowptr64, colind64, x, mfma_linear=False)["ms"]
     if not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(g, x_cpu)
     return result

@@ -36,8 +36,10 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
 _finder = None
 
 
-def install():
-    """Idempotent.  Returns the list of cogdl module names that are now served by cogdl_amd."""
+def install(linear=False):
+    """Idempotent.  Returns the list of cogdl module names that are now served by cogdl_amd.
+    linear=True additionally routes torch.nn.functional.linear -- i.e. the unchanged nn.Linear inside every CogDL
+    layer -- through cogdl_amd.linear (hand-written MFMA weight gradient for full-graph shapes)."""
     global _finder
     if _finder is None:
         _finder = _Finder()
@@ -51,6 +53,10 @@ def install():
             if pkg is not None:
                 setattr(pkg, op, mod)
     _rebind_graph_build()
+    if linear:
+        from . import linear as _linear
+
+        _linear.install()
     su = sys.modules.get("cogdl.utils.spmm_utils")
     if su is not None:  # force the dispatcher to re-resolve the callables
         for k in ("spmm_flag", "mh_spmm_flag", "fused_gat_flag", "spmm_cpu_flag"):
@@ -78,6 +84,8 @@ def _rebind_graph_build():
 
 
 def uninstall():
+    if "cogdl_amd.linear" in sys.modules:
+        sys.modules["cogdl_amd.linear"].uninstall()
     for name in _COO2CSR_HOLDERS:
         mod = sys.modules.get(name)
         if mod is not None and hasattr(mod, "_cogdl_amd_orig_coo2csr_index"):

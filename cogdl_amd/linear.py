@@ -1,0 +1,81 @@
+"""The dense side of a CogDL layer: `self.linear(x)` = torch.nn.Linear, whose backward
+torch sends to hipBLASLt.  For the tall-skinny shapes of full-graph training (x: [num_nodes, in], grad: [num_nodes, out])
+the weight gradient  grad_out^T . x  is a reduction over 10^5..10^8 rows that hipBLASLt runs on a handful of workgroups
+(ogbn-arxiv-shaped GCN: 349 + 442 us of a 2.2 ms epoch); `cogdl_hip_linear_wgrad_f32` streams both operands once through
+fp32 MFMA instead.
+
+    linear(x, weight, bias)        functional form with the hand-written weight/bias gradient
+    install() / uninstall()        make torch.nn.functional.linear -- hence every unchanged nn.Linear inside CogDL's
+                                   layers -- take it for the shapes it covers (2-D fp32 GPU input with many rows);
+                                   everything else goes to torch's own implementation, as before.
+The forward product and grad_input stay torch.addmm / torch.mm (hipBLASLt is adequate there).
+"""
+import torch
+
+from . import _lib
+
+MIN_ROWS = 4096      # below this the reduction is too short to matter
+MAX_FEATURES = 4096  # in/out features covered by the kernel's tiling
+
+_orig_linear = torch.nn.functional.linear
+
+
+def linear_wgrad(x, grad_out, want_bias=True):
+    """(grad_weight [out, in], grad_bias [out] | None) for y = x @ W^T + b; x [K, in], grad_out [K, out], fp32, GPU."""
+    dev = _lib.require_cuda(x, grad_out)
+    x, grad_out = x.contiguous(), grad_out.contiguous()
+    k, in_f = x.shape
+    out_f = grad_out.shape[1]
+    grad_w = torch.empty((out_f, in_f), dtype=torch.float32, device=dev)
+    grad_b = torch.empty(out_f, dtype=torch.float32, device=dev) if want_bias else None
+    ws, ws_bytes = _lib.workspace("cogdl_hip_linear_wgrad_workspace_bytes", dev, k, in_f, out_f)
+    with torch.cuda.device(dev):
+        rc = _lib.hip().cogdl_hip_linear_wgrad_f32(_lib.ptr(x), _lib.ptr(grad_out), _lib.ptr(grad_w), _lib.ptr(grad_b), k,
+                                                   in_f, out_f, _lib.ptr(ws), ws_bytes, _lib.stream_of(x))
+    _lib.check(rc, "linear_wgrad")
+    return grad_w, grad_b
+
+
+class LinearFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return _orig_linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        grad_x = grad_out.mm(weight) if ctx.needs_input_grad[0] else None
+        grad_w = grad_b = None
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            grad_w, grad_b = linear_wgrad(x, grad_out, want_bias=need_b)
+        elif need_b:
+            grad_b = grad_out.sum(0)
+        return grad_x, grad_w, grad_b
+
+
+def covers(x, weight, bias):
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and x.shape[0] >= MIN_ROWS and weight.dim() == 2 and max(weight.shape) <= MAX_FEATURES
+            and (bias is None or bias.dtype == torch.float32)
+            and torch.is_grad_enabled() and weight.requires_grad and not torch.is_autocast_enabled())
+
+
+def linear(x, weight, bias=None):
+    """Drop-in for torch.nn.functional.linear."""
+    if covers(x, weight, bias):
+        return LinearFunction.apply(x, weight, bias)
+    return _orig_linear(x, weight, bias)
+
+
+def install():
+    """Idempotent: torch.nn.functional.linear (what nn.Linear.forward calls) -> `linear` above."""
+    _lib.hip()  # fail loudly if the library is missing
+    torch.nn.functional.linear = linear
+
+
+def uninstall():
+    torch.nn.functional.linear = _orig_linear

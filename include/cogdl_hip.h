@@ -225,6 +225,19 @@ COGDL_API size_t cogdl_hip_coo2csr_index_workspace_bytes(int64_t nnz, int64_t nu
 COGDL_API int cogdl_hip_coo2csr_index(const int64_t *row, int64_t nnz, int64_t num_nodes, int64_t *row_ptr,
                             int64_t *perm, int *bad_flag, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * linear_wgrad: grad_w[out, in] = grad_out[k_rows, out]^T . x[k_rows, in], grad_b[out] = column sums of grad_out
+ * (grad_b may be NULL) -- the weight/bias gradient of the `self.linear(x)` inside every CogDL layer
+ * (cogdl/layers/gcn_layer.py:52, gat_layer.py:60, sage_layer.py:72; torch.nn.Linear's backward, which torch hands to
+ * hipBLASLt).  fp32, row-major, k_rows = number of nodes: a split-K v_mfma_f32_32x32x2_f32 kernel that streams both
+ * operands once (csrc/linear_wgrad.hip).  SURVEY.md section 8f rank 3: the one dense product of the path worth a
+ * hand-written MFMA kernel.  workspace: cogdl_hip_linear_wgrad_workspace_bytes; x, grad_out 16-byte aligned.
+ * ------------------------------------------------------------------------------------- */
+COGDL_API size_t cogdl_hip_linear_wgrad_workspace_bytes(int64_t k_rows, int64_t in_features, int64_t out_features);
+COGDL_API int cogdl_hip_linear_wgrad_f32(const float *x, const float *grad_out, float *grad_w, float *grad_b,
+                               int64_t k_rows, int64_t in_features, int64_t out_features, void *workspace,
+                               size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,6 +143,20 @@ def reddit():
            g.nnz * (6 + 256) + n * 260, g.nnz)
 
 
+def linear():
+    """The dense side: weight/bias gradient on tall-skinny operands; bytes = K*(in+out)*4."""
+    from cogdl_amd.linear import linear_wgrad
+
+    for k, i, o in ((169_343, 128, 64), (169_343, 64, 40), (169_343, 256, 256), (232_965, 602, 64), (2_449_029, 100, 128)):
+        x, g = torch.randn(k, i, device=DEV), torch.randn(k, o, device=DEV)
+        ms = timeit(lambda: linear_wgrad(x, g), 20)
+        ms_t = timeit(lambda: (g.t() @ x, g.sum(0)), 10)
+        nbytes = k * (i + o) * 4
+        report("linear_wgrad (MFMA)", "K=%d in=%d out=%d" % (k, i, o), ms, nbytes, k)
+        print("    torch g.t() @ x + g.sum(0): %.1f us;  %.1f TFLOP/s fp32 MFMA (peak 157)" % (ms_t * 1e3, 2.0 * k * i * o / ms / 1e9),
+              flush=True)
+
+
 def main():
     argv = sys.argv[1:]
     json_path = None
@@ -159,6 +173,8 @@ def main():
         gat_suite(g, "arxiv-rmat", 4, 32, dtypes=(torch.float32,))
     if not args or "reddit" in args:
         reddit()
+    if not args or "linear" in args:
+        linear()
     if json_path:
         json.dump(ROWS, open(json_path, "w"), indent=1)
 
