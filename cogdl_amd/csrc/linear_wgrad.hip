@@ -24,7 +24,7 @@ namespace cogdl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kWgradUnroll = 8;      // row pairs in flight per wave
+constexpr int kWgradUnroll = 4;      // row pairs per batch; two batches in flight per wave
 constexpr int kWgradMaxSlabs = 512;
 
 struct WgradGeom {
@@ -87,24 +87,64 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float *__restri
 #pragma unroll
     for (int a = 0; a < WN; ++a) bs[a] = 0.f;
 
-    // this wave's row pairs: p = ks, ks + KW, ...; rows k_begin + 2p + half
-    for (int64_t k = k_begin + 2 * ks + half; k - half < k_end; k += (int64_t)2 * KW * kWgradUnroll) {
-        float xv[kWgradUnroll][WM], gv[kWgradUnroll][WN];
+    // Loads are bounds-checked BUFFER loads on a per-slab descriptor: rows past the slab (and lanes past the last
+    // column, which get an offset beyond any slab) read 0 without a branch, so the 3*kWgradUnroll loads of a batch are
+    // straight-line code the compiler can keep in flight behind the MFMAs of the previous batch.
+    const int slab_rows = (int)(k_end - k_begin);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x + k_begin * in_f), 0, slab_rows * in_f * (int)sizeof(float), 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(g + k_begin * out_f), 0, slab_rows * out_f * (int)sizeof(float), 0x00020000);
+    constexpr int kOob = (int)0x80000000;  // as an unsigned byte offset: beyond every slab
+    int xcol[WM], gcol[WN];
+#pragma unroll
+    for (int b = 0; b < WM; ++b) xcol[b] = (m_base + 32 * b < in_f) ? (m_base + 32 * b) * 4 : kOob;
+#pragma unroll
+    for (int a = 0; a < WN; ++a) gcol[a] = (n_base + 32 * a < out_f) ? (n_base + 32 * a) * 4 : kOob;
+    const int x_row_bytes = in_f * 4, g_row_bytes = out_f * 4;
+    constexpr int kStep = 2 * KW * kWgradUnroll;  // rows covered by one batch of this wave
+    // Batch i of this wave = rows r0(i) + 2*KW*u, u < kWgradUnroll, r0(i) = 2*ks + half + i*kStep.  When the whole batch
+    // lies inside the slab (all but the last one or two) the per-row part of the address is the SCALAR offset of the
+    // buffer instruction (u * 2*KW * row_bytes: not bounds-checked, and needs no check) and the lane part is one add per
+    // column stream; only the tail batches pay for per-row checks.
+    auto load_batch = [&](int i, float (&xv)[kWgradUnroll][WM], float (&gv)[kWgradUnroll][WN]) {
+        const int r0 = 2 * ks + half + i * kStep;
+        const bool full = 2 * ks + 1 + i * kStep + 2 * KW * (kWgradUnroll - 1) < slab_rows;  // wave-uniform
+        if (full) {
+            int xo[WM], go[WN];
+#pragma unroll
+            for (int b = 0; b < WM; ++b) xo[b] = r0 * x_row_bytes + xcol[b];  // (top bit of xcol survives: no wrap)
+#pragma unroll
+            for (int a = 0; a < WN; ++a) go[a] = r0 * g_row_bytes + gcol[a];
+#pragma unroll
+            for (int u = 0; u < kWgradUnroll; ++u) {
+#pragma unroll
+                for (int b = 0; b < WM; ++b)
+                    xv[u][b] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, xo[b], u * 2 * KW * x_row_bytes, 0));
+#pragma unroll
+                for (int a = 0; a < WN; ++a)
+                    gv[u][a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gr, go[a], u * 2 * KW * g_row_bytes, 0));
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < kWgradUnroll; ++u) {
-            const int64_t kk = k + (int64_t)2 * KW * u;
-            const bool ok = kk < k_end;
+            const int r = r0 + 2 * KW * u;                       // row inside the slab; past its end -> reads 0
+            const int xrow = (r < slab_rows) ? r * x_row_bytes : kOob;
+            const int grow = (r < slab_rows) ? r * g_row_bytes : kOob;
+            // offset = row + column, with the top bit forced whenever either part is out of bounds (pure bit math:
+            // no branches, and the sum of two out-of-bounds markers cannot wrap back into range)
 #pragma unroll
-            for (int b = 0; b < WM; ++b) {
-                const int m = m_base + 32 * b;
-                xv[u][b] = (ok && m < in_f) ? x[kk * in_f + m] : 0.f;
-            }
+            for (int b = 0; b < WM; ++b)
+                xv[u][b] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                    xr, (xrow + xcol[b]) | (((xrow | xcol[b]) >> 31) & kOob), 0, 0));
 #pragma unroll
-            for (int a = 0; a < WN; ++a) {
-                const int n = n_base + 32 * a;
-                gv[u][a] = (ok && n < out_f) ? g[kk * out_f + n] : 0.f;
-            }
+            for (int a = 0; a < WN; ++a)
+                gv[u][a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                    gr, (grow + gcol[a]) | (((grow | gcol[a]) >> 31) & kOob), 0, 0));
         }
+    };
+    auto mfma_batch = [&](const float (&xv)[kWgradUnroll][WM], const float (&gv)[kWgradUnroll][WN]) {
 #pragma unroll
         for (int u = 0; u < kWgradUnroll; ++u)
 #pragma unroll
@@ -114,6 +154,16 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float *__restri
                 for (int b = 0; b < WM; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[u][a], xv[u][b], acc[a][b], 0, 0, 0);
             }
+    };
+    // two register buffers: the loads of batch i+1 are in flight behind the MFMAs of batch i
+    const int n_batches = (slab_rows - 2 * ks + kStep - 1) / kStep;  // wave-uniform; batches past it read zeros
+    float xa[kWgradUnroll][WM], ga[kWgradUnroll][WN], xb[kWgradUnroll][WM], gb[kWgradUnroll][WN];
+    load_batch(0, xa, ga);
+    for (int i = 0; i < n_batches; i += 2) {
+        load_batch(i + 1, xb, gb);
+        mfma_batch(xa, ga);
+        load_batch(i + 2, xa, ga);
+        mfma_batch(xb, gb);
     }
 
     // fragment order [tile][register][lane], one partial per (slab, k-split instance)
