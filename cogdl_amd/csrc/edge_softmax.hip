@@ -358,6 +358,11 @@ static int launch_pow2(const int32_t *rowptr, const float *a, const float *g, fl
     return launch_status();
 }
 
+// A piece of the long-row path is T edges x H values for a whole workgroup: with few heads the generic threshold makes
+// pieces too small to amortise their two launches' bookkeeping (measured, reddit-shaped graph, H = 1: T 1024 -> 573 us,
+// 2048 -> 469 us; arxiv R-MAT, H = 1: T 128 -> 128 us, 512 -> 72 us; H = 8 is best at the generic threshold).
+static int es_thresh_scale(int64_t h) { return h >= 8 ? 1 : (h >= 4 ? 2 : 4); }
+
 template <bool BACKWARD>
 static int edge_softmax_dispatch(const int32_t *rowptr, const float *a, const float *g, float *out, int64_t m,
                                  int64_t nnz, int64_t h, void *ws, size_t wsb, hipStream_t s) {
@@ -368,9 +373,9 @@ static int edge_softmax_dispatch(const int32_t *rowptr, const float *a, const fl
     LongRows lr{};
     lr.thresh = INT_MAX;
     if (ws) {
-        if (wsb < rowreduce_workspace_bytes(nnz, 2 * h)) return COGDL_HIP_EWORKSPACE;
+        if (wsb < rowreduce_workspace_bytes(nnz, 2 * h, es_thresh_scale(h))) return COGDL_HIP_EWORKSPACE;
         if (!aligned_to(ws, 256)) return COGDL_HIP_EALIGN;
-        plan_long_rows(lr, nnz);
+        plan_long_rows(lr, nnz, es_thresh_scale(h));
         lr.partial = (float *)((char *)ws + kFoundBytes);
         lr.rec_stride = 2 * h;
     }
@@ -401,7 +406,7 @@ using namespace cogdl;
 
 extern "C" size_t cogdl_hip_edge_softmax_workspace_bytes(int64_t nnz, int64_t h) {
     if (nnz <= 0 || h <= 0) return 0;
-    return rowreduce_workspace_bytes(nnz, 2 * h);
+    return rowreduce_workspace_bytes(nnz, 2 * h, es_thresh_scale(h));
 }
 
 extern "C" int cogdl_hip_edge_softmax_fwd(const int32_t *rowptr, const float *values, float *out, int64_t m,

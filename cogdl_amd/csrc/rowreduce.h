@@ -87,14 +87,14 @@ inline int pick_long_thresh(int64_t nnz) {
 inline int64_t n_chunks_for(int64_t nnz, int thresh) { return (nnz + thresh - 1) / thresh; }
 // Workspace of an operator whose piece record holds `rec_stride` floats.
 constexpr size_t kFoundBytes = 8192;  // found[] of <= 2048 long-row workgroups, in front of the records
-inline size_t rowreduce_workspace_bytes(int64_t nnz, int64_t rec_stride) {
+inline size_t rowreduce_workspace_bytes(int64_t nnz, int64_t rec_stride, int thresh_scale = 1) {
     if (nnz <= 0 || rec_stride <= 0) return 0;
-    const int64_t n_chunks = n_chunks_for(nnz, pick_long_thresh(nnz));
+    const int64_t n_chunks = n_chunks_for(nnz, pick_long_thresh(nnz) * thresh_scale);
     return kFoundBytes + ((size_t)n_chunks * 2 * (size_t)rec_stride * sizeof(float) + 255) / 256 * 256;
 }
 // Fill the scheduling fields of the long-row path (everything but `partial`/`rec_stride`).
-inline void plan_long_rows(LongRows &lr, int64_t nnz) {
-    lr.thresh = pick_long_thresh(nnz);
+inline void plan_long_rows(LongRows &lr, int64_t nnz, int thresh_scale = 1) {
+    lr.thresh = pick_long_thresh(nnz) * thresh_scale;
     lr.n_chunks = n_chunks_for(nnz, lr.thresh);
     lr.nnz = nnz;
     const int64_t max_wg = std::min(2040, std::max(64, g_tuning[kTuneLongGrid]));
