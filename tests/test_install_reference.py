@@ -1,0 +1,84 @@
+"""Drop-in check against the REAL reference package (build container only: skipped where /root/reference is absent,
+e.g. on the GPU box).  cogdl_amd.install() must make CogDL's own, unchanged code -- Graph, the spmm dispatcher,
+Graph.sample_adj, coo2csr_index, GCNLayer -- run on the cogdl_amd operators.  CPU-only here, so what is exercised is
+the host library (sampler, COO->CSR, CPU SpMM) plus the module plumbing; the GPU kernels behind the same names are
+covered by the -m gpu suite."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("COGDL_REFERENCE", "/root/reference")
+
+SCRIPT = r'''
+import os, shutil, sys, tempfile
+ROOT, REF = sys.argv[1], sys.argv[2]
+scratch = tempfile.mkdtemp(prefix="cogdl_refcopy_")          # the reference writes into its own tree when imported
+shutil.copytree(os.path.join(REF, "cogdl"), os.path.join(scratch, "cogdl"))
+sys.dont_write_bytecode = True
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests", "golden", "_stubs"), scratch]
+import torch
+import cogdl_amd
+served = cogdl_amd.install()
+import cogdl
+from cogdl.data import Graph
+from cogdl.layers import GCNLayer
+from cogdl.utils import spmm_utils, graph_utils
+import cogdl.data.data as cdata
+cogdl_amd.install()                                            # again, now that cogdl is imported: rebinds coo2csr_index
+
+# 1. the operator modules CogDL sees are ours
+import cogdl.operators.spmm as m_spmm, cogdl.operators.sample as m_sample, cogdl.operators.edge_softmax as m_es
+assert m_spmm.__name__ == "cogdl_amd.operators.spmm" and m_sample.__name__ == "cogdl_amd.operators.sample"
+assert m_es.__name__ == "cogdl_amd.operators.edge_softmax", m_es.__name__
+assert graph_utils.coo2csr_index.__module__ == "cogdl_amd.graph_build"
+assert cdata.coo2csr_index.__module__ == "cogdl_amd.graph_build"
+
+# 2. Graph construction (COO -> CSR through our host operator) reproduces the documented example (graph.rst:53-61)
+edges = torch.tensor([[0, 1], [1, 3], [2, 1], [4, 2], [0, 3]]).t().contiguous()
+g = Graph(edge_index=edges, x=torch.randn(5, 8))
+assert g.row_indptr.tolist() == [0, 2, 3, 4, 4, 5] and g.col_indices.tolist() == [1, 3, 3, 1, 2]
+
+# 3. the dispatcher's CPU inference path runs our spmm_cpu and equals the scatter fallback
+torch.manual_seed(0)
+n = 300
+ei = torch.randint(0, n, (2, 2500))
+g = Graph(edge_index=ei, x=torch.randn(n, 16))
+g.add_remaining_self_loops(); g.sym_norm()
+x = torch.randn(n, 16)
+with torch.no_grad():
+    y = spmm_utils.spmm(g, x)
+assert spmm_utils.CONFIGS["fast_spmm_cpu"] is m_spmm.spmm_cpu, "dispatcher did not pick up cogdl_amd's spmm_cpu"
+row, col = g.edge_index
+want = torch.zeros_like(x).index_add_(0, row, x[col] * g.edge_weight.unsqueeze(-1))
+assert torch.allclose(y, want, rtol=1e-5, atol=1e-6)
+
+# 4. an unchanged GCNLayer trains one step through the dispatcher
+layer = GCNLayer(16, 4)
+out = layer(g, x.requires_grad_())
+out.sum().backward()
+assert layer.linear.weight.grad is not None and out.shape == (n, 4)
+
+# 5. Graph.sample_adj (unchanged data.py:792-832) on our sampler: seeds first, padded row_ptr, valid relabelling
+batch = torch.tensor([5, 17, 3])
+nodes, sub = g.sample_adj(batch, 4, replace=False)
+assert nodes[:3].tolist() == [5, 17, 3]
+rp, ci = sub.row_indptr, sub.col_indices
+assert rp.numel() == nodes.numel() + 1 and int(ci.max()) < nodes.numel()
+deg = g.row_indptr[batch + 1] - g.row_indptr[batch]
+assert (rp[1:4] - rp[0:3]).tolist() == torch.clamp(deg, max=4).tolist()
+nodes_all, sub_all = g.sample_adj(batch, -1)
+for i, b in enumerate(batch.tolist()):
+    mine = sorted(nodes_all[sub_all.col_indices[sub_all.row_indptr[i]:sub_all.row_indptr[i + 1]]].tolist())
+    assert mine == sorted(g.col_indices[g.row_indptr[b]:g.row_indptr[b + 1]].tolist())
+shutil.rmtree(scratch, ignore_errors=True)
+print("INSTALL-OK", served)
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "cogdl")), reason="reference package not present")
+def test_reference_package_runs_on_cogdl_amd_after_install():
+    proc = subprocess.run([sys.executable, "-c", SCRIPT, ROOT, REF], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0 and "INSTALL-OK" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-4000:]
