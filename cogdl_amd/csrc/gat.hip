@@ -294,7 +294,7 @@ struct GatFwdChunkOp {
 // Row pass: D[v,h] and grad_attn_row[v,h].  The whole [H*F] row must fit one group.
 template <int VEC_, int LPR_, int UNROLL_>
 struct GatBwdRowOp {
-    static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = 1;
+    static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_ + 1;
     static constexpr bool kReduce = true;
     static constexpr int kLds = 0;
     const float *attn_row, *attn_col, *feat, *edge_max, *edge_sum, *out, *grad_out;
@@ -308,7 +308,14 @@ struct GatBwdRowOp {
         float g[VEC];
         float d, ar, mx, inv;
     };
-    struct State { float gacc; };
+    // grad_attn_row[v,h] = sum_e c_e (<g, feat[col_e]> - D) with c_e = a_e * LeakyReLU'(.)
+    //                    = < g, sum_e c_e feat[col_e] >  -  D * sum_e c_e :
+    // the per-edge dot product (a cross-lane reduction per edge) becomes ONE reduction per row over a weighted
+    // accumulation s[] of the gathered rows, exactly the shape of an SpMM.
+    struct State {
+        float s[VEC];
+        float csum;
+    };
     struct LaneVals {};
     struct Batch {
         float v[UNROLL][VEC];
@@ -342,8 +349,12 @@ struct GatBwdRowOp {
         }
         c.d = head_sum<LPR>(d, lph);
     }
-    __device__ __forceinline__ void init_zero(State &s) const { s.gacc = 0.f; }
-    __device__ __forceinline__ void init(const Ctx &, State &s, int64_t, bool) const { s.gacc = 0.f; }
+    __device__ __forceinline__ void init_zero(State &s) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.s[i] = 0.f;
+        s.csum = 0.f;
+    }
+    __device__ __forceinline__ void init(const Ctx &, State &s, int64_t, bool) const { init_zero(s); }
     __device__ __forceinline__ void lane_load(const Ctx &, LaneVals &, int64_t) const {}
     __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t, const LaneVals &, int,
                                           int) const {
@@ -352,33 +363,47 @@ struct GatBwdRowOp {
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
                                           int) const {
-        float dot = 0.f;
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) dot = fmaf(c.g[i], c.col_ok ? b.v[u][i] : 0.f, dot);
-        dot = head_sum<LPR>(dot, lph);
         if (valid) {
             const float pre = c.ar + b.ac[u];
-            const float a = expf(leaky(pre, slope) - c.mx) * c.inv;
-            s.gacc += a * (dot - c.d) * (pre > 0.f ? 1.f : slope);
+            const float ce = expf(leaky(pre, slope) - c.mx) * c.inv * (pre > 0.f ? 1.f : slope);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) s.s[i] = fmaf(ce, b.v[u][i], s.s[i]);
+            s.csum += ce;
         }
     }
     __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
+        float dot = 0.f;  // (all lanes of the group take part in the reduction)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) dot = fmaf(c.g[i], c.col_ok ? s.s[i] : 0.f, dot);
+        dot = head_sum<LPR>(dot, lph);
         if (ok && c.head_lane) {
             dvec[row * heads + c.hd] = c.d;
-            grad_attn_row[row * heads + c.hd] = s.gacc;
+            grad_attn_row[row * heads + c.hd] = dot - c.d * s.csum;
         }
     }
-    __device__ __forceinline__ void pack(const State &s, float (&rec)[kRec]) const { rec[0] = s.gacc; }
-    __device__ __forceinline__ void unpack(State &s, const float (&rec)[kRec]) const { s.gacc = rec[0]; }
-    __device__ __forceinline__ void merge(const Ctx &, State &a, const State &b) const { a.gacc += b.gacc; }
+    __device__ __forceinline__ void pack(const State &s, float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) rec[i] = s.s[i];
+        rec[VEC] = s.csum;
+    }
+    __device__ __forceinline__ void unpack(State &s, const float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.s[i] = rec[i];
+        s.csum = rec[VEC];
+    }
+    __device__ __forceinline__ void merge(const Ctx &, State &a, const State &b) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) a.s[i] += b.s[i];
+        a.csum += b.csum;
+    }
 };
 
 // Column pass over the CSC (colptr, rowind): grad_feat[u,h,:] and grad_attn_col[u,h].
 template <int VEC_, int LPR_, int UNROLL_>
 struct GatBwdColOp {
-    static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_ + 1;
+    static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = 2 * VEC_ + 1;
     static constexpr bool kReduce = true;
     static constexpr int kLds = 0;
     const float *attn_row, *attn_col, *feat, *edge_max, *edge_sum, *dvec, *grad_out;
@@ -392,9 +417,13 @@ struct GatBwdColOp {
         float f[VEC];
         float ac;
     };
+    // grad_attn_col[u,h] = sum_e c_e (<feat[u], g[row_e]> - D[row_e]) = <feat[u], sum_e c_e g[row_e]> - sum_e c_e D[row_e]:
+    // a second weighted accumulation t[] next to grad_feat's (weights c_e = a_e * LeakyReLU' instead of a_e) and one
+    // cross-lane reduction per column instead of one per edge.
     struct State {
         float acc[VEC];
-        float gacc;
+        float t[VEC];
+        float cd;
     };
     struct LaneVals {};
     struct Batch {
@@ -421,8 +450,8 @@ struct GatBwdColOp {
     }
     __device__ __forceinline__ void init_zero(State &s) const {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) s.acc[i] = 0.f;
-        s.gacc = 0.f;
+        for (int i = 0; i < VEC; ++i) s.acc[i] = s.t[i] = 0.f;
+        s.cd = 0.f;
     }
     __device__ __forceinline__ void init(const Ctx &, State &s, int64_t, bool) const { init_zero(s); }
     __device__ __forceinline__ void lane_load(const Ctx &, LaneVals &, int64_t) const {}
@@ -437,40 +466,53 @@ struct GatBwdColOp {
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
                                           int) const {
-        float dot = 0.f;
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) dot = fmaf(c.f[i], c.col_ok ? b.g[u][i] : 0.f, dot);
-        dot = head_sum<LPR>(dot, lph);
         if (valid) {
             const float pre = b.ar[u] + c.ac;
             const float a = expf(leaky(pre, slope) - b.mx[u]) / b.ls[u];
+            const float ce = a * (pre > 0.f ? 1.f : slope);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) s.acc[i] = fmaf(a, b.g[u][i], s.acc[i]);
-            s.gacc += a * (dot - b.dd[u]) * (pre > 0.f ? 1.f : slope);
+            for (int i = 0; i < VEC; ++i) {
+                s.acc[i] = fmaf(a, b.g[u][i], s.acc[i]);
+                s.t[i] = fmaf(ce, b.g[u][i], s.t[i]);
+            }
+            s.cd = fmaf(ce, b.dd[u], s.cd);
         }
     }
     __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t u_node, bool ok) const {
+        float dot = 0.f;  // (all lanes of the group take part in the reduction)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) dot = fmaf(c.f[i], c.col_ok ? s.t[i] : 0.f, dot);
+        dot = head_sum<LPR>(dot, lph);
         if (ok && c.col_ok) {
             store_vec<float, VEC>(grad_feat + u_node * (int64_t)(heads * fdim) + c.cc, s.acc);
-            if (c.head_lane) grad_attn_col[u_node * heads + c.hd] = s.gacc;
+            if (c.head_lane) grad_attn_col[u_node * heads + c.hd] = dot - s.cd;
         }
     }
     __device__ __forceinline__ void pack(const State &s, float (&rec)[kRec]) const {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) rec[i] = s.acc[i];
-        rec[VEC] = s.gacc;
+        for (int i = 0; i < VEC; ++i) {
+            rec[i] = s.acc[i];
+            rec[VEC + i] = s.t[i];
+        }
+        rec[2 * VEC] = s.cd;
     }
     __device__ __forceinline__ void unpack(State &s, const float (&rec)[kRec]) const {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) s.acc[i] = rec[i];
-        s.gacc = rec[VEC];
+        for (int i = 0; i < VEC; ++i) {
+            s.acc[i] = rec[i];
+            s.t[i] = rec[VEC + i];
+        }
+        s.cd = rec[2 * VEC];
     }
     __device__ __forceinline__ void merge(const Ctx &, State &a, const State &b) const {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) a.acc[i] += b.acc[i];
-        a.gacc += b.gacc;
+        for (int i = 0; i < VEC; ++i) {
+            a.acc[i] += b.acc[i];
+            a.t[i] += b.t[i];
+        }
+        a.cd += b.cd;
     }
 };
 
@@ -633,8 +675,8 @@ extern "C" size_t cogdl_hip_gat_bwd_workspace_bytes(int64_t v, int64_t h, int64_
     const int vec = gat_bwd_vec(h, f, 16);
     if (vec > 0 && nnz > 0) {
         const int lpr = gat_bwd_lpr(h, f, vec);
-        total += rowreduce_workspace_bytes(nnz, 1 * lpr);
         total += rowreduce_workspace_bytes(nnz, (int64_t)(vec + 1) * lpr);
+        total += rowreduce_workspace_bytes(nnz, (int64_t)(2 * vec + 1) * lpr);
     }
     return total + 256;
 }
@@ -663,8 +705,8 @@ extern "C" int cogdl_hip_gat_bwd(const int32_t *rowptr, const int32_t *colind, c
               nullptr, nullptr, 0, 0};
     // the long-row scratch is used only when the caller's workspace covers all of it
     const int lpr = gat_bwd_lpr(h, f, vec);
-    const size_t need_row = rowreduce_workspace_bytes(nnz, 1 * lpr);
-    const size_t need_col = rowreduce_workspace_bytes(nnz, (int64_t)(vec + 1) * lpr);
+    const size_t need_row = rowreduce_workspace_bytes(nnz, (int64_t)(vec + 1) * lpr);
+    const size_t need_col = rowreduce_workspace_bytes(nnz, (int64_t)(2 * vec + 1) * lpr);
     if (nnz > 0 && workspace_bytes >= dvec_bytes(v, h) + need_row + need_col) {
         b.ws_row = (char *)workspace + dvec_bytes(v, h);
         b.wsb_row = need_row;
