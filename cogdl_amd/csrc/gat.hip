@@ -99,6 +99,7 @@ struct GatFwdOp {
         }
     }
     __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
+    __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
         if (ok && c.col_ok) {
@@ -247,6 +248,7 @@ struct GatFwdChunkOp {
             for (int i = 0; i < VEC; ++i) s.acc[i] = fmaf(p, b.v[u][i], s.acc[i]);
         }
     }
+    __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
         const float lsum_col = __shfl(s.lsum, c.lane0 + c.hd, kWave);  // (all lanes of the group take part)
@@ -372,6 +374,7 @@ struct GatBwdRowOp {
         }
     }
     __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
+    __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
         float dot = 0.f;  // (all lanes of the group take part in the reduction)
@@ -479,6 +482,7 @@ struct GatBwdColOp {
         }
     }
     __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
+    __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t u_node, bool ok) const {
         float dot = 0.f;  // (all lanes of the group take part in the reduction)

@@ -9,7 +9,7 @@
 namespace cogdl {
 
 // Per-edge outputs (no per-row state): long rows are cut into chunks processed by whole workgroups.
-template <int VEC_, int LPR_, int UNROLL_>
+template <int VEC_, int LPR_, int UNROLL_, bool ONE_HEAD>
 struct MhsddmmOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = 1;
     static constexpr bool kReduce = false;
@@ -19,16 +19,17 @@ struct MhsddmmOp {
     int heads, fdim, lph;  // lph = lanes per head
 
     struct Ctx {
-        int c0, hd;
+        int l, c0, hd;
         bool col_ok, head_lane;
         float a[VEC];
     };
-    struct State {};
+    struct State { float p[UNROLL_]; };  // ONE_HEAD: the batch's per-lane partial dot products
     struct LaneVals {};
     struct Batch { float b[UNROLL][VEC]; };
 
     __device__ __forceinline__ Ctx make_ctx(int l, int) const {
         Ctx c;
+        c.l = l;
         c.col_ok = l * VEC < heads * fdim;
         c.c0 = c.col_ok ? l * VEC : 0;
         c.hd = c.c0 / fdim;
@@ -47,15 +48,28 @@ struct MhsddmmOp {
                                           int) const {
         load_vec<float, VEC>(feat + (int64_t)col * (heads * fdim) + c.c0, b.b[u]);
     }
-    __device__ __forceinline__ void apply(const Ctx &c, State &, const Batch &b, int u, bool valid, int64_t e,
+    __device__ __forceinline__ void apply(const Ctx &c, State &s_, const Batch &b, int u, bool valid, int64_t e,
                                           int) const {
         float p = 0.f;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) p = fmaf(c.a[i], c.col_ok ? b.b[u][i] : 0.f, p);
+        if constexpr (ONE_HEAD) {
+            s_.p[u] = p;  // reduced jointly in batch_end
+        } else {
 #pragma unroll
-        for (int s = LPR / 2; s > 0; s >>= 1)
-            if (s < lph) p += __shfl_xor(p, s, kWave);
-        if (valid && c.head_lane) out[e * heads + c.hd] = p;
+            for (int s = LPR / 2; s > 0; s >>= 1)
+                if (s < lph) p += __shfl_xor(p, s, kWave);
+            if (valid && c.head_lane) out[e * heads + c.hd] = p;
+        }
+    }
+    // Single head: the whole group reduces, so the UNROLL dot products of a batch share one transpose reduce.
+    __device__ __forceinline__ void batch_end(const Ctx &c, State &s_, int base, int j, int cnt) const {
+        if constexpr (ONE_HEAD) {
+            const float r = transpose_reduce<UNROLL, LPR>(s_.p, c.l);
+            constexpr int kSpan = LPR / UNROLL;
+            const int idx = c.l / kSpan;
+            if (c.l % kSpan == 0 && j + idx < cnt) out[base + j + idx] = r;
+        }
     }
     __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
@@ -100,7 +114,11 @@ struct MhsddmmArgs {
 template <int VEC, int LPR>
 static int launch_mhsddmm(const MhsddmmArgs &a, void *ws, size_t wsb, hipStream_t s) {
     // one head: reduce over the whole (zero-padded) group, so F/VEC need not be a power of two
-    MhsddmmOp<VEC, LPR, 4> op{a.grad, a.feat, a.out, (int)a.h, (int)a.f, (a.h == 1) ? LPR : (int)(a.f / VEC)};
+    if (a.h == 1) {
+        MhsddmmOp<VEC, LPR, 4, true> op{a.grad, a.feat, a.out, 1, (int)a.f, LPR};
+        return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, 1, ws, wsb, s);
+    }
+    MhsddmmOp<VEC, LPR, 4, false> op{a.grad, a.feat, a.out, (int)a.h, (int)a.f, (int)(a.f / VEC)};
     return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, 1, ws, wsb, s);
 }
 

@@ -36,6 +36,8 @@
 //   constant   kLds: floats of LDS scratch per lane (0: none); the group's LPR*kLds floats are passed to chunk_begin
 //   void chunk_begin(Ctx&, State&, base, cnt, my_c, sub, l, lds)   before the gathers of each LPR-chunk of edges
 //                                                 (fused GAT: the chunk's softmax weights, once per (edge, head))
+//   void batch_end(Ctx, State&, base, j, cnt)    after the UNROLL applies of one batch (per-edge outputs: one joint
+//                                                 cross-lane reduction of the batch's partial dot products)
 //   void chunk_end(Ctx, State&, base, cnt)       after each LPR-chunk of edges (per-edge outputs: coalesced store)
 //   void row_end(Ctx, State, row, ok)            write the finished row
 //   void pack(State, float(&)[kRec]) / unpack / merge(Ctx, State& a, State b)   (kReduce only; b's edges follow a's;
@@ -155,6 +157,35 @@ __device__ __forceinline__ float group_bcast(float v, int sub, int jj) {
     return __int_as_float(group_bcast<LPR>(__float_as_int(v), sub, jj));
 }
 
+// Joint reduction of U per-lane partials over an aligned group of W lanes ("transpose reduce"): the first log2(U)
+// butterfly stages exchange HALF of the values each (a lane keeps the upper or the lower half by its stride bit), the
+// remaining stages reduce the single survivor: U - 1 + log2(W / U) shuffles instead of U * log2(W).  On return the lane
+// l (relative to its group) with (l % (W / U)) == 0 holds the total of p[l / (W / U)].
+template <int U, int W>
+__device__ __forceinline__ float transpose_reduce(const float (&p)[U], int l) {
+    static_assert(U <= W && (U & (U - 1)) == 0, "U must be a power of two <= W");
+    float v[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) v[i] = p[i];
+    int n = U;
+#pragma unroll
+    for (int s = W / 2; s >= W / U && s > 0; s >>= 1) {
+        const bool upper = (l & s) != 0;
+        n >>= 1;
+#pragma unroll
+        for (int i = 0; i < U / 2; ++i) {
+            if (i < n) {
+                const float send = upper ? v[i] : v[i + n];
+                const float keep = upper ? v[i + n] : v[i];
+                v[i] = keep + __shfl_xor(send, s, kWave);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = W / U / 2; s > 0; s >>= 1) v[0] += __shfl_xor(v[0], s, kWave);
+    return v[0];
+}
+
 // Fold edges [start, end) of one row into st, in order.  All lanes of the group execute it.
 template <class Op>
 __device__ __forceinline__ void reduce_edges(const Op &op, typename Op::Ctx &ctx, typename Op::State &st,
@@ -181,6 +212,7 @@ __device__ __forceinline__ void reduce_edges(const Op &op, typename Op::Ctx &ctx
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) op.apply(ctx, st, b, u, (j + u) < cnt, base + j + u, j + u);
+            op.batch_end(ctx, st, base, j, cnt);
         }
         op.chunk_end(ctx, st, base, cnt);
     }

@@ -102,6 +102,7 @@ struct SpmmOp {
         }
     }
     __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
+    __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
         if (ok && c.col_ok) store_vec<T, VEC>(out + row * (int64_t)k + c.col0, s.acc);
