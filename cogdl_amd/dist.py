@@ -63,7 +63,12 @@ def exchange_rows(send, send_counts, recv_counts, group=None, async_op=False):
         work = dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts),
                                       input_split_sizes=list(send_counts), group=group, async_op=async_op)
         return recv, (work if async_op else _Done())
-    # gloo (CPU tests) has no all_to_all: pairwise isend/irecv
+    # gloo (tests) has no all_to_all: pairwise isend/irecv; GPU tensors are staged through the host (gloo moves host
+    # memory only) -- this is how the world-size-2 test drives the HIP kernels on a box with a single GPU
+    if send.is_cuda:
+        recv_host, _ = exchange_rows(send.cpu(), send_counts, recv_counts, group)
+        recv.copy_(recv_host)
+        return recv, _Done()
     rank = dist.get_rank(group)
     s_off = [0]
     r_off = [0]
@@ -179,10 +184,13 @@ class _ShardedSpMM(torch.autograd.Function):
         gx = be.spmm(cp_l, ri_l, w_l, g)  # overlaps with the reverse all-to-all
         work.wait()
         off = 0
-        for q in range(sh.world):  # fixed peer order; ids within one peer are unique => deterministic
+        for q in range(sh.world):  # fixed peer order => deterministic
             n = sh.send_counts[q]
             if n:
-                gx.index_add_(0, sh.send_idx[off:off + n], back[off:off + n])
+                # The rows one peer asked for are unique, so "add" is gather + add + scatter: no atomics (torch's
+                # index_add_ would issue one fp32 atomic per element -- ~30 G atomics/s on MI355X, 10x slower).
+                idx = sh.send_idx[off:off + n]
+                gx.index_copy_(0, idx, gx.index_select(0, idx) + back[off:off + n])
             off += n
         return gx, None
 

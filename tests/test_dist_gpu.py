@@ -78,3 +78,54 @@ def test_local_plus_halo_blocks_equal_whole(oracle):
     y = be.spmm(rp_r, ci_r, w_r, x[halo_ids].to(DEV), out=y)
     want = oracle.csr_spmm_f64(g.rowptr, g.colind, g.weight, x)[:half]
     np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+
+
+def _gpu_worker(rank, world, port, n, out_dir):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # two ranks share the one GPU: gloo, not RCCL
+    try:
+        from cogdl_amd import synth as sy
+        from cogdl_amd.dist import ShardedCSR, partition_bounds, sharded_spmm
+
+        torch.cuda.set_device(0)
+        g = sy.scaled(n, 8, seed=11, topology="rmat")  # same global graph on every rank; hub rows included
+        bounds = partition_bounds(n, world)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        e0, e1 = int(g.rowptr[lo]), int(g.rowptr[hi])
+        rowptr = (g.rowptr[lo:hi + 1] - g.rowptr[lo]).long().to(DEV)
+        sh = ShardedCSR(rowptr, g.colind[e0:e1].long().to(DEV), g.weight[e0:e1].to(DEV), bounds)  # HipBackend
+        x = torch.randn(n, 32, generator=torch.Generator().manual_seed(5))
+        gout = torch.randn(n, 32, generator=torch.Generator().manual_seed(6))
+        xl = x[lo:hi].to(DEV).requires_grad_()
+        y = sharded_spmm(sh, xl)
+        y.backward(gout[lo:hi].to(DEV))
+        np.savez(os.path.join(out_dir, "r%d.npz" % rank), y=y.detach().cpu().numpy(), gx=xl.grad.cpu().numpy(), lo=lo,
+                 hi=hi, n_halo=sh.n_halo)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_hip_kernels_with_halo(tmp_path, oracle):
+    """World size 2 with a real halo: both ranks run the HIP kernels (local block, remote block via csr_spmm_acc,
+    transposed blocks in backward) on the one GPU, rows travel through gloo.  sharded == unsharded."""
+    import torch.multiprocessing as mp
+
+    n, world = 6000, 2
+    mp.spawn(_gpu_worker, args=(world, 29641, n, str(tmp_path)), nprocs=world, join=True)
+    g = synth.scaled(n, 8, seed=11, topology="rmat")
+    x = torch.randn(n, 32, generator=torch.Generator().manual_seed(5))
+    gout = torch.randn(n, 32, generator=torch.Generator().manual_seed(6))
+    want_y = oracle.csr_spmm_f64(g.rowptr, g.colind, g.weight, x)
+    colptr, rowind, w_t, _ = oracle.csr2csc(g.rowptr, g.colind, g.weight, n_cols=n)
+    want_gx = oracle.csr_spmm_f64(colptr, rowind, w_t, gout)
+    halo = 0
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
+        lo, hi = int(z["lo"]), int(z["hi"])
+        np.testing.assert_allclose(z["y"], want_y[lo:hi], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(z["gx"], want_gx[lo:hi], rtol=1e-5, atol=1e-5)
+        halo += int(z["n_halo"])
+    assert halo > 0
