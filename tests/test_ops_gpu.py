@@ -78,9 +78,19 @@ def test_edge_softmax_reference_golden(golden):
     np.testing.assert_allclose(got, z["softmax"], rtol=2e-5, atol=1e-7)
 
 
+@pytest.fixture(params=[0, 1], ids=["vec4-lanes-auto", "scalar-lanes"])
+def es_lanes(request):
+    """edge_softmax picks 16-byte or 4-byte lanes per shape; tuning key 7 forces the 4-byte kernels."""
+    from cogdl_amd import _lib
+
+    _lib.hip().cogdl_hip_set_tuning(7, request.param)
+    yield request.param
+    _lib.hip().cogdl_hip_set_tuning(7, 0)
+
+
 @pytest.mark.parametrize("h", [1, 2, 3, 4, 8, 16, 32, 64, 5, 100, 256])
 @pytest.mark.parametrize("deg,scale", [(3, 1.0), (40, 10.0), (700, 1.0)])
-def test_edge_softmax_fwd_bwd(oracle, h, deg, scale):
+def test_edge_softmax_fwd_bwd(oracle, es_lanes, h, deg, scale):
     g = synth.random_csr(60, 60, deg, seed=h + deg)
     v = rand(g.nnz, h, seed=3, scale=scale)
     gr = rand(g.nnz, h, seed=4)
@@ -271,7 +281,7 @@ def test_hub_rows_sddmm_scatter_max(oracle, hubs, k):
 
 @pytest.mark.parametrize("hubs", HUBS)
 @pytest.mark.parametrize("h", [1, 8, 5, 100])
-def test_hub_rows_edge_softmax(oracle, hubs, h):
+def test_hub_rows_edge_softmax(oracle, es_lanes, hubs, h):
     g = synth.hub_csr(60, 60, hubs=hubs, seed=h)
     v = rand(g.nnz, h, seed=3, scale=4.0)
     gr = rand(g.nnz, h, seed=4)
