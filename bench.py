@@ -143,7 +143,7 @@ def gcn_epoch_ms(gd, rowptr64, colind64, x, reps=20, warmup=5, mfma_linear=True)
     return {"model": "CogDL gcn default: 2 x GCNLayer, hidden 64, relu, dropout 0.5, Adam; full-graph step = 1 epoch",
             "ms": ts[len(ts) // 2], "min_ms": ts[0], "reps": reps,
             "spmm_calls_per_epoch": 4, "spmm_widths": [hidden, classes],
-            "linear_weight_grad": "cogdl_hip_linear_wgrad_f32 (MFMA split-K)" if mfma_linear else "torch / hipBLASLt"}
+            "linear": "cogdl_amd.linear: MFMA forward / grad_input / split-K weight gradient" if mfma_linear else "torch / hipBLASLt"}
 
 
 def bench_single(args):
@@ -215,7 +215,7 @@ def bench_single(args):
                      "GEdges_s_fwd_alone": g.nnz / (fwd_ms * 1e-3) / 1e9},
     }
     result["gnn_epoch"] = gcn_epoch_ms(gd, rowptr64, colind64, x)
-    result["gnn_epoch"]["ms_with_torch_linear_backward"] = gcn_epoch_ms(gd, rowptr64, colind64, x, mfma_linear=False)["ms"]
+    result["gnn_epoch"]["ms_with_torch_linear"] = gcn_epoch_ms(gd, rowptr64, colind64, x, mfma_linear=False)["ms"]
     if not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(g, x_cpu)
     return result

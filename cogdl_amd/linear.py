@@ -8,7 +8,8 @@ fp32 MFMA instead.
     install() / uninstall()        make torch.nn.functional.linear -- hence every unchanged nn.Linear inside CogDL's
                                    layers -- take it for the shapes it covers (2-D fp32 GPU input with many rows);
                                    everything else goes to torch's own implementation, as before.
-The forward product and grad_input stay torch.addmm / torch.mm (hipBLASLt is adequate there).
+The forward product and grad_input go through `cogdl_hip_linear_fwd_f32` (LDS-staged MFMA, weights resident in LDS)
+where that kernel is the faster one (<= 64 output columns, weight <= 96 KB), else stay torch.addmm / torch.mm.
 """
 import torch
 
@@ -36,18 +37,43 @@ def linear_wgrad(x, grad_out, want_bias=True):
     return grad_w, grad_b
 
 
+ERANGE = 6  # COGDL_HIP_ERANGE: shape outside the hand-written kernel's coverage
+
+
+def tall_skinny_matmul(x, w, bias, w_is_n_by_k):
+    """x[R, K] . B (+ bias) through cogdl_hip_linear_fwd_f32, B = w^T (w [N, K]) or w ([K, N]); None if the kernel
+    declines the shape (the caller then uses torch's own product)."""
+    dev = x.device
+    x, w = x.contiguous(), w.contiguous()
+    rows, k = x.shape
+    n = w.shape[0] if w_is_n_by_k else w.shape[1]
+    out = torch.empty((rows, n), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.hip().cogdl_hip_linear_fwd_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out), rows, k, n,
+                                                 1 if w_is_n_by_k else 0, _lib.stream_of(x))
+    if rc == ERANGE:
+        return None
+    _lib.check(rc, "linear_fwd")
+    return out
+
+
 class LinearFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return _orig_linear(x, weight, bias)
+        out = tall_skinny_matmul(x, weight, bias, True)
+        return out if out is not None else _orig_linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, grad_out):
         x, weight = ctx.saved_tensors
         grad_out = grad_out.contiguous()
-        grad_x = grad_out.mm(weight) if ctx.needs_input_grad[0] else None
+        grad_x = None
+        if ctx.needs_input_grad[0]:
+            grad_x = tall_skinny_matmul(grad_out, weight, None, False)
+            if grad_x is None:
+                grad_x = grad_out.mm(weight)
         grad_w = grad_b = None
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:

@@ -239,6 +239,15 @@ COGDL_API int cogdl_hip_linear_wgrad_f32(const float *x, const float *grad_out, 
                                int64_t k_rows, int64_t in_features, int64_t out_features, void *workspace,
                                size_t workspace_bytes, void *stream);
 
+/* linear_fwd: out[rows, n] = x[rows, k] . B (+ bias[n]) for tall-skinny x (rows = number of nodes), fp32.
+ * w_is_n_by_k != 0: B = w^T, w stored [n, k] -- torch.nn.Linear's forward x . W^T + b;
+ * w_is_n_by_k == 0: B = w stored [k, n]      -- its grad_input = grad_out . W.
+ * Every wave stages 32-row tiles of x through LDS into v_mfma_f32_32x32x2_f32; B stays resident in LDS
+ * (csrc/linear_fwd.hip).  Returns COGDL_HIP_ERANGE for shapes it does not cover (n > 64 or B larger than 96 KB):
+ * the caller then keeps its BLAS call.  x 16-byte aligned. */
+COGDL_API int cogdl_hip_linear_fwd_f32(const float *x, const float *w, const float *bias, float *out, int64_t rows,
+                             int64_t k_dim, int64_t n_dim, int w_is_n_by_k, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

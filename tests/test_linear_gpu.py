@@ -72,3 +72,30 @@ def test_functional_linear_hook_matches_torch():
     assert torch.allclose(lin.weight.grad, ref[1], rtol=1e-4, atol=2e-3)
     assert torch.allclose(lin.bias.grad, ref[2], rtol=1e-4, atol=2e-3)
     assert torch.nn.functional.linear is cl._orig_linear
+
+
+@pytest.mark.parametrize("rows,k,n", [(1000, 128, 64), (169_343, 128, 64), (169_343, 64, 40), (5003, 100, 47), (33, 7, 3),
+                                      (4097, 66, 33), (2000, 256, 64), (31, 300, 17), (1, 5, 1)])
+@pytest.mark.parametrize("transposed_w", [True, False])
+def test_tall_skinny_matmul_matches_float64(rows, k, n, transposed_w):
+    from cogdl_amd.linear import tall_skinny_matmul
+
+    gen = torch.Generator().manual_seed(rows + k + n)
+    x = torch.randn(rows, k, generator=gen)
+    w = torch.randn(n, k, generator=gen) if transposed_w else torch.randn(k, n, generator=gen)
+    bias = torch.randn(n, generator=gen) if transposed_w else None
+    x[:, 0] += 2.0  # asymmetric: row/column mix-ups show
+    got = tall_skinny_matmul(x.to(DEV), w.to(DEV), None if bias is None else bias.to(DEV), transposed_w)
+    assert got is not None
+    b64 = w.double().t() if transposed_w else w.double()
+    want = x.double() @ b64 + (bias.double() if bias is not None else 0.0)
+    scale = x.abs().double() @ b64.abs() + 1.0
+    assert np.all(np.abs(got.cpu().numpy() - want.numpy()) <= 1e-5 * scale.numpy())
+
+
+def test_tall_skinny_matmul_declines_big_weights():
+    from cogdl_amd.linear import tall_skinny_matmul
+
+    x = torch.randn(100, 1024, device=DEV)
+    assert tall_skinny_matmul(x, torch.randn(64, 1024, device=DEV), None, True) is None   # 1024 x 64 x 4 B > 96 KB
+    assert tall_skinny_matmul(x, torch.randn(65, 1024, device=DEV), None, True) is None   # > 64 columns

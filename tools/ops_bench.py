@@ -155,6 +155,18 @@ def linear():
         report("linear_wgrad (MFMA)", "K=%d in=%d out=%d" % (k, i, o), ms, nbytes, k)
         print("    torch g.t() @ x + g.sum(0): %.1f us;  %.1f TFLOP/s fp32 MFMA (peak 157)" % (ms_t * 1e3, 2.0 * k * i * o / ms / 1e9),
               flush=True)
+        from cogdl_amd.linear import tall_skinny_matmul
+
+        w, b = torch.randn(o, i, device=DEV), torch.randn(o, device=DEV)
+        if tall_skinny_matmul(x, w, b, True) is not None:
+            ms = timeit(lambda: tall_skinny_matmul(x, w, b, True), 20)
+            ms_t = timeit(lambda: torch.addmm(b, x, w.t()), 10)
+            report("linear_fwd (MFMA)", "K=%d in=%d out=%d" % (k, i, o), ms, nbytes, k)
+            print("    torch addmm: %.1f us;  %.1f TFLOP/s" % (ms_t * 1e3, 2.0 * k * i * o / ms / 1e9), flush=True)
+            ms = timeit(lambda: tall_skinny_matmul(g, w, None, False), 20)
+            ms_t = timeit(lambda: g @ w, 10)
+            report("linear_dgrad (MFMA)", "K=%d in=%d out=%d" % (k, i, o), ms, nbytes, k)
+            print("    torch g @ w: %.1f us" % (ms_t * 1e3), flush=True)
 
 
 def main():
