@@ -1,0 +1,195 @@
+// gspmm.hip -- "source (op) edge feature, then aggregate" for gfx950: the s_{add,sub,mul}_e_{sum,mean} family and
+// scatter_add of cogdl/operators/ops.py:4-103.  The reference composes them from torch ops on a COO graph
+// (ops.py:43-52): it materialises the [E, F] message tensor  msg = (n_feat[col] OP e_feat) * weight  and scatters it
+// with scatter_add_ (atomics on a GPU: non-deterministic).  Here the message never exists in memory:
+//
+//     out[v, :] = scale_v * SUM_{j in row v}  w[id_j] * ( x[colind[j], :]  OP  efeat[id_j, :] )         id_j = eid[j] | j
+//
+// over the destination-sorted (CSR) view of the edges; `eid` maps a CSR position to the caller's edge id when the
+// caller's edges are not row-sorted (stable sort => the edges of a row keep the caller's order, so the per-element
+// sum has the same association as a sequential scatter_add_ over the COO list).  Same engine as csr_spmm
+// (rowreduce.h): a group of LPR lanes per row, coalesced vector gathers of the source row AND of the edge-feature
+// row, strictly sequential accumulation, hub rows split over workgroups and merged in a fixed order.  No atomics.
+// fp32 only (the reference operators are fp32 torch code).
+// HBM-bound: algorithmic bytes per edge = 4 (colind) [+ 4 eid] [+ 4 w] + F*4 (source row) + F*4 | 4 (edge feature).
+#include "rowreduce.h"
+
+namespace cogdl {
+
+template <int VEC_, int LPR_, int UNROLL_>
+struct GspmmOp {
+    static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_;
+    static constexpr bool kReduce = true;
+    static constexpr int kLds = 0;
+    const int32_t *rowptr;  // for the mean
+    const int32_t *eid;     // CSR position -> edge id of efeat / weight (NULL: identity)
+    const float *x;         // [n_src, k] (NULL: the message is the edge feature alone -> scatter_add)
+    const float *ef;        // [E, k] or [E] (NULL: the message is the source row alone)
+    const float *w;         // [E] or NULL
+    float *out;             // [m, k]
+    int k;
+    int op;         // COGDL_HIP_GSPMM_{ADD,SUB,MUL}
+    int ef_scalar;  // efeat is [E]: one value per edge, broadcast over the columns
+    int mean;
+
+    struct Ctx {
+        int col0;
+        bool col_ok;
+        const float *xcol, *efcol;
+    };
+    struct State { float acc[VEC]; };
+    struct LaneVals {
+        int id;
+        float w, es;
+    };
+    struct Batch {
+        float v[UNROLL][VEC];
+        float e[UNROLL][VEC];
+        float w[UNROLL];
+    };
+
+    __device__ __forceinline__ Ctx make_ctx(int l, int tile) const {
+        Ctx c;
+        c.col0 = (tile * LPR + l) * VEC;
+        c.col_ok = c.col0 < k;
+        const int cc = c.col_ok ? c.col0 : 0;
+        c.xcol = x ? x + cc : nullptr;
+        c.efcol = (ef && !ef_scalar) ? ef + cc : nullptr;
+        return c;
+    }
+    __device__ __forceinline__ void row_load(Ctx &, int64_t, bool) const {}
+    __device__ __forceinline__ void init_zero(State &s) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.acc[i] = 0.f;
+    }
+    __device__ __forceinline__ void init(const Ctx &, State &s, int64_t, bool) const { init_zero(s); }
+    __device__ __forceinline__ void lane_load(const Ctx &, LaneVals &lv, int64_t e) const {
+        lv.id = eid ? eid[e] : (int)e;
+        lv.w = w ? w[lv.id] : 1.f;
+        lv.es = (ef && ef_scalar) ? ef[lv.id] : 0.f;
+    }
+    __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t, const LaneVals &lv, int sub,
+                                          int jj) const {
+        b.w[u] = group_bcast<LPR>(lv.w, sub, jj);
+        if (c.xcol) load_vec<float, VEC>(c.xcol + (int64_t)col * k, b.v[u]);
+        if (c.efcol) {
+            const int id = group_bcast<LPR>(lv.id, sub, jj);
+            load_vec<float, VEC>(c.efcol + (int64_t)id * k, b.e[u]);
+        } else {
+            const float es = group_bcast<LPR>(lv.es, sub, jj);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) b.e[u][i] = es;
+        }
+    }
+    // msg = (src OP e) * w, then out += msg: the reference's torch expression (ops.py:19-26,49-51), each step rounded
+    // to fp32 (the library is built with -ffp-contract=off).  Multiplying by w == 1.f is exact.
+    __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
+                                          int) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float msg;
+            if (!c.xcol) msg = b.e[u][i];
+            else if (!ef) msg = b.v[u][i];
+            else if (op == COGDL_HIP_GSPMM_ADD) msg = b.v[u][i] + b.e[u][i];
+            else if (op == COGDL_HIP_GSPMM_SUB) msg = b.v[u][i] - b.e[u][i];
+            else msg = b.v[u][i] * b.e[u][i];
+            if (w) msg = msg * b.w[u];
+            s.acc[i] = s.acc[i] + (valid ? msg : 0.f);
+        }
+    }
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
+    __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
+    __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
+    __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
+        if (!(ok && c.col_ok)) return;
+        float r[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) r[i] = s.acc[i];
+        if (mean) {  // op_aggr "mean" (ops.py:31-37): out * deg^-1 with 1/0 -> 0
+            const int deg = rowptr[row + 1] - rowptr[row];
+            const float inv = deg > 0 ? 1.0f / (float)deg : 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) r[i] = r[i] * inv;
+        }
+        store_vec<float, VEC>(out + row * (int64_t)k + c.col0, r);
+    }
+    __device__ __forceinline__ void pack(const State &s, float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) rec[i] = s.acc[i];
+    }
+    __device__ __forceinline__ void unpack(State &s, const float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.acc[i] = rec[i];
+    }
+    __device__ __forceinline__ void merge(const Ctx &, State &a, const State &b) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) a.acc[i] += b.acc[i];
+    }
+};
+
+struct GspmmArgs {
+    const int32_t *rowptr, *colind, *eid;
+    const float *x, *ef, *w;
+    float *out;
+    int64_t m, nnz;
+    int k, op, ef_scalar, mean;
+};
+
+constexpr int kGspmmUnroll = 4;  // two gathers per edge: half of csr_spmm's unroll keeps the same loads in flight
+
+template <int VEC, int LPR>
+static int launch_gspmm(const GspmmArgs &a, void *ws, size_t wsb, hipStream_t s) {
+    GspmmOp<VEC, LPR, kGspmmUnroll> op{a.rowptr, a.eid, a.x, a.ef, a.w, a.out, a.k, a.op, a.ef_scalar, a.mean};
+    const int64_t tiles = ((int64_t)a.k + (int64_t)LPR * VEC - 1) / ((int64_t)LPR * VEC);
+    return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, tiles, ws, wsb, s);
+}
+
+template <int VEC>
+static int gspmm_lpr(const GspmmArgs &a, int lpr, void *ws, size_t wsb, hipStream_t s) {
+    switch (lpr) {
+        case 4: return launch_gspmm<VEC, 4>(a, ws, wsb, s);
+        case 8: return launch_gspmm<VEC, 8>(a, ws, wsb, s);
+        case 16: return launch_gspmm<VEC, 16>(a, ws, wsb, s);
+        case 32: return launch_gspmm<VEC, 32>(a, ws, wsb, s);
+        default: return launch_gspmm<VEC, 64>(a, ws, wsb, s);
+    }
+}
+
+static int gspmm_alignment(const GspmmArgs &a) {
+    uintptr_t v = reinterpret_cast<uintptr_t>(a.out);
+    if (a.x) v |= reinterpret_cast<uintptr_t>(a.x);
+    if (a.ef && !a.ef_scalar) v |= reinterpret_cast<uintptr_t>(a.ef);
+    return (v % 16 == 0) ? 16 : (v % 8 == 0) ? 8 : 4;
+}
+
+}  // namespace cogdl
+
+using namespace cogdl;
+
+extern "C" size_t cogdl_hip_gspmm_workspace_bytes(int64_t nnz, int64_t k) {
+    if (nnz <= 0 || k <= 0) return 0;
+    const RowGeometry g = spmm_geometry(k, k, 4, 16);
+    return rowreduce_workspace_bytes(nnz, g.tiles * g.vec * g.lpr);
+}
+
+extern "C" int cogdl_hip_gspmm(const int32_t *rowptr, const int32_t *colind, const int32_t *eid, const float *x,
+                               const float *efeat, int efeat_is_scalar, const float *weight, int op, int mean,
+                               float *out, int64_t m, int64_t k, int64_t nnz, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+    if (m < 0 || k < 0 || nnz < 0) return COGDL_HIP_EINVAL;
+    if (m == 0 || k == 0) return COGDL_HIP_OK;
+    if (!rowptr || !out || (!x && !efeat) || (nnz > 0 && !colind)) return COGDL_HIP_EINVAL;
+    if (op < COGDL_HIP_GSPMM_ADD || op > COGDL_HIP_GSPMM_MUL) return COGDL_HIP_EINVAL;
+    if (!x && efeat_is_scalar) return COGDL_HIP_EINVAL;  // scatter_add of a scalar per edge: pass it as [E, 1], k = 1
+    if (k > 0x7fffffff || nnz > 0x7fffffff) return COGDL_HIP_ERANGE;
+    GspmmArgs a{rowptr, colind, eid, x, efeat, weight, out, m, nnz, (int)k, op, efeat_is_scalar ? 1 : 0, mean ? 1 : 0};
+    if (!aligned_to(out, 4) || (x && !aligned_to(x, 4)) || (efeat && !aligned_to(efeat, 4))) return COGDL_HIP_EALIGN;
+    const RowGeometry g = spmm_geometry(k, k, 4, gspmm_alignment(a));
+    // The workspace was sized for the 16-byte-aligned geometry; a narrower one needs at most as many floats.
+    hipStream_t s = (hipStream_t)stream;
+    switch (g.vec) {
+        case 4: return gspmm_lpr<4>(a, g.lpr, workspace, workspace_bytes, s);
+        case 2: return gspmm_lpr<2>(a, g.lpr, workspace, workspace_bytes, s);
+        default: return gspmm_lpr<1>(a, g.lpr, workspace, workspace_bytes, s);
+    }
+}

@@ -16,7 +16,7 @@ import importlib.abc
 import importlib.util
 import sys
 
-REPLACED = ("spmm", "edge_softmax", "mhspmm", "scatter_max", "fused_gat", "sample")
+REPLACED = ("spmm", "edge_softmax", "mhspmm", "scatter_max", "fused_gat", "sample", "ops")
 _PREFIX = "cogdl.operators."
 
 
@@ -52,6 +52,12 @@ def install(linear=False):
             pkg = sys.modules.get("cogdl.operators")
             if pkg is not None:
                 setattr(pkg, op, mod)
+                if op == "ops":  # cogdl/operators/__init__.py:1-16 re-exports the s_* names from .ops
+                    saved = pkg.__dict__.setdefault("_cogdl_amd_orig_ops", {})
+                    for attr in dir(mod):
+                        if attr.startswith("s_") and hasattr(pkg, attr):
+                            saved.setdefault(attr, getattr(pkg, attr))
+                            setattr(pkg, attr, getattr(mod, attr))
     _rebind_graph_build()
     if linear:
         from . import linear as _linear
@@ -91,6 +97,10 @@ def uninstall():
         if mod is not None and hasattr(mod, "_cogdl_amd_orig_coo2csr_index"):
             mod.coo2csr_index = mod._cogdl_amd_orig_coo2csr_index
             del mod._cogdl_amd_orig_coo2csr_index
+    pkg = sys.modules.get("cogdl.operators")
+    if pkg is not None:
+        for attr, orig in pkg.__dict__.pop("_cogdl_amd_orig_ops", {}).items():
+            setattr(pkg, attr, orig)
     global _finder
     if _finder is not None:
         sys.meta_path.remove(_finder)

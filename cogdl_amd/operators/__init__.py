@@ -7,8 +7,8 @@
     fused_gat.py     fused_gat_func                         (cogdl/operators/fused_gat.py)
     sample.py        sample_adj_c, subgraph_c, coo2csr_cpu, coo2csr_cpu_index  (cogdl/operators/sample.py)
 
-The pure-PyTorch `s_*` message ops of cogdl/operators/ops.py are not part of the replaced
-path and stay CogDL's own (cogdl_amd.install() leaves cogdl.operators.ops untouched).
+    ops.py           scatter_add, op_aggr, s_*_e_sum / s_*_e_mean (fused HIP), s_*_e, s_*_t   (cogdl/operators/ops.py)
+
 Submodules are imported lazily: GPU modules load libcogdl_hip.so at import and raise if it
 is missing; `sample` only needs libcogdl_host.so and is safe in forked CPU workers.
 """

@@ -1,0 +1,304 @@
+"""Drop-in for cogdl/operators/ops.py: `scatter_add`, `op_aggr` and the `s_*` message operators, same names, arguments
+and results (reference lines cited per function).
+
+The reference composes everything from torch ops over the COO edge list: the aggregating operators materialise the
+[E, F] message tensor and `scatter_add_` it (ops.py:4-11, 43-52; atomics on a GPU, so the fp32 sums depend on the run).
+Here fp32 GPU inputs of the aggregating operators (`scatter_add`, `op_aggr`, `s_{add,sub,mul}_e_{sum,mean}`) go to one
+fused HIP kernel (cogdl_hip_gspmm, csrc/gspmm.hip) over the destination-sorted view of the edges: no message tensor,
+no atomics, per output element the edges are added in the caller's edge order.  The destination sort is a stable GPU
+sort done once per edge list (cogdl_hip_coo2csr_index) and memoised on the identity of the index tensors; the caller's
+tensors and the Graph are never reordered.  Everything else -- CPU tensors, other dtypes, and the purely elementwise
+`s_*_e` / `s_*_t` operators (a gather and one arithmetic op: torch already runs those at memory speed) -- executes the
+reference's own torch expressions.
+"""
+import collections
+
+import torch
+
+from .. import _lib
+
+_lib.hip()
+
+_OPS = {"add": 0, "sub": 1, "mul": 2}  # COGDL_HIP_GSPMM_*
+
+
+# --------------------------------------------------------------------------------------------- destination plans
+class EdgePlan:
+    """Destination-sorted view of an edge list: rowptr int32 [n+1], perm int32 [E] (sorted position -> edge id; stable),
+    sorted (perm is the identity)."""
+    __slots__ = ("rowptr", "perm", "sorted", "n", "keep", "_col_key", "_colind")
+
+    def __init__(self, dst, n):
+        from ..graph_build import coo2csr_index
+
+        row_ptr, perm = coo2csr_index(dst, dst, n)  # raises on ids outside [0, n) (scatter_add_ would, too)
+        self.rowptr = row_ptr.int()
+        self.perm = perm.int()
+        e = dst.numel()
+        self.sorted = bool(e == 0 or (perm == torch.arange(e, device=dst.device)).all().item())
+        self.n = n
+        self.keep = dst  # pins the key tensor: its data_ptr cannot be recycled while the plan lives
+        self._col_key, self._colind = None, None
+
+    def colind(self, col):
+        """The source ids in sorted order as int32 (memoised on the identity of `col`)."""
+        key = (col.data_ptr(), col._version, col.numel())
+        if key != self._col_key:
+            self._colind = (col if self.sorted else col.index_select(0, self.perm.long())).int()
+            self._col_key = key
+        return self._colind
+
+
+_PLANS = collections.OrderedDict()
+_MAX_PLANS = 16
+
+
+def edge_plan(dst, n):
+    """Memoised on the identity + version of `dst` (Graph.edge_index hands out the same tensors call after call,
+    cogdl/data/data.py:305-309)."""
+    key = (dst.data_ptr(), dst._version, dst.numel(), dst.device.index, int(n))
+    plan = _PLANS.get(key)
+    if plan is None:
+        plan = EdgePlan(dst, int(n))
+        _PLANS[key] = plan
+        while len(_PLANS) > _MAX_PLANS:
+            _PLANS.popitem(last=False)
+    else:
+        _PLANS.move_to_end(key)
+    return plan
+
+
+def clear_plans():
+    _PLANS.clear()
+
+
+def _gspmm(plan, colind, x, efeat, ef_scalar, weight, op, mean, k):
+    """out[v] = scale_v * sum_{j in row v} weight[id] * (x[colind[j]] OP efeat[id]); colind int32 in sorted order."""
+    dev = plan.rowptr.device
+    nnz = plan.perm.numel()
+    out = torch.empty((plan.n, k), dtype=torch.float32, device=dev)
+    ws, ws_bytes = _lib.workspace("cogdl_hip_gspmm_workspace_bytes", dev, nnz, k)
+    eid = None if plan.sorted else plan.perm
+    with torch.cuda.device(dev):
+        rc = _lib.hip().cogdl_hip_gspmm(_lib.ptr(plan.rowptr), _lib.ptr(colind), _lib.ptr(eid), _lib.ptr(x),
+                                        _lib.ptr(efeat), int(ef_scalar), _lib.ptr(weight), op, int(mean),
+                                        _lib.ptr(out), plan.n, k, nnz, _lib.ptr(ws), ws_bytes,
+                                        _lib.stream_of(out))
+    _lib.check(rc, "gspmm")
+    return out
+
+
+def _hip_ok(*tensors):
+    return all(t is None or (t.is_cuda and t.dtype == torch.float32) for t in tensors)
+
+
+# --------------------------------------------------------------------------------------------- scatter_add / op_aggr
+class _ScatterRows(torch.autograd.Function):
+    """out[v] = scale_v * sum_{e: dst[e] == v} data[e]  (op_aggr, ops.py:28-40)."""
+
+    @staticmethod
+    def forward(ctx, data, dst, num_nodes, mean):
+        plan = edge_plan(dst, num_nodes)
+        data = data.contiguous()
+        ctx.plan, ctx.mean = plan, mean
+        ctx.save_for_backward(dst)
+        # message = the edge row alone; the engine still walks a column array: the permutation serves as one
+        return _gspmm(plan, plan.perm, None, data, False, None, 0, mean, data.shape[1])
+
+    @staticmethod
+    def backward(ctx, grad):
+        (dst,) = ctx.saved_tensors
+        if ctx.mean:
+            grad = grad * _deg_inv(ctx.plan).view(-1, 1)
+        return grad.index_select(0, dst), None, None, None
+
+
+def _deg_inv(plan):
+    deg = (plan.rowptr[1:] - plan.rowptr[:-1]).float()
+    inv = deg.pow(-1)
+    inv[torch.isinf(inv)] = 0
+    return inv
+
+
+def _scatter_add_torch(data, dst, num_nodes, dim=0):
+    num_edges, num_feats = data.shape
+    out = torch.zeros((num_nodes, num_feats), dtype=data.dtype, device=data.device)
+    if len(dst.shape) == 1:
+        dst = dst.view(-1, 1)
+    return out.scatter_add_(dim=dim, index=dst.expand(num_edges, num_feats), src=data)
+
+
+def _rows_index(dst, data):
+    """dst as the reference accepts it (1-D, or [E, 1] to be expanded) -> 1-D int64, or None if it is a general index."""
+    if dst.dim() == 2 and dst.shape[1] == 1:
+        dst = dst.reshape(-1)
+    if dst.dim() != 1 or dst.dtype != torch.int64 or dst.numel() != data.shape[0] or not dst.is_cuda:
+        return None
+    return dst
+
+
+def scatter_add(data, dst, num_nodes, dim=0):
+    """ops.py:4-11: zeros([num_nodes, F]).scatter_add_(dim, dst expanded over the columns, data)."""
+    idx = _rows_index(dst, data) if (dim == 0 and data.dim() == 2 and _hip_ok(data)) else None
+    if idx is None or data.shape[0] == 0 or data.shape[1] == 0:
+        return _scatter_add_torch(data, dst, num_nodes, dim)
+    return _ScatterRows.apply(data, idx, int(num_nodes), False)
+
+
+def op_src_edge(op, src, e_feat):
+    """ops.py:17-25: the message of one edge, src OP e_feat with OP in add | sub | mul."""
+    if op not in _BINARY:
+        raise NotImplementedError
+    return _BINARY[op](src, e_feat)
+
+
+def op_aggr(op, msg, dst, num_nodes):
+    """ops.py:28-40: "sum" | "mean" of the messages per destination (an empty destination gives 0)."""
+    if op not in ("sum", "mean"):
+        raise NotImplementedError
+    idx = _rows_index(dst, msg) if (msg.dim() == 2 and _hip_ok(msg)) else None
+    if idx is not None and msg.shape[0] > 0 and msg.shape[1] > 0:
+        return _ScatterRows.apply(msg, idx, int(num_nodes), op == "mean")
+    out = _scatter_add_torch(msg, dst, num_nodes)
+    if op == "mean":  # counts are exact in fp32 either way: same deg^-1 as the reference's scatter_add_ of ones
+        inv = torch.bincount(dst.reshape(-1), minlength=num_nodes).float().pow(-1)
+        out = out * torch.where(torch.isinf(inv), torch.zeros_like(inv), inv).view(-1, 1)
+    return out
+
+
+# --------------------------------------------------------------------------------------------- src OP edge -> aggregate
+class _SrcOpEdgeAggr(torch.autograd.Function):
+    """out[v] = scale_v * sum_{e: row[e] == v} (n_feat[col[e]] OP e_feat[e]) * data[e]  (ops.py:43-52), fused."""
+
+    @staticmethod
+    def forward(ctx, n_feat, e_feat, data, row, col, op1, mean):
+        nnode = n_feat.shape[0]
+        plan = edge_plan(row, nnode)
+        colind = plan.colind(col)
+        n_feat = n_feat.contiguous()
+        e_feat = e_feat.contiguous()
+        ef_scalar = e_feat.shape[1] == 1 and n_feat.shape[1] != 1
+        weight = None if data is None else data.contiguous()
+        ctx.plan, ctx.op1, ctx.mean, ctx.has_w = plan, op1, mean, data is not None
+        ctx.save_for_backward(n_feat, e_feat, weight, row, col)
+        return _gspmm(plan, colind, n_feat, e_feat, ef_scalar, weight, _OPS[op1], mean, n_feat.shape[1])
+
+    @staticmethod
+    def backward(ctx, grad):
+        n_feat, e_feat, weight, row, col = ctx.saved_tensors
+        if ctx.mean:
+            grad = grad * _deg_inv(ctx.plan).view(-1, 1)
+        g_msg = grad.index_select(0, row)  # d out / d (message * weight)
+        g_w = None
+        if ctx.has_w:
+            if ctx.needs_input_grad[2]:
+                g_w = (op_src_edge(ctx.op1, n_feat.index_select(0, col), e_feat) * g_msg).sum(dim=1)
+            g_msg = g_msg * weight.view(-1, 1)
+        g_x = g_e = None
+        if ctx.needs_input_grad[0]:
+            d_src = g_msg * e_feat if ctx.op1 == "mul" else g_msg
+            g_x = scatter_add(d_src.contiguous(), col, n_feat.shape[0])
+        if ctx.needs_input_grad[1]:
+            if ctx.op1 == "mul":
+                g_e = g_msg * n_feat.index_select(0, col)
+            elif ctx.op1 == "sub":
+                g_e = -g_msg
+            else:
+                g_e = g_msg
+            if e_feat.shape[1] == 1 and g_e.shape[1] != 1:
+                g_e = g_e.sum(dim=1, keepdim=True)
+        return g_x, g_e, g_w, None, None, None, None
+
+
+def src_op_e_aggr_coo(op1, op2, n_feat, e_feat, row, col, data=None):
+    """ops.py:43-52: out = aggr_{op2 in sum|mean} over edges (row <- col) of (n_feat[col] op1 e_feat) * data."""
+    nnode = n_feat.shape[0]
+    if len(e_feat.shape) == 1:
+        e_feat = e_feat.view(-1, 1)
+    fused = (op1 in _OPS and op2 in ("sum", "mean") and n_feat.dim() == 2 and e_feat.dim() == 2
+             and _hip_ok(n_feat, e_feat, data) and row.is_cuda and row.dtype == torch.int64 and row.dim() == 1
+             and col.dtype == torch.int64 and e_feat.shape[0] == row.numel() and row.numel() > 0
+             and n_feat.shape[1] > 0 and e_feat.shape[1] in (1, n_feat.shape[1])
+             and (data is None or (data.dim() == 1 and data.numel() == row.numel())))
+    if fused:
+        return _SrcOpEdgeAggr.apply(n_feat, e_feat, data, row, col, op1, op2 == "mean")
+    src = n_feat[col]
+    msg = op_src_edge(op1, src, e_feat)
+    if data is not None:
+        msg = msg * data.view(-1, 1)
+    return op_aggr(op2, msg, row, nnode)
+
+
+def _named(fn, name, doc):
+    fn.__name__ = fn.__qualname__ = name
+    fn.__doc__ = doc
+    return fn
+
+
+def _make_aggr(op1, op2, lines):
+    def f(g, n_feat, e_feat, weight=False):
+        row, col = g.edge_index
+        return src_op_e_aggr_coo(op1, op2, n_feat, e_feat, row, col, data=g.edge_weight if weight else None)
+
+    return _named(f, "s_%s_e_%s" % (op1, op2),
+                  "out[v] = %s over the edges (v <- u) of (n_feat[u] %s e_feat[e]) [* g.edge_weight[e]]  (ops.py:%s)."
+                  % (op2, op1, lines))
+
+
+s_add_e_sum = _make_aggr("add", "sum", "55-61")
+s_mul_e_sum = _make_aggr("mul", "sum", "64-70")
+s_sub_e_sum = _make_aggr("sub", "sum", "73-79")
+s_add_e_mean = _make_aggr("add", "mean", "82-88")
+s_mul_e_mean = _make_aggr("mul", "mean", "91-97")
+s_sub_e_mean = _make_aggr("sub", "mean", "100-106")
+
+
+# --------------------------------------------------------------------------------------------- elementwise operators
+# One gather and one arithmetic op per element: plain torch, exactly the reference's expressions (bit-identical).
+_BINARY = {"add": torch.add, "sub": torch.sub, "mul": torch.mul}
+
+
+def _make_src_edge(op, lines):
+    def f(g, n_feat, e_feat):
+        return _BINARY[op](n_feat[g.edge_index[1]], e_feat)
+
+    return _named(f, "s_%s_e" % op, "[E, F] message n_feat[col] %s e_feat  (ops.py:%s)." % (op, lines))
+
+
+s_add_e = _make_src_edge("add", "112-114")
+s_sub_e = _make_src_edge("sub", "117-119")
+s_mul_e = _make_src_edge("mul", "122-124")
+
+
+def src_op_target_coo(op, g, src, tgt):
+    """ops.py:130-147: source row OP target row per edge; tgt None: both ends are gathered from `src`."""
+    if tgt is None:
+        row, col = g.edge_index
+        src, tgt = src[col], src[row]
+    if op in _BINARY:
+        return _BINARY[op](src, tgt)
+    if op == "dot":
+        return (src * tgt).sum(1, keepdim=True)
+    if op == "div":
+        out = src / tgt
+        out[torch.isinf(out)] = 0  # x / 0 -> 0 like the reference (0 / 0 stays nan, ops.py:143-145)
+        return out
+    raise NotImplementedError
+
+
+def _make_src_target(op, lines):
+    def f(g, src, dst=None):
+        return src_op_target_coo(op, g, src, dst)
+
+    return _named(f, "s_%s_t" % op, "per edge: src[col] %s (dst if given else src[row])  (ops.py:%s)." % (op, lines))
+
+
+s_add_t = _make_src_target("add", "150-151")
+s_mul_t = _make_src_target("mul", "154-155")
+s_sub_t = _make_src_target("sub", "158-159")
+s_dot_t = _make_src_target("dot", "162-163")
+s_div_t = _make_src_target("div", "166-167")
+
+
+def message_passing(send_func, msg_func, rec_fun):
+    """ops.py:170-171: a stub in the reference as well."""

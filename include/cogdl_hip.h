@@ -175,6 +175,26 @@ COGDL_API int cogdl_hip_scatter_max_bwd(const float *grad, const int32_t *max_id
                               int64_t k, int64_t n_src, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * gspmm ("source OP edge feature, then aggregate"): the s_{add,sub,mul}_e_{sum,mean} operators and scatter_add of
+ * cogdl/operators/ops.py:4-11 (scatter_add), :19-26 (op_src_edge), :28-40 (op_aggr), :43-52 (src_op_e_aggr_coo),
+ * :55-103, which the reference composes from torch ops over the COO edge list (an [E, F] message tensor, then
+ * scatter_add_).  Over the destination-sorted (CSR) view of the same edges:
+ *   out[v,:] = scale_v * sum_{j in row v} weight[id_j] * ( x[colind[j],:] OP efeat[id_j,:] ),  id_j = eid ? eid[j] : j
+ *   eid     CSR position -> edge id of efeat/weight (perm of cogdl_hip_coo2csr_index, as int32), NULL = identity;
+ *   x       [n_src, k] or NULL (message = the edge feature alone: scatter_add(efeat, dst));
+ *   efeat   [E, k], or [E] with efeat_is_scalar != 0 (ops.py:45-46 views a 1-D e_feat as [E, 1]), or NULL (message =
+ *           the source row alone);   weight [E] or NULL (ops.py:49-50);   op: COGDL_HIP_GSPMM_*;
+ *   mean    != 0: scale_v = 1 / deg(v) (0 for an empty row), else 1.
+ * fp32; per output element the edges are added in row order with every step rounded like the torch expression, so
+ * rows up to the long-row threshold equal a sequential CPU scatter_add_ bit for bit.  No atomics (deterministic).
+ * ------------------------------------------------------------------------------------- */
+enum { COGDL_HIP_GSPMM_ADD = 0, COGDL_HIP_GSPMM_SUB = 1, COGDL_HIP_GSPMM_MUL = 2 };
+COGDL_API size_t cogdl_hip_gspmm_workspace_bytes(int64_t nnz, int64_t k);
+COGDL_API int cogdl_hip_gspmm(const int32_t *rowptr, const int32_t *colind, const int32_t *eid, const float *x,
+                    const float *efeat, int efeat_is_scalar, const float *weight, int op, int mean, float *out,
+                    int64_t m, int64_t k, int64_t nnz, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Fused GAT attention + aggregation (no [E,H] tensor is materialised in forward):
  *   s[e,h] = LeakyReLU(attn_row[row(e),h] + attn_col[colind[e],h]);  a = softmax_row(s)
  *   out[v,h,:] = sum_e a[e,h] * feat[colind[e],h,:]

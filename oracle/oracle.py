@@ -65,6 +65,7 @@ class _Sigs:
     oracle_mhtranspose = ([_vp] * 3 + [_i64, _i64], None)
     oracle_scatter_max_fwd = ([_vp] * 5 + [_i64, _i64, _i32], None)
     oracle_scatter_max_bwd = ([_vp] * 3 + [_i64] * 3, None)
+    oracle_src_op_e_aggr = ([_vp] * 4 + [_i32, _vp, _i32, _i32, _vp, _i64, _i64, _i64], None)
     oracle_coo2csr = ([_vp] * 3 + [_i64, _i64] + [_vp] * 3, None)
     oracle_coo2csr_index = ([_vp, _i64, _i64, _vp, _vp], None)
     oracle_sample_adj = ([_vp, _vp, _i64, _vp, _i64, _i64, _i32] + [_vp] * 4 + [_i64, _i64, _vp], _i32)
@@ -194,6 +195,24 @@ def scatter_max_bwd(grad, max_id, n_src):
     m, k = grad.shape
     out = np.empty((n_src, k), np.float32)
     lib().oracle_scatter_max_bwd(_p(grad), _p(max_id), _p(out), m, k, n_src)
+    return out
+
+
+# ---------------------------------------------------------------------------- message ops
+GSPMM_OPS = {"add": 0, "sub": 1, "mul": 2}
+
+
+def src_op_e_aggr(op1, op2, x, ef, row, col, n, w=None):
+    """ops.py:43-52 over the COO list in order; x None: scatter_add(ef, row, n); ef 1-D: one scalar per edge."""
+    row, col = _np(row, np.int64), _np(col, np.int64)
+    ef = _np(ef, np.float32)
+    x = None if x is None else _np(x, np.float32)
+    w = None if w is None else _np(w, np.float32)
+    ef_scalar = ef.ndim == 1 or (x is not None and ef.shape[1] == 1 and x.shape[1] != 1)
+    k = x.shape[1] if x is not None else ef.shape[1]
+    out = np.empty((n, k), np.float32)
+    lib().oracle_src_op_e_aggr(_p(row), _p(col), _p(x), _p(ef), int(ef_scalar), _p(w), GSPMM_OPS[op1],
+                               int(op2 == "mean"), _p(out), n, k, row.shape[0])
     return out
 
 

@@ -15,6 +15,10 @@ the repo -- only the numeric inputs/outputs of its public functions:
   gcn_layer.npz       Graph.sym_norm + GCNLayer fwd/bwd  layers/gcn_layer.py:51-64
   gat_layer.npz       GATLayer fwd/bwd (unfused path)    layers/gat_layer.py:59-86
   sage_layer.npz      Graph.sample_adj(-1) + SAGELayer(mean) fwd   layers/sage_layer.py:8-12,69-87
+  message_ops.npz     scatter_add, s_*_e_sum / s_*_e_mean (+ autograd grads) on an UNSORTED COO graph   operators/ops.py:4-103
+
+`python tests/golden/make_golden.py NAME...` rewrites only the named fixtures (every fixture draws from the same seeded
+generator in file order, so the others stay what they were).
 """
 import os
 import shutil
@@ -51,7 +55,11 @@ def main():
     torch.manual_seed(1234)
     torch.set_num_threads(4)
 
+    only = set(sys.argv[1:])
+
     def save(name, **arrays):
+        if only and name not in only:
+            return
         out = {}
         for k, v in arrays.items():
             out[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
@@ -167,6 +175,37 @@ def main():
     save("sage_layer", g_row_indptr=gr.row_indptr, g_col_indices=gr.col_indices, batch=batch, nodes=nodes,
          block_row_indptr=block.row_indptr, block_col_indices=block.col_indices, x_src=x_src,
          fc_W=sage.fc.weight, fc_b=sage.fc.bias, out=out)
+
+    # ---- message operators (pure torch in the reference): unsorted COO, empty destinations, repeated edges ------
+    from cogdl.operators import ops as ref_ops
+
+    gen2 = torch.Generator().manual_seed(4321)
+    n, e, f = 300, 2000, 12
+    row = torch.randint(0, n - 20, (e,), generator=gen2)  # the last 20 nodes receive nothing
+    col = torch.randint(0, n, (e,), generator=gen2)
+    x = torch.randn(n, f, generator=gen2)
+    ef = torch.randn(e, f, generator=gen2)
+    es = torch.randn(e, generator=gen2)
+    w = torch.rand(e, generator=gen2) + 0.5
+    G = torch.randn(n, f, generator=gen2)
+    gr = Graph(edge_index=(row.clone(), col.clone()), edge_weight=w.clone(), num_nodes=n)
+    assert gr._adj.row_ptr is None  # still COO: the operators below never build the CSR
+    res = {}
+    for op1 in ("add", "sub", "mul"):
+        for op2 in ("sum", "mean"):
+            fn = getattr(ref_ops, "s_%s_e_%s" % (op1, op2))
+            res["%s_%s" % (op1, op2)] = fn(gr, x, ef)
+            res["%s_%s_w" % (op1, op2)] = fn(gr, x, ef, weight=True)
+    res["mul_sum_scalar"] = ref_ops.s_mul_e_sum(gr, x, es)  # 1-D e_feat is viewed [E, 1] (ops.py:45-46)
+    res["scatter_add"] = ref_ops.scatter_add(ef, row, n)
+    xg, eg = x.clone().requires_grad_(), ef.clone().requires_grad_()
+    (ref_ops.s_mul_e_mean(gr, xg, eg, weight=True) * G).sum().backward()
+    res["grad_x_mul_mean_w"], res["grad_e_mul_mean_w"] = xg.grad, eg.grad
+    xg, sg = x.clone().requires_grad_(), es.clone().requires_grad_()
+    (ref_ops.s_sub_e_sum(gr, xg, sg) * G).sum().backward()
+    res["grad_x_sub_sum_scalar"], res["grad_e_sub_sum_scalar"] = xg.grad, sg.grad
+    assert gr._adj.row_ptr is None
+    save("message_ops", row=row, col=col, n=n, x=x, ef=ef, es=es, w=w, G=G, **res)
 
 
 if __name__ == "__main__":

@@ -73,6 +73,21 @@ nodes_all, sub_all = g.sample_adj(batch, -1)
 for i, b in enumerate(batch.tolist()):
     mine = sorted(nodes_all[sub_all.col_indices[sub_all.row_indptr[i]:sub_all.row_indptr[i + 1]]].tolist())
     assert mine == sorted(g.col_indices[g.row_indptr[b]:g.row_indptr[b + 1]].tolist())
+
+# 6. the message operators CogDL re-exports (cogdl/operators/__init__.py) are ours and pass the reference's own
+#    exact-equality checks (tests/test_ops.py:59-110) on a reference Graph
+import cogdl.operators as cops
+assert cops.ops.__name__ == "cogdl_amd.operators.ops" and cops.s_add_e_sum.__module__ == "cogdl_amd.operators.ops"
+tg = Graph(x=torch.randn(100, 10), edge_index=torch.randint(0, 100, (2, 200)))
+ea = torch.randn(tg.num_edges, 10)
+trow, tcol = tg.edge_index
+msg = tg.x[tcol] * ea
+want = torch.zeros(100, 10).scatter_add_(0, trow.view(-1, 1).expand(200, 10), msg)
+assert (cops.s_mul_e_sum(tg, tg.x, ea) == want).all()
+tdeg = torch.zeros(100).scatter_add_(0, trow, torch.ones(200))
+tinv = tdeg.pow(-1); tinv[torch.isinf(tinv)] = 0
+assert (cops.s_mul_e_mean(tg, tg.x, ea) == want * tinv.view(-1, 1)).all()
+assert (cops.s_sub_t(tg, tg.x) == tg.x[tcol] - tg.x[trow]).all()
 shutil.rmtree(scratch, ignore_errors=True)
 print("INSTALL-OK", served)
 '''

@@ -133,3 +133,19 @@ def test_scatter_max_quirk_region(oracle):
     assert np.array_equal(ref_like[pos], true_max[pos])
     deg = np.diff(g.rowptr.numpy())
     assert np.all(true_max[deg == 0] == 0) and np.all(idx[deg == 0] == -1)
+
+
+def test_message_ops_oracle_bit_exact_vs_reference(golden, oracle):
+    # cogdl/operators/ops.py:4-103 run by the reference itself on an unsorted COO graph (tests/golden/make_golden.py)
+    z = golden("message_ops")
+    n = int(z["n"])
+    for op1 in ("add", "sub", "mul"):
+        for op2 in ("sum", "mean"):
+            for wkey, w in (("", None), ("_w", z["w"])):
+                out = oracle.src_op_e_aggr(op1, op2, z["x"], z["ef"], z["row"], z["col"], n, w=w)
+                assert out.tobytes() == z["%s_%s%s" % (op1, op2, wkey)].tobytes(), (op1, op2, wkey)
+    out = oracle.src_op_e_aggr("mul", "sum", z["x"], z["es"], z["row"], z["col"], n)
+    assert out.tobytes() == z["mul_sum_scalar"].tobytes()
+    out = oracle.src_op_e_aggr("add", "sum", None, z["ef"], z["row"], z["col"], n)
+    assert out.tobytes() == z["scatter_add"].tobytes()
+    assert not z["scatter_add"][n - 20:].any()  # destinations nobody points at stay zero

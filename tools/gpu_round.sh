@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc ops
+# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc ops epoch
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -30,6 +30,12 @@ fi
 if has ops; then
   timeout 1500 python tools/ops_bench.py --json gpurun_out/ops_bench.json > gpurun_out/ops_bench.txt 2>&1; echo "ops rc=$?" >> gpurun_out/ops_bench.txt
   tail -60 gpurun_out/ops_bench.txt
+fi
+if has epoch; then
+  rm -rf gpurun_out/prof_epoch
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_epoch" -o ep -- python "$GRAFT_REPO_ROOT/tools/epoch_probe.py") > gpurun_out/epoch_probe.log 2>&1
+  python tools/epoch_breakdown.py "$(find gpurun_out/prof_epoch -name '*kernel_stats.csv' | head -1)" > gpurun_out/epoch_breakdown.txt 2>&1
+  tail -3 gpurun_out/epoch_probe.log; cat gpurun_out/epoch_breakdown.txt
 fi
 if has pmc; then
   for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do

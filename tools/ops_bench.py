@@ -70,6 +70,33 @@ def arxiv():
                        nnz * (4 + f * 4) + n * (4 + f * 4 + f * 4), nnz)
                 _, mid = scatter_max_fp(g.rowptr, g.colind, x)
                 report("scatter_max_bwd", cfg, timeit(lambda: scatter_max_bp(y, mid, n)), n * f * (4 + 4 + 4 + 4), nnz)
+        # message operators (cogdl/operators/ops.py): fused kernel vs the reference's torch composition on the GPU
+        from cogdl_amd.operators import ops as mops
+        import types
+        rows = torch.repeat_interleave(torch.arange(n, device=DEV), (g.rowptr[1:] - g.rowptr[:-1]).long())
+        shuffle = torch.randperm(nnz, device=DEV)  # an UNSORTED edge list, as Graph(edge_index=...) holds it
+        coo = types.SimpleNamespace(edge_index=(rows[shuffle].contiguous(), g.colind.long()[shuffle].contiguous()),
+                                    edge_weight=g.weight[shuffle].contiguous())
+        for f in (64,):
+            x, ef = torch.randn(n, f, device=DEV), torch.randn(nnz, f, device=DEV)
+            cfg = "arxiv-%s F=%d f32 COO" % (topo, f)
+            mops.s_mul_e_sum(coo, x, ef, weight=True)  # builds and caches the destination plan
+            report("s_mul_e_sum(fused)", cfg, timeit(lambda: mops.s_mul_e_sum(coo, x, ef, weight=True)),
+                   nnz * (4 + 4 + 4 + 2 * f * 4) + n * (4 + f * 4), nnz)
+
+            def torch_composition():
+                r, c = coo.edge_index
+                msg = x[c] * ef * coo.edge_weight.view(-1, 1)
+                return torch.zeros(n, f, device=DEV).scatter_add_(0, r.view(-1, 1).expand(nnz, f), msg)
+
+            report("s_mul_e_sum(torch ref)", cfg, timeit(torch_composition),
+                   nnz * (4 + 4 + 4 + 2 * f * 4) + n * (4 + f * 4), nnz)
+            report("scatter_add(fused)", cfg, timeit(lambda: mops.scatter_add(ef, coo.edge_index[0], n)),
+                   nnz * (4 + f * 4) + n * (4 + f * 4), nnz)
+            report("scatter_add(torch ref)", cfg,
+                   timeit(lambda: torch.zeros(n, f, device=DEV).scatter_add_(
+                       0, coo.edge_index[0].view(-1, 1).expand(nnz, f), ef)),
+                   nnz * (4 + f * 4) + n * (4 + f * 4), nnz)
         report("csr2csc", "arxiv-%s" % topo, timeit(lambda: csr2csc(g.rowptr, g.colind, n), reps=10),
                nnz * (4 + 4) * 2 + 8 * (n + 1), nnz)
         plan = csr2csc(g.rowptr, g.colind, n)
