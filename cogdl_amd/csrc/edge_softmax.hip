@@ -19,6 +19,11 @@
 
 namespace cogdl {
 
+// exp of a non-positive difference (value - running max): the hardware exponential (v_exp_f32 of x * log2 e, 1 ulp)
+// -- its relative error |x| * 2^-24 is below 2e-6 wherever the result is not negligible; the libm expf costs ~10x the
+// instructions and made the forward VALU-bound (2.25 exponentials per element).
+__device__ __forceinline__ float es_exp(float x) { return __expf(x); }
+
 struct MaxSum {
     float m, s;
 };
@@ -26,8 +31,8 @@ struct MaxSum {
 __device__ __forceinline__ MaxSum combine(MaxSum a, MaxSum b) {
     const float m = fmaxf(a.m, b.m);
     // exp(-inf - -inf) guards: an empty partial has s == 0 and m == -inf
-    const float sa = (a.s == 0.f) ? 0.f : a.s * expf(a.m - m);
-    const float sb = (b.s == 0.f) ? 0.f : b.s * expf(b.m - m);
+    const float sa = (a.s == 0.f) ? 0.f : a.s * es_exp(a.m - m);
+    const float sb = (b.s == 0.f) ? 0.f : b.s * es_exp(b.m - m);
     return {m, sa + sb};
 }
 
@@ -39,7 +44,7 @@ __device__ __forceinline__ MaxSum head_reduce_maxsum(MaxSum v, int h) {
 #pragma unroll
     for (int s = LPR / 2; s > 0; s >>= 1)
         if (s >= h) m = fmaxf(m, __shfl_xor(m, s, kWave));
-    float sum = (v.s == 0.f) ? 0.f : v.s * expf(v.m - m);
+    float sum = (v.s == 0.f) ? 0.f : v.s * es_exp(v.m - m);
 #pragma unroll
     for (int s = LPR / 2; s > 0; s >>= 1)
         if (s >= h) sum += __shfl_xor(sum, s, kWave);
@@ -78,8 +83,8 @@ __device__ __forceinline__ MaxSum maxsum_strided(const float *__restrict__ a, in
         const float mn = fmaxf(acc.m, bm);
         float ssum = 0.f;
 #pragma unroll
-        for (int u = 0; u < kEsUnroll; ++u) ssum += expf(v[u] - mn);  // masked slots: exp(-inf) == 0
-        acc.s = ((acc.s == 0.f) ? 0.f : acc.s * expf(acc.m - mn)) + ssum;
+        for (int u = 0; u < kEsUnroll; ++u) ssum += es_exp(v[u] - mn);  // masked slots: exp(-inf) == 0
+        acc.s = ((acc.s == 0.f) ? 0.f : acc.s * es_exp(acc.m - mn)) + ssum;
         acc.m = mn;
     }
     return acc;
@@ -109,7 +114,7 @@ __device__ __forceinline__ void write_strided(const float *__restrict__ a, const
                                               float *__restrict__ out, int64_t i0, int64_t end, int64_t stride,
                                               float mx, float inv) {
     if (i0 + stride >= end) {
-        if (i0 < end) out[i0] = BACKWARD ? a[i0] * (g[i0] - mx) : expf(a[i0] - mx) * inv;
+        if (i0 < end) out[i0] = BACKWARD ? a[i0] * (g[i0] - mx) : es_exp(a[i0] - mx) * inv;
         return;
     }
     for (; i0 < end; i0 += stride * kEsUnroll) {
@@ -124,7 +129,7 @@ __device__ __forceinline__ void write_strided(const float *__restrict__ a, const
 #pragma unroll
         for (int u = 0; u < kEsUnroll; ++u) {
             const int64_t idx = i0 + u * stride;
-            if (idx < end) out[idx] = BACKWARD ? v[u] * (w[u] - mx) : expf(v[u] - mx) * inv;
+            if (idx < end) out[idx] = BACKWARD ? v[u] * (w[u] - mx) : es_exp(v[u] - mx) * inv;
         }
     }
 }
@@ -170,8 +175,8 @@ __device__ __forceinline__ MaxSum4 maxsum_strided4(const float *__restrict__ a, 
             const float mn = fmaxf(acc.m[c], bm);
             float ssum = 0.f;
 #pragma unroll
-            for (int u = 0; u < kEsUnroll; ++u) ssum += expf(v[u][c] - mn);
-            acc.s[c] = ((acc.s[c] == 0.f) ? 0.f : acc.s[c] * expf(acc.m[c] - mn)) + ssum;
+            for (int u = 0; u < kEsUnroll; ++u) ssum += es_exp(v[u][c] - mn);
+            acc.s[c] = ((acc.s[c] == 0.f) ? 0.f : acc.s[c] * es_exp(acc.m[c] - mn)) + ssum;
             acc.m[c] = mn;
         }
     }
@@ -223,8 +228,8 @@ __device__ __forceinline__ void write_strided4(const float *__restrict__ a, cons
                 float4 o;
                 if constexpr (BACKWARD) o = make_float4(v[u][0] * (w[u][0] - mx[0]), v[u][1] * (w[u][1] - mx[1]),
                                                         v[u][2] * (w[u][2] - mx[2]), v[u][3] * (w[u][3] - mx[3]));
-                else o = make_float4(expf(v[u][0] - mx[0]) * inv[0], expf(v[u][1] - mx[1]) * inv[1],
-                                     expf(v[u][2] - mx[2]) * inv[2], expf(v[u][3] - mx[3]) * inv[3]);
+                else o = make_float4(es_exp(v[u][0] - mx[0]) * inv[0], es_exp(v[u][1] - mx[1]) * inv[1],
+                                     es_exp(v[u][2] - mx[2]) * inv[2], es_exp(v[u][3] - mx[3]) * inv[3]);
                 *reinterpret_cast<float4 *>(out + idx) = o;
             }
         }
@@ -239,6 +244,68 @@ __device__ __forceinline__ int es_cols(int h) {
     int c = 1;
     while (c < h && c < 256) c <<= 1;
     return c;
+}
+
+// 16-byte-lane variant of the piece statistics (H a power of two in [4, 64], 16-byte aligned operands): thread
+// (r, ci) reads the heads 4 ci .. 4 ci + 3 of the edges lo + r, lo + r + R, ... with R = 256 / (H / 4) -- four times the
+// bytes in flight of the 4-byte walk, which is what bounds a piece (a hub row's piece is a handful of dependent batches).
+template <bool BACKWARD>
+__device__ __forceinline__ void edge_softmax_long_stats_block4(const int32_t *__restrict__ rowptr,
+                                                               const float *__restrict__ a,
+                                                               const float *__restrict__ g, int64_t m, int h,
+                                                               const LongRows &lr) {
+    __shared__ float red_m[4 * kWave], red_s[4 * kWave];  // [wave][head]
+    __shared__ int32_t tbl[kMaxChunksPerBlock + 1];
+    const int64_t c_begin = (int64_t)blockIdx.x * lr.chunks_per_block;
+    if (c_begin >= lr.n_chunks) return;
+    const int n = (int)min((int64_t)lr.chunks_per_block, lr.n_chunks - c_begin);
+    if (!build_chunk_table(lr, rowptr, m, c_begin, n + 1, tbl)) return;
+    const int C = h / 4, R = 256 / C;  // C <= 16 lanes across the heads
+    const int r = threadIdx.x / C, ci = threadIdx.x % C;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    for (int t = 0; t < n; ++t) {
+        const int64_t c = c_begin + t;
+        for (int slot = 0; slot < 2; ++slot) {
+            int32_t row;
+            int lo, hi;
+            if (!decode_piece(lr, rowptr, tbl, c, t, slot, row, lo, hi)) continue;
+            float *rec = lr.partial + (2 * c + slot) * lr.rec_stride;
+            const int64_t i0 = ((int64_t)lo + r) * h + 4 * ci, iend = (int64_t)hi * h, istr = (int64_t)R * h;
+            MaxSum4 acc;
+            float dot[4];
+            if constexpr (!BACKWARD) acc = maxsum_strided4(a, i0, iend, istr);
+            else dot_strided4(a, g, i0, iend, istr, dot);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // lanes with equal ci: strides C .. 32 inside the wave
+                if constexpr (!BACKWARD) {
+                    const MaxSum v = head_reduce_maxsum<kWave>(MaxSum{acc.m[q], acc.s[q]}, C);
+                    acc.m[q] = v.m;
+                    acc.s[q] = v.s;
+                } else {
+                    dot[q] = head_reduce_sum<kWave>(dot[q], C);
+                }
+            }
+            if (lane < C) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    red_m[wave * h + 4 * ci + q] = BACKWARD ? dot[q] : acc.m[q];
+                    red_s[wave * h + 4 * ci + q] = BACKWARD ? 0.f : acc.s[q];
+                }
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < h) {  // the four wave partials in wave order
+                MaxSum tot{red_m[threadIdx.x], red_s[threadIdx.x]};
+                float dsum = red_m[threadIdx.x];
+                for (int q = 1; q < 4; ++q) {
+                    if constexpr (!BACKWARD) tot = combine(tot, MaxSum{red_m[q * h + threadIdx.x], red_s[q * h + threadIdx.x]});
+                    else dsum += red_m[q * h + threadIdx.x];
+                }
+                rec[2 * threadIdx.x] = BACKWARD ? dsum : tot.m;
+                rec[2 * threadIdx.x + 1] = tot.s;
+            }
+            __syncthreads();
+        }
+    }
 }
 
 template <bool BACKWARD>
@@ -313,7 +380,7 @@ __device__ __forceinline__ void edge_softmax_long_stats_block(const int32_t *__r
 
 // Second launch: every piece workgroup merges the records of ITS row in chunk order (a row of 10^5 edges has ~100
 // records of 2H floats: cheaper than a third launch) and writes the piece's outputs.
-template <bool BACKWARD>
+template <bool BACKWARD, bool VEC4>
 __global__ __launch_bounds__(256) void edge_softmax_long_apply_kernel(const int32_t *__restrict__ rowptr,
                                                                       const float *__restrict__ a,
                                                                       const float *__restrict__ g,
@@ -324,7 +391,7 @@ __global__ __launch_bounds__(256) void edge_softmax_long_apply_kernel(const int3
     if (c_begin >= lr.n_chunks) return;
     const int n = (int)min((int64_t)lr.chunks_per_block, lr.n_chunks - c_begin);
     if (!build_chunk_table(lr, rowptr, m, c_begin, n + 1, tbl)) return;
-    const int C = es_cols(h), R = 256 / C;
+    const int C = VEC4 ? h / 4 : es_cols(h), R = 256 / C;
     const int r = threadIdx.x / C, ci = threadIdx.x % C;
     const int ch = lr.thresh;
     // A hub row spans many consecutive chunks of this workgroup's run: its merged statistics are computed once (per
@@ -363,6 +430,16 @@ __global__ __launch_bounds__(256) void edge_softmax_long_apply_kernel(const int3
                 __syncthreads();
                 cached_row = row;
             }
+            if constexpr (VEC4) {  // H a power of two in [4, 64]: 16-byte lanes, heads 4 ci .. 4 ci + 3
+                float sa4[4], sb4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    sa4[q] = st_a[4 * ci + q];
+                    sb4[q] = st_b[4 * ci + q];
+                }
+                write_strided4<BACKWARD>(a, g, out, ((int64_t)lo + r) * h + 4 * ci, (int64_t)hi * h, (int64_t)R * h, sa4, sb4);
+                continue;
+            }
             for (int hd = ci; hd < h; hd += C) {
                 float sa, sb;
                 if (h <= kStatCap) {
@@ -382,9 +459,10 @@ __global__ __launch_bounds__(256) void edge_softmax_pow2_kernel(const int32_t *_
                                                                 const float *__restrict__ a,  // values | softmax
                                                                 const float *__restrict__ g,  // unused | grad
                                                                 float *__restrict__ out, int64_t m, int h,
-                                                                XcdMap n_rowblocks, LongRows lr) {
+                                                                XcdMap n_rowblocks, LongRows lr, int long_vec4) {
     if (blockIdx.x < lr.n_long_blocks) {
-        edge_softmax_long_stats_block<BACKWARD>(rowptr, a, g, m, h, lr);
+        if (long_vec4) edge_softmax_long_stats_block4<BACKWARD>(rowptr, a, g, m, h, lr);
+        else edge_softmax_long_stats_block<BACKWARD>(rowptr, a, g, m, h, lr);
         return;
     }
     constexpr int RPW = kWave / LPR;
@@ -417,9 +495,10 @@ template <int LPR, bool BACKWARD>
 __global__ __launch_bounds__(256) void edge_softmax_vec4_kernel(const int32_t *__restrict__ rowptr,
                                                                 const float *__restrict__ a,
                                                                 const float *__restrict__ g, float *__restrict__ out,
-                                                                int64_t m, int h, XcdMap n_rowblocks, LongRows lr) {
+                                                                int64_t m, int h, XcdMap n_rowblocks, LongRows lr, int long_vec4) {
     if (blockIdx.x < lr.n_long_blocks) {
-        edge_softmax_long_stats_block<BACKWARD>(rowptr, a, g, m, h, lr);
+        if (long_vec4) edge_softmax_long_stats_block4<BACKWARD>(rowptr, a, g, m, h, lr);
+        else edge_softmax_long_stats_block<BACKWARD>(rowptr, a, g, m, h, lr);
         return;
     }
     constexpr int RPW = kWave / LPR;
@@ -463,9 +542,10 @@ __global__ __launch_bounds__(256) void edge_softmax_generic_kernel(const int32_t
                                                                    const float *__restrict__ a,
                                                                    const float *__restrict__ g,
                                                                    float *__restrict__ out, int64_t m, int h,
-                                                                   XcdMap n_rowblocks, LongRows lr) {
+                                                                   XcdMap n_rowblocks, LongRows lr, int long_vec4) {
     if (blockIdx.x < lr.n_long_blocks) {
-        edge_softmax_long_stats_block<BACKWARD>(rowptr, a, g, m, h, lr);
+        if (long_vec4) edge_softmax_long_stats_block4<BACKWARD>(rowptr, a, g, m, h, lr);
+        else edge_softmax_long_stats_block<BACKWARD>(rowptr, a, g, m, h, lr);
         return;
     }
     const int64_t rb = xcd_remap(blockIdx.x - lr.n_long_blocks, n_rowblocks);
@@ -488,33 +568,37 @@ __global__ __launch_bounds__(256) void edge_softmax_generic_kernel(const int32_t
 
 template <bool BACKWARD>
 static void launch_long(const int32_t *rowptr, const float *a, const float *g, float *out, int64_t m, int h,
-                        const LongRows &lr, hipStream_t s) {
+                        const LongRows &lr, hipStream_t s, bool vec4 = false) {
     if (lr.n_long_blocks == 0) return;
-    hipLaunchKernelGGL((edge_softmax_long_apply_kernel<BACKWARD>), dim3(lr.n_long_blocks), dim3(256), 0, s, rowptr, a, g,
-                       out, m, h, lr);
+    if (vec4)
+        hipLaunchKernelGGL((edge_softmax_long_apply_kernel<BACKWARD, true>), dim3(lr.n_long_blocks), dim3(256), 0, s, rowptr,
+                           a, g, out, m, h, lr);
+    else
+        hipLaunchKernelGGL((edge_softmax_long_apply_kernel<BACKWARD, false>), dim3(lr.n_long_blocks), dim3(256), 0, s, rowptr,
+                           a, g, out, m, h, lr);
 }
 
 template <int LPR, bool BACKWARD>
 static int launch_vec4(const int32_t *rowptr, const float *a, const float *g, float *out, int64_t m, int h,
-                       const LongRows &lr, hipStream_t s) {
+                       const LongRows &lr, hipStream_t s, int lv4) {
     constexpr int RPB = (kWave / LPR) * 4;
     const int64_t nrb = (m + RPB - 1) / RPB;
     if (!grid_fits(make_xcd_map(nrb), 4096)) return COGDL_HIP_ERANGE;
     hipLaunchKernelGGL((edge_softmax_vec4_kernel<LPR, BACKWARD>), dim3(lr.n_long_blocks + xcd_grid(make_xcd_map(nrb))), dim3(256),
-                       0, s, rowptr, a, g, out, m, h, make_xcd_map(nrb), lr);
-    launch_long<BACKWARD>(rowptr, a, g, out, m, h, lr, s);
+                       0, s, rowptr, a, g, out, m, h, make_xcd_map(nrb), lr, lv4);
+    launch_long<BACKWARD>(rowptr, a, g, out, m, h, lr, s, lv4 != 0);
     return launch_status();
 }
 
 template <int LPR, bool BACKWARD>
 static int launch_pow2(const int32_t *rowptr, const float *a, const float *g, float *out, int64_t m, int h,
-                       const LongRows &lr, hipStream_t s) {
+                       const LongRows &lr, hipStream_t s, int lv4) {
     constexpr int RPB = (kWave / LPR) * 4;
     const int64_t nrb = (m + RPB - 1) / RPB;
     if (!grid_fits(make_xcd_map(nrb), 4096)) return COGDL_HIP_ERANGE;
     hipLaunchKernelGGL((edge_softmax_pow2_kernel<LPR, BACKWARD>), dim3(lr.n_long_blocks + xcd_grid(make_xcd_map(nrb))), dim3(256),
-                       0, s, rowptr, a, g, out, m, h, make_xcd_map(nrb), lr);
-    launch_long<BACKWARD>(rowptr, a, g, out, m, h, lr, s);
+                       0, s, rowptr, a, g, out, m, h, make_xcd_map(nrb), lr, lv4);
+    launch_long<BACKWARD>(rowptr, a, g, out, m, h, lr, s, lv4 != 0);
     return launch_status();
 }
 
@@ -544,7 +628,7 @@ static int edge_softmax_dispatch(const int32_t *rowptr, const float *a, const fl
         const int64_t nrb = (m + 3) / 4;
         if (!grid_fits(make_xcd_map(nrb), 4096)) return COGDL_HIP_ERANGE;
         hipLaunchKernelGGL((edge_softmax_generic_kernel<BACKWARD>), dim3(lr.n_long_blocks + xcd_grid(make_xcd_map(nrb))), dim3(256),
-                           0, s, rowptr, a, g, out, m, (int)h, make_xcd_map(nrb), lr);
+                           0, s, rowptr, a, g, out, m, (int)h, make_xcd_map(nrb), lr, 0);
         launch_long<BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s);
         return launch_status();
     }
@@ -553,26 +637,29 @@ static int edge_softmax_dispatch(const int32_t *rowptr, const float *a, const fl
     // 16-byte lanes: always for the backward (its reduction is a plain sum); for the forward only on long runs -- with
     // one vector per lane every lane holds 4 different heads, and the (max, sum) butterfly then spans 4x more lane
     // strides than the 4-byte layout (measured, arxiv-shaped graph: H = 8 forward 101 -> 117 us, backward 82 -> 66 us;
-    // reddit-shaped: forward 2.02 -> 1.89 ms).  tuning key 7: 1 = never.
+    // reddit-shaped: forward 2.02 -> 1.89 ms).
     const bool vec4_pays = BACKWARD || run >= 1024;
-    if (h >= 4 && vec4_pays && g_tuning[kTuneEsScalar] == 0 && aligned_to(a, 16) && aligned_to(out, 16) &&
-        (!BACKWARD || aligned_to(g, 16))) {
+    const bool vec4_layout = h >= 4 && aligned_to(a, 16) && aligned_to(out, 16) && (!BACKWARD || aligned_to(g, 16));
+    // tuning key 7 (experiments): bit 0 = 4-byte lanes in the row kernels, bit 1 = 4-byte lanes in the hub-row path
+    const bool vec4_ok = vec4_layout && (g_tuning[kTuneEsScalar] & 1) == 0;
+    const int lv4 = (vec4_layout && (g_tuning[kTuneEsScalar] & 2) == 0) ? 1 : 0;  // hub rows: 16-byte lanes whenever
+    if (vec4_ok && vec4_pays) {                                                   // the layout allows (bytes in flight)
         int lpr4 = 8;  // 16-byte lanes: a quarter of the lanes for the same run, at least H/4
         while (lpr4 < 64 && (lpr4 * 4 < h || lpr4 * 4 < run)) lpr4 <<= 1;
         switch (lpr4) {
-            case 8: return launch_vec4<8, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s);
-            case 16: return launch_vec4<16, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s);
-            case 32: return launch_vec4<32, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s);
-            default: return launch_vec4<64, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s);
+            case 8: return launch_vec4<8, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s, lv4);
+            case 16: return launch_vec4<16, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s, lv4);
+            case 32: return launch_vec4<32, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s, lv4);
+            default: return launch_vec4<64, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s, lv4);
         }
     }
     int lpr = 8;
     while (lpr < 64 && (lpr < h || lpr < run)) lpr <<= 1;
     switch (lpr) {
-        case 8: return launch_pow2<8, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s);
-        case 16: return launch_pow2<16, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s);
-        case 32: return launch_pow2<32, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s);
-        default: return launch_pow2<64, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s);
+        case 8: return launch_pow2<8, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s, lv4);
+        case 16: return launch_pow2<16, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s, lv4);
+        case 32: return launch_pow2<32, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s, lv4);
+        default: return launch_pow2<64, BACKWARD>(rowptr, a, g, out, m, (int)h, lr, s, lv4);
     }
 }
 

@@ -78,9 +78,10 @@ def test_edge_softmax_reference_golden(golden):
     np.testing.assert_allclose(got, z["softmax"], rtol=2e-5, atol=1e-7)
 
 
-@pytest.fixture(params=[0, 1], ids=["vec4-lanes-auto", "scalar-lanes"])
+@pytest.fixture(params=[0, 1, 3], ids=["vec4-lanes-auto", "scalar-row-lanes", "scalar-lanes-everywhere"])
 def es_lanes(request):
-    """edge_softmax picks 16-byte or 4-byte lanes per shape; tuning key 7 forces the 4-byte kernels."""
+    """edge_softmax picks 16-byte or 4-byte lanes per shape; tuning key 7: bit 0 forces the 4-byte row kernels,
+    bit 1 the 4-byte hub-row path."""
     from cogdl_amd import _lib
 
     _lib.hip().cogdl_hip_set_tuning(7, request.param)
