@@ -21,6 +21,11 @@
 
 namespace cogdl {
 
+// Per-edge exponentials (argument = score - row max <= 0): the hardware exponential, as in edge_softmax.hip -- relative
+// error |x| * 2^-24 (< 2e-6 wherever the weight is not negligible); the rare state merges keep libm's expf.
+__device__ __forceinline__ float gat_exp(float x) { return __expf(x); }
+
+
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 static bool pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -91,7 +96,7 @@ struct GatFwdOp {
             const float sc = leaky(c.ar + b.ac[u], slope);
             const float mn = fmaxf(s.mx, sc);
             const float scale = (s.lsum == 0.f) ? 0.f : expf(s.mx - mn);
-            const float p = expf(sc - mn);
+            const float p = gat_exp(sc - mn);
             s.lsum = s.lsum * scale + p;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) s.acc[i] = fmaf(p, b.v[u][i], s.acc[i] * scale);
@@ -225,7 +230,7 @@ struct GatFwdChunkOp {
         const float scale = (s.lsum == 0.f) ? 0.f : expf(s.mx - mn);
         float psum = 0.f;
         for (int r = 0; r < rounds; ++r) {
-            const float p = expf(lds[r * LPR + l] - mn);  // exp(-inf) == 0 for the masked tail
+            const float p = gat_exp(lds[r * LPR + l] - mn);  // exp(-inf) == 0 for the masked tail
             lds[r * LPR + l] = p;
             psum += p;
         }
@@ -367,7 +372,7 @@ struct GatBwdRowOp {
                                           int) const {
         if (valid) {
             const float pre = c.ar + b.ac[u];
-            const float ce = expf(leaky(pre, slope) - c.mx) * c.inv * (pre > 0.f ? 1.f : slope);
+            const float ce = gat_exp(leaky(pre, slope) - c.mx) * c.inv * (pre > 0.f ? 1.f : slope);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) s.s[i] = fmaf(ce, b.v[u][i], s.s[i]);
             s.csum += ce;
@@ -471,7 +476,7 @@ struct GatBwdColOp {
                                           int) const {
         if (valid) {
             const float pre = b.ar[u] + c.ac;
-            const float a = expf(leaky(pre, slope) - b.mx[u]) / b.ls[u];
+            const float a = gat_exp(leaky(pre, slope) - b.mx[u]) / b.ls[u];
             const float ce = a * (pre > 0.f ? 1.f : slope);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
