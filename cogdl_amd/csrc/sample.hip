@@ -1,0 +1,269 @@
+// sample.hip -- neighbour sampling of a GPU-resident CSR graph on gfx950.
+// Same contract as sampler.sample_adj (cogdl/operators/sample/sample.cpp:6-144), which the reference runs
+// single-threaded on the CPU (libc rand(), an unordered_map for the relabelling) inside DataLoader workers:
+//   seeds get the local ids 0..batch-1, every other sampled node the next id in DISCOVERY order (seed rows in order,
+//   a row's sampled edges in emission order); out_indices holds local ids, out_edges the CSR positions.
+// Pipeline (all stream-ordered, no host round trip, no atomics => deterministic for a given seed):
+//   1. counts per seed + exclusive scan                                  -> out_indptr
+//   2. one WAVE per seed picks its edges and appends (node id, position) to a flat sequence Q = [seeds | picks]
+//        all / with replacement: lanes work independently (counter-based RNG: hash(seed, row, draw))
+//        without replacement:    Floyd's algorithm, the membership test of each draw is one wave-wide ballot over
+//                                the chosen set in LDS; the chosen positions are emitted in ascending order
+//   3. discovery-order relabelling without a hash table: stable radix sort of (node id, position in Q) (rocPRIM);
+//      the head of every run of equal ids is that node's FIRST occurrence; an exclusive scan of the first-occurrence
+//      flags over Q gives the local ids; a running maximum over the sorted order hands every duplicate its head.
+// Integer work, latency bound at mini-batch sizes (~15 small launches); int64 in and out like the reference.
+#include "common.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+namespace cogdl {
+
+constexpr int kSampleMaxK = 1024;  // without replacement: chosen set of one seed lives in LDS
+
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+static unsigned sample_key_bits(int64_t num_nodes) {  // one more than the ids need: the padding key 1 << bits
+    unsigned b = 1;
+    while (b < 32 && (int64_t(1) << b) < num_nodes) ++b;
+    return b;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// draw `j` of seed row `i`: a pure function of (seed, i, j) -- independent of scheduling
+__device__ __forceinline__ uint64_t draw(uint64_t seed, uint64_t i, uint64_t j) { return mix64(mix64(seed ^ mix64(i)) + j); }
+
+__device__ __forceinline__ int64_t count_for(int64_t deg, int64_t k, int replace) {
+    if (k < 0) return deg;
+    if (replace) return deg > 0 ? k : 0;
+    return deg < k ? deg : k;
+}
+
+// flags: bit 0 = a seed outside [0, num_nodes), bit 1 = a neighbour id outside, bit 2 = output capacity exceeded
+__global__ void sample_counts_kernel(const int64_t *__restrict__ indptr, const int64_t *__restrict__ node_idx,
+                                     int64_t batch, int64_t num_nodes, int64_t k, int replace,
+                                     int32_t *__restrict__ cnt, int *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > batch) return;
+    int32_t c = 0;
+    if (i < batch) {
+        const int64_t s = node_idx[i];
+        if (s < 0 || s >= num_nodes) atomicOr(flags, 1);
+        else c = (int32_t)count_for(indptr[s + 1] - indptr[s], k, replace);
+    }
+    cnt[i] = c;  // cnt[batch] = 0: the scan then also yields the total
+}
+
+__global__ __launch_bounds__(256) void sample_pick_kernel(const int64_t *__restrict__ indptr,
+                                                          const int64_t *__restrict__ indices,
+                                                          const int64_t *__restrict__ node_idx, int64_t batch,
+                                                          int64_t num_nodes, int64_t k, int replace, uint64_t seed,
+                                                          const int64_t *__restrict__ out_indptr,
+                                                          int64_t *__restrict__ out_edges, uint32_t *__restrict__ keys,
+                                                          int64_t cap_edges, int *__restrict__ flags) {
+    __shared__ int32_t chosen_all[4][kSampleMaxK];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= batch) return;
+    const int64_t s = node_idx[i];
+    if (s < 0 || s >= num_nodes) return;  // flagged by the count kernel; its count is 0
+    if (lane == 0) keys[i] = (uint32_t)s;
+    const int64_t start = indptr[s], deg = indptr[s + 1] - start;
+    const int64_t off = out_indptr[i], cnt = out_indptr[i + 1] - off;
+    auto emit = [&](int64_t j, int64_t pos) {
+        if (off + j >= cap_edges) {
+            atomicOr(flags, 4);
+            return;
+        }
+        const int64_t nb = indices[pos];
+        if (nb < 0 || nb >= num_nodes) atomicOr(flags, 2);
+        out_edges[off + j] = pos;
+        keys[batch + off + j] = (uint32_t)nb;
+    };
+    if (k < 0 || (!replace && deg <= k)) {  // the whole row, in CSR order
+        for (int64_t j = lane; j < cnt; j += kWave) emit(j, start + j);
+    } else if (replace) {
+        for (int64_t j = lane; j < cnt; j += kWave) emit(j, start + (int64_t)(draw(seed, (uint64_t)i, (uint64_t)j) % (uint64_t)deg));
+    } else {
+        // Floyd: for jj = deg-k .. deg-1 draw t in [0, jj]; take t unless already chosen, then take jj.  Uniform over
+        // the k-subsets.  The loop is wave-uniform; the set lives in LDS, one ballot per draw tests membership.
+        volatile int32_t *chosen = chosen_all[wave];
+        const int kk = (int)k;
+        int n = 0;
+        for (int64_t jj = deg - kk; jj < deg; ++jj) {
+            const int32_t t = (int32_t)(draw(seed, (uint64_t)i, (uint64_t)jj) % (uint64_t)(jj + 1));
+            bool hit = false;
+            for (int r = lane; r < n; r += kWave) hit |= (chosen[r] == t);
+            const int32_t pick = __any(hit) ? (int32_t)jj : t;
+            if (lane == 0) chosen[n] = pick;
+            ++n;
+            __builtin_amdgcn_wave_barrier();  // LDS operations of one wave complete in order: the write is visible
+        }
+        for (int r = lane; r < kk; r += kWave) {  // ascending CSR position: rank by counting (the values are distinct)
+            const int32_t v = chosen[r];
+            int rank = 0;
+            for (int q = 0; q < kk; ++q) rank += (chosen[q] < v) ? 1 : 0;
+            emit(rank, start + v);
+        }
+    }
+}
+
+// Unused tail of the sequence (capacity > actual number of picks): a key above every node id, so it sorts last.
+__global__ void sample_pad_kernel(const int64_t *__restrict__ out_indptr, int64_t batch, int64_t cap_edges,
+                                  uint32_t *__restrict__ keys, uint32_t pad_key) {
+    const int64_t total = out_indptr[batch];
+    for (int64_t j = total + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cap_edges;
+         j += (int64_t)gridDim.x * blockDim.x)
+        keys[batch + j] = pad_key;
+}
+
+// sorted order j: first[pos[j]] = is this the first occurrence of its node in Q; head[j] = j for run heads, else 0
+__global__ void sample_mark_kernel(const uint32_t *__restrict__ skeys, const int32_t *__restrict__ spos, int64_t len,
+                                   uint32_t pad_key, int32_t *__restrict__ first, int32_t *__restrict__ head) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= len) return;
+    const uint32_t key = skeys[j];
+    const bool is_head = key != pad_key && (j == 0 || skeys[j - 1] != key);
+    first[spos[j]] = is_head ? 1 : 0;  // the sort is stable: a run's head is its smallest position in Q
+    head[j] = is_head ? (int32_t)j : 0;
+}
+
+struct MaxOp {
+    __device__ __host__ int32_t operator()(int32_t a, int32_t b) const { return a > b ? a : b; }
+};
+
+__global__ void sample_relabel_kernel(const uint32_t *__restrict__ skeys, const int32_t *__restrict__ spos,
+                                      const int32_t *__restrict__ first, const int32_t *__restrict__ rank,
+                                      const int32_t *__restrict__ head_of, int64_t len, int64_t batch,
+                                      uint32_t pad_key, const int64_t *__restrict__ out_indptr,
+                                      int64_t *__restrict__ out_indices, int64_t *__restrict__ out_nodes,
+                                      int64_t *__restrict__ out_counts, const int *__restrict__ flags) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) {
+        out_counts[0] = (int64_t)rank[len - 1] + first[len - 1];  // nodes
+        out_counts[1] = out_indptr[batch];                        // edges
+        out_counts[2] = *flags;                                   // 0, or why the result is invalid
+    }
+    if (j >= len) return;
+    const uint32_t key = skeys[j];
+    if (key == pad_key) return;
+    const int32_t hj = head_of[j];
+    const int64_t id = rank[spos[hj]];
+    const int32_t p = spos[j];
+    if (p >= batch) out_indices[p - batch] = id;
+    if (hj == (int32_t)j) out_nodes[id] = (int64_t)key;
+}
+
+struct SampleWs {
+    int32_t *cnt;                  // [batch + 1]
+    uint32_t *keys, *skeys;        // [len]
+    int32_t *spos, *first, *rank, *head, *head_of;  // [len]
+    int *flags;
+    char *temp;
+    size_t temp_bytes, total;
+};
+
+static SampleWs carve(void *base, int64_t batch, int64_t cap_edges, int64_t num_nodes) {
+    const int64_t len = batch + cap_edges;
+    SampleWs w{};
+    size_t sort_t = 0, scan_t = 0, scan64_t = 0, max_t = 0;
+    rocprim::counting_iterator<int32_t> iota(0);
+    (void)rocprim::radix_sort_pairs(nullptr, sort_t, (uint32_t *)nullptr, (uint32_t *)nullptr, iota, (int32_t *)nullptr,
+                                    (size_t)std::max<int64_t>(len, 1), 0u, sample_key_bits(num_nodes) + 1, nullptr);
+    (void)rocprim::exclusive_scan(nullptr, scan_t, (int32_t *)nullptr, (int32_t *)nullptr, int32_t(0),
+                                  (size_t)std::max<int64_t>(len, 1), rocprim::plus<int32_t>(), nullptr);
+    (void)rocprim::exclusive_scan(nullptr, scan64_t, (int32_t *)nullptr, (int64_t *)nullptr, int64_t(0),
+                                  (size_t)(batch + 1), rocprim::plus<int64_t>(), nullptr);
+    (void)rocprim::inclusive_scan(nullptr, max_t, (int32_t *)nullptr, (int32_t *)nullptr,
+                                  (size_t)std::max<int64_t>(len, 1), MaxOp(), nullptr);
+    w.temp_bytes = std::max(std::max(sort_t, scan_t), std::max(scan64_t, max_t));
+    char *p = (char *)base;
+    auto take = [&](size_t bytes) {
+        char *q = p;
+        p += align256(bytes);
+        return q;
+    };
+    w.flags = (int *)take(256);
+    w.cnt = (int32_t *)take((size_t)(batch + 1) * 4);
+    w.keys = (uint32_t *)take((size_t)len * 4);
+    w.skeys = (uint32_t *)take((size_t)len * 4);
+    w.spos = (int32_t *)take((size_t)len * 4);
+    w.first = (int32_t *)take((size_t)len * 4);
+    w.rank = (int32_t *)take((size_t)len * 4);
+    w.head = (int32_t *)take((size_t)len * 4);
+    w.head_of = (int32_t *)take((size_t)len * 4);
+    w.temp = take(w.temp_bytes);
+    w.total = (size_t)(p - (char *)base);
+    return w;
+}
+
+}  // namespace cogdl
+
+using namespace cogdl;
+
+extern "C" size_t cogdl_hip_sample_adj_workspace_bytes(int64_t batch, int64_t cap_edges, int64_t num_nodes) {
+    if (batch < 0 || cap_edges < 0 || num_nodes < 0) return 0;
+    return carve(nullptr, batch, cap_edges, num_nodes).total;
+}
+
+extern "C" int cogdl_hip_sample_adj(const int64_t *indptr, const int64_t *indices, int64_t num_nodes,
+                                    const int64_t *node_idx, int64_t batch, int64_t num_neighbors, int replace,
+                                    uint64_t seed, int64_t *out_indptr, int64_t *out_indices, int64_t *out_nodes,
+                                    int64_t *out_edges, int64_t cap_edges, int64_t *out_counts, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    if (batch < 0 || cap_edges < 0 || num_nodes < 0 || !out_indptr || !out_counts || !workspace) return COGDL_HIP_EINVAL;
+    if (batch > 0 && (!indptr || !node_idx || !out_nodes)) return COGDL_HIP_EINVAL;
+    if (cap_edges > 0 && (!indices || !out_indices || !out_edges)) return COGDL_HIP_EINVAL;
+    if (num_nodes > (int64_t(1) << 31) || batch + cap_edges > 0x7fffffff) return COGDL_HIP_ERANGE;
+    if (!replace && num_neighbors > kSampleMaxK) return COGDL_HIP_ERANGE;
+    if (!aligned_to(workspace, 256)) return COGDL_HIP_EALIGN;
+    const SampleWs w = carve(workspace, batch, cap_edges, num_nodes);
+    if (workspace_bytes < w.total) return COGDL_HIP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t len = batch + cap_edges;
+    const uint32_t pad_key = 1u << sample_key_bits(num_nodes);
+    auto fail = [](hipError_t e) {
+        g_last_hip_error = (int)e;
+        return COGDL_HIP_ELAUNCH;
+    };
+    hipError_t e = hipMemsetAsync(w.flags, 0, sizeof(int), s);
+    if (e != hipSuccess) return fail(e);
+    hipLaunchKernelGGL(sample_counts_kernel, dim3((unsigned)((batch + 256) / 256)), dim3(256), 0, s, indptr, node_idx, batch,
+                       num_nodes, num_neighbors, replace, w.cnt, w.flags);
+    size_t tb = w.temp_bytes;
+    e = rocprim::exclusive_scan(w.temp, tb, w.cnt, out_indptr, int64_t(0), (size_t)(batch + 1), rocprim::plus<int64_t>(), s);
+    if (e != hipSuccess) return fail(e);
+    if (len == 0) {
+        e = hipMemsetAsync(out_counts, 0, 3 * sizeof(int64_t), s);
+        return e == hipSuccess ? launch_status() : fail(e);
+    }
+    if (batch > 0)
+        hipLaunchKernelGGL(sample_pick_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, s, indptr, indices, node_idx,
+                           batch, num_nodes, num_neighbors, replace, seed, out_indptr, out_edges, w.keys, cap_edges, w.flags);
+    if (cap_edges > 0)
+        hipLaunchKernelGGL(sample_pad_kernel, dim3((unsigned)std::min<int64_t>((cap_edges + 255) / 256, 1024)), dim3(256), 0, s,
+                           out_indptr, batch, cap_edges, w.keys, pad_key);
+    rocprim::counting_iterator<int32_t> iota(0);
+    tb = w.temp_bytes;
+    e = rocprim::radix_sort_pairs(w.temp, tb, w.keys, w.skeys, iota, w.spos, (size_t)len, 0u,
+                                  sample_key_bits(num_nodes) + 1, s);
+    if (e != hipSuccess) return fail(e);
+    const unsigned blocks = (unsigned)((len + 255) / 256);
+    hipLaunchKernelGGL(sample_mark_kernel, dim3(blocks), dim3(256), 0, s, w.skeys, w.spos, len, pad_key, w.first, w.head);
+    tb = w.temp_bytes;
+    e = rocprim::exclusive_scan(w.temp, tb, w.first, w.rank, int32_t(0), (size_t)len, rocprim::plus<int32_t>(), s);
+    if (e != hipSuccess) return fail(e);
+    tb = w.temp_bytes;
+    e = rocprim::inclusive_scan(w.temp, tb, w.head, w.head_of, (size_t)len, MaxOp(), s);
+    if (e != hipSuccess) return fail(e);
+    hipLaunchKernelGGL(sample_relabel_kernel, dim3(blocks), dim3(256), 0, s, w.skeys, w.spos, w.first, w.rank, w.head_of, len,
+                       batch, pad_key, out_indptr, out_indices, out_nodes, out_counts, w.flags);
+    return launch_status();
+}

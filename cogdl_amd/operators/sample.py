@@ -1,5 +1,8 @@
 """Drop-in for cogdl/operators/sample.py: `sample_adj_c`, `subgraph_c`, `coo2csr_cpu`,
 `coo2csr_cpu_index` (operators/sample.py:8-12) on libcogdl_host.so -- HIP-free, fork-safe.
+`sample_adj_c` additionally accepts a graph that lives on the GPU (indptr/indices CUDA tensors): sampling and
+relabelling then run there (cogdl_hip_sample_adj, csrc/sample.hip) and the results stay on the GPU; libcogdl_hip.so
+is only loaded on that path, so CPU callers -- CogDL's forked DataLoader workers -- never touch the HIP runtime.
 
 Semantics follow cogdl/operators/sample/sample.cpp; differences:
   * non-contiguous inputs are made contiguous (the reference reads raw data_ptr and silently
@@ -46,7 +49,51 @@ def coo2csr_cpu_index(row, col, num_nodes):
     return row_ptr, perm
 
 
+def _sample_adj_gpu(indptr, indices, node_idx, num_neighbors, replace, seed):
+    """Graph on the GPU -> (row_ptr, col, nodes, edges) on the GPU.  row_ptr comes back already padded to
+    len(nodes) + 1 entries: Graph.sample_adj (cogdl/data/data.py:828-830) would otherwise build that padding on the
+    CPU and fail to concatenate it with a GPU tensor."""
+    dev = indptr.device
+    indptr, indices = indptr.to(torch.long).contiguous(), indices.to(torch.long).contiguous()
+    if not torch.is_tensor(node_idx):
+        node_idx = torch.as_tensor(node_idx, dtype=torch.long)
+    node_idx = node_idx.to(device=dev, dtype=torch.long).contiguous()
+    n, b = indptr.numel() - 1, node_idx.numel()
+    num_neighbors = int(num_neighbors)
+    if num_neighbors < 0:  # capacity = the seeds' total degree (ids clamped here: the kernel reports bad ones)
+        safe = node_idx.clamp(0, max(n - 1, 0))
+        cap_e = int((indptr[safe + 1] - indptr[safe]).sum()) if b and n else 0
+    else:
+        cap_e = b * num_neighbors
+    if seed is None:
+        seed = 0 if num_neighbors < 0 else int(torch.randint(0, 2 ** 62, (1,)).item())
+    out_indptr = torch.empty(b + 1, dtype=torch.long, device=dev)
+    out_indices = torch.empty(cap_e, dtype=torch.long, device=dev)
+    out_nodes = torch.empty(b + cap_e, dtype=torch.long, device=dev)
+    out_edges = torch.empty(cap_e, dtype=torch.long, device=dev)
+    counts = torch.empty(3, dtype=torch.long, device=dev)
+    lib = _lib.hip()
+    ws_bytes = lib.cogdl_hip_sample_adj_workspace_bytes(b, cap_e, n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.cogdl_hip_sample_adj(_lib.ptr(indptr), _lib.ptr(indices), n, _lib.ptr(node_idx), b, num_neighbors,
+                                      int(bool(replace)), seed, _lib.ptr(out_indptr), _lib.ptr(out_indices),
+                                      _lib.ptr(out_nodes), _lib.ptr(out_edges), cap_e, _lib.ptr(counts),
+                                      _lib.ptr(ws), ws_bytes, _lib.stream_of(indptr))
+    _lib.check(rc, "sample_adj")
+    nn, ne, flags = (int(v) for v in counts.tolist())  # the one synchronisation: output sizes
+    if flags & 1:
+        raise _lib.BackendError("sample_adj: seed node id out of range [0, %d)" % n)
+    if flags:
+        raise _lib.BackendError("sample_adj: %s" % ("neighbour id out of range" if flags & 2 else "capacity exceeded"))
+    if nn > b:  # pad like data.py:828-830 does: every non-seed node is a row without edges
+        out_indptr = torch.cat([out_indptr, out_indptr[-1:].expand(nn - b)])
+    return out_indptr, out_indices[:ne], out_nodes[:nn], out_edges[:ne]
+
+
 def sample_adj_c(indptr, indices, node_idx, num_neighbors, replace, seed=None):
+    if torch.is_tensor(indptr) and indptr.is_cuda:
+        return _sample_adj_gpu(indptr, indices, node_idx, num_neighbors, replace, seed)
     indptr, indices, node_idx = _i64(indptr), _i64(indices), _i64(node_idx)
     n, b = indptr.numel() - 1, node_idx.numel()
     num_neighbors = int(num_neighbors)

@@ -247,6 +247,28 @@ COGDL_API int cogdl_hip_coo2csr_index(const int64_t *row, int64_t nnz, int64_t n
                             int64_t *perm, int *bad_flag, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * sample_adj on the GPU: neighbour sampling + relabelling of a GPU-resident CSR graph, the contract of
+ * sampler.sample_adj (cogdl/operators/sample/sample.cpp:6-144; the reference runs it single-threaded on the CPU
+ * with libc rand()) and of cogdl_host_sample_adj (include/cogdl_host.h), int64 in and out, device pointers:
+ *   -> out_indptr[batch+1], out_indices[E'] (LOCAL ids), out_nodes[N'] (global id of every local id: the seeds
+ *      first, then new nodes in discovery order), out_edges[E'] (CSR positions of the picked edges);
+ *   num_neighbors < 0: all neighbours (identical to the reference); replace != 0: num_neighbors uniform draws per
+ *   seed with a neighbour; else min(deg, num_neighbors) distinct neighbours (Floyd), emitted in ascending CSR
+ *   position; num_neighbors <= 1024 without replacement (else COGDL_HIP_ERANGE).  Seeds must be distinct.
+ *   Randomness: a counter-based generator keyed by (seed, seed row, draw) -- reproducible, scheduling-independent.
+ *   cap_edges >= sum of the per-seed counts (batch * num_neighbors always suffices for num_neighbors >= 0);
+ *   out_nodes holds batch + cap_edges entries.  out_counts (DEVICE int64[3]) = {N', E', flags}; flags != 0 marks
+ *   an invalid result: bit 0 seed id out of range, bit 1 neighbour id out of range, bit 2 capacity exceeded.
+ *   Nothing synchronises; the caller reads out_counts when it needs the sizes.
+ * ------------------------------------------------------------------------------------- */
+COGDL_API size_t cogdl_hip_sample_adj_workspace_bytes(int64_t batch, int64_t cap_edges, int64_t num_nodes);
+COGDL_API int cogdl_hip_sample_adj(const int64_t *indptr, const int64_t *indices, int64_t num_nodes,
+                         const int64_t *node_idx, int64_t batch, int64_t num_neighbors, int replace,
+                         uint64_t seed, int64_t *out_indptr, int64_t *out_indices, int64_t *out_nodes,
+                         int64_t *out_edges, int64_t cap_edges, int64_t *out_counts, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * linear_wgrad: grad_w[out, in] = grad_out[k_rows, out]^T . x[k_rows, in], grad_b[out] = column sums of grad_out
  * (grad_b may be NULL) -- the weight/bias gradient of the `self.linear(x)` inside every CogDL layer
  * (cogdl/layers/gcn_layer.py:52, gat_layer.py:60, sage_layer.py:72; torch.nn.Linear's backward, which torch hands to

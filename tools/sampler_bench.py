@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Host-side neighbour sampler (BASELINE.json configs[3]: GraphSAGE on ogbn-products, fan-out [10,10]):
-cogdl_amd.operators.sample.sample_adj_c vs the reference's own sampler.so (oracle/_ref, built from
-cogdl/operators/sample/sample.cpp).  CPU only.  Usage: python tools/sampler_bench.py [nodes] [avg_degree]"""
+"""Neighbour sampler (BASELINE.json configs[3]: GraphSAGE on ogbn-products, fan-out [10,10]):
+cogdl_amd.operators.sample.sample_adj_c on the host (libcogdl_host.so) and, where a GPU is visible, on a GPU-resident
+graph (cogdl_hip_sample_adj) vs the reference's own sampler.so (oracle/_ref, built from
+cogdl/operators/sample/sample.cpp; only where /root/reference exists).  Usage: python tools/sampler_bench.py [nodes] [avg_degree]"""
 import os
 import sys
 import time
@@ -15,8 +16,16 @@ from cogdl_amd.operators.sample import sample_adj_c  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_449_029
 deg = float(sys.argv[2]) if len(sys.argv) > 2 else 50.5
 t0 = time.time()
-g = synth.scaled(n, deg, seed=0, topology="rmat", norm=None, self_loops=False)
-indptr, indices = g.rowptr.long(), g.colind.long()
+GPU = torch.cuda.is_available()
+if GPU:  # build on the GPU (seconds instead of half a minute), keep a host copy for the host operator
+    src, dst = synth.rmat_pairs(n, int(n * deg / 2), 0, device="cuda:0")
+    g = synth.finalize(src, dst, n, norm=None, self_loops=False)
+    del src, dst
+    indptr_d, indices_d = g.rowptr.long(), g.colind.long()
+    indptr, indices = indptr_d.cpu(), indices_d.cpu()
+else:
+    g = synth.scaled(n, deg, seed=0, topology="rmat", norm=None, self_loops=False)
+    indptr, indices = g.rowptr.long(), g.colind.long()
 print("products-like graph: N=%d nnz=%d (%.1f s to build)" % (n, g.nnz, time.time() - t0), flush=True)
 
 ref = None
@@ -29,19 +38,36 @@ except Exception as e:  # the reference build only exists where /root/reference 
     print("reference sampler unavailable:", e)
 
 
-def two_hop(fn, seeds, fanout):
+def two_hop(fn, seeds, fanout, on_gpu=False):
     """What cogdl/data/sampler.py:NeighborSampler does per mini-batch: one sample_adj per layer, outermost first."""
     nodes = seeds
     edges = 0
     for k in fanout:
-        rp, ci, nodes, eid = fn(indptr, indices, nodes, k, False)
+        rp, ci, nodes, eid = fn(indptr_d, indices_d, nodes, k, False) if on_gpu else fn(indptr, indices, nodes, k, False)
         edges += ci.numel()
     return nodes.numel(), edges
 
 
-for batch in (128, 1024):
-    for name, fn in (("cogdl_amd", sample_adj_c), ("reference", None if ref is None else ref.sample_adj)):
+for batch in (128, 1024, 8192):
+    for name, fn in (("cogdl_amd", sample_adj_c), ("reference", None if ref is None else ref.sample_adj),
+                     ("cogdl_amd GPU", sample_adj_c if GPU else None)):
         if fn is None:
+            continue
+        if name.endswith("GPU"):
+            gen = torch.Generator().manual_seed(1)
+            reps = 40
+            two_hop(fn, torch.randint(0, n, (batch,), generator=gen), [10, 10], True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tot_nodes = tot_edges = 0
+            for _ in range(reps):
+                a, b = two_hop(fn, torch.randint(0, n, (batch,), generator=gen), [10, 10], True)
+                tot_nodes += a
+                tot_edges += b
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            print("%-13s batch %5d fan-out [10,10]: %8.2f ms/batch  %6.2f M sampled edges/s  (%d nodes, %d edges per batch)" % (
+                name, batch, dt * 1e3, tot_edges / reps / dt / 1e6, tot_nodes // reps, tot_edges // reps), flush=True)
             continue
         gen = torch.Generator().manual_seed(1)
         reps = 40 if batch == 128 else 10
@@ -53,5 +79,5 @@ for batch in (128, 1024):
             tot_nodes += a
             tot_edges += b
         dt = (time.perf_counter() - t0) / reps
-        print("%-10s batch %5d fan-out [10,10]: %8.2f ms/batch  %6.2f M sampled edges/s  (%d nodes, %d edges per batch)" % (
+        print("%-13s batch %5d fan-out [10,10]: %8.2f ms/batch  %6.2f M sampled edges/s  (%d nodes, %d edges per batch)" % (
             name, batch, dt * 1e3, tot_edges / reps / dt / 1e6, tot_nodes // reps, tot_edges // reps), flush=True)
