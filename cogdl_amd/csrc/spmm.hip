@@ -48,6 +48,7 @@ struct SpmmOp {
     int k;       // feature width (heads * fdim for WMODE 2)
     int fdim;
     int acc_mode;  // != 0: out += A x
+    const int32_t *eid;  // WMODE 2: attention row of edge e is att[eid[e]] (a transposed view of A; NULL: att[e])
 
     struct Ctx {
         int col0, heads, hd;
@@ -55,7 +56,10 @@ struct SpmmOp {
         const T *xcol;
     };
     struct State { float acc[VEC]; };
-    struct LaneVals { float w; };
+    struct LaneVals {
+        float w;
+        int id;
+    };
     struct Batch {
         float v[UNROLL][VEC];
         float w[UNROLL];
@@ -82,11 +86,15 @@ struct SpmmOp {
     }
     __device__ __forceinline__ void lane_load(const Ctx &, LaneVals &lv, int64_t e) const {
         if constexpr (WMODE == 1) lv.w = to_f32<T>(val[e]);
+        if constexpr (WMODE == 2) lv.id = eid ? eid[e] : 0;
     }
     __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t e, const LaneVals &lv,
                                           int sub, int jj) const {
         if constexpr (WMODE == 1) b.w[u] = group_bcast<LPR>(lv.w, sub, jj);
-        else if constexpr (WMODE == 2) b.w[u] = att[e * c.heads + c.hd];  // 4*H-byte run per edge
+        else if constexpr (WMODE == 2) {  // 4*H-byte run per edge
+            const int64_t arow = eid ? (int64_t)group_bcast<LPR>(lv.id, sub, jj) : e;
+            b.w[u] = att[arow * c.heads + c.hd];
+        }
         else b.w[u] = 1.f;
         load_vec<T, VEC>(c.xcol + (int64_t)col * k, b.v[u]);
     }
@@ -131,11 +139,12 @@ struct SpmmArgs {
     T *out;
     int64_t m, nnz;
     int k, fdim, acc_mode;
+    const int32_t *eid;
 };
 
 template <typename T, int VEC, int LPR, int UNROLL, int WMODE, bool EXACT>
 static int launch_spmm(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) {
-    SpmmOp<T, VEC, LPR, UNROLL, WMODE, EXACT> op{a.val, a.att, a.x, a.out, a.k, a.fdim, a.acc_mode};
+    SpmmOp<T, VEC, LPR, UNROLL, WMODE, EXACT> op{a.val, a.att, a.x, a.out, a.k, a.fdim, a.acc_mode, a.eid};
     const int64_t tiles = ((int64_t)a.k + (int64_t)LPR * VEC - 1) / ((int64_t)LPR * VEC);
     return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, tiles, ws, wsb, s);
 }
@@ -235,10 +244,11 @@ static int csr_spmm_entry(const int32_t *rowptr, const int32_t *colind, const vo
 }
 
 template <typename T>
-static int mhspmm_typed(const int32_t *rowptr, const int32_t *colind, const float *att, const void *feat, void *out,
-                        int64_t v, int64_t h, int64_t f, int64_t nnz, void *ws, size_t wsb, hipStream_t s) {
+static int mhspmm_typed(const int32_t *rowptr, const int32_t *colind, const float *att, const int32_t *eid,
+                        const void *feat, void *out, int64_t v, int64_t h, int64_t f, int64_t nnz, void *ws, size_t wsb,
+                        hipStream_t s) {
     if (!aligned_to(feat, sizeof(T)) || !aligned_to(out, sizeof(T))) return COGDL_HIP_EALIGN;
-    SpmmArgs<T> a{rowptr, colind, nullptr, att, (const T *)feat, (T *)out, v, nnz, (int)(h * f), (int)f, 0};
+    SpmmArgs<T> a{rowptr, colind, nullptr, att, (const T *)feat, (T *)out, v, nnz, (int)(h * f), (int)f, 0, eid};
     return spmm_auto<T, 2>(a, ws, wsb, s);
 }
 
@@ -277,6 +287,13 @@ extern "C" int cogdl_hip_csr_spmm_acc(const int32_t *rowptr, const int32_t *coli
 extern "C" int cogdl_hip_mhspmm(const int32_t *rowptr, const int32_t *colind, const float *att, const void *feat,
                                 void *out, int64_t v, int64_t h, int64_t f, int64_t nnz, int dtype, void *workspace,
                                 size_t workspace_bytes, void *stream) {
+    return cogdl_hip_mhspmm_eid(rowptr, colind, att, nullptr, feat, out, v, h, f, nnz, dtype, workspace, workspace_bytes,
+                                stream);
+}
+
+extern "C" int cogdl_hip_mhspmm_eid(const int32_t *rowptr, const int32_t *colind, const float *att, const int32_t *eid,
+                                    const void *feat, void *out, int64_t v, int64_t h, int64_t f, int64_t nnz, int dtype,
+                                    void *workspace, size_t workspace_bytes, void *stream) {
     if (v < 0 || h < 0 || f < 0 || nnz < 0) return COGDL_HIP_EINVAL;
     if (v == 0 || h == 0 || f == 0) return COGDL_HIP_OK;
     if (!rowptr || !att || !feat || !out) return COGDL_HIP_EINVAL;
@@ -284,11 +301,11 @@ extern "C" int cogdl_hip_mhspmm(const int32_t *rowptr, const int32_t *colind, co
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
         case COGDL_HIP_F32:
-            return mhspmm_typed<float>(rowptr, colind, att, feat, out, v, h, f, nnz, workspace, workspace_bytes, s);
+            return mhspmm_typed<float>(rowptr, colind, att, eid, feat, out, v, h, f, nnz, workspace, workspace_bytes, s);
         case COGDL_HIP_F16:
-            return mhspmm_typed<__half>(rowptr, colind, att, feat, out, v, h, f, nnz, workspace, workspace_bytes, s);
+            return mhspmm_typed<__half>(rowptr, colind, att, eid, feat, out, v, h, f, nnz, workspace, workspace_bytes, s);
         case COGDL_HIP_BF16:
-            return mhspmm_typed<__hip_bfloat16>(rowptr, colind, att, feat, out, v, h, f, nnz, workspace,
+            return mhspmm_typed<__hip_bfloat16>(rowptr, colind, att, eid, feat, out, v, h, f, nnz, workspace,
                                                 workspace_bytes, s);
         default: return COGDL_HIP_EDTYPE;
     }

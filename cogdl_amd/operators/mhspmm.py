@@ -2,7 +2,8 @@
 -> [N,H,F] (operators/mhspmm.py:34-64).
 
 Backward (same maths as MHSPMMFunction.backward, operators/mhspmm.py:52-64):
-    grad_feat = mhspmm(A^T, attention[perm], grad_out)      -- A^T/perm from the cached plan; the
+    grad_feat = mhspmm(A^T, attention[perm], grad_out)      -- A^T/perm from the cached plan, the permutation
+                applied inside the kernel (cogdl_hip_mhspmm_eid); the
                 reference transposes arange(nnz) through a float32 cuSPARSE call, which loses
                 edge ids above 2^24 (Reddit has 1.1e8 edges); here perm is int32 throughout.
     grad_att  = mhsddmm(A, grad_out, feat)
@@ -10,13 +11,14 @@ Backward (same maths as MHSPMMFunction.backward, operators/mhspmm.py:52-64):
 import torch
 
 from .. import _lib
-from ..plan import PLANS, Fingerprint, gather_rows
+from ..plan import PLANS, Fingerprint
 
 _lib.hip()
 
 
-def mhspmm_raw(rowptr, colind, att, feat):
-    dev = _lib.require_cuda(rowptr, colind, att, feat)
+def mhspmm_raw(rowptr, colind, att, feat, eid=None):
+    """out[v,h,:] = sum_e att[eid[e] | e, h] * feat[colind[e],h,:]"""
+    dev = _lib.require_cuda(rowptr, colind, att, feat, eid)
     if feat.dim() != 3:
         raise _lib.BackendError("feat must be [N, H, F], got %s" % (tuple(feat.shape),))
     if feat.dtype not in _lib.DTYPE_CODE:
@@ -30,9 +32,9 @@ def mhspmm_raw(rowptr, colind, att, feat):
     ws, ws_bytes = _lib.workspace("cogdl_hip_mhspmm_workspace_bytes", dev, colind.numel(), h, f,
                                   _lib.DTYPE_CODE[feat.dtype])
     with torch.cuda.device(dev):
-        rc = _lib.hip().cogdl_hip_mhspmm(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(att), _lib.ptr(feat),
-                                         _lib.ptr(out), v, h, f, colind.numel(), _lib.DTYPE_CODE[feat.dtype],
-                                         _lib.ptr(ws), ws_bytes, _lib.stream_of(feat))
+        rc = _lib.hip().cogdl_hip_mhspmm_eid(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(att), _lib.ptr(eid),
+                                             _lib.ptr(feat), _lib.ptr(out), v, h, f, colind.numel(),
+                                             _lib.DTYPE_CODE[feat.dtype], _lib.ptr(ws), ws_bytes, _lib.stream_of(feat))
     _lib.check(rc, "mhspmm")
     return out
 
@@ -65,8 +67,8 @@ class MHSPMMFunction(torch.autograd.Function):
         grad_feat = grad_att = None
         if ctx.needs_input_grad[2]:
             plan = PLANS.get(ctx.fp, rowptr, colind, feat.shape[0])
-            att_t = gather_rows(plan.perm, attention.detach().float().contiguous())
-            grad_feat = mhspmm_raw(plan.colptr, plan.rowind, att_t, grad_out.to(feat.dtype))
+            # A^T with the attention left in CSR order: the kernel reads att[perm[j]] (no transposed [E, H] copy)
+            grad_feat = mhspmm_raw(plan.colptr, plan.rowind, attention.detach(), grad_out.to(feat.dtype), eid=plan.perm)
         if ctx.needs_input_grad[3]:
             grad_att = mhsddmm_raw(rowptr, colind, grad_out, feat.detach()).to(attention.dtype)
         return None, None, grad_feat, grad_att

@@ -155,6 +155,13 @@ COGDL_API size_t cogdl_hip_mhspmm_workspace_bytes(int64_t nnz, int64_t h, int64_
 COGDL_API int cogdl_hip_mhspmm(const int32_t *rowptr, const int32_t *colind, const float *att,
                      const void *feat, void *out, int64_t v, int64_t h, int64_t f, int64_t nnz, int dtype,
                      void *workspace, size_t workspace_bytes, void *stream);
+/* mhspmm over a permuted view: the attention row of CSR position e is att[eid[e],:] (eid NULL = identity).  With
+ * (rowptr, colind, eid) = (colptr, rowind, perm) of cogdl_hip_csr2csc this is the backward product A^T with the
+ * attention left in its forward (CSR) order -- no transposed copy of the [E, H] tensor (the reference permutes it
+ * with mhtranspose first, operators/mhspmm.py:57-60). */
+COGDL_API int cogdl_hip_mhspmm_eid(const int32_t *rowptr, const int32_t *colind, const float *att, const int32_t *eid,
+                         const void *feat, void *out, int64_t v, int64_t h, int64_t f, int64_t nnz, int dtype,
+                         void *workspace, size_t workspace_bytes, void *stream);
 COGDL_API int cogdl_hip_mhsddmm(const int32_t *rowptr, const int32_t *colind, const float *grad,
                       const float *feat, float *out, int64_t v, int64_t h, int64_t f, int64_t nnz,
                       void *stream);

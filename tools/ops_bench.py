@@ -138,6 +138,10 @@ def gat_suite(g, tag, h, f, dtypes=(torch.float32, torch.bfloat16), reps=10):
     report("csr2csc", tag, timeit(lambda: csr2csc(g.rowptr, g.colind, n), reps=3, warm=1), nnz * 16 + 8 * (n + 1), nnz)
     plan = csr2csc(g.rowptr, g.colind, n)
     report("gather_rows(att[E,H])", cfg0, timeit(lambda: gather_rows(plan.perm, sm), reps), nnz * (4 + 8 * h), nnz)
+    # backward product of mhspmm: A^T with the attention read through the permutation inside the kernel
+    report("mhspmm(A^T, att[perm] in-kernel)", cfg0 + " f32",
+           timeit(lambda: mhspmm_raw(plan.colptr, plan.rowind, sm, grad, eid=plan.perm), reps),
+           nnz * (4 + 4 + h * 4 + h * f * 4) + n * (4 + h * f * 4), nnz)
     # fused backward through the autograd function (plan cached after the first call)
     ar_g, ac_g, ft_g = ar.clone().requires_grad_(), ac.clone().requires_grad_(), feat.clone().requires_grad_()
 
