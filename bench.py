@@ -8,7 +8,8 @@ N = 1 : BASELINE.json configs[1] -- "GCN on ogbn-arxiv (170k nodes, 1.2M edges, 
         value = GEdges/s = 2 * nnz * steps / time.
 N > 1 : configs[4] -- vertex-sharded csr_spmm (1-D row partition, halo rows exchanged with an RCCL all-to-all
         overlapped with the local-column SpMM), weak scaling: a fixed papers100M-like shard per GPU (10 % of a row's
-        sources in other shards = a locality-preserving partition; --remote-frac sets it).
+        sources in other shards, taken from boundary regions that give a halo of 0.25 x the shard's rows = a
+        locality-preserving partition; --remote-frac / --halo-frac set them, the halo volume is reported).
         value = global nnz * 2 * steps / time (max over ranks).
 
 One JSON line on stdout (rank 0).  Extra objects: roofline (dominant kernel, HIP-event timed inside the timed
@@ -88,11 +89,13 @@ def cpu_baseline(g, x, budget_s=10.0):
 
 def load_pmc_traffic(phase="arxiv_uniform_F128"):
     """HBM-side bytes per launch of the main csr_spmm kernel from the committed rocprofv3 --pmc summary
-    (profiles/pmc_spmm_arxiv.json, made by tools/gpu_round.sh pmc + tools/pmc_summarize.py: separate passes for
+    (profiles/rNN_pmc_spmm_arxiv.json, the latest round's; made by tools/gpu_round.sh pmc + tools/pmc_summarize.py: separate passes for
     FETCH_SIZE and WRITE_SIZE, FETCH_SIZE calibrated on a 1 GiB copy = the guide's gfx950 x2 correction).
     None when no summary is committed (PMC counters cannot be read from inside the bench process)."""
-    path = os.path.join(ROOT, "profiles", "pmc_spmm_arxiv.json")
+    import glob
+
     try:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_spmm_arxiv.json")))[-1]
         return json.load(open(path))["phases"][phase]["main"]["hbm_bytes_per_launch"]
     except Exception:
         return None
@@ -239,6 +242,9 @@ def main():
     ap.add_argument("--shard-degree", type=float, default=0.0, help="N>1: mean in-degree (default 28.8)")
     ap.add_argument("--remote-frac", type=float, default=-1.0,
                     help="N>1: fraction of a row's sources owned by other ranks (default 0.1; (N-1)/N = random partition)")
+    ap.add_argument("--halo-frac", type=float, default=0.25,
+                    help="N>1: halo rows per rank as a fraction of its own rows (remote sources come from boundary "
+                         "regions of that total size; <= 0: uniform over the owner shard = worst-case halo)")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")

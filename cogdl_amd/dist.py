@@ -201,12 +201,16 @@ def sharded_spmm(sh, x_local):
 
 
 # ------------------------------------------------------------------------------- bench (N > 1)
-def _papers_like_shard(rank, world, shard_nodes, degree, remote_frac, seed, device):
+def _papers_like_shard(rank, world, shard_nodes, degree, remote_frac, seed, device, halo_frac=0.25):
     """This rank's rows of a papers100M-shaped graph: `shard_nodes` rows, mean in-degree `degree`; a fraction
-    `remote_frac` of every row's sources lies in OTHER shards (uniform over them), the rest inside the own shard --
-    the shape a locality-preserving (METIS-like) 1-D partition of a citation graph has.  remote_frac = (world-1)/world
-    is a random partition of a structureless graph: the worst case for a 1-D partition.  Self loop appended,
-    row-normalised weights."""
+    `remote_frac` of every row's sources lies in OTHER shards (owner uniform over them), the rest inside the own shard
+    -- the shape a locality-preserving (METIS-like) 1-D partition of a citation graph has.  The remote sources of the
+    pair (this rank, owner q) come from a BOUNDARY region of q: a contiguous slice of halo_frac * shard_nodes /
+    (world - 1) nodes, one slice per requesting rank, so that a rank's halo table holds about halo_frac * shard_nodes
+    rows (ghost-node ratios of 0.2-0.4 are what METIS partitions of citation graphs show).  halo_frac <= 0: remote
+    sources uniform over the whole owner shard (no reuse: the halo then approaches one row per remote EDGE);
+    together with remote_frac = (world-1)/world that is a random partition of a structureless graph, the worst case
+    for a 1-D partition.  Self loop appended, row-normalised weights."""
     g = torch.Generator(device="cpu").manual_seed(seed * 1000003 + rank)
     nnz = int(shard_nodes * degree)
     lo = rank * shard_nodes
@@ -219,6 +223,11 @@ def _papers_like_shard(rank, world, shard_nodes, degree, remote_frac, seed, devi
         owner = torch.where(is_remote, other, torch.full_like(other, rank))
     else:
         owner = torch.zeros(nnz, dtype=torch.long)
+    if world > 1 and halo_frac > 0:
+        pool = max(1, int(halo_frac * shard_nodes / (world - 1)))
+        slot = (rank - owner - 1) % world  # 0 .. world-2 for owner != rank: this rank's slice of the owner's boundary
+        boundary = slot * pool + torch.randint(0, pool, (nnz,), generator=g)
+        cols = torch.where(owner != rank, boundary, cols)
     cols = cols + owner * shard_nodes
     rows, cols = rows.to(device), cols.to(device)
     rows = torch.cat([rows, torch.arange(shard_nodes, device=device)])
@@ -246,7 +255,8 @@ def bench_sharded_spmm(args):
     degree = args.shard_degree or 28.8                         # 3.2e9 symmetrised edges / 111e6 nodes
     f = args.feat
     remote_frac = args.remote_frac if args.remote_frac >= 0 else 0.1
-    rowptr, cols, w = _papers_like_shard(rank, world, shard_nodes, degree, remote_frac, 0, dev)
+    halo_frac = getattr(args, "halo_frac", 0.25)
+    rowptr, cols, w = _papers_like_shard(rank, world, shard_nodes, degree, remote_frac, 0, dev, halo_frac)
     bounds = torch.arange(world + 1, dtype=torch.long) * shard_nodes
     sh = ShardedCSR(rowptr, cols, w, bounds)
     del cols
@@ -300,9 +310,12 @@ def bench_sharded_spmm(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "papers100M-like 1-D vertex-sharded csr_spmm fwd+bwd (configs[4]); %.0f%% of every "
-                                   "row's sources in other shards (locality-preserving partition; --remote-frac %.3f "
-                                   "= random partition, worst-case halo)" % (100 * remote_frac, (world - 1) / world),
+                                   "row's sources in other shards, drawn from boundary regions sized for a halo of "
+                                   "%.2f x the shard's rows (locality-preserving partition; --remote-frac %.3f "
+                                   "--halo-frac 0 = random partition, worst-case halo)"
+                                   % (100 * remote_frac, max(halo_frac, 0.0), (world - 1) / world),
                        "nodes_per_gpu": shard_nodes, "nnz_global": nnz_global, "feat": f, "remote_frac": remote_frac,
+                       "halo_frac": halo_frac, "halo_rows_rank0": sh.n_halo,
                        "parallelism": "vertex-shard x%d, RCCL all-to-all halo exchange overlapped with local SpMM" % world},
             "halo_GB_per_step_all_ranks": float(halo_gb) * 2 / 1e9,
             "local_block_spmm_ms_rank0": loc_ms,

@@ -62,7 +62,8 @@ COGDL_API int cogdl_hip_last_hip_error(void);
  * round-robin, default 32), key 1 = long-row threshold override (0 = automatic), key 3 = cap on the number of
  * long-row workgroups (default 1024), key 4 = cap on the fused-GAT vector width (0 = widest), key 5 = fused-GAT
  * forward kernel (0 = automatic, 1 = edge-wise online softmax, 2 = chunk-wise softmax where the shape allows),
- * key 6 = csr_spmm/mhspmm vector width cap (negative: force), key 7 = 1: edge_softmax without 16-byte lanes.
+ * key 6 = csr_spmm/mhspmm vector width cap (negative: force), key 7 = edge_softmax lane width (bit 0: 4-byte lanes in
+ * the row kernels, bit 1: 4-byte lanes in the hub-row path; 0 = 16-byte lanes where the layout allows).
  * Defaults are the measured optima. */
 COGDL_API int cogdl_hip_set_tuning(int key, int value);
 

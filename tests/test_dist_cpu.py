@@ -77,3 +77,31 @@ def test_sharded_equals_unsharded(tmp_path, oracle, world, n):
         total_halo += int(z["n_halo"])
         total_send += int(z["send"])
     assert total_halo == total_send  # every requested halo row is sent by exactly one owner
+
+
+def test_papers_like_shard_generator_shape():
+    """bench.py's N>1 workload: remote sources come from per-peer boundary slices, so the halo is bounded."""
+    from cogdl_amd.dist import _papers_like_shard
+
+    world, s, deg = 4, 20000, 12.0
+    for rank in range(world):
+        rowptr, cols, w = _papers_like_shard(rank, world, s, deg, 0.1, 0, "cpu", halo_frac=0.25)
+        assert rowptr.numel() == s + 1 and int(rowptr[-1]) == cols.numel() == w.numel()
+        assert int(cols.min()) >= 0 and int(cols.max()) < world * s
+        owner = cols // s
+        remote = owner != rank
+        assert 0.07 < float(remote.float().mean()) < 0.12  # 10 % of the random edges (self loops are local)
+        halo = torch.unique(cols[remote])
+        pool = int(0.25 * s / (world - 1))
+        assert halo.numel() <= (world - 1) * pool
+        for q in range(world):  # this rank's slice of every peer's boundary region
+            if q != rank:
+                off = halo[(halo // s) == q] - q * s
+                slot = (rank - q - 1) % world
+                assert int(off.min()) >= slot * pool and int(off.max()) < (slot + 1) * pool
+        sums = torch.zeros(s).index_add_(0, torch.repeat_interleave(torch.arange(s), rowptr[1:] - rowptr[:-1]), w)
+        assert torch.allclose(sums, torch.ones(s), atol=1e-5)
+    # worst case: uniform remote sources -> about one halo row per remote edge
+    rowptr, cols, _ = _papers_like_shard(0, world, s, deg, 0.1, 0, "cpu", halo_frac=0.0)
+    remote = (cols // s) != 0
+    assert torch.unique(cols[remote]).numel() > 0.6 * int(remote.sum())
