@@ -6,8 +6,7 @@
 //
 // v_mfma_f32_32x32x2_f32 wants its A operand as A[i = l & 31][k = l >> 5]: 32 different ROWS of x across the lanes,
 // i.e. a transposed read of the row-major x.  So every wave stages its 32-row tile of x through its own LDS region
-// (coalesced 16-byte global reads, +1 padded rows: bank (row + k) % 32, conflict-free operand reads), 64 columns at a
-// time.  B is small: the whole of it sits in LDS ([k][n], n contiguous: B[k = l >> 5][n = l & 31] is a conflict-free
+// (coalesced 16-byte global reads, +2 padded rows: conflict-free operand reads), 64 columns at a time.  B is small: the whole of it sits in LDS ([k][n], n contiguous: B[k = l >> 5][n = l & 31] is a conflict-free
 // read), loaded once per workgroup; workgroups are persistent and their waves walk row tiles independently (no
 // workgroup barrier after the prologue).  fp32 in, fp32 accumulate (an fma chain over k per output element).
 // Shapes with more than 64 output columns or a B beyond 96 KB are declined (COGDL_HIP_ERANGE): the caller keeps its BLAS.
@@ -18,7 +17,8 @@ namespace cogdl {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kFwdKC = 64;                        // columns of x staged per step
-constexpr int kFwdXsStride = kFwdKC + 1;          // padded row of the staged tile (floats)
+constexpr int kFwdXsStride = kFwdKC + 2;          // padded row of the staged tile: bank (2 row + k) % 64 -- the operand
+                                                  // read of lane (row, k parity) touches 64 distinct banks
 constexpr size_t kFwdMaxBBytes = 96 * 1024;
 
 template <int NT>  // 32-wide output tiles per wave (N <= 32 * NT)
@@ -27,18 +27,32 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
                                                          int64_t rows, int k_dim, int n_dim, int w_is_n_by_k, int k_pad) {
     extern __shared__ float smem[];
     float *bs = smem;                                                   // [k_pad][32 * NT]
-    float *xs = smem + (size_t)k_pad * 32 * NT + (threadIdx.x >> 6) * 32 * kFwdXsStride;  // this wave's [32][KC + 1]
+    float *xs = smem + (size_t)k_pad * 32 * NT + (threadIdx.x >> 6) * 32 * kFwdXsStride;  // this wave's [32][KC + 2]
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int half = lane >> 5, j = lane & 31;
-    // prologue: B, zero padded: bs[k][n] = w_is_n_by_k ? w[n][k] : w[k][n].  w is read in ITS memory order (coalesced);
-    // the transposition, if any, happens in the scattered LDS writes.
+    // prologue: B, zero padded: bs[k][n ^ swz(k)] = w_is_n_by_k ? w[n][k] : w[k][n].  w is read in ITS memory order
+    // (coalesced), eight independent loads per thread in flight (a load-store loop would pay the L2 latency once per
+    // element: ~20 us for a 32 KB weight); the transposition, if any, happens in the scattered LDS writes.  For
+    // NT == 2 the columns of odd rows are XOR-ed with 32, so that the two half-waves of an operand read (rows k, k + 1)
+    // use complementary banks.
+    constexpr int kSwz = (NT == 2) ? 32 : 0;
     for (int e = threadIdx.x; e < k_pad * 32 * NT; e += 256) bs[e] = 0.f;
     __syncthreads();
-    for (int e = threadIdx.x; e < k_dim * n_dim; e += 256) {
-        const int k = w_is_n_by_k ? e % k_dim : e / n_dim;
-        const int n = w_is_n_by_k ? e / k_dim : e % n_dim;
-        bs[k * 32 * NT + n] = w[e];
+    const int w_elems = k_dim * n_dim;
+    for (int e0 = threadIdx.x; e0 < w_elems; e0 += 256 * 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = (e0 + u * 256 < w_elems) ? w[e0 + u * 256] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 256;
+            if (e < w_elems) {
+                const int k = w_is_n_by_k ? e % k_dim : e / n_dim;
+                const int n = w_is_n_by_k ? e / k_dim : e % n_dim;
+                bs[k * 32 * NT + (n ^ ((k & 1) * kSwz))] = t[u];
+            }
+        }
     }
     __syncthreads();
     const bool vec_ok = (k_dim & 3) == 0;
@@ -46,22 +60,35 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
     const int n_chunks = (k_pad + kFwdKC - 1) / kFwdKC;
     // Flat sequence of steps (tile, K-chunk) for this wave.  The global loads of step s+1 are issued BEFORE the MFMAs of
     // step s (register double buffer), so the x stream overlaps the matrix pipe inside one wave as well.
+    // Branch-free when rows are whole 16-byte groups (k_dim % 4 == 0): a lane outside the matrix reads a dummy address
+    // and selects zeros.  With per-lane branches the compiler parks the wave on vmcnt(0) at every join, i.e. the eight
+    // loads of a step became eight serial HBM round trips.
     auto load_step = [&](int64_t tile, int chunk, float (&v)[8][4]) {
         const int64_t row0 = tile * 32;
         const int k0 = chunk * kFwdKC;
+        const int c = k0 + 4 * (lane & 15);
+        if (vec_ok) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t row = row0 + (lane >> 4) + 4 * i;
+                const bool ok = row < rows && c < k_dim;  // tile >= n_tiles implies row >= rows
+                float t[4];
+                load_vec<float, 4>(ok ? x + row * k_dim + c : x, t);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[i][q] = ok ? t[q] : 0.f;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int64_t row = row0 + (lane >> 4) + 4 * i;
-            const int c = k0 + 4 * (lane & 15);
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[i][q] = 0.f;
-            if (tile < n_tiles && row < rows) {
+            if (row < rows) {
                 const float *p = x + row * k_dim + c;
-                if (vec_ok && c + 3 < k_dim) load_vec<float, 4>(p, v[i]);
-                else
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (c + q < k_dim) v[i][q] = p[q];
+                for (int q = 0; q < 4; ++q)
+                    if (c + q < k_dim) v[i][q] = p[q];
             }
         }
     };
@@ -75,12 +102,32 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
     for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    // A finished tile is written at the START of the following step, before that step's prefetch goes out: on gfx9
+    // stores count in vmcnt like loads, so stores issued after the prefetch would make the next `vmcnt(0)` wait for
+    // their write acknowledgements as well (one exposed HBM round trip per tile); issued first they drain behind a whole
+    // step of MFMAs.
+    float res[NT][16];
+    int64_t res_row0 = -1;  // tile whose results sit in `res` (-1: none)
+    auto flush = [&]() {
+        if (res_row0 < 0) return;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int n = 32 * a + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = res_row0 + (r & 3) + 8 * (r >> 2) + 4 * half;  // C/D map of the 32x32 MFMA
+                if (row < rows && n < n_dim) out[row * n_dim + n] = res[a][r];
+            }
+        }
+        res_row0 = -1;
+    };
     while (tile < n_tiles) {
         // stage the current step's 32 x 64 block of x (the wave's own LDS writes are visible to its own later reads)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) xs[((lane >> 4) + 4 * i) * kFwdXsStride + 4 * (lane & 15) + q] = v[i][q];
+        flush();
         // next step's loads go out now
         const bool last_chunk = chunk + 1 == n_chunks;
         const int64_t next_tile = last_chunk ? tile + tile_step : tile;
@@ -94,9 +141,9 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 a_op[t] = xs[j * kFwdXsStride + kk + 2 * t + half];
-                const float *brow = bs + (size_t)(k0 + kk + 2 * t + half) * 32 * NT + j;
+                const float *brow = bs + (size_t)(k0 + kk + 2 * t + half) * 32 * NT;  // row parity == half
 #pragma unroll
-                for (int a = 0; a < NT; ++a) b_op[t][a] = brow[32 * a];
+                for (int a = 0; a < NT; ++a) b_op[t][a] = brow[(j + 32 * a) ^ (half * kSwz)];
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t)
@@ -105,22 +152,22 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_op[t], b_op[t][a], acc[a], 0, 0, 0);
         }
         if (last_chunk) {
-            const int64_t row0 = tile * 32;
 #pragma unroll
             for (int a = 0; a < NT; ++a) {
                 const int n = 32 * a + j;
                 const float b = (bias && n < n_dim) ? bias[n] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;  // C/D map of the 32x32 MFMA
-                    if (row < rows && n < n_dim) out[row * n_dim + n] = acc[a][r] + b;
+                    res[a][r] = acc[a][r] + b;
                     acc[a][r] = 0.f;
                 }
             }
+            res_row0 = tile * 32;
         }
         tile = next_tile;
         chunk = next_chunk;
     }
+    flush();
 }
 
 template <int NT>
@@ -137,8 +184,13 @@ static int launch_fwd_gemm(const float *x, const float *w, const float *bias, fl
         attr_set = true;
     }
     const int64_t n_tiles = (rows + 31) / 32;
-    const int64_t per_cu = std::max<int64_t>(1, (160 * 1024) / (int64_t)lds);
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, 256 * std::min<int64_t>(per_cu, 4)));
+    // persistent workgroups: exactly as many as are resident at once (LDS- or register-limited), or a second round
+    // of workgroups would start when the first is done
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&linear_fwd_kernel<NT>), 256,
+                                                     lds) != hipSuccess || per_cu < 1)
+        per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(2, (160 * 1024) / (int64_t)lds));
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, (int64_t)256 * std::min(per_cu, 4)));
     hipLaunchKernelGGL((linear_fwd_kernel<NT>), dim3(grid), dim3(256), lds, s, x, w, bias, out, rows, (int)k_dim, (int)n_dim,
                        w_is_n_by_k, k_pad);
     return launch_status();
