@@ -186,10 +186,17 @@ static int launch_fwd_gemm(const float *x, const float *w, const float *bias, fl
     const int64_t n_tiles = (rows + 31) / 32;
     // persistent workgroups: exactly as many as are resident at once (LDS- or register-limited), or a second round
     // of workgroups would start when the first is done
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&linear_fwd_kernel<NT>), 256,
-                                                     lds) != hipSuccess || per_cu < 1)
-        per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(2, (160 * 1024) / (int64_t)lds));
+    static thread_local size_t cached_lds = 0;  // the occupancy query costs a few microseconds of host time
+    static thread_local int cached_per_cu = 0;
+    if (cached_per_cu == 0 || cached_lds != lds) {
+        int q = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void *>(&linear_fwd_kernel<NT>), 256,
+                                                         lds) != hipSuccess || q < 1)
+            q = (int)std::max<int64_t>(1, std::min<int64_t>(2, (160 * 1024) / (int64_t)lds));
+        cached_lds = lds;
+        cached_per_cu = q;
+    }
+    const int per_cu = cached_per_cu;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, (int64_t)256 * std::min(per_cu, 4)));
     hipLaunchKernelGGL((linear_fwd_kernel<NT>), dim3(grid), dim3(256), lds, s, x, w, bias, out, rows, (int)k_dim, (int)n_dim,
                        w_is_n_by_k, k_pad);

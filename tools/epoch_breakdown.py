@@ -9,10 +9,12 @@ CATS = [
     ("cogdl_amd csr_spmm (4 launches: F=64 and F=40, fwd + bwd)", ("rowreduce_main_kernel<cogdl::SpmmOp", "rowreduce_combine_kernel<cogdl::SpmmOp")),
     ("cogdl_amd MFMA linear kernels (fwd, grad_input, split-K weight gradient + reduce)", ("linear_fwd_kernel", "linear_wgrad")),
     ("cogdl_amd structure fingerprint", ("fingerprint",)),
-    ("cogdl_amd csr2csc / gather (plan build, first epoch only)", ("csr2csc", "gather_rows", "rocprim", "transpose")),
+    # our rocPRIM kernels come from the system headers (namespace ROCPRIM_400200_NS here); torch bundles its own copy
+    # (ROCPRIM_400001_NS) and uses it for nonzero / sort inside boolean-mask indexing -- those fall through to that row
+    ("cogdl_amd csr2csc / gather (plan build, first epoch only)", ("csr2csc", "gather_rows_kernel", "rowind_from_perm", "colptr_from", "ROCPRIM_400200")),
     ("hipBLASLt / rocBLAS GEMMs", ("Cijk_", "gemm", "rocblas")),
     ("torch cross_entropy (log_softmax + nll_loss fwd/bwd)", ("softmax", "nll_loss")),
-    ("torch boolean-mask indexing out[train_mask] fwd/bwd", ("index", "nonzero", "masked", "vectorized_gather", "scan", "Scan", "DeviceSelect", "radix", "Radix", "cub", "sort")),
+    ("torch boolean-mask indexing out[train_mask] fwd/bwd", ("index", "nonzero", "masked", "vectorized_gather", "rocprim", "scan", "Scan", "DeviceSelect", "radix", "Radix", "cub", "sort")),
     ("torch Adam (multi_tensor_apply)", ("multi_tensor_apply", "adam", "Adam")),
     ("torch dropout", ("dropout", "Dropout")),
 ]
