@@ -60,9 +60,13 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
     const int n_chunks = (k_pad + kFwdKC - 1) / kFwdKC;
     // Flat sequence of steps (tile, K-chunk) for this wave.  The global loads of step s+1 are issued BEFORE the MFMAs of
     // step s (register double buffer), so the x stream overlaps the matrix pipe inside one wave as well.
-    // Branch-free when rows are whole 16-byte groups (k_dim % 4 == 0): a lane outside the matrix reads a dummy address
-    // and selects zeros.  With per-lane branches the compiler parks the wave on vmcnt(0) at every join, i.e. the eight
-    // loads of a step became eight serial HBM round trips.
+    // Branch-free when rows are whole 16-byte groups (k_dim % 4 == 0): a lane outside the matrix reads a dummy address.
+    // Nothing may TOUCH the loaded registers before the next step stages them -- a select on the data (or per-lane
+    // branches, at whose joins the compiler parks the wave on vmcnt(0)) puts the wait for the prefetch in front of the
+    // MFMAs it was meant to overlap with.  The zeroing of out-of-range lanes therefore happens at staging time.
+    auto lane_ok = [&](int64_t tile, int chunk, int i) {
+        return tile * 32 + (lane >> 4) + 4 * i < rows && chunk * kFwdKC + 4 * (lane & 15) < k_dim;
+    };
     auto load_step = [&](int64_t tile, int chunk, float (&v)[8][4]) {
         const int64_t row0 = tile * 32;
         const int k0 = chunk * kFwdKC;
@@ -71,11 +75,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int64_t row = row0 + (lane >> 4) + 4 * i;
-                const bool ok = row < rows && c < k_dim;  // tile >= n_tiles implies row >= rows
-                float t[4];
-                load_vec<float, 4>(ok ? x + row * k_dim + c : x, t);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[i][q] = ok ? t[q] : 0.f;
+                load_vec<float, 4>(lane_ok(tile, chunk, i) ? x + row * k_dim + c : x, v[i]);  // tile >= n_tiles: not ok
             }
             return;
         }
@@ -124,9 +124,12 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
     while (tile < n_tiles) {
         // stage the current step's 32 x 64 block of x (the wave's own LDS writes are visible to its own later reads)
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i) {
+            const bool ok = !vec_ok || lane_ok(tile, chunk, i);  // the slow path zeroed its registers itself
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xs[((lane >> 4) + 4 * i) * kFwdXsStride + 4 * (lane & 15) + q] = v[i][q];
+            for (int q = 0; q < 4; ++q)
+                xs[((lane >> 4) + 4 * i) * kFwdXsStride + 4 * (lane & 15) + q] = ok ? v[i][q] : 0.f;
+        }
         flush();
         // next step's loads go out now
         const bool last_chunk = chunk + 1 == n_chunks;
