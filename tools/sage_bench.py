@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[3] end to end (not bench.py's contract line; a profile for SURVEY.md section 8e/8f):
+GraphSAGE on an ogbn-products-shaped graph with neighbour-sampling mini-batches, everything resident in HBM.
+
+One training step = what cogdl/data/sampler.py:NeighborSampler.sample + cogdl/models/nn/graphsage.py:forward do per
+mini-batch -- sample_adj per layer (fan-out [10, 10], without replacement), gather the input features of the outermost
+frontier, two SAGELayers (mean aggregator = row-normalised csr_spmm over the sampled block, cat, Linear; relu +
+dropout in between), cross-entropy, Adam -- with the graph (118 M edges), the features ([N, 100] fp32 = 0.98 GB) and
+the sampler on the GPU: sample_adj_c -> cogdl_hip_sample_adj, aggregation -> csrspmm -> cogdl_hip_csr_spmm.
+The reference samples on the CPU in DataLoader workers (sample.cpp, single-threaded per worker), gathers x[n_id] on the
+host and copies every batch over PCIe.
+
+N > 1 GPUs (python -m torch.distributed.run --nproc-per-node N tools/sage_bench.py): independent replicas, the
+gradients all-reduced by torch DDP over RCCL as in cogdl/trainer/trainer.py:291-303.  Prints one JSON line.
+Usage: python tools/sage_bench.py [--batch 1024] [--steps 50] [--nodes 2449029] [--degree 50.5]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cogdl_amd import synth  # noqa: E402
+from cogdl_amd.operators.sample import sample_adj_c  # noqa: E402
+from cogdl_amd.operators.spmm import csrspmm  # noqa: E402
+
+
+class SageMean(torch.nn.Module):
+    """SAGELayer(aggr='mean') of cogdl/layers/sage_layer.py:8-12,69-87: fc(cat(x, row_norm(A) x))."""
+
+    def __init__(self, in_feats, out_feats):
+        super().__init__()
+        self.fc = torch.nn.Linear(2 * in_feats, out_feats)
+
+    def forward(self, block, x):
+        row_ptr, col = block
+        deg = (row_ptr[1:] - row_ptr[:-1])
+        w = torch.repeat_interleave(1.0 / deg.clamp(min=1).float(), deg)  # Graph.row_norm(): 1 / in-degree per edge
+        h = csrspmm(row_ptr.int(), col.int(), x, w)  # the .int() copies CogDL's dispatcher makes (spmm_utils.py:106)
+        return self.fc(torch.cat([x, h], dim=-1))
+
+
+class Sage(torch.nn.Module):
+    def __init__(self, feats, hidden, classes):
+        super().__init__()
+        self.convs = torch.nn.ModuleList([SageMean(feats, hidden), SageMean(hidden, classes)])
+
+    def forward(self, x, adjs):  # graphsage.py:93-104
+        for i, (block, n_dst) in enumerate(adjs):
+            x = self.convs[i](block, x)[:n_dst]
+            if i != len(adjs) - 1:
+                x = F.dropout(F.relu(x), p=0.5, training=self.training)
+        return x
+
+
+def sample_blocks(indptr, indices, seeds, fanout):
+    """NeighborSampler.sample (cogdl/data/sampler.py:93-116): outermost hop last, blocks returned innermost first."""
+    adjs = []
+    batch = seeds
+    for k in fanout:
+        row_ptr, col, nodes, _ = sample_adj_c(indptr, indices, batch, k, False)
+        adjs.append(((row_ptr, col), batch.numel()))
+        batch = nodes
+    return batch, adjs[::-1]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nodes", type=int, default=2_449_029)
+    ap.add_argument("--degree", type=float, default=50.5)
+    ap.add_argument("--feat", type=int, default=100)
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--classes", type=int, default=47)
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    n = args.nodes
+    src, dst = synth.rmat_pairs(n, int(n * args.degree / 2), 0, device=dev)  # every replica holds the whole graph
+    g = synth.finalize(src, dst, n, norm=None, self_loops=False)
+    del src, dst
+    indptr, indices = g.rowptr.long(), g.colind.long()
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    x_all = torch.randn(n, args.feat, device=dev, generator=gen)
+    y_all = torch.randint(0, args.classes, (n,), device=dev, generator=gen)
+    torch.manual_seed(0)
+    model = Sage(args.feat, args.hidden, args.classes).to(dev)
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index]) if world > 1 else model
+    opt = torch.optim.Adam(net.parameters(), lr=0.01)
+
+    def step():
+        seeds = torch.randint(0, n, (args.batch,), device=dev, generator=gen).unique()
+        n_id, adjs = sample_blocks(indptr, indices, seeds, [10, 10])
+        opt.zero_grad(set_to_none=True)
+        out = net(x_all[n_id], adjs)
+        loss = F.cross_entropy(out, y_all[seeds])
+        loss.backward()
+        opt.step()
+        return seeds.numel(), n_id.numel(), sum(b[0][1].numel() for b in adjs)
+
+    net.train()
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    seeds = nodes = edges = 0
+    for _ in range(args.steps):
+        a, b, c = step()
+        seeds, nodes, edges = seeds + a, nodes + b, edges + c
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    tot = torch.tensor([seeds], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(tot)
+    # the sampling part alone (its own loop: no synchronisation inside the timed training steps)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        sample_blocks(indptr, indices, torch.randint(0, n, (args.batch,), device=dev, generator=gen).unique(), [10, 10])
+    torch.cuda.synchronize()
+    ms_sample = (time.perf_counter() - t1) / 20 * 1e3
+    if rank == 0:
+        print(json.dumps({
+            "metric": "GraphSAGE mini-batch training, seed nodes/s (products-shaped graph, fan-out [10,10]) @%d GPU" % world,
+            "value": float(tot) / float(dt), "unit": "seed nodes/s", "n_gpus": world, "steps": args.steps,
+            "ms_per_step": float(dt) / args.steps * 1e3, "ms_sampling_alone_rank0": ms_sample,
+            "batch": args.batch, "frontier_nodes_per_step": nodes // args.steps, "sampled_edges_per_step": edges // args.steps,
+            "config": {"nodes": n, "nnz": int(g.nnz), "feat": args.feat, "hidden": args.hidden, "classes": args.classes,
+                       "sampler": "cogdl_hip_sample_adj (GPU-resident graph)", "features": "resident in HBM",
+                       "parallelism": "replicas + DDP all-reduce (RCCL)" if world > 1 else "single GPU"}}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
