@@ -116,7 +116,7 @@ class SPMMFunction(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             plan = PLANS.get(ctx.fp, rowptr, colind, ctx.n_src)
             w_t = plan.transposed_values(w) if w is not None else None
-            grad_feat = csr_spmm_raw(plan.colptr, plan.rowind, w_t, grad_out)
+            grad_feat = csr_spmm_raw(plan.colptr, plan.rowind, w_t, grad_out, split_long_rows=plan.has_hub_columns())
         if w is not None and ctx.needs_input_grad[3]:
             grad_w = csr_sddmm_raw(rowptr, colind, grad_out, feat.detach()).to(w.dtype)
         return None, None, grad_feat, grad_w, None

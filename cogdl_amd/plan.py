@@ -23,12 +23,20 @@ from . import _lib
 
 
 class CscPlan:
-    __slots__ = ("colptr", "rowind", "perm", "m", "n_cols", "nnz", "_val_key", "_val_t")
+    __slots__ = ("colptr", "rowind", "perm", "m", "n_cols", "nnz", "_val_key", "_val_t", "_max_col_degree")
 
     def __init__(self, colptr, rowind, perm, m, n_cols, nnz):
         self.colptr, self.rowind, self.perm = colptr, rowind, perm
         self.m, self.n_cols, self.nnz = m, n_cols, nnz
         self._val_key, self._val_t = None, None
+        self._max_col_degree = None
+
+    def has_hub_columns(self):
+        """Does A^T have rows beyond the long-row threshold?  (One reduction + sync, once per plan.)  When it does not,
+        the backward SpMM runs without the chunk-parallel path: no scratch, no combine launch."""
+        if self._max_col_degree is None:
+            self._max_col_degree = int((self.colptr[1:] - self.colptr[:-1]).max()) if self.n_cols else 0
+        return self._max_col_degree > _lib.hip().cogdl_hip_long_row_threshold(self.nnz)
 
     def transposed_values(self, w):
         """w[perm], memoised on the identity+version of `w` (CogDL passes the same
