@@ -21,7 +21,10 @@ constexpr int kFwdXsStride = kFwdKC + 2;          // padded row of the staged ti
                                                   // read of lane (row, k parity) touches 64 distinct banks
 constexpr size_t kFwdMaxBBytes = 96 * 1024;
 
-template <int NT>  // 32-wide output tiles per wave (N <= 32 * NT)
+// NT: 32-wide output tiles per wave (N <= 32 * NT).  VEC: rows of x are whole 16-byte groups (k_dim % 4 == 0) -- the
+// buffer-addressed fast path; a template parameter so that the element-wise path's pending-load bookkeeping cannot leak
+// into the fast loop's s_waitcnt placement.
+template <int NT, bool VEC>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                          const float *__restrict__ bias, float *__restrict__ out,
                                                          int64_t rows, int k_dim, int n_dim, int w_is_n_by_k, int k_pad) {
@@ -29,7 +32,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
     float *bs = smem;                                                   // [k_pad][32 * NT]
     float *xs = smem + (size_t)k_pad * 32 * NT + (threadIdx.x >> 6) * 32 * kFwdXsStride;  // this wave's [32][KC + 2]
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: tile ids and descriptors stay in SGPRs
     const int half = lane >> 5, j = lane & 31;
     // prologue: B, zero padded: bs[k][n ^ swz(k)] = w_is_n_by_k ? w[n][k] : w[k][n].  w is read in ITS memory order
     // (coalesced), eight independent loads per thread in flight (a load-store loop would pay the L2 latency once per
@@ -55,32 +58,46 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
         }
     }
     __syncthreads();
-    const bool vec_ok = (k_dim & 3) == 0;
     const int64_t n_tiles = (rows + 31) / 32;
     const int n_chunks = (k_pad + kFwdKC - 1) / kFwdKC;
-    // Flat sequence of steps (tile, K-chunk) for this wave.  The global loads of step s+1 are issued BEFORE the MFMAs of
-    // step s (register double buffer), so the x stream overlaps the matrix pipe inside one wave as well.
-    // Branch-free when rows are whole 16-byte groups (k_dim % 4 == 0): a lane outside the matrix reads a dummy address.
-    // Nothing may TOUCH the loaded registers before the next step stages them -- a select on the data (or per-lane
-    // branches, at whose joins the compiler parks the wave on vmcnt(0)) puts the wait for the prefetch in front of the
-    // MFMAs it was meant to overlap with.  The zeroing of out-of-range lanes therefore happens at staging time.
-    auto lane_ok = [&](int64_t tile, int chunk, int i) {
-        return tile * 32 + (lane >> 4) + 4 * i < rows && chunk * kFwdKC + 4 * (lane & 15) < k_dim;
+    const int64_t tile_step = (int64_t)gridDim.x * 4;
+    // ---- addressing: bounds-checked BUFFER loads/stores on per-tile descriptors ---------------------------------------
+    // A tile's descriptor covers exactly its valid rows, so rows past the matrix read 0 / drop the store; a lane past the
+    // last column gets an offset beyond any tile (kOob).  Everything is straight-line code: one add per load or store,
+    // no per-lane branches (at whose joins the compiler parks the wave on vmcnt(0)), no selects on loaded data (which
+    // would put the wait for a prefetch in front of the MFMAs it overlaps with), exact vmcnt bookkeeping by the compiler.
+    constexpr int kOob = (int)0x80000000;
+    const int x_row_bytes = k_dim * 4, o_row_bytes = n_dim * 4;
+    const int ld_lane = (lane >> 4) * x_row_bytes + 16 * (lane & 15);  // row (lane >> 4), columns 4 (lane & 15) .. + 3
+    int st_lane[NT];                                                   // row 4 half, column 32 a + j of the output tile
+#pragma unroll
+    for (int a = 0; a < NT; ++a) st_lane[a] = (32 * a + j < n_dim) ? 4 * half * o_row_bytes + (32 * a + j) * 4 : kOob;
+    auto x_rsrc = [&](int64_t tile) {
+        const int64_t row0 = tile * 32;
+        const int valid = (int)max((int64_t)0, min((int64_t)32, rows - row0));
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (valid ? row0 : 0) * k_dim), 0, valid * x_row_bytes,
+                                                 0x00020000);
     };
     auto load_step = [&](int64_t tile, int chunk, float (&v)[8][4]) {
-        const int64_t row0 = tile * 32;
         const int k0 = chunk * kFwdKC;
-        const int c = k0 + 4 * (lane & 15);
-        if (vec_ok) {
+        if constexpr (VEC) {
+            const __amdgpu_buffer_rsrc_t r = x_rsrc(tile);
+            const int col_ok = k0 + 4 * (lane & 15) < k_dim;  // whole 16-byte groups: k_dim % 4 == 0
+            const int base = col_ok ? ld_lane : kOob;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int64_t row = row0 + (lane >> 4) + 4 * i;
-                load_vec<float, 4>(lane_ok(tile, chunk, i) ? x + row * k_dim + c : x, v[i]);  // tile >= n_tiles: not ok
+                const auto q = __builtin_amdgcn_raw_buffer_load_b128(r, base + i * 4 * x_row_bytes, k0 * 4, 0);
+                v[i][0] = __uint_as_float(q[0]);
+                v[i][1] = __uint_as_float(q[1]);
+                v[i][2] = __uint_as_float(q[2]);
+                v[i][3] = __uint_as_float(q[3]);
             }
             return;
         }
+        const int64_t row0 = tile * 32;
+        const int c = k0 + 4 * (lane & 15);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 8; ++i) {  // rows that are not whole 16-byte groups: element-wise, checked
             const int64_t row = row0 + (lane >> 4) + 4 * i;
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[i][q] = 0.f;
@@ -92,7 +109,9 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
             }
         }
     };
-    const int64_t tile_step = (int64_t)gridDim.x * 4;
+    float bias_v[NT];  // this lane's output columns 32 a + j
+#pragma unroll
+    for (int a = 0; a < NT; ++a) bias_v[a] = (bias && 32 * a + j < n_dim) ? bias[32 * a + j] : 0.f;
     int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     int chunk = 0;
     float v[8][4];
@@ -103,33 +122,29 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
     // A finished tile is written at the START of the following step, before that step's prefetch goes out: on gfx9
-    // stores count in vmcnt like loads, so stores issued after the prefetch would make the next `vmcnt(0)` wait for
-    // their write acknowledgements as well (one exposed HBM round trip per tile); issued first they drain behind a whole
-    // step of MFMAs.
+    // stores count in vmcnt like loads; issued here they drain behind a whole step of MFMAs.
     float res[NT][16];
-    int64_t res_row0 = -1;  // tile whose results sit in `res` (-1: none)
+    int64_t res_tile = -1;  // tile whose results sit in `res` (-1: none)
     auto flush = [&]() {
-        if (res_row0 < 0) return;
+        if (res_tile < 0) return;  // wave-uniform
+        const int64_t row0 = res_tile * 32;
+        const int valid = (int)min((int64_t)32, rows - row0);
+        const __amdgpu_buffer_rsrc_t r =
+            __builtin_amdgcn_make_buffer_rsrc(out + row0 * n_dim, 0, valid * o_row_bytes, 0x00020000);
 #pragma unroll
-        for (int a = 0; a < NT; ++a) {
-            const int n = 32 * a + j;
+        for (int a = 0; a < NT; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = res_row0 + (r & 3) + 8 * (r >> 2) + 4 * half;  // C/D map of the 32x32 MFMA
-                if (row < rows && n < n_dim) out[row * n_dim + n] = res[a][r];
-            }
-        }
-        res_row0 = -1;
+            for (int q = 0; q < 16; ++q)  // C/D map of the 32x32 MFMA: register q holds row (q & 3) + 8 (q >> 2) + 4 half
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[a][q]), r,
+                                                      st_lane[a] + ((q & 3) + 8 * (q >> 2)) * o_row_bytes, 0, 0);
+        res_tile = -1;
     };
     while (tile < n_tiles) {
         // stage the current step's 32 x 64 block of x (the wave's own LDS writes are visible to its own later reads)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const bool ok = !vec_ok || lane_ok(tile, chunk, i);  // the slow path zeroed its registers itself
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                xs[((lane >> 4) + 4 * i) * kFwdXsStride + 4 * (lane & 15) + q] = ok ? v[i][q] : 0.f;
-        }
+            for (int q = 0; q < 4; ++q) xs[((lane >> 4) + 4 * i) * kFwdXsStride + 4 * (lane & 15) + q] = v[i][q];
         flush();
         // next step's loads go out now
         const bool last_chunk = chunk + 1 == n_chunks;
@@ -138,34 +153,46 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
         load_step(next_tile, next_chunk, v);
         const int k0 = chunk * kFwdKC;
         const int kc = min(kFwdKC, k_pad - k0);
-        // 8 k-pairs per trip: their LDS operand reads are issued together, ahead of the 8 * NT MFMAs (k_pad % 16 == 0)
-        for (int kk = 0; kk < kc; kk += 16) {
-            float a_op[8], b_op[8][NT];
+        // The chunk is a sequence of groups of two k-pairs (4 columns, 2 * NT MFMAs = 128 * NT pipe cycles).  The LDS
+        // operand reads of group g + 1 are issued before the MFMAs of group g (two register sets), so that their
+        // latency hides behind the matrix pipe instead of opening a bubble after every group.
+        const int n_groups = kc / 4;  // a multiple of 4 (k_pad % 16 == 0)
+        float a_op[2][2], b_op[2][2][NT];
+        auto read_group = [&](int g, float (&ao)[2], float (&bo)[2][NT]) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                a_op[t] = xs[j * kFwdXsStride + kk + 2 * t + half];
-                const float *brow = bs + (size_t)(k0 + kk + 2 * t + half) * 32 * NT;  // row parity == half
+            for (int p2 = 0; p2 < 2; ++p2) {
+                ao[p2] = xs[j * kFwdXsStride + 4 * g + 2 * p2 + half];
+                const float *brow = bs + (size_t)(k0 + 4 * g + 2 * p2 + half) * 32 * NT;  // row parity == half
 #pragma unroll
-                for (int a = 0; a < NT; ++a) b_op[t][a] = brow[(j + 32 * a) ^ (half * kSwz)];
+                for (int a = 0; a < NT; ++a) bo[p2][a] = brow[(j + 32 * a) ^ (half * kSwz)];
             }
+        };
+        read_group(0, a_op[0], b_op[0]);
+        for (int g4 = 0; g4 < n_groups; g4 += 4) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
+            for (int u = 0; u < 4; ++u) {
+                const int g = g4 + u;
+                // unconditional: the read past the chunk's last group stays inside the LDS allocation (row padding of
+                // xs / the region behind bs) and is discarded; a condition here would cost the exact lgkmcnt bookkeeping
+                read_group(g + 1, a_op[(u + 1) & 1], b_op[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of the MFMAs (the scheduler sinks them otherwise)
 #pragma unroll
-                for (int a = 0; a < NT; ++a)
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_op[t], b_op[t][a], acc[a], 0, 0, 0);
+                for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+                    for (int a = 0; a < NT; ++a)
+                        acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_op[u & 1][p2], b_op[u & 1][p2][a], acc[a], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (last_chunk) {
 #pragma unroll
-            for (int a = 0; a < NT; ++a) {
-                const int n = 32 * a + j;
-                const float b = (bias && n < n_dim) ? bias[n] : 0.f;
+            for (int a = 0; a < NT; ++a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    res[a][r] = acc[a][r] + b;
+                    res[a][r] = acc[a][r] + bias_v[a];
                     acc[a][r] = 0.f;
                 }
-            }
-            res_row0 = tile * 32;
+            res_tile = tile;
         }
         tile = next_tile;
         chunk = next_chunk;
@@ -173,7 +200,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
     flush();
 }
 
-template <int NT>
+template <int NT, bool VEC>
 static int launch_fwd_gemm(const float *x, const float *w, const float *bias, float *out, int64_t rows, int64_t k_dim,
                            int64_t n_dim, int w_is_n_by_k, hipStream_t s) {
     const int k_pad = (int)((k_dim + 15) / 16 * 16);  // whole trips of 8 k-pairs; the padding is zeros in B and x
@@ -182,7 +209,7 @@ static int launch_fwd_gemm(const float *x, const float *w, const float *bias, fl
     const size_t lds = b_bytes + (size_t)4 * 32 * kFwdXsStride * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {  // more than 64 KB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_fwd_kernel<NT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_fwd_kernel<NT, VEC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kFwdMaxBBytes + 40 * 1024));
         attr_set = true;
     }
@@ -193,7 +220,7 @@ static int launch_fwd_gemm(const float *x, const float *w, const float *bias, fl
     static thread_local int cached_per_cu = 0;
     if (cached_per_cu == 0 || cached_lds != lds) {
         int q = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void *>(&linear_fwd_kernel<NT>), 256,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void *>(&linear_fwd_kernel<NT, VEC>), 256,
                                                          lds) != hipSuccess || q < 1)
             q = (int)std::max<int64_t>(1, std::min<int64_t>(2, (160 * 1024) / (int64_t)lds));
         cached_lds = lds;
@@ -201,7 +228,7 @@ static int launch_fwd_gemm(const float *x, const float *w, const float *bias, fl
     }
     const int per_cu = cached_per_cu;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, (int64_t)256 * std::min(per_cu, 4)));
-    hipLaunchKernelGGL((linear_fwd_kernel<NT>), dim3(grid), dim3(256), lds, s, x, w, bias, out, rows, (int)k_dim, (int)n_dim,
+    hipLaunchKernelGGL((linear_fwd_kernel<NT, VEC>), dim3(grid), dim3(256), lds, s, x, w, bias, out, rows, (int)k_dim, (int)n_dim,
                        w_is_n_by_k, k_pad);
     return launch_status();
 }
@@ -223,6 +250,10 @@ extern "C" int cogdl_hip_linear_fwd_f32(const float *x, const float *w, const fl
     if (n_dim > 64 || k_dim > 4096) return COGDL_HIP_ERANGE;
     if (!aligned_to(x, 16) || !aligned_to(out, 4)) return COGDL_HIP_EALIGN;
     hipStream_t s = (hipStream_t)stream;
-    if (n_dim <= 32) return launch_fwd_gemm<1>(x, w, bias, out, rows, k_dim, n_dim, w_is_n_by_k, s);
-    return launch_fwd_gemm<2>(x, w, bias, out, rows, k_dim, n_dim, w_is_n_by_k, s);
+    const bool vec = (k_dim & 3) == 0;
+    if (n_dim <= 32)
+        return vec ? launch_fwd_gemm<1, true>(x, w, bias, out, rows, k_dim, n_dim, w_is_n_by_k, s)
+                   : launch_fwd_gemm<1, false>(x, w, bias, out, rows, k_dim, n_dim, w_is_n_by_k, s);
+    return vec ? launch_fwd_gemm<2, true>(x, w, bias, out, rows, k_dim, n_dim, w_is_n_by_k, s)
+               : launch_fwd_gemm<2, false>(x, w, bias, out, rows, k_dim, n_dim, w_is_n_by_k, s);
 }
