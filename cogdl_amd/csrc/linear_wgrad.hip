@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float *__restri
     constexpr int WM = (TPW < TM) ? TPW : TM;        // ... = WM tiles along in  x  WN along out
     constexpr int WN = TPW / WM;
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: batch selection = scalar branches
     const int half = lane >> 5, j = lane & 31;
     const int ks = wave / WPI;                       // which share of the row pairs
     const int t0 = (wave % WPI) * TPW;               // first tile of this wave
@@ -107,26 +107,25 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float *__restri
     // lies inside the slab (all but the last one or two) the per-row part of the address is the SCALAR offset of the
     // buffer instruction (u * 2*KW * row_bytes: not bounds-checked, and needs no check) and the lane part is one add per
     // column stream; only the tail batches pay for per-row checks.
-    auto load_batch = [&](int i, float (&xv)[kWgradUnroll][WM], float (&gv)[kWgradUnroll][WN]) {
+    auto load_full = [&](int i, float (&xv)[kWgradUnroll][WM], float (&gv)[kWgradUnroll][WN]) {
         const int r0 = 2 * ks + half + i * kStep;
-        const bool full = 2 * ks + 1 + i * kStep + 2 * KW * (kWgradUnroll - 1) < slab_rows;  // wave-uniform
-        if (full) {
-            int xo[WM], go[WN];
+        int xo[WM], go[WN];
 #pragma unroll
-            for (int b = 0; b < WM; ++b) xo[b] = r0 * x_row_bytes + xcol[b];  // (top bit of xcol survives: no wrap)
+        for (int b = 0; b < WM; ++b) xo[b] = r0 * x_row_bytes + xcol[b];  // (top bit of xcol survives: no wrap)
 #pragma unroll
-            for (int a = 0; a < WN; ++a) go[a] = r0 * g_row_bytes + gcol[a];
+        for (int a = 0; a < WN; ++a) go[a] = r0 * g_row_bytes + gcol[a];
 #pragma unroll
-            for (int u = 0; u < kWgradUnroll; ++u) {
+        for (int u = 0; u < kWgradUnroll; ++u) {
 #pragma unroll
-                for (int b = 0; b < WM; ++b)
-                    xv[u][b] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, xo[b], u * 2 * KW * x_row_bytes, 0));
+            for (int b = 0; b < WM; ++b)
+                xv[u][b] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, xo[b], u * 2 * KW * x_row_bytes, 0));
 #pragma unroll
-                for (int a = 0; a < WN; ++a)
-                    gv[u][a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gr, go[a], u * 2 * KW * g_row_bytes, 0));
-            }
-            return;
+            for (int a = 0; a < WN; ++a)
+                gv[u][a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gr, go[a], u * 2 * KW * g_row_bytes, 0));
         }
+    };
+    auto load_tail = [&](int i, float (&xv)[kWgradUnroll][WM], float (&gv)[kWgradUnroll][WN]) {
+        const int r0 = 2 * ks + half + i * kStep;
 #pragma unroll
         for (int u = 0; u < kWgradUnroll; ++u) {
             const int r = r0 + 2 * KW * u;                       // row inside the slab; past its end -> reads 0
@@ -155,14 +154,36 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float *__restri
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[u][a], xv[u][b], acc[a][b], 0, 0, 0);
             }
     };
-    // two register buffers: the loads of batch i+1 are in flight behind the MFMAs of batch i
-    const int n_batches = (slab_rows - 2 * ks + kStep - 1) / kStep;  // wave-uniform; batches past it read zeros
+    // Two register buffers: the loads of batch i+1 are in flight behind the MFMAs of batch i.  The pipelined loop runs
+    // over the FULL batches only and its loads are unconditional (an index past the last full batch is clamped: the
+    // reload is discarded): with the full/tail choice inside the loop the loads sat in two conditional blocks, the
+    // compiler could not count them and made the MFMAs of batch i wait for the loads of batch i+1 (vmcnt(0)).
+    const int n_batches = (slab_rows - 2 * ks + kStep - 1) / kStep;  // wave-uniform; batches past it would read zeros
+    const int full_span = slab_rows - 2 * ks - 2 - 2 * KW * (kWgradUnroll - 1);  // >= i * kStep  <=>  batch i is full
+    const int n_full = full_span >= 0 ? min(n_batches, full_span / kStep + 1) : 0;
     float xa[kWgradUnroll][WM], ga[kWgradUnroll][WN], xb[kWgradUnroll][WM], gb[kWgradUnroll][WN];
-    load_batch(0, xa, ga);
-    for (int i = 0; i < n_batches; i += 2) {
-        load_batch(i + 1, xb, gb);
-        mfma_batch(xa, ga);
-        load_batch(i + 2, xa, ga);
+    if (n_full > 0) {
+        load_full(0, xa, ga);
+        int i = 0;
+        for (; i + 1 < n_full; i += 2) {  // two batches per trip: A holds batch i on entry
+            // Pin the order.  The loads are side-effect-free intrinsics: without the memory clobber LLVM sinks them to
+            // their first use (behind the MFMAs, one register buffer, zero overlap); the sched_barrier stops the machine
+            // scheduler from doing the same later.
+            load_full(i + 1, xb, gb);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_batch(xa, ga);
+            __builtin_amdgcn_sched_barrier(0);
+            load_full(min(i + 2, n_full - 1), xa, ga);  // (past the end: a discarded reload of the last full batch)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_batch(xb, gb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (i < n_full) mfma_batch(xa, ga);  // odd count: the last full batch sits in A
+    }
+    for (int i = n_full; i < n_batches; ++i) {  // at most two checked tail batches
+        load_tail(i, xb, gb);
         mfma_batch(xb, gb);
     }
 
