@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc ops epoch
+# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc ops epoch e2e sampler
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -36,6 +36,13 @@ if has epoch; then
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_epoch" -o ep -- python "$GRAFT_REPO_ROOT/tools/epoch_probe.py") > gpurun_out/epoch_probe.log 2>&1
   python tools/epoch_breakdown.py "$(find gpurun_out/prof_epoch -name '*kernel_stats.csv' | head -1)" > gpurun_out/epoch_breakdown.txt 2>&1
   tail -3 gpurun_out/epoch_probe.log; cat gpurun_out/epoch_breakdown.txt
+fi
+if has e2e; then
+  (echo "# tools/sage_bench.py (configs[3]) and tools/gat_bench.py (configs[2]) on one MI355X"; timeout 400 python tools/sage_bench.py 2>&1 | tail -1; timeout 300 python tools/sage_bench.py --batch 8192 --steps 30 2>&1 | tail -1; timeout 600 python tools/gat_bench.py 2>&1 | tail -5) > gpurun_out/e2e.txt 2>&1
+  cat gpurun_out/e2e.txt | cut -c1-300
+fi
+if has sampler; then
+  timeout 600 python tools/sampler_bench.py > gpurun_out/sampler_bench.txt 2>&1; tail -10 gpurun_out/sampler_bench.txt
 fi
 if has pmc; then
   for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
