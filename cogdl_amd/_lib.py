@@ -118,6 +118,23 @@ def workspace(query, device, *args):
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
 
+class _NoCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_CTX = _NoCtx()
+
+
+def on_device(dev):
+    """Context that makes `dev` the current HIP device for a launch -- a no-op object when it already is (the usual
+    case: two device switches per operator call are measurable when an epoch is ~100 launches)."""
+    return _NO_CTX if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+
 def ptr(t):
     """Raw address of a tensor's first element (None -> NULL)."""
     return None if t is None else t.data_ptr()

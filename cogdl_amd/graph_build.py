@@ -26,7 +26,7 @@ def coo2csr_index(row, col, num_nodes=None):
     lib = _lib.hip()
     ws_bytes = lib.cogdl_hip_coo2csr_index_workspace_bytes(nnz, num_nodes)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.cogdl_hip_coo2csr_index(_lib.ptr(row), nnz, num_nodes, _lib.ptr(row_ptr), _lib.ptr(perm), _lib.ptr(bad),
                                          _lib.ptr(ws), ws_bytes, _lib.stream_of(row))
     _lib.check(rc, "coo2csr_index")

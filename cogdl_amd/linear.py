@@ -30,7 +30,7 @@ def linear_wgrad(x, grad_out, want_bias=True):
     grad_w = torch.empty((out_f, in_f), dtype=torch.float32, device=dev)
     grad_b = torch.empty(out_f, dtype=torch.float32, device=dev) if want_bias else None
     ws, ws_bytes = _lib.workspace("cogdl_hip_linear_wgrad_workspace_bytes", dev, k, in_f, out_f)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.hip().cogdl_hip_linear_wgrad_f32(_lib.ptr(x), _lib.ptr(grad_out), _lib.ptr(grad_w), _lib.ptr(grad_b), k,
                                                    in_f, out_f, _lib.ptr(ws), ws_bytes, _lib.stream_of(x))
     _lib.check(rc, "linear_wgrad")
@@ -48,7 +48,7 @@ def tall_skinny_matmul(x, w, bias, w_is_n_by_k):
     rows, k = x.shape
     n = w.shape[0] if w_is_n_by_k else w.shape[1]
     out = torch.empty((rows, n), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.hip().cogdl_hip_linear_fwd_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out), rows, k, n,
                                                  1 if w_is_n_by_k else 0, _lib.stream_of(x))
     if rc == ERANGE:

@@ -18,7 +18,7 @@ def _launch(fn_name, rowptr, a, g=None):
     m, (nnz, h) = rowptr.numel() - 1, a.shape
     fn = getattr(_lib.hip(), fn_name)
     ws, ws_bytes = _lib.workspace("cogdl_hip_edge_softmax_workspace_bytes", dev, nnz, h)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         if g is None:
             rc = fn(_lib.ptr(rowptr), _lib.ptr(a), _lib.ptr(out), m, nnz, h, _lib.ptr(ws), ws_bytes,
                     _lib.stream_of(a))

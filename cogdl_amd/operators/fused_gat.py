@@ -30,7 +30,7 @@ def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat):
     edge_sum = torch.empty((v, h), dtype=torch.float32, device=dev)
     nnz, code = col_ind.numel(), _lib.DTYPE_CODE[feat.dtype]
     ws, ws_bytes = _lib.workspace("cogdl_hip_gat_fwd_workspace_bytes", dev, nnz, h, f, code)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.hip().cogdl_hip_gat_fwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(attn_row),
                                           _lib.ptr(attn_col), _lib.ptr(feat), float(negative_slope), _lib.ptr(out),
                                           _lib.ptr(edge_max), _lib.ptr(edge_sum), v, h, f, nnz, code,
@@ -79,7 +79,7 @@ class FusedGATFunction(torch.autograd.Function):
         nnz = col_ind.numel()
         ws_bytes = lib.cogdl_hip_gat_bwd_workspace_bytes(v, h, f, nnz)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = lib.cogdl_hip_gat_bwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(plan.colptr),
                                        _lib.ptr(plan.rowind), _lib.ptr(ar), _lib.ptr(ac), _lib.ptr(feat),
                                        ctx.negative_slope, _lib.ptr(edge_max), _lib.ptr(edge_sum), _lib.ptr(o),

@@ -31,7 +31,7 @@ def mhspmm_raw(rowptr, colind, att, feat, eid=None):
     out = torch.empty((v, h, f), dtype=feat.dtype, device=dev)
     ws, ws_bytes = _lib.workspace("cogdl_hip_mhspmm_workspace_bytes", dev, colind.numel(), h, f,
                                   _lib.DTYPE_CODE[feat.dtype])
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.hip().cogdl_hip_mhspmm_eid(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(att), _lib.ptr(eid),
                                              _lib.ptr(feat), _lib.ptr(out), v, h, f, colind.numel(),
                                              _lib.DTYPE_CODE[feat.dtype], _lib.ptr(ws), ws_bytes, _lib.stream_of(feat))
@@ -45,7 +45,7 @@ def mhsddmm_raw(rowptr, colind, grad, feat):
     v, (_, h, f) = rowptr.numel() - 1, feat.shape
     nnz = colind.numel()
     out = torch.empty((nnz, h), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.hip().cogdl_hip_mhsddmm(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(grad), _lib.ptr(feat),
                                           _lib.ptr(out), v, h, f, nnz, _lib.stream_of(feat))
     _lib.check(rc, "mhsddmm")

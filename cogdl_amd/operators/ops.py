@@ -79,7 +79,7 @@ def _gspmm(plan, colind, x, efeat, ef_scalar, weight, op, mean, k):
     out = torch.empty((plan.n, k), dtype=torch.float32, device=dev)
     ws, ws_bytes = _lib.workspace("cogdl_hip_gspmm_workspace_bytes", dev, nnz, k)
     eid = None if plan.sorted else plan.perm
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.hip().cogdl_hip_gspmm(_lib.ptr(plan.rowptr), _lib.ptr(colind), _lib.ptr(eid), _lib.ptr(x),
                                         _lib.ptr(efeat), int(ef_scalar), _lib.ptr(weight), op, int(mean),
                                         _lib.ptr(out), plan.n, k, nnz, _lib.ptr(ws), ws_bytes,

@@ -75,7 +75,7 @@ def _sample_adj_gpu(indptr, indices, node_idx, num_neighbors, replace, seed):
     lib = _lib.hip()
     ws_bytes = lib.cogdl_hip_sample_adj_workspace_bytes(b, cap_e, n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.cogdl_hip_sample_adj(_lib.ptr(indptr), _lib.ptr(indices), n, _lib.ptr(node_idx), b, num_neighbors,
                                       int(bool(replace)), seed, _lib.ptr(out_indptr), _lib.ptr(out_indices),
                                       _lib.ptr(out_nodes), _lib.ptr(out_edges), cap_e, _lib.ptr(counts),

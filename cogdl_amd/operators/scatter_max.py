@@ -19,7 +19,7 @@ def scatter_max_fp(rowptr, colind, feat):
     max_id = torch.empty((m, k), dtype=torch.int32, device=dev)
     nnz = colind.numel()
     ws, ws_bytes = _lib.workspace("cogdl_hip_scatter_max_workspace_bytes", dev, nnz, k)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.hip().cogdl_hip_scatter_max_fwd(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(feat), _lib.ptr(out),
                                                   _lib.ptr(max_id), m, k, nnz, _lib.ptr(ws), ws_bytes,
                                                   _lib.stream_of(feat))
@@ -32,7 +32,7 @@ def scatter_max_bp(grad, max_id, n_src):
     grad = grad.contiguous().float()
     m, k = grad.shape
     out = torch.empty((n_src, k), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.hip().cogdl_hip_scatter_max_bwd(_lib.ptr(grad), _lib.ptr(max_id), _lib.ptr(out), m, k, n_src,
                                                   _lib.stream_of(grad))
     _lib.check(rc, "scatter_max_bwd")

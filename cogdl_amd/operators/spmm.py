@@ -59,7 +59,7 @@ def csr_spmm_raw(rowptr, colind, val, x, variant=-1, out=None, split_long_rows=T
     code = _lib.DTYPE_CODE[x.dtype]
     ws, ws_bytes = (_lib.workspace("cogdl_hip_csr_spmm_workspace_bytes", dev, nnz, k, code) if split_long_rows
                     else (None, 0))
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         if KERNEL_EVENTS is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -85,7 +85,7 @@ def csr_sddmm_raw(rowptr, colind, d1, d2):
     m, k = rowptr.numel() - 1, d1.shape[1]
     nnz = colind.numel()
     out = torch.empty(nnz, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.hip().cogdl_hip_csr_sddmm(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(d1), _lib.ptr(d2),
                                             _lib.ptr(out), m, k, nnz, _lib.stream_of(d1))
     _lib.check(rc, "csr_sddmm")

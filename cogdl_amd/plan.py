@@ -63,7 +63,7 @@ def csr2csc(rowptr, colind, n_cols=None):
     lib = _lib.hip()
     ws_bytes = lib.cogdl_hip_csr2csc_workspace_bytes(m, n_cols, nnz)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.cogdl_hip_csr2csc(_lib.ptr(rowptr), _lib.ptr(colind), m, n_cols, nnz, _lib.ptr(colptr),
                                    _lib.ptr(rowind), _lib.ptr(perm), _lib.ptr(ws), ws_bytes, _lib.stream_of(rowptr))
     _lib.check(rc, "csr2csc")
@@ -77,7 +77,7 @@ def gather_rows(perm, src):
     out = torch.empty_like(src)
     n = perm.numel()
     h = src.numel() // max(n, 1) if n else 0
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.hip().cogdl_hip_gather_rows(_lib.ptr(perm), _lib.ptr(src), _lib.ptr(out), n, h,
                                               src.element_size(), _lib.stream_of(src))
     _lib.check(rc, "gather_rows")
@@ -87,26 +87,47 @@ def gather_rows(perm, src):
 FINGERPRINT_PARTS = 256  # COGDL_HIP_FINGERPRINT_PARTS
 
 
+_PINNED_POOL = []  # recycled [FINGERPRINT_PARTS] int64 pinned buffers (+ their events): no host allocation per call
+
+
 class Fingerprint:
     """A structure hash in flight: the kernel writes its per-workgroup partials straight into pinned host memory
-    (device-visible on ROCm: no memset, no device-to-host copy kernel); an event guards them."""
-    __slots__ = ("host", "event", "meta")
+    (device-visible on ROCm: no memset, no device-to-host copy kernel); an event guards them.  Buffers and events are
+    recycled through a small pool when the Fingerprint dies (a pinned allocation per forward call is ~10 us of host
+    time, and a training epoch is launch-bound)."""
+    __slots__ = ("host", "event", "meta", "_key")
 
     def __init__(self, rowptr, colind, n_cols):
         dev = rowptr.device
         m, nnz = rowptr.numel() - 1, colind.numel()
-        self.host = torch.empty(FINGERPRINT_PARTS, dtype=torch.int64, pin_memory=True)
-        with torch.cuda.device(dev):
+        if _PINNED_POOL:
+            self.host, self.event = _PINNED_POOL.pop()
+        else:
+            self.host = torch.empty(FINGERPRINT_PARTS, dtype=torch.int64, pin_memory=True)
+            self.event = torch.cuda.Event()
+        stream = torch.cuda.current_stream(dev)
+        with _lib.on_device(dev):
             rc = _lib.hip().cogdl_hip_csr_fingerprint(_lib.ptr(rowptr), _lib.ptr(colind), m, nnz,
-                                                      self.host.data_ptr(), _lib.stream_of(rowptr))
+                                                      self.host.data_ptr(), stream.cuda_stream)
         _lib.check(rc, "csr_fingerprint")
-        self.event = torch.cuda.Event()
-        self.event.record(torch.cuda.current_stream(dev))
+        self.event.record(stream)
         self.meta = (dev.index, m, nnz, int(n_cols))
+        self._key = None
 
     def key(self):
-        self.event.synchronize()
-        return self.meta + (int(self.host.sum()),)  # int64 sum wraps: the sum modulo 2^64
+        if self._key is None:
+            self.event.synchronize()
+            self._key = self.meta + (int(self.host.sum()),)  # int64 sum wraps: the sum modulo 2^64
+        return self._key
+
+    def __del__(self):
+        # Back to the pool -- but only once the kernel that writes the buffer is known to be done (else a recycled
+        # buffer could be overwritten late); a buffer whose event has not fired yet is simply dropped.
+        try:
+            if len(_PINNED_POOL) < 64 and (self._key is not None or self.event.query()):
+                _PINNED_POOL.append((self.host, self.event))
+        except Exception:  # interpreter shutdown
+            pass
 
 
 class PlanCache:
