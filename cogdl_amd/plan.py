@@ -36,6 +36,7 @@ class CscPlan:
         the backward SpMM runs without the chunk-parallel path: no scratch, no combine launch."""
         if self._max_col_degree is None:
             self._max_col_degree = int((self.colptr[1:] - self.colptr[:-1]).max()) if self.n_cols else 0
+        # (the threshold is re-read every call: tests move it through the tuning knobs)
         return self._max_col_degree > _lib.hip().cogdl_hip_long_row_threshold(self.nnz)
 
     def transposed_values(self, w):
