@@ -43,17 +43,41 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
     for (int e = threadIdx.x; e < k_pad * 32 * NT; e += 256) bs[e] = 0.f;
     __syncthreads();
     const int w_elems = k_dim * n_dim;
-    for (int e0 = threadIdx.x; e0 < w_elems; e0 += 256 * 8) {
-        float t[8];
+    float *tmp = smem + (size_t)k_pad * 32 * NT;  // the (still unused) x staging area of the four waves
+    const bool via_tmp = w_is_n_by_k && (int64_t)n_dim * (k_dim + 1) <= 4 * 32 * kFwdXsStride;
+    if (via_tmp) {
+        // w is [n][k]: a direct scatter bs[k][n] = w[e] has all lanes of a wave on one bank (k-stride 32 * NT floats:
+        // 64-way conflicts, ~3 us per workgroup for a 32 KB weight).  Two conflict-free hops instead: w -> tmp[n][k] with
+        // an odd row stride (coalesced read, linear write), then tmp -> bs with n running across the lanes.
+        const int ts = k_dim + 1;
+        for (int e0 = threadIdx.x; e0 < w_elems; e0 += 256 * 8) {
+            float t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = (e0 + u * 256 < w_elems) ? w[e0 + u * 256] : 0.f;
+            for (int u = 0; u < 8; ++u) t[u] = (e0 + u * 256 < w_elems) ? w[e0 + u * 256] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * 256;
-            if (e < w_elems) {
-                const int k = w_is_n_by_k ? e % k_dim : e / n_dim;
-                const int n = w_is_n_by_k ? e / k_dim : e % n_dim;
-                bs[k * 32 * NT + (n ^ ((k & 1) * kSwz))] = t[u];
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 256;
+                if (e < w_elems) tmp[(e / k_dim) * ts + e % k_dim] = t[u];
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < w_elems; e += 256) {
+            const int k = e / n_dim, n = e % n_dim;
+            bs[k * 32 * NT + (n ^ ((k & 1) * kSwz))] = tmp[n * ts + k];
+        }
+    } else {
+        for (int e0 = threadIdx.x; e0 < w_elems; e0 += 256 * 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = (e0 + u * 256 < w_elems) ? w[e0 + u * 256] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 256;
+                if (e < w_elems) {
+                    const int k = w_is_n_by_k ? e % k_dim : e / n_dim;
+                    const int n = w_is_n_by_k ? e / k_dim : e % n_dim;
+                    bs[k * 32 * NT + (n ^ ((k & 1) * kSwz))] = t[u];
+                }
             }
         }
     }
