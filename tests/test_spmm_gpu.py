@@ -232,6 +232,14 @@ def test_fingerprint_tracks_content_not_pointers():
     unaligned views (scalar path of the hash) and odd sizes."""
     from cogdl_amd.plan import Fingerprint
 
+    big = synth.arxiv_like(seed=0).to(DEV)  # 2.5 M entries: the unrolled 16-byte stream of the hash kernel
+    kb = Fingerprint(big.rowptr, big.colind, big.num_nodes).key()
+    shifted = torch.empty(big.nnz + 1, dtype=torch.int32, device=DEV)
+    shifted[1:] = big.colind  # same content through the element-wise path
+    assert Fingerprint(big.rowptr, shifted[1:], big.num_nodes).key() == kb
+    c = big.colind.clone()
+    c[big.nnz // 3] ^= 1
+    assert Fingerprint(big.rowptr, c, big.num_nodes).key() != kb
     g = synth.scaled(3001, 9, seed=3).to(DEV)
     k0 = Fingerprint(g.rowptr, g.colind, 3001).key()
     assert Fingerprint(g.rowptr.clone(), g.colind.clone(), 3001).key() == k0
