@@ -76,6 +76,7 @@ struct RowSched {
     int64_t m;
     XcdMap rowblocks;
     LongRows lr;
+    int sort_rows;  // deal a workgroup's rows to its lane groups by decreasing length (see rowreduce_main_kernel)
 };
 
 // Threshold above which a row is split.  The sequential time of a row of T edges (~T/UNROLL gather round trips of
@@ -279,6 +280,9 @@ __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSche
     }
 }
 
+// tuning key 2: 1 = keep the natural row -> lane-group assignment inside a workgroup (experiments)
+__device__ __forceinline__ bool g_sort_rows(const RowSched &s) { return s.sort_rows != 0; }
+
 // Grid: [ n_long_blocks long-row workgroups | row-block workgroups ]  x  column tiles.  The long-row workgroups come
 // first so that the (critical-path) hub rows start at once; they cost a graph without hub rows ~17 dependent
 // L2-resident loads in <= 1024 workgroups, overlapped with the row blocks.
@@ -298,12 +302,52 @@ __global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const 
     const int wave = threadIdx.x >> 6;
     const int sub = lane / LPR;
     const int l = lane % LPR;
-    const int64_t row = rb * GPB + wave * RPW + sub;
-    const bool ok = row < s.m;
+    int64_t row = rb * GPB + wave * RPW + sub;
+    bool ok = row < s.m;
     int start = 0, end = 0;
     if (ok) {
         start = s.rowptr[row];
         end = s.rowptr[row + 1];
+    }
+    if constexpr (RPW > 1) {
+        // Several rows share a wave, and a wave takes as long as its LONGEST row: on a skewed graph a wave with one
+        // 100-edge row and three 5-edge rows idles 70 % of its lanes.  The workgroup's GPB rows are therefore dealt to
+        // the row groups in order of decreasing length (ranks by counting through LDS, ties by row id): wave 0 gets the
+        // RPW longest rows, wave 3 the shortest, the sum over waves of their longest row -- the lane time spent --
+        // drops by 2-3x on R-MAT graphs.  Only the row -> lane-group assignment changes: every row is still reduced
+        // sequentially by one group in CSR order (bit-identical results).
+        if (g_sort_rows(s)) {
+            __shared__ int sort_deg[GPB], sort_start[GPB], sort_slot[GPB];
+            const int slot = wave * RPW + sub;
+            const int deg = ok ? end - start : -1;
+            if (l == 0) {
+                sort_deg[slot] = deg;
+                sort_start[slot] = start;
+            }
+            __syncthreads();
+            // only where it pays: a workgroup whose longest row is well above its mean (uniform graphs skip the ranking
+            // and its second barrier; the test is workgroup-uniform)
+            int dmax = 0, dsum = 0;
+            for (int q = 0; q < GPB; ++q) {
+                const int dq = max(sort_deg[q], 0);
+                dmax = max(dmax, dq);
+                dsum += dq;
+            }
+            if (dmax * GPB >= 2 * dsum + 8 * GPB) {
+                int rank = 0;
+                for (int q = 0; q < GPB; ++q) {
+                    const int dq = sort_deg[q];
+                    rank += (dq > deg || (dq == deg && q < slot)) ? 1 : 0;
+                }
+                if (l == 0) sort_slot[rank] = slot;
+                __syncthreads();
+                const int mine = sort_slot[slot];  // the row (by its natural slot) this group reduces
+                row = rb * GPB + mine;
+                ok = sort_deg[mine] >= 0;
+                start = sort_start[mine];
+                end = start + max(sort_deg[mine], 0);
+            }
+        }
     }
     if constexpr (LPR == kWave) {  // whole wave on one row: make the loop bounds scalar
         start = __builtin_amdgcn_readfirstlane(start);
@@ -391,6 +435,7 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
     s.colind = colind;
     s.m = m;
     s.rowblocks = make_xcd_map(n_rowblocks);
+    s.sort_rows = g_tuning[kTuneRowSort] == 0 ? 1 : 0;
     s.lr.thresh = INT_MAX;
     if (nnz > 0 && (!Op::kReduce || workspace)) {
         plan_long_rows(s.lr, nnz);

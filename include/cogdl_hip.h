@@ -59,7 +59,8 @@ COGDL_API const char *cogdl_hip_strerror(int status);
 /* hipError_t of the most recent COGDL_HIP_ELAUNCH on this thread (0 if none). */
 COGDL_API int cogdl_hip_last_hip_error(void);
 /* Run-time tuning knobs for experiments and tests: key 0 = XCD stripe of the row-block -> workgroup map (0 = hardware
- * round-robin, default 32), key 1 = long-row threshold override (0 = automatic), key 3 = cap on the number of
+ * round-robin, default 32), key 1 = long-row threshold override (0 = automatic), key 2 = 1: keep the natural row -> lane-group assignment
+ * inside a workgroup (default 0: rows dealt by decreasing length), key 3 = cap on the number of
  * long-row workgroups (default 1024), key 4 = cap on the fused-GAT vector width (0 = widest), key 5 = fused-GAT
  * forward kernel (0 = automatic, 1 = edge-wise online softmax, 2 = chunk-wise softmax where the shape allows),
  * key 6 = csr_spmm/mhspmm vector width cap (negative: force), key 7 = edge_softmax lane width (bit 0: 4-byte lanes in
