@@ -280,6 +280,40 @@ __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSche
     }
 }
 
+// Deal the GPB rows of a workgroup to its GPB lane groups by decreasing length -- if the workgroup is skewed (longest
+// row well above the mean; the test is workgroup-uniform, uniform graphs pay one barrier and one pass over GPB LDS
+// words).  `slot` = this group's natural position, `leader` = one lane per group.  On return (true) `mine` is the
+// natural position of the row this group now owns and (ok, start, end) describe that row.  Called by ALL threads.
+template <int GPB>
+__device__ __forceinline__ bool deal_rows_by_length(int slot, bool leader, bool &ok, int &start, int &end, int &mine) {
+    __shared__ int sort_deg[GPB], sort_start[GPB], sort_slot[GPB];
+    const int deg = ok ? end - start : -1;
+    if (leader) {
+        sort_deg[slot] = deg;
+        sort_start[slot] = start;
+    }
+    __syncthreads();
+    int dmax = 0, dsum = 0;
+    for (int q = 0; q < GPB; ++q) {
+        const int dq = max(sort_deg[q], 0);
+        dmax = max(dmax, dq);
+        dsum += dq;
+    }
+    if (dmax * GPB < 2 * dsum + 8 * GPB) return false;
+    int rank = 0;  // by (length descending, natural position ascending)
+    for (int q = 0; q < GPB; ++q) {
+        const int dq = sort_deg[q];
+        rank += (dq > deg || (dq == deg && q < slot)) ? 1 : 0;
+    }
+    if (leader) sort_slot[rank] = slot;
+    __syncthreads();
+    mine = sort_slot[slot];
+    ok = sort_deg[mine] >= 0;
+    start = sort_start[mine];
+    end = start + max(sort_deg[mine], 0);
+    return true;
+}
+
 // tuning key 2: 1 = keep the natural row -> lane-group assignment inside a workgroup (experiments)
 __device__ __forceinline__ bool g_sort_rows(const RowSched &s) { return s.sort_rows != 0; }
 
@@ -317,36 +351,8 @@ __global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const 
         // drops by 2-3x on R-MAT graphs.  Only the row -> lane-group assignment changes: every row is still reduced
         // sequentially by one group in CSR order (bit-identical results).
         if (g_sort_rows(s)) {
-            __shared__ int sort_deg[GPB], sort_start[GPB], sort_slot[GPB];
-            const int slot = wave * RPW + sub;
-            const int deg = ok ? end - start : -1;
-            if (l == 0) {
-                sort_deg[slot] = deg;
-                sort_start[slot] = start;
-            }
-            __syncthreads();
-            // only where it pays: a workgroup whose longest row is well above its mean (uniform graphs skip the ranking
-            // and its second barrier; the test is workgroup-uniform)
-            int dmax = 0, dsum = 0;
-            for (int q = 0; q < GPB; ++q) {
-                const int dq = max(sort_deg[q], 0);
-                dmax = max(dmax, dq);
-                dsum += dq;
-            }
-            if (dmax * GPB >= 2 * dsum + 8 * GPB) {
-                int rank = 0;
-                for (int q = 0; q < GPB; ++q) {
-                    const int dq = sort_deg[q];
-                    rank += (dq > deg || (dq == deg && q < slot)) ? 1 : 0;
-                }
-                if (l == 0) sort_slot[rank] = slot;
-                __syncthreads();
-                const int mine = sort_slot[slot];  // the row (by its natural slot) this group reduces
-                row = rb * GPB + mine;
-                ok = sort_deg[mine] >= 0;
-                start = sort_start[mine];
-                end = start + max(sort_deg[mine], 0);
-            }
+            int mine;
+            if (deal_rows_by_length<GPB>(wave * RPW + sub, l == 0, ok, start, end, mine)) row = rb * GPB + mine;
         }
     }
     if constexpr (LPR == kWave) {  // whole wave on one row: make the loop bounds scalar
