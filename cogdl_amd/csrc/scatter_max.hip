@@ -106,6 +106,96 @@ struct ScatterMaxOp {
     }
 };
 
+// Backward as a GATHER over the transposed structure (colptr / rowind from cogdl_hip_csr2csc): source node u sums
+// grad[v, c] over its out-edges (u -> v) whose forward winner was u.  No atomics, no zero-fill (every element of
+// grad_src is written once), contributions added in ascending v -- the order of the sequential reference loop -- so
+// rows up to the long-row threshold are bit-identical to it and the result is the same on every run.  A multi-edge
+// (u, v) appears as adjacent CSC entries (the transpose is stable) and counts once, as one winner does.
+// Algorithmic bytes per edge: 4 + F * 4 (grad row) + F * 4 (max_id row): twice the forward's.
+template <int VEC_, int LPR_, int UNROLL_>
+struct ScatterMaxBwdOp {
+    static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_;
+    static constexpr bool kReduce = true;
+    static constexpr int kLds = 0;
+    const int32_t *colptr;
+    const int32_t *rowind;
+    const float *grad;
+    const int32_t *max_id;
+    float *out;
+    int k;
+
+    struct Ctx {
+        int col0, row, start;
+        bool col_ok;
+        const float *gcol;
+        const int32_t *mcol;
+    };
+    struct State { float acc[VEC]; };
+    struct LaneVals { int prev; };
+    struct Batch {
+        float g[UNROLL][VEC];
+        int id[UNROLL][VEC];
+        bool dup[UNROLL];
+    };
+
+    __device__ __forceinline__ Ctx make_ctx(int l, int tile) const {
+        Ctx c;
+        c.col0 = (tile * LPR + l) * VEC;
+        c.col_ok = c.col0 < k;
+        const int cc = c.col_ok ? c.col0 : 0;
+        c.gcol = grad + cc;
+        c.mcol = max_id + cc;
+        c.row = -1;
+        c.start = 0;
+        return c;
+    }
+    __device__ __forceinline__ void row_load(Ctx &c, int64_t row, bool ok) const {
+        c.row = (int)row;
+        c.start = ok ? colptr[row] : 0;
+    }
+    __device__ __forceinline__ void init_zero(State &s) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.acc[i] = 0.f;
+    }
+    __device__ __forceinline__ void init(const Ctx &, State &s, int64_t, bool) const { init_zero(s); }
+    __device__ __forceinline__ void lane_load(const Ctx &c, LaneVals &lv, int64_t e) const {
+        lv.prev = (e > c.start) ? rowind[e - 1] : -1;  // the entry before e in the same column (multi-edge test)
+    }
+    __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t, const LaneVals &lv, int sub,
+                                          int jj) const {
+        b.dup[u] = group_bcast<LPR>(lv.prev, sub, jj) == col;
+        load_vec<float, VEC>(c.gcol + (int64_t)col * k, b.g[u]);
+        float t[VEC];
+        load_vec<float, VEC>(reinterpret_cast<const float *>(c.mcol) + (int64_t)col * k, t);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) b.id[u][i] = __float_as_int(t[i]);
+    }
+    __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
+                                          int) const {
+        const bool take = valid && !b.dup[u];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.acc[i] = s.acc[i] + ((take && b.id[u][i] == c.row) ? b.g[u][i] : 0.f);
+    }
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
+    __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
+    __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
+    __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
+        if (ok && c.col_ok) store_vec<float, VEC>(out + row * (int64_t)k + c.col0, s.acc);
+    }
+    __device__ __forceinline__ void pack(const State &s, float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) rec[i] = s.acc[i];
+    }
+    __device__ __forceinline__ void unpack(State &s, const float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.acc[i] = rec[i];
+    }
+    __device__ __forceinline__ void merge(const Ctx &, State &a, const State &b) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) a.acc[i] += b.acc[i];
+    }
+};
+
 __global__ void scatter_max_bwd_kernel(const float *__restrict__ grad, const int32_t *__restrict__ max_id,
                                        float *__restrict__ grad_src, int64_t total, int k) {
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -148,6 +238,30 @@ static int dispatch_smax(const SmaxArgs &a, const RowGeometry &g, void *ws, size
         case 16: return launch_smax<VEC, 16>(a, g.tiles, ws, wsb, s);
         case 32: return launch_smax<VEC, 32>(a, g.tiles, ws, wsb, s);
         default: return launch_smax<VEC, 64>(a, g.tiles, ws, wsb, s);
+    }
+}
+
+struct SmaxBwdArgs {
+    const int32_t *colptr, *rowind;
+    const float *grad;
+    const int32_t *max_id;
+    float *out;
+    int64_t n_src, k, nnz;
+};
+
+template <int VEC, int LPR>
+static int launch_smax_bwd(const SmaxBwdArgs &a, int64_t tiles, void *ws, size_t wsb, hipStream_t s) {
+    ScatterMaxBwdOp<VEC, LPR, 4> op{a.colptr, a.rowind, a.grad, a.max_id, a.out, (int)a.k};  // two gathers per edge
+    return launch_rowreduce(op, a.colptr, a.rowind, a.n_src, a.nnz, tiles, ws, wsb, s);
+}
+
+template <int VEC>
+static int dispatch_smax_bwd(const SmaxBwdArgs &a, const RowGeometry &g, void *ws, size_t wsb, hipStream_t s) {
+    switch (g.lpr) {
+        case 8: return launch_smax_bwd<VEC, 8>(a, g.tiles, ws, wsb, s);
+        case 16: return launch_smax_bwd<VEC, 16>(a, g.tiles, ws, wsb, s);
+        case 32: return launch_smax_bwd<VEC, 32>(a, g.tiles, ws, wsb, s);
+        default: return launch_smax_bwd<VEC, 64>(a, g.tiles, ws, wsb, s);
     }
 }
 }  // namespace cogdl
@@ -196,4 +310,29 @@ extern "C" int cogdl_hip_scatter_max_bwd(const float *grad, const int32_t *max_i
     const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(scatter_max_bwd_kernel, dim3(blocks), dim3(256), 0, s, grad, max_id, grad_src, total, (int)k);
     return launch_status();
+}
+
+extern "C" size_t cogdl_hip_scatter_max_bwd_workspace_bytes(int64_t nnz, int64_t k) {
+    if (nnz <= 0 || k <= 0) return 0;
+    const RowGeometry g = smax_geometry(k, 16);
+    return rowreduce_workspace_bytes(nnz, g.tiles * g.vec * g.lpr);
+}
+
+extern "C" int cogdl_hip_scatter_max_bwd_csc(const int32_t *colptr, const int32_t *rowind, const float *grad,
+                                             const int32_t *max_id, float *grad_src, int64_t n_src, int64_t k,
+                                             int64_t nnz, void *workspace, size_t workspace_bytes, void *stream) {
+    if (n_src < 0 || k < 0 || nnz < 0) return COGDL_HIP_EINVAL;
+    if (n_src == 0 || k == 0) return COGDL_HIP_OK;
+    if (!colptr || !grad_src || (nnz > 0 && (!rowind || !grad || !max_id))) return COGDL_HIP_EINVAL;
+    if (k > 0x7fffffff || nnz > 0x7fffffff) return COGDL_HIP_ERANGE;
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(max_id) |
+                           reinterpret_cast<uintptr_t>(grad_src);
+    const RowGeometry g = smax_geometry(k, (bits % 16 == 0) ? 16 : (bits % 8 == 0) ? 8 : 4);
+    SmaxBwdArgs a{colptr, rowind, grad, max_id, grad_src, n_src, k, nnz};
+    hipStream_t s = (hipStream_t)stream;
+    switch (g.vec) {
+        case 4: return dispatch_smax_bwd<4>(a, g, workspace, workspace_bytes, s);
+        case 2: return dispatch_smax_bwd<2>(a, g, workspace, workspace_bytes, s);
+        default: return dispatch_smax_bwd<1>(a, g, workspace, workspace_bytes, s);
+    }
 }

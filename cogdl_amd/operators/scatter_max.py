@@ -3,6 +3,7 @@
 import torch
 
 from .. import _lib
+from ..plan import PLANS, Fingerprint
 
 _lib.hip()
 
@@ -28,6 +29,8 @@ def scatter_max_fp(rowptr, colind, feat):
 
 
 def scatter_max_bp(grad, max_id, n_src):
+    """The reference's formulation (one fp32 atomic per element into a zeroed buffer); kept for callers without the
+    graph structure at hand.  The autograd Function uses scatter_max_bp_csc."""
     dev = _lib.require_cuda(grad, max_id)
     grad = grad.contiguous().float()
     m, k = grad.shape
@@ -39,18 +42,37 @@ def scatter_max_bp(grad, max_id, n_src):
     return out
 
 
+def scatter_max_bp_csc(colptr, rowind, grad, max_id, n_src):
+    """The backward as a gather over the transposed structure: no atomics, no zero-fill, deterministic (and equal to
+    the sequential reference loop bit for bit while a source node has at most `long-row threshold` out-edges)."""
+    dev = _lib.require_cuda(colptr, rowind, grad, max_id)
+    grad = grad.contiguous().float()
+    k, nnz = grad.shape[1], rowind.numel()
+    out = torch.empty((n_src, k), dtype=torch.float32, device=dev)
+    ws, ws_bytes = _lib.workspace("cogdl_hip_scatter_max_bwd_workspace_bytes", dev, nnz, k)
+    with _lib.on_device(dev):
+        rc = _lib.hip().cogdl_hip_scatter_max_bwd_csc(_lib.ptr(colptr), _lib.ptr(rowind), _lib.ptr(grad),
+                                                      _lib.ptr(max_id), _lib.ptr(out), n_src, k, nnz, _lib.ptr(ws),
+                                                      ws_bytes, _lib.stream_of(grad))
+    _lib.check(rc, "scatter_max_bwd_csc")
+    return out
+
+
 class ScatterMaxFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rowptr, colind, feat):
+        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None  # before the kernel
         out, max_id = scatter_max_fp(rowptr, colind, feat)
-        ctx.save_for_backward(max_id)
+        ctx.save_for_backward(max_id, rowptr, colind)
         ctx.n_src = feat.shape[0]
         return out
 
     @staticmethod
     def backward(ctx, grad):
-        (max_id,) = ctx.saved_tensors
-        return None, None, scatter_max_bp(grad, max_id, ctx.n_src)
+        max_id, rowptr, colind = ctx.saved_tensors
+        # the cached transpose of the structure (the plan SpMM's backward uses, too) turns the scatter into a gather
+        plan = PLANS.get(ctx.fp, rowptr, colind, ctx.n_src)
+        return None, None, scatter_max_bp_csc(plan.colptr, plan.rowind, grad, max_id, ctx.n_src)
 
 
 def scatter_max(rowptr, colind, feat):

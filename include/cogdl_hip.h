@@ -182,6 +182,14 @@ COGDL_API int cogdl_hip_scatter_max_fwd(const int32_t *rowptr, const int32_t *co
                               void *workspace, size_t workspace_bytes, void *stream);
 COGDL_API int cogdl_hip_scatter_max_bwd(const float *grad, const int32_t *max_id, float *grad_src, int64_t m,
                               int64_t k, int64_t n_src, void *stream);
+/* The same backward as a gather over the transposed structure (colptr[n_src+1], rowind[nnz] of cogdl_hip_csr2csc):
+ * grad_src[u,c] = sum over the out-edges (u -> v) with max_id[v,c] == u of grad[v,c], in ascending v.  No atomics and no
+ * zero-fill: deterministic, and bit-identical to the sequential reference loop for rows up to the long-row threshold.
+ * A multi-edge counts once.  workspace: cogdl_hip_scatter_max_bwd_workspace_bytes (optional, hub rows). */
+COGDL_API size_t cogdl_hip_scatter_max_bwd_workspace_bytes(int64_t nnz, int64_t k);
+COGDL_API int cogdl_hip_scatter_max_bwd_csc(const int32_t *colptr, const int32_t *rowind, const float *grad,
+                                  const int32_t *max_id, float *grad_src, int64_t n_src, int64_t k, int64_t nnz,
+                                  void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * gspmm ("source OP edge feature, then aggregate"): the s_{add,sub,mul}_e_{sum,mean} operators and scatter_add of

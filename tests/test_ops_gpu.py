@@ -8,7 +8,7 @@ import torch
 from cogdl_amd import synth
 from cogdl_amd.operators.edge_softmax import csr_edge_softmax
 from cogdl_amd.operators.mhspmm import csrmhspmm, mhsddmm_raw, mhspmm_raw
-from cogdl_amd.operators.scatter_max import scatter_max, scatter_max_bp, scatter_max_fp
+from cogdl_amd.operators.scatter_max import scatter_max, scatter_max_bp, scatter_max_bp_csc, scatter_max_fp
 from cogdl_amd.operators.spmm import csr_sddmm_raw
 from cogdl_amd.plan import csr2csc, gather_rows
 
@@ -169,7 +169,9 @@ def test_scatter_max_fwd_bwd(oracle, k):
     np.testing.assert_allclose(got_g, want_g, rtol=1e-5, atol=1e-5)  # atomics: order differs
     xd = x.to(DEV).requires_grad_()
     scatter_max(g.rowptr.to(DEV), g.colind.to(DEV), xd).backward(gr.to(DEV))
-    np.testing.assert_allclose(xd.grad.cpu().numpy(), want_g, rtol=1e-5, atol=1e-5)
+    # the autograd path gathers over the cached transpose: no atomics, ascending-row order = the reference loop's
+    # (random_csr has multi-edges: a duplicated winner edge must count once)
+    assert xd.grad.cpu().numpy().tobytes() == want_g.tobytes()
 
 
 def test_scatter_max_all_negative_rows_are_true_max(oracle):
@@ -278,6 +280,30 @@ def test_hub_rows_sddmm_scatter_max(oracle, hubs, k):
     out, idx = scatter_max_fp(rp, ci, d2.to(DEV))
     assert out.cpu().numpy().tobytes() == want.tobytes()
     assert np.array_equal(idx.cpu().numpy(), want_id)
+
+
+@pytest.mark.parametrize("hubs", HUBS)
+@pytest.mark.parametrize("k", [8, 100])
+def test_scatter_max_bwd_gather_hub_sources(oracle, hubs, k):
+    """The gather formulation of the backward on SOURCE nodes with thousands of out-edges (and many multi-edges): exact
+    up to the long-row threshold, re-association only beyond it, run-to-run identical."""
+    from cogdl_amd import _lib
+
+    gt = synth.hub_csr(60, 70, hubs=hubs, seed=k, weighted=False)  # row u of gt = the out-edges of source u
+    colptr, rowind, _, _ = oracle.csr2csc(gt.rowptr, gt.colind, None, n_cols=70)  # forward structure: 70 dst x 60 src
+    rp, ci = torch.from_numpy(colptr).to(DEV), torch.from_numpy(rowind).to(DEV)
+    x, gr = rand(60, k, seed=3), rand(70, k, seed=4)
+    _, idx = scatter_max_fp(rp, ci, x.to(DEV))
+    want = oracle.scatter_max_bwd(gr, idx.cpu().numpy(), 60)
+    plan = csr2csc(rp, ci, 60)
+    got = scatter_max_bp_csc(plan.colptr, plan.rowind, gr.to(DEV), idx, 60)
+    assert torch.equal(got, scatter_max_bp_csc(plan.colptr, plan.rowind, gr.to(DEV), idx, 60))
+    got = got.cpu().numpy()
+    short = np.diff(gt.rowptr.numpy()) <= _lib.hip().cogdl_hip_long_row_threshold(gt.nnz)
+    assert got[short].tobytes() == want[short].tobytes()
+    scale = oracle.scatter_max_bwd(gr.abs(), idx.cpu().numpy(), 60)
+    assert np.all(np.abs(got - want) <= 1e-5 * scale + 1e-12)
+    np.testing.assert_allclose(scatter_max_bp(gr.to(DEV), idx, 60).cpu().numpy(), want, rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("hubs", HUBS)

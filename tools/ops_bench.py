@@ -13,7 +13,7 @@ from cogdl_amd import synth  # noqa: E402
 from cogdl_amd.operators.edge_softmax import _launch as es_launch  # noqa: E402
 from cogdl_amd.operators.fused_gat import FusedGATFunction, gat_forward  # noqa: E402
 from cogdl_amd.operators.mhspmm import mhsddmm_raw, mhspmm_raw  # noqa: E402
-from cogdl_amd.operators.scatter_max import scatter_max_bp, scatter_max_fp  # noqa: E402
+from cogdl_amd.operators.scatter_max import scatter_max_bp, scatter_max_bp_csc, scatter_max_fp  # noqa: E402
 from cogdl_amd.operators.spmm import csr_sddmm_raw, csr_spmm_raw  # noqa: E402
 from cogdl_amd.plan import csr2csc, gather_rows  # noqa: E402
 
@@ -69,7 +69,10 @@ def arxiv():
                 report("scatter_max_fwd", cfg, timeit(lambda: scatter_max_fp(g.rowptr, g.colind, x)),
                        nnz * (4 + f * 4) + n * (4 + f * 4 + f * 4), nnz)
                 _, mid = scatter_max_fp(g.rowptr, g.colind, x)
-                report("scatter_max_bwd", cfg, timeit(lambda: scatter_max_bp(y, mid, n)), n * f * (4 + 4 + 4 + 4), nnz)
+                report("scatter_max_bwd(atomic)", cfg, timeit(lambda: scatter_max_bp(y, mid, n)), n * f * (4 + 4 + 4 + 4), nnz)
+                tplan = csr2csc(g.rowptr, g.colind, n)
+                report("scatter_max_bwd(gather)", cfg, timeit(lambda: scatter_max_bp_csc(tplan.colptr, tplan.rowind, y, mid, n)),
+                       nnz * (4 + 2 * f * 4) + n * (4 + f * 4), nnz)
         # message operators (cogdl/operators/ops.py): fused kernel vs the reference's torch composition on the GPU
         from cogdl_amd.operators import ops as mops
         import types
