@@ -9,7 +9,9 @@
 //     row blocks               one group of Op::LPR lanes per row ("row group"), 64/LPR rows per wave, 4 waves per
 //                              workgroup; colind (and per-edge scalars) are read in coalesced chunks of LPR edges and
 //                              broadcast lane-to-lane; gathers are issued Op::UNROLL at a time; the state is updated
-//                              strictly in CSR edge order.  Rows longer than `thresh` edges are skipped.
+//                              strictly in CSR edge order.  Rows longer than `thresh` edges are skipped.  When several
+//                              rows share a wave, a skewed workgroup deals its rows to the lane groups by decreasing
+//                              length (deal_rows_by_length): same per-row arithmetic, better-filled waves.
 //     long-row workgroups      power-law graphs: a row of 10^4..10^5 edges would serialise one lane group for longer
 //                              than the rest of the launch takes.  Edges are cut into aligned chunks of `thresh` edges;
 //                              every piece (long row  x  chunk) is processed by a whole workgroup: its 256/LPR groups
