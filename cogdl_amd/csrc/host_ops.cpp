@@ -171,37 +171,64 @@ int cogdl_host_sample_adj(const int64_t *indptr, const int64_t *indices, int64_t
     }
     int64_t n_nodes = batch, n_edges = 0;
     ids.n_touched = batch;
+    // Every sampled edge costs three dependent random reads (indptr[seed], indices[edge], the id map): at products scale
+    // each is a cache miss, and a one-seed-at-a-time loop pays them serially (~100 ns each).  The seeds are therefore
+    // processed in blocks of kBlock with one pass per dependent level, each pass prefetching what the next one reads,
+    // so the misses of a block overlap.  Picks, their order and the relabelling are exactly those of the plain loop.
+    constexpr int64_t kBlock = 256;
+    thread_local std::vector<int64_t> blk_edge, blk_src, blk_cnt;
     std::vector<int64_t> pick;
     out_indptr[0] = 0;
-    for (int64_t i = 0; i < batch; ++i) {
-        const int64_t begin = indptr[node_idx[i]];
-        const int64_t deg = indptr[node_idx[i] + 1] - begin;
-        SplitMix64 rng(stream_seed(seed, (uint64_t)i));  // per-seed stream: result independent of batching
-        pick.clear();
-        if (num_neighbors < 0) {
-            for (int64_t j = 0; j < deg; ++j) pick.push_back(j);
-        } else if (replace) {
-            if (deg > 0)
-                for (int64_t j = 0; j < num_neighbors; ++j) pick.push_back(rng.below(deg));
-        } else {
-            sample_without_replacement(deg, num_neighbors, rng, pick);
-        }
-        if (n_edges + (int64_t)pick.size() > cap_edges) return COGDL_HOST_ECAP;
-        for (int64_t p : pick) {
-            const int64_t edge = begin + p;
-            const int64_t src = indices[edge];
-            if (src < 0 || src >= num_nodes) return COGDL_HOST_ERANGE;
-            int64_t &id = local[(size_t)src];
-            if (id < 0) {
-                if (n_nodes >= cap_nodes) return COGDL_HOST_ECAP;
-                id = n_nodes;
-                out_nodes[n_nodes++] = src;
-                ids.n_touched = n_nodes;
+    for (int64_t b0 = 0; b0 < batch; b0 += kBlock) {
+        const int64_t b1 = std::min(batch, b0 + kBlock);
+        for (int64_t i = b0; i < b1; ++i) __builtin_prefetch(indptr + node_idx[i]);
+        // level 1: row extents -> picks (edge positions), prefetch the neighbour ids
+        blk_edge.clear();
+        blk_cnt.assign((size_t)(b1 - b0), 0);
+        for (int64_t i = b0; i < b1; ++i) {
+            const int64_t begin = indptr[node_idx[i]];
+            const int64_t deg = indptr[node_idx[i] + 1] - begin;
+            SplitMix64 rng(stream_seed(seed, (uint64_t)i));  // per-seed stream: result independent of batching
+            pick.clear();
+            if (num_neighbors < 0) {
+                for (int64_t j = 0; j < deg; ++j) pick.push_back(j);
+            } else if (replace) {
+                if (deg > 0)
+                    for (int64_t j = 0; j < num_neighbors; ++j) pick.push_back(rng.below(deg));
+            } else {
+                sample_without_replacement(deg, num_neighbors, rng, pick);
             }
-            out_indices[n_edges] = id;
-            out_edges[n_edges++] = edge;
+            blk_cnt[(size_t)(i - b0)] = (int64_t)pick.size();
+            for (int64_t q : pick) {
+                blk_edge.push_back(begin + q);
+                __builtin_prefetch(indices + begin + q);
+            }
         }
-        out_indptr[i + 1] = n_edges;
+        if (n_edges + (int64_t)blk_edge.size() > cap_edges) return COGDL_HOST_ECAP;
+        // level 2: neighbour ids, prefetch their id-map entries
+        blk_src.resize(blk_edge.size());
+        for (size_t e = 0; e < blk_edge.size(); ++e) {
+            const int64_t src = indices[blk_edge[e]];
+            if (src < 0 || src >= num_nodes) return COGDL_HOST_ERANGE;
+            blk_src[e] = src;
+            __builtin_prefetch(&local[(size_t)src], 1);
+        }
+        // level 3: relabel in discovery order
+        size_t e = 0;
+        for (int64_t i = b0; i < b1; ++i) {
+            for (int64_t c = 0; c < blk_cnt[(size_t)(i - b0)]; ++c, ++e) {
+                int64_t &id = local[(size_t)blk_src[e]];
+                if (id < 0) {
+                    if (n_nodes >= cap_nodes) return COGDL_HOST_ECAP;
+                    id = n_nodes;
+                    out_nodes[n_nodes++] = blk_src[e];
+                    ids.n_touched = n_nodes;
+                }
+                out_indices[n_edges] = id;
+                out_edges[n_edges++] = blk_edge[e];
+            }
+            out_indptr[i + 1] = n_edges;
+        }
     }
     out_counts[0] = n_nodes;
     out_counts[1] = n_edges;
