@@ -48,8 +48,8 @@ HIP_SIGNATURES = {
     "cogdl_hip_gspmm": ([_vp] * 5 + [_i32, _vp, _i32, _i32, _vp, _i64, _i64, _i64, _vp, _sz, _vp], _i32),
     "cogdl_hip_gat_fwd_workspace_bytes": ([_i64, _i64, _i64, _i32], _sz),
     "cogdl_hip_gat_fwd": ([_vp] * 5 + [_f32] + [_vp] * 3 + [_i64, _i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
-    "cogdl_hip_gat_bwd_workspace_bytes": ([_i64, _i64, _i64, _i64], _sz),
-    "cogdl_hip_gat_bwd": ([_vp] * 7 + [_f32] + [_vp] * 8 + [_sz, _i64, _i64, _i64, _i64, _i64, _vp], _i32),
+    "cogdl_hip_gat_bwd_workspace_bytes": ([_i64, _i64, _i64, _i64, _i32], _sz),
+    "cogdl_hip_gat_bwd": ([_vp] * 7 + [_f32] + [_vp] * 8 + [_sz, _i64, _i64, _i64, _i64, _i64, _i32, _vp], _i32),
     "cogdl_hip_csr_fingerprint": ([_vp, _vp, _i64, _i64, _vp, _vp], _i32),
     "cogdl_hip_linear_fwd_f32": ([_vp] * 4 + [_i64, _i64, _i64, _i32, _vp], _i32),
     "cogdl_hip_linear_wgrad_workspace_bytes": ([_i64, _i64, _i64], _sz),
@@ -69,6 +69,7 @@ HOST_SIGNATURES = {
     "cogdl_host_csr_spmm_f32": ([_vp] * 5 + [_i64, _i64, _i32], _i32),
 }
 
+EUNSUPPORTED = 7  # COGDL_HIP_EUNSUPPORTED
 DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 _hip = None
@@ -174,3 +175,15 @@ def require_cuda(*tensors):
         elif t.device != dev:
             raise BackendError("tensors on different devices: %s vs %s" % (dev, t.device))
     return dev
+
+
+def csr_structure(rowptr, colind):
+    """The int32 CSR index arrays as the kernels (and the structure hash / transpose that read them through raw
+    pointers) need them: dtype-checked, then made contiguous ONCE -- the returned tensors are the ones to launch
+    with, to hash and to save for backward (a strided view would be read as if it were dense)."""
+    if rowptr.dtype != torch.int32 or colind.dtype != torch.int32:
+        raise BackendError("rowptr/colind must be int32 (got %s/%s)" % (rowptr.dtype, colind.dtype))
+    if rowptr.dim() != 1 or colind.dim() != 1 or rowptr.numel() < 1:
+        raise BackendError("rowptr/colind must be 1-D (rowptr non-empty), got shapes %s/%s"
+                           % (tuple(rowptr.shape), tuple(colind.shape)))
+    return rowptr.contiguous(), colind.contiguous()

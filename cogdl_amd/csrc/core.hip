@@ -27,6 +27,7 @@ extern "C" const char *cogdl_hip_strerror(int status) {
         case COGDL_HIP_ELAUNCH: return "HIP launch/runtime error";
         case COGDL_HIP_EWORKSPACE: return "workspace too small";
         case COGDL_HIP_ERANGE: return "size out of range for int32 CSR indices";
+        case COGDL_HIP_EUNSUPPORTED: return "shape not covered by this entry point";
         default: return "unknown status";
     }
 }

@@ -299,12 +299,15 @@ struct GatFwdChunkOp {
 
 // ------------------------------------------------------------------------------------------ backward
 // Row pass: D[v,h] and grad_attn_row[v,h].  The whole [H*F] row must fit one group.
-template <int VEC_, int LPR_, int UNROLL_>
+template <typename T, int VEC_, int LPR_, int UNROLL_>
 struct GatBwdRowOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_ + 1;
     static constexpr bool kReduce = true;
     static constexpr int kLds = 0;
-    const float *attn_row, *attn_col, *feat, *edge_max, *edge_sum, *out, *grad_out;
+    const float *attn_row, *attn_col;
+    const T *feat;  // feat / out / grad_out in the layer's dtype (f32, f16, bf16): read natively, fp32 arithmetic
+    const float *edge_max, *edge_sum;
+    const T *out, *grad_out;
     float *dvec, *grad_attn_row;
     float slope;
     int heads, fdim, lph;
@@ -344,9 +347,9 @@ struct GatBwdRowOp {
         float d = 0.f;
         c.ar = c.mx = c.inv = 0.f;
         if (ok && c.col_ok) {
-            load_vec<float, VEC>(grad_out + row * (int64_t)k + c.cc, c.g);
+            load_vec<T, VEC>(grad_out + row * (int64_t)k + c.cc, c.g);
             float o[VEC];
-            load_vec<float, VEC>(out + row * (int64_t)k + c.cc, o);
+            load_vec<T, VEC>(out + row * (int64_t)k + c.cc, o);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) d = fmaf(c.g[i], o[i], d);
             c.ar = attn_row[row * heads + c.hd];
@@ -366,7 +369,7 @@ struct GatBwdRowOp {
     __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t, const LaneVals &, int,
                                           int) const {
         b.ac[u] = attn_col[(int64_t)col * heads + c.hd];
-        load_vec<float, VEC>(feat + (int64_t)col * (heads * fdim) + c.cc, b.v[u]);
+        load_vec<T, VEC>(feat + (int64_t)col * (heads * fdim) + c.cc, b.v[u]);
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
                                           int) const {
@@ -409,13 +412,17 @@ struct GatBwdRowOp {
 };
 
 // Column pass over the CSC (colptr, rowind): grad_feat[u,h,:] and grad_attn_col[u,h].
-template <int VEC_, int LPR_, int UNROLL_>
+template <typename T, int VEC_, int LPR_, int UNROLL_>
 struct GatBwdColOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = 2 * VEC_ + 1;
     static constexpr bool kReduce = true;
     static constexpr int kLds = 0;
-    const float *attn_row, *attn_col, *feat, *edge_max, *edge_sum, *dvec, *grad_out;
-    float *grad_feat, *grad_attn_col;
+    const float *attn_row, *attn_col;
+    const T *feat;
+    const float *edge_max, *edge_sum, *dvec;
+    const T *grad_out;
+    T *grad_feat;  // rounded once on store (fp32 accumulation)
+    float *grad_attn_col;
     float slope;
     int heads, fdim, lph;
 
@@ -452,7 +459,7 @@ struct GatBwdColOp {
         for (int i = 0; i < VEC; ++i) c.f[i] = 0.f;
         c.ac = 0.f;
         if (ok && c.col_ok) {
-            load_vec<float, VEC>(feat + u_node * (int64_t)(heads * fdim) + c.cc, c.f);
+            load_vec<T, VEC>(feat + u_node * (int64_t)(heads * fdim) + c.cc, c.f);
             c.ac = attn_col[u_node * heads + c.hd];
         }
     }
@@ -470,7 +477,7 @@ struct GatBwdColOp {
         b.mx[u] = edge_max[rh];
         b.ls[u] = edge_sum[rh];
         b.dd[u] = dvec[rh];
-        load_vec<float, VEC>(grad_out + (int64_t)r * (heads * fdim) + c.cc, b.g[u]);
+        load_vec<T, VEC>(grad_out + (int64_t)r * (heads * fdim) + c.cc, b.g[u]);
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
                                           int) const {
@@ -495,7 +502,7 @@ struct GatBwdColOp {
         for (int i = 0; i < VEC; ++i) dot = fmaf(c.f[i], c.col_ok ? s.t[i] : 0.f, dot);
         dot = head_sum<LPR>(dot, lph);
         if (ok && c.col_ok) {
-            store_vec<float, VEC>(grad_feat + u_node * (int64_t)(heads * fdim) + c.cc, s.acc);
+            store_vec<T, VEC>(grad_feat + u_node * (int64_t)(heads * fdim) + c.cc, s.acc);
             if (c.head_lane) grad_attn_col[u_node * heads + c.hd] = dot - s.cd;
         }
     }
@@ -602,22 +609,30 @@ static int gat_fwd_typed(const FwdArgs &a, void *ws, size_t wsb, hipStream_t s) 
 
 struct BwdArgs {
     const int32_t *rowptr, *colind, *colptr, *rowind;
-    const float *ar, *ac, *feat, *emax, *esum, *out, *gout;
+    const float *ar, *ac;
+    const void *feat;
+    const float *emax, *esum;
+    const void *out, *gout;
     float slope;
-    float *gfeat, *gar, *gac, *dvec;
+    void *gfeat;
+    float *gar, *gac, *dvec;
     int64_t v, n_src, h, f, nnz;
     void *ws_row, *ws_col;  // long-row scratch of the two passes (either both or none)
     size_t wsb_row, wsb_col;
 };
 
 // Backward geometry: the whole [H*F] row in ONE group (the per-head dot products are reduced with shuffles):
-// vec in {1,2,4} with F % vec == 0, H*F/vec <= 64 lanes and F/vec a power of two (unless H == 1).
-static int gat_bwd_vec(int64_t h, int64_t f, int align) {
-    auto ok = [&](int vec) { return f % vec == 0 && h * f / vec <= kWave && (h == 1 || pow2(f / vec)); };
-    if (ok(4) && align >= 16) return 4;  // fat lanes first: the per-edge attention maths is repeated per lane
-    if (ok(2) && align >= 8) return 2;
-    if (ok(1)) return 1;
-    return 0;
+// vec in {1,2,4} (and 8 for 2-byte elements) with F % vec == 0, H*F/vec <= 64 lanes and F/vec a power of two
+// (unless H == 1); a lane's vector is at most 16 bytes and must be aligned to its size.
+static int gat_bwd_vec(int64_t h, int64_t f, int align, int elem_bytes) {
+    auto ok = [&](int vec) {
+        return vec * elem_bytes <= 16 && align >= vec * elem_bytes && f % vec == 0 && h * f / vec <= kWave &&
+               (h == 1 || pow2(f / vec));
+    };
+    // fat lanes first: the per-edge attention maths is repeated per lane
+    for (int vec = 8; vec > 1; vec >>= 1)
+        if (ok(vec)) return vec;
+    return (h * f <= kWave && (h == 1 || pow2(f))) ? 1 : 0;
 }
 static int gat_bwd_lpr(int64_t h, int64_t f, int vec) {
     const int64_t need = (h * f + vec - 1) / vec;
@@ -626,25 +641,37 @@ static int gat_bwd_lpr(int64_t h, int64_t f, int vec) {
     return lpr;
 }
 
-template <int VEC, int LPR>
+template <typename T, int VEC, int LPR>
 static int launch_bwd(const BwdArgs &b, hipStream_t s) {
     const int lph = (b.h == 1) ? LPR : (int)(b.f / VEC);  // one head: reduce over the whole (zero-padded) group
-    GatBwdRowOp<VEC, LPR, 4> row_op{b.ar, b.ac, b.feat, b.emax, b.esum, b.out, b.gout, b.dvec, b.gar, b.slope,
-                                     (int)b.h, (int)b.f, lph};
+    GatBwdRowOp<T, VEC, LPR, 4> row_op{b.ar, b.ac, (const T *)b.feat, b.emax, b.esum, (const T *)b.out,
+                                        (const T *)b.gout, b.dvec, b.gar, b.slope, (int)b.h, (int)b.f, lph};
     int rc = launch_rowreduce(row_op, b.rowptr, b.colind, b.v, b.nnz, 1, b.ws_row, b.wsb_row, s);
     if (rc != COGDL_HIP_OK) return rc;
-    GatBwdColOp<VEC, LPR, 4> col_op{b.ar, b.ac, b.feat, b.emax, b.esum, b.dvec, b.gout, b.gfeat, b.gac, b.slope,
-                                     (int)b.h, (int)b.f, lph};
+    GatBwdColOp<T, VEC, LPR, 4> col_op{b.ar, b.ac, (const T *)b.feat, b.emax, b.esum, b.dvec, (const T *)b.gout,
+                                        (T *)b.gfeat, b.gac, b.slope, (int)b.h, (int)b.f, lph};
     return launch_rowreduce(col_op, b.colptr, b.rowind, b.n_src, b.nnz, 1, b.ws_col, b.wsb_col, s);
 }
 
-template <int VEC>
+template <typename T, int VEC>
 static int dispatch_bwd(const BwdArgs &b, hipStream_t s) {
     switch (gat_bwd_lpr(b.h, b.f, VEC)) {
-        case 8: return launch_bwd<VEC, 8>(b, s);
-        case 16: return launch_bwd<VEC, 16>(b, s);
-        case 32: return launch_bwd<VEC, 32>(b, s);
-        default: return launch_bwd<VEC, 64>(b, s);
+        case 8: return launch_bwd<T, VEC, 8>(b, s);
+        case 16: return launch_bwd<T, VEC, 16>(b, s);
+        case 32: return launch_bwd<T, VEC, 32>(b, s);
+        default: return launch_bwd<T, VEC, 64>(b, s);
+    }
+}
+
+template <typename T>
+static int gat_bwd_typed(const BwdArgs &b, int vec, hipStream_t s) {
+    switch (vec) {
+        case 8:
+            if constexpr (sizeof(T) == 2) return dispatch_bwd<T, 8>(b, s);
+            return COGDL_HIP_EINVAL;
+        case 4: return dispatch_bwd<T, 4>(b, s);
+        case 2: return dispatch_bwd<T, 2>(b, s);
+        default: return dispatch_bwd<T, 1>(b, s);
     }
 }
 
@@ -679,9 +706,9 @@ extern "C" int cogdl_hip_gat_fwd(const int32_t *rowptr, const int32_t *colind, c
 }
 
 // Layout of the backward workspace: [D: v*h floats][long-row scratch of the row pass][... of the column pass].
-extern "C" size_t cogdl_hip_gat_bwd_workspace_bytes(int64_t v, int64_t h, int64_t f, int64_t nnz) {
+extern "C" size_t cogdl_hip_gat_bwd_workspace_bytes(int64_t v, int64_t h, int64_t f, int64_t nnz, int dtype) {
     size_t total = dvec_bytes(v, h);
-    const int vec = gat_bwd_vec(h, f, 16);
+    const int vec = gat_bwd_vec(h, f, 16, dtype == COGDL_HIP_F32 ? 4 : 2);
     if (vec > 0 && nnz > 0) {
         const int lpr = gat_bwd_lpr(h, f, vec);
         total += rowreduce_workspace_bytes(nnz, (int64_t)(vec + 1) * lpr);
@@ -690,25 +717,29 @@ extern "C" size_t cogdl_hip_gat_bwd_workspace_bytes(int64_t v, int64_t h, int64_
     return total + 256;
 }
 
-// Returns COGDL_HIP_EINVAL for shapes the fused backward does not cover (the [H*F] row must fit one group of
+// Returns COGDL_HIP_EUNSUPPORTED for shapes the fused backward does not cover (the [H*F] row must fit one group of
 // 64 lanes * 4 columns, and F/VEC must be a power of two unless H == 1): callers then use the unfused
 // edge_softmax + mhspmm operators instead.
 extern "C" int cogdl_hip_gat_bwd(const int32_t *rowptr, const int32_t *colind, const int32_t *colptr,
                                  const int32_t *rowind, const float *attn_row, const float *attn_col,
-                                 const float *feat, float negative_slope, const float *edge_max,
-                                 const float *edge_sum, const float *out, const float *grad_out, float *grad_feat,
+                                 const void *feat, float negative_slope, const float *edge_max,
+                                 const float *edge_sum, const void *out, const void *grad_out, void *grad_feat,
                                  float *grad_attn_row, float *grad_attn_col, void *workspace, size_t workspace_bytes,
-                                 int64_t v, int64_t n_src, int64_t h, int64_t f, int64_t nnz, void *stream) {
+                                 int64_t v, int64_t n_src, int64_t h, int64_t f, int64_t nnz, int dtype,
+                                 void *stream) {
     if (v < 0 || n_src < 0 || h <= 0 || f <= 0 || nnz < 0) return COGDL_HIP_EINVAL;
+    if (dtype != COGDL_HIP_F32 && dtype != COGDL_HIP_F16 && dtype != COGDL_HIP_BF16) return COGDL_HIP_EDTYPE;
+    const int elem_bytes = dtype == COGDL_HIP_F32 ? 4 : 2;
     if (!rowptr || !colptr || !attn_row || !attn_col || !feat || !edge_max || !edge_sum || !out || !grad_out ||
         !grad_feat || !grad_attn_row || !grad_attn_col || !workspace)
         return COGDL_HIP_EINVAL;
     if (workspace_bytes < dvec_bytes(v, h) || !aligned_to(workspace, 256)) return COGDL_HIP_EWORKSPACE;
     const uintptr_t bits = reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out) |
                            reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_feat);
-    const int align = (bits % 16 == 0) ? 16 : (bits % 8 == 0) ? 8 : 4;
-    const int vec = gat_bwd_vec(h, f, align);
-    if (vec == 0) return COGDL_HIP_EINVAL;
+    const int align = (bits % 16 == 0) ? 16 : (bits % 8 == 0) ? 8 : (bits % 4 == 0) ? 4 : 2;
+    if (align < elem_bytes) return COGDL_HIP_EALIGN;
+    const int vec = gat_bwd_vec(h, f, align, elem_bytes);
+    if (vec == 0) return COGDL_HIP_EUNSUPPORTED;
     BwdArgs b{rowptr, colind, colptr, rowind, attn_row, attn_col, feat, edge_max, edge_sum, out, grad_out,
               negative_slope, grad_feat, grad_attn_row, grad_attn_col, (float *)workspace, v, n_src, h, f, nnz,
               nullptr, nullptr, 0, 0};
@@ -723,9 +754,9 @@ extern "C" int cogdl_hip_gat_bwd(const int32_t *rowptr, const int32_t *colind, c
         b.wsb_col = need_col;
     }
     hipStream_t s = (hipStream_t)stream;
-    switch (vec) {
-        case 1: return dispatch_bwd<1>(b, s);
-        case 2: return dispatch_bwd<2>(b, s);
-        default: return dispatch_bwd<4>(b, s);
+    switch (dtype) {
+        case COGDL_HIP_F32: return gat_bwd_typed<float>(b, vec, s);
+        case COGDL_HIP_F16: return gat_bwd_typed<__half>(b, vec, s);
+        default: return gat_bwd_typed<__hip_bfloat16>(b, vec, s);
     }
 }

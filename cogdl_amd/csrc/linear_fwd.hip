@@ -9,7 +9,7 @@
 // (coalesced 16-byte global reads, +2 padded rows: conflict-free operand reads), 64 columns at a time.  B is small: the whole of it sits in LDS ([k][n], n contiguous: B[k = l >> 5][n = l & 31] is a conflict-free
 // read), loaded once per workgroup; workgroups are persistent and their waves walk row tiles independently (no
 // workgroup barrier after the prologue).  fp32 in, fp32 accumulate (an fma chain over k per output element).
-// Shapes with more than 64 output columns or a B beyond 96 KB are declined (COGDL_HIP_ERANGE): the caller keeps its BLAS.
+// Shapes with more than 64 output columns or a B beyond 96 KB are declined (COGDL_HIP_EUNSUPPORTED): the caller keeps its BLAS.
 #include "common.h"
 
 namespace cogdl {
@@ -229,7 +229,7 @@ static int launch_fwd_gemm(const float *x, const float *w, const float *bias, fl
                            int64_t n_dim, int w_is_n_by_k, hipStream_t s) {
     const int k_pad = (int)((k_dim + 15) / 16 * 16);  // whole trips of 8 k-pairs; the padding is zeros in B and x
     const size_t b_bytes = (size_t)k_pad * 32 * NT * sizeof(float);
-    if (b_bytes > kFwdMaxBBytes) return COGDL_HIP_ERANGE;
+    if (b_bytes > kFwdMaxBBytes) return COGDL_HIP_EUNSUPPORTED;
     const size_t lds = b_bytes + (size_t)4 * 32 * kFwdXsStride * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {  // more than 64 KB of dynamic LDS needs the opt-in
@@ -262,7 +262,7 @@ static int launch_fwd_gemm(const float *x, const float *w, const float *bias, fl
 using namespace cogdl;
 
 // out[rows, n] = x[rows, k] . B (+ bias[n]);  w_is_n_by_k != 0: B = w^T with w stored [n, k] (Linear forward);
-// w_is_n_by_k == 0: B = w stored [k, n] (grad_input = grad_out . W).  COGDL_HIP_ERANGE: shape not covered.
+// w_is_n_by_k == 0: B = w stored [k, n] (grad_input = grad_out . W).  COGDL_HIP_EUNSUPPORTED: shape not covered.
 extern "C" int cogdl_hip_linear_fwd_f32(const float *x, const float *w, const float *bias, float *out, int64_t rows,
                                         int64_t k_dim, int64_t n_dim, int w_is_n_by_k, void *stream) {
     if (rows < 0 || k_dim <= 0 || n_dim <= 0) return COGDL_HIP_EINVAL;
@@ -271,7 +271,7 @@ extern "C" int cogdl_hip_linear_fwd_f32(const float *x, const float *w, const fl
     // Measured on MI355X (profiles/r01_ops_bench.txt): with <= 64 output columns this kernel beats hipBLASLt on the
     // node-count-tall shapes (169 k x 128 -> 64: 30-44 us vs 83 us; x 64 -> 40: vs 38-65 us); with 128 columns and more
     // hipBLASLt wins (2.4 M x 100 -> 128: 0.90 ms vs 1.6 ms here).  Decline those.
-    if (n_dim > 64 || k_dim > 4096) return COGDL_HIP_ERANGE;
+    if (n_dim > 64 || k_dim > 4096) return COGDL_HIP_EUNSUPPORTED;
     if (!aligned_to(x, 16) || !aligned_to(out, 4)) return COGDL_HIP_EALIGN;
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (k_dim & 3) == 0;

@@ -37,7 +37,7 @@ def linear_wgrad(x, grad_out, want_bias=True):
     return grad_w, grad_b
 
 
-ERANGE = 6  # COGDL_HIP_ERANGE: shape outside the hand-written kernel's coverage
+EUNSUPPORTED = _lib.EUNSUPPORTED  # shape outside the hand-written kernel's coverage: torch's product is used
 
 
 def tall_skinny_matmul(x, w, bias, w_is_n_by_k):
@@ -51,7 +51,7 @@ def tall_skinny_matmul(x, w, bias, w_is_n_by_k):
     with _lib.on_device(dev):
         rc = _lib.hip().cogdl_hip_linear_fwd_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out), rows, k, n,
                                                  1 if w_is_n_by_k else 0, _lib.stream_of(x))
-    if rc == ERANGE:
+    if rc == EUNSUPPORTED:
         return None
     _lib.check(rc, "linear_fwd")
     return out
@@ -86,7 +86,10 @@ class LinearFunction(torch.autograd.Function):
 def covers(x, weight, bias):
     return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
             and x.shape[0] >= MIN_ROWS and weight.dim() == 2 and max(weight.shape) <= MAX_FEATURES
-            and (bias is None or bias.dtype == torch.float32)
+            # anything torch would reject (shape or device mismatch) must reach torch so that IT raises
+            and x.shape[1] == weight.shape[1] and weight.is_cuda and weight.device == x.device
+            and (bias is None or (bias.dtype == torch.float32 and bias.is_cuda and bias.device == x.device
+                                  and bias.dim() == 1 and bias.shape[0] == weight.shape[0]))
             and torch.is_grad_enabled() and weight.requires_grad and not torch.is_autocast_enabled())
 
 

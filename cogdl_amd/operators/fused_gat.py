@@ -57,6 +57,7 @@ def _unfused_backward(negative_slope, row_ptr, col_ind, in_feat, attn_row, attn_
 class FusedGATFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, negative_slope, in_feat):
+        row_ptr, col_ind = _lib.csr_structure(row_ptr, col_ind)
         ctx.fp = Fingerprint(row_ptr, col_ind, in_feat.shape[0])  # before the kernel: lands early for backward
         out, edge_max, edge_sum = gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat)
         ctx.save_for_backward(row_ptr, col_ind, edge_max, edge_sum, in_feat, attn_row, attn_col, out)
@@ -68,24 +69,26 @@ class FusedGATFunction(torch.autograd.Function):
         row_ptr, col_ind, edge_max, edge_sum, in_feat, attn_row, attn_col, out = ctx.saved_tensors
         dev = grad_out.device
         v, (n_src, h, f) = row_ptr.numel() - 1, in_feat.shape
-        g = grad_out.contiguous().float()
-        feat, o = in_feat.detach().contiguous().float(), out.detach().contiguous().float()
+        # feat / out / grad_out are read in the layer's dtype (bf16 for configs[2]): no fp32 copies
+        dt = in_feat.dtype
+        g = grad_out.contiguous() if grad_out.dtype == dt else grad_out.to(dt).contiguous()
+        feat, o = in_feat.detach().contiguous(), out.detach().contiguous()
         ar, ac = attn_row.detach().contiguous().float(), attn_col.detach().contiguous().float()
         plan = PLANS.get(ctx.fp, row_ptr, col_ind, n_src)
-        grad_feat = torch.empty((n_src, h, f), dtype=torch.float32, device=dev)
+        grad_feat = torch.empty((n_src, h, f), dtype=dt, device=dev)
         grad_ar = torch.empty((v, h), dtype=torch.float32, device=dev)
         grad_ac = torch.empty((n_src, h), dtype=torch.float32, device=dev)
         lib = _lib.hip()
-        nnz = col_ind.numel()
-        ws_bytes = lib.cogdl_hip_gat_bwd_workspace_bytes(v, h, f, nnz)
+        nnz, code = col_ind.numel(), _lib.DTYPE_CODE[dt]
+        ws_bytes = lib.cogdl_hip_gat_bwd_workspace_bytes(v, h, f, nnz, code)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with _lib.on_device(dev):
             rc = lib.cogdl_hip_gat_bwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(plan.colptr),
                                        _lib.ptr(plan.rowind), _lib.ptr(ar), _lib.ptr(ac), _lib.ptr(feat),
                                        ctx.negative_slope, _lib.ptr(edge_max), _lib.ptr(edge_sum), _lib.ptr(o),
                                        _lib.ptr(g), _lib.ptr(grad_feat), _lib.ptr(grad_ar), _lib.ptr(grad_ac),
-                                       _lib.ptr(ws), ws_bytes, v, n_src, h, f, nnz, _lib.stream_of(g))
-        if rc == 1:  # COGDL_HIP_EINVAL: shape outside the fused backward's coverage
+                                       _lib.ptr(ws), ws_bytes, v, n_src, h, f, nnz, code, _lib.stream_of(g))
+        if rc == _lib.EUNSUPPORTED:  # a valid call whose shape the fused backward declines (any other status raises)
             grad_feat, grad_ar, grad_ac = _unfused_backward(ctx.negative_slope, row_ptr, col_ind, in_feat, attn_row,
                                                             attn_col, grad_out)
         else:

@@ -55,6 +55,7 @@ def mhsddmm_raw(rowptr, colind, grad, feat):
 class MHSPMMFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rowptr, colind, feat, attention):
+        rowptr, colind = _lib.csr_structure(rowptr, colind)
         ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None  # before the kernel
         out = mhspmm_raw(rowptr, colind, attention, feat)
         ctx.save_for_backward(rowptr, colind, feat, attention)

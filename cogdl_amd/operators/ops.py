@@ -16,6 +16,7 @@ import collections
 import torch
 
 from .. import _lib
+from ..plan import tensor_key
 
 _lib.hip()
 
@@ -26,7 +27,7 @@ _OPS = {"add": 0, "sub": 1, "mul": 2}  # COGDL_HIP_GSPMM_*
 class EdgePlan:
     """Destination-sorted view of an edge list: rowptr int32 [n+1], perm int32 [E] (sorted position -> edge id; stable),
     sorted (perm is the identity)."""
-    __slots__ = ("rowptr", "perm", "sorted", "n", "keep", "_col_key", "_colind")
+    __slots__ = ("rowptr", "perm", "sorted", "n", "keep", "_col_key", "_col_src", "_colind")
 
     def __init__(self, dst, n):
         from ..graph_build import coo2csr_index
@@ -38,14 +39,15 @@ class EdgePlan:
         self.sorted = bool(e == 0 or (perm == torch.arange(e, device=dst.device)).all().item())
         self.n = n
         self.keep = dst  # pins the key tensor: its data_ptr cannot be recycled while the plan lives
-        self._col_key, self._colind = None, None
+        self._col_key, self._col_src, self._colind = None, None, None
 
     def colind(self, col):
-        """The source ids in sorted order as int32 (memoised on the identity of `col`)."""
-        key = (col.data_ptr(), col._version, col.numel())
-        if key != self._col_key:
+        """The source ids in sorted order as int32, memoised on the identity (address, version, layout) of `col`; the
+        memo keeps `col` alive so that its address cannot be recycled for a different tensor under the same key."""
+        key = tensor_key(col)
+        if key != self._col_key or self._col_src is None:
             self._colind = (col if self.sorted else col.index_select(0, self.perm.long())).int()
-            self._col_key = key
+            self._col_key, self._col_src = key, col
         return self._colind
 
 
@@ -56,7 +58,7 @@ _MAX_PLANS = 16
 def edge_plan(dst, n):
     """Memoised on the identity + version of `dst` (Graph.edge_index hands out the same tensors call after call,
     cogdl/data/data.py:305-309)."""
-    key = (dst.data_ptr(), dst._version, dst.numel(), dst.device.index, int(n))
+    key = tensor_key(dst) + (int(n),)
     plan = _PLANS.get(key)
     if plan is None:
         plan = EdgePlan(dst, int(n))

@@ -61,6 +61,7 @@ def scatter_max_bp_csc(colptr, rowind, grad, max_id, n_src):
 class ScatterMaxFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rowptr, colind, feat):
+        rowptr, colind = _lib.csr_structure(rowptr, colind)
         ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None  # before the kernel
         out, max_id = scatter_max_fp(rowptr, colind, feat)
         ctx.save_for_backward(max_id, rowptr, colind)

@@ -23,12 +23,13 @@ from . import _lib
 
 
 class CscPlan:
-    __slots__ = ("colptr", "rowind", "perm", "m", "n_cols", "nnz", "_val_key", "_val_t", "_max_col_degree")
+    __slots__ = ("colptr", "rowind", "perm", "m", "n_cols", "nnz", "_val_key", "_val_src", "_val_t",
+                 "_max_col_degree")
 
     def __init__(self, colptr, rowind, perm, m, n_cols, nnz):
         self.colptr, self.rowind, self.perm = colptr, rowind, perm
         self.m, self.n_cols, self.nnz = m, n_cols, nnz
-        self._val_key, self._val_t = None, None
+        self._val_key, self._val_src, self._val_t = None, None, None
         self._max_col_degree = None
 
     def has_hub_columns(self):
@@ -40,16 +41,29 @@ class CscPlan:
         return self._max_col_degree > _lib.hip().cogdl_hip_long_row_threshold(self.nnz)
 
     def transposed_values(self, w):
-        """w[perm], memoised on the identity+version of `w` (CogDL passes the same
-        graph.raw_edge_weight tensor every call, cogdl/utils/spmm_utils.py:102)."""
-        key = (w.data_ptr(), w._version, w.dtype, w.numel())
-        if key != self._val_key:
-            self._val_t = gather_rows(self.perm, w.detach())
-            self._val_key = key
+        """w[perm].  Constant edge weights (CogDL passes the same graph.raw_edge_weight tensor every call,
+        cogdl/utils/spmm_utils.py:102) are gathered once: the memo is keyed on the address, version counter and
+        layout of `w` AND holds a reference to it, so the keyed storage cannot be freed and handed to a different
+        tensor while the key is live (a fresh tensor at a recycled address would otherwise alias the key: every new
+        tensor starts at version 0).  Weights that take part in autograd (learned / attention weights: a new
+        tensor every step) are gathered per call and never memoised."""
+        src = w.detach()
+        if w.requires_grad:
+            return gather_rows(self.perm, src)
+        key = tensor_key(w)
+        if key != self._val_key or self._val_src is None:
+            self._val_t = gather_rows(self.perm, src)
+            self._val_key, self._val_src = key, src  # src shares w's storage: pins the address
         return self._val_t
 
     def nbytes(self):
         return 4 * (self.colptr.numel() + self.rowind.numel() + self.perm.numel())
+
+
+def tensor_key(t):
+    """Identity of a tensor's contents as far as can be told without reading them: address, version counter, dtype
+    and layout.  Only sound while the caller also keeps a reference to `t` (or a view of its storage)."""
+    return (t.data_ptr(), t._version, t.dtype, tuple(t.shape), tuple(t.stride()), t.device.index)
 
 
 def csr2csc(rowptr, colind, n_cols=None):
@@ -88,30 +102,52 @@ def gather_rows(perm, src):
 FINGERPRINT_PARTS = 256  # COGDL_HIP_FINGERPRINT_PARTS
 
 
-_PINNED_POOL = []  # recycled [FINGERPRINT_PARTS] int64 pinned buffers (+ their events): no host allocation per call
+_PINNED_POOL = {}  # device index -> recycled ([FINGERPRINT_PARTS] int64 pinned buffer, event) pairs
+_PENDING = []      # (device index, buffer, event) whose hash kernel had not finished when their Fingerprint died
+_POOL_MAX = 64
+
+
+def _reap_pending():
+    """Move parked buffers whose kernel has completed back to the pool.  A buffer is never released to torch's
+    pinned allocator while a kernel may still write it: the kernel holds a raw pointer the allocator knows nothing
+    about, so a freed block could be re-issued (a DataLoader pin thread, a non_blocking copy) and scribbled on."""
+    if not _PENDING:
+        return
+    still = []
+    for dev_index, host, event in _PENDING:
+        if event.query():
+            pool = _PINNED_POOL.setdefault(dev_index, [])
+            if len(pool) < _POOL_MAX:
+                pool.append((host, event))
+        else:
+            still.append((dev_index, host, event))
+    _PENDING[:] = still
 
 
 class Fingerprint:
     """A structure hash in flight: the kernel writes its per-workgroup partials straight into pinned host memory
     (device-visible on ROCm: no memset, no device-to-host copy kernel); an event guards them.  Buffers and events are
-    recycled through a small pool when the Fingerprint dies (a pinned allocation per forward call is ~10 us of host
-    time, and a training epoch is launch-bound)."""
+    recycled through a small per-device pool when the Fingerprint dies (a pinned allocation per forward call is
+    ~10 us of host time, and a training epoch is launch-bound)."""
     __slots__ = ("host", "event", "meta", "_key")
 
     def __init__(self, rowptr, colind, n_cols):
         dev = rowptr.device
         m, nnz = rowptr.numel() - 1, colind.numel()
-        if _PINNED_POOL:
-            self.host, self.event = _PINNED_POOL.pop()
+        _reap_pending()
+        pool = _PINNED_POOL.get(dev.index)
+        if pool:
+            self.host, self.event = pool.pop()
         else:
             self.host = torch.empty(FINGERPRINT_PARTS, dtype=torch.int64, pin_memory=True)
-            self.event = torch.cuda.Event()
+            with _lib.on_device(dev):
+                self.event = torch.cuda.Event()
         stream = torch.cuda.current_stream(dev)
         with _lib.on_device(dev):
             rc = _lib.hip().cogdl_hip_csr_fingerprint(_lib.ptr(rowptr), _lib.ptr(colind), m, nnz,
                                                       self.host.data_ptr(), stream.cuda_stream)
-        _lib.check(rc, "csr_fingerprint")
-        self.event.record(stream)
+            _lib.check(rc, "csr_fingerprint")
+            self.event.record(stream)
         self.meta = (dev.index, m, nnz, int(n_cols))
         self._key = None
 
@@ -122,12 +158,17 @@ class Fingerprint:
         return self._key
 
     def __del__(self):
-        # Back to the pool -- but only once the kernel that writes the buffer is known to be done (else a recycled
-        # buffer could be overwritten late); a buffer whose event has not fired yet is simply dropped.
+        # Back to the pool once the kernel that writes the buffer is known to be done; otherwise the pair is parked
+        # on _PENDING (keeping the pinned block allocated) until a later call finds its event complete.
         try:
-            if len(_PINNED_POOL) < 64 and (self._key is not None or self.event.query()):
-                _PINNED_POOL.append((self.host, self.event))
-        except Exception:  # interpreter shutdown
+            dev_index = self.meta[0]
+            if self._key is not None or self.event.query():
+                pool = _PINNED_POOL.setdefault(dev_index, [])
+                if len(pool) < _POOL_MAX:
+                    pool.append((self.host, self.event))
+            else:
+                _PENDING.append((dev_index, self.host, self.event))
+        except Exception:  # interpreter shutdown / half-constructed object
             pass
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define COGDL_HIP_ABI_VERSION 2
+#define COGDL_HIP_ABI_VERSION 3
 
 /* Exported with default visibility (the library is built -fvisibility=hidden). */
 #if defined(COGDL_HIP_BUILD)
@@ -45,7 +45,9 @@ enum cogdl_hip_status {
     COGDL_HIP_EALIGN = 3,      /* pointer not aligned to the element size */
     COGDL_HIP_ELAUNCH = 4,     /* hipLaunchKernel / runtime error (see cogdl_hip_last_hip_error) */
     COGDL_HIP_EWORKSPACE = 5,  /* workspace too small */
-    COGDL_HIP_ERANGE = 6       /* size exceeds what int32 CSR indices can address */
+    COGDL_HIP_ERANGE = 6,      /* size exceeds what int32 CSR indices can address */
+    COGDL_HIP_EUNSUPPORTED = 7 /* valid call, but a shape this entry point declines (see its comment): the caller
+                                * is expected to take its documented alternative -- never returned for a bad call */
 };
 
 enum cogdl_hip_dtype {
@@ -222,25 +224,27 @@ COGDL_API int cogdl_hip_gspmm(const int32_t *rowptr, const int32_t *colind, cons
  * backward consumes like the reference's ctx.save_for_backward does (fused_gat.py:20).
  * Forward workspace (optional): cogdl_hip_gat_fwd_workspace_bytes -- hub rows are then split over whole
  * workgroups and their (max, sum, acc) states merged like flash-attention blocks.
- * Backward (fp32) needs the CSC view (colptr,rowind from cogdl_hip_csr2csc), the forward
- * output and a workspace of cogdl_hip_gat_bwd_workspace_bytes(v, h, f, nnz) bytes (D[v,h] plus the
- * long-row scratch of its two passes; a workspace of only v*h floats disables the long-row path).  It returns
- * COGDL_HIP_EINVAL for shapes it does not cover (H*F must fit 64 lanes x 4 columns and
- * F/vec must be a power of two unless H == 1); callers then compose the unfused operators.
+ * Backward needs the CSC view (colptr,rowind from cogdl_hip_csr2csc), the forward
+ * output and a workspace of cogdl_hip_gat_bwd_workspace_bytes(v, h, f, nnz, dtype) bytes (D[v,h] plus the
+ * long-row scratch of its two passes; a workspace of only v*h floats disables the long-row path).
+ * feat / out / grad_out / grad_feat have element type `dtype` (f32, f16 or bf16: read natively, fp32
+ * arithmetic, grad_feat rounded once on store); attention vectors, statistics and their gradients are fp32.
+ * It returns COGDL_HIP_EUNSUPPORTED for shapes it does not cover (H*F must fit 64 lanes x one 16-byte vector
+ * and F/vec must be a power of two unless H == 1); callers then compose the unfused operators.
  * ------------------------------------------------------------------------------------- */
 COGDL_API size_t cogdl_hip_gat_fwd_workspace_bytes(int64_t nnz, int64_t h, int64_t f, int dtype);
 COGDL_API int cogdl_hip_gat_fwd(const int32_t *rowptr, const int32_t *colind, const float *attn_row,
                       const float *attn_col, const void *feat, float negative_slope, void *out,
                       float *edge_max, float *edge_sum, int64_t v, int64_t h, int64_t f, int64_t nnz,
                       int dtype, void *workspace, size_t workspace_bytes, void *stream);
-COGDL_API size_t cogdl_hip_gat_bwd_workspace_bytes(int64_t v, int64_t h, int64_t f, int64_t nnz);
+COGDL_API size_t cogdl_hip_gat_bwd_workspace_bytes(int64_t v, int64_t h, int64_t f, int64_t nnz, int dtype);
 COGDL_API int cogdl_hip_gat_bwd(const int32_t *rowptr, const int32_t *colind, const int32_t *colptr,
                       const int32_t *rowind, const float *attn_row, const float *attn_col,
-                      const float *feat, float negative_slope, const float *edge_max,
-                      const float *edge_sum, const float *out, const float *grad_out,
-                      float *grad_feat, float *grad_attn_row, float *grad_attn_col,
+                      const void *feat, float negative_slope, const float *edge_max,
+                      const float *edge_sum, const void *out, const void *grad_out,
+                      void *grad_feat, float *grad_attn_row, float *grad_attn_col,
                       void *workspace, size_t workspace_bytes, int64_t v, int64_t n_src, int64_t h,
-                      int64_t f, int64_t nnz, void *stream);
+                      int64_t f, int64_t nnz, int dtype, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Helpers used by the graph-plan cache and the vertex-sharded (multi-GPU) SpMM.
@@ -302,7 +306,7 @@ COGDL_API int cogdl_hip_linear_wgrad_f32(const float *x, const float *grad_out, 
  * w_is_n_by_k != 0: B = w^T, w stored [n, k] -- torch.nn.Linear's forward x . W^T + b;
  * w_is_n_by_k == 0: B = w stored [k, n]      -- its grad_input = grad_out . W.
  * Every wave stages 32-row tiles of x through LDS into v_mfma_f32_32x32x2_f32; B stays resident in LDS
- * (csrc/linear_fwd.hip).  Returns COGDL_HIP_ERANGE for shapes it does not cover (n > 64 or B larger than 96 KB):
+ * (csrc/linear_fwd.hip).  Returns COGDL_HIP_EUNSUPPORTED for shapes it does not cover (n > 64 or B larger than 96 KB):
  * the caller then keeps its BLAS call.  x 16-byte aligned. */
 COGDL_API int cogdl_hip_linear_fwd_f32(const float *x, const float *w, const float *bias, float *out, int64_t rows,
                              int64_t k_dim, int64_t n_dim, int w_is_n_by_k, void *stream);

@@ -151,3 +151,26 @@ def test_gradcheck_like_against_torch_composition():
         ((out / deg) * G).sum().backward()
         for a, b in ((xa, xb), (ea, eb), (wa, wb)):
             assert torch.allclose(a.grad, b.grad, rtol=1e-4, atol=1e-5), op1
+
+
+def test_fresh_source_ids_on_a_fixed_destination_list(oracle):
+    """Regression (ADVICE medium): `col` resampled every step against a persistent `row` tensor (negative sampling).
+    Each step's `col` dies with its frame and the allocator recycles its address for the next one; the plan's sorted
+    source-id memo must not serve the previous step's ids."""
+    ops.clear_plans()
+    n, e = 400, 3000
+    row, _ = _coo(n, e, seed=3)
+    row_d = row.to(DEV)
+    x = torch.randn(n, 8, generator=torch.Generator().manual_seed(1))
+    ef = torch.randn(e, 8, generator=torch.Generator().manual_seed(2))
+    xd, efd = x.to(DEV), ef.to(DEV)
+
+    def step(k):
+        col = torch.randint(0, n, (e,), generator=torch.Generator().manual_seed(50 + k))
+        got = ops.s_mul_e_sum(_graph(row_d, col.to(DEV)), xd, efd).cpu().numpy()  # col.to(DEV) is freed on return
+        want = oracle.src_op_e_aggr("mul", "sum", x, ef, row, col, n)
+        assert got.tobytes() == want.tobytes(), k
+
+    for k in range(4):
+        step(k)
+    assert len(ops._PLANS) == 1  # one destination plan served all four steps

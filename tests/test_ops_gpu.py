@@ -421,3 +421,31 @@ def test_full_size_reddit_shaped_gat_properties():
     del score, att, sums, unfused, mx
     outb, _, _ = gat_forward(ar, ac, g.rowptr, g.colind, 0.2, feat.bfloat16())
     assert torch.allclose(outb.float(), out, rtol=2.0 ** -6, atol=2e-2)
+
+
+def test_gat_bwd_status_codes_distinguish_unsupported_from_invalid():
+    """COGDL_HIP_EUNSUPPORTED (7) = a valid call whose shape the fused backward declines -> the operator composes the
+    unfused kernels; COGDL_HIP_EINVAL (1) = a bad call -> BackendError, never masked by the fallback."""
+    from cogdl_amd import _lib
+
+    lib = _lib.hip()
+    g = synth.random_csr(20, 20, 3, seed=1, weighted=False)
+    rp, ci = g.rowptr.to(DEV), g.colind.to(DEV)
+    v, nnz = 20, g.nnz
+
+    def call(h, f, null_feat=False):
+        t = lambda *s: torch.zeros(*s, device=DEV)  # noqa: E731
+        ar, ac, feat, out, go = t(v, h), t(v, h), t(v, h, f), t(v, h, f), t(v, h, f)
+        emax, esum, gf, gar, gac = t(v, h), t(v, h) + 1, t(v, h, f), t(v, h), t(v, h)
+        wsb = lib.cogdl_hip_gat_bwd_workspace_bytes(v, h, f, nnz, 0)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        return lib.cogdl_hip_gat_bwd(_lib.ptr(rp), _lib.ptr(ci), _lib.ptr(rp), _lib.ptr(ci), _lib.ptr(ar), _lib.ptr(ac),
+                                     None if null_feat else _lib.ptr(feat), 0.2, _lib.ptr(emax), _lib.ptr(esum),
+                                     _lib.ptr(out), _lib.ptr(go), _lib.ptr(gf), _lib.ptr(gar), _lib.ptr(gac),
+                                     _lib.ptr(ws), wsb, v, v, h, f, nnz, 0, _lib.stream_of(rp))
+
+    assert call(8, 8) == 0
+    assert call(3, 5) == _lib.EUNSUPPORTED == 7
+    assert call(8, 8, null_feat=True) == 1
+    assert lib.cogdl_hip_strerror(7) == b"shape not covered by this entry point"
+    torch.cuda.synchronize()
