@@ -149,6 +149,29 @@ def gcn_epoch_ms(gd, rowptr64, colind64, x, reps=20, warmup=5, mfma_linear=True)
             "linear": "cogdl_amd.linear: MFMA forward / grad_input / split-K weight gradient" if mfma_linear else "torch / hipBLASLt"}
 
 
+def trainer_epoch(budget_s=240):
+    """`gnn_epoch.trainer_ms`: the reference's OWN Trainer.train_step (cogdl/trainer/trainer.py:500-540) timed inside
+    `experiment(model='gcn', dataset=<arxiv-shaped NodeDataset>)`, run by the unchanged reference package (staged
+    copy under oracle/_ref/pkg) in child interpreters -- on cuda:0 on top of cogdl_amd.install() (with and without the
+    MFMA linear hook) and on the reference's own CPU path beside it.  None where the staged package is absent."""
+    import subprocess
+
+    from tools import refpkg
+
+    if not refpkg.available():
+        return None
+    out = {}
+    for key, argv in (("gpu", ["gpu", "30"]), ("gpu_mfma_linear", ["gpu", "30", "linear"]), ("cpu_reference", ["cpu", "3"])):
+        try:
+            proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trainer_epoch.py")] + argv,
+                                  capture_output=True, text=True, timeout=budget_s)
+            line = [ln for ln in proc.stdout.splitlines() if ln.startswith("TRAINER ")]
+            out[key] = json.loads(line[-1][8:]) if line else {"error": (proc.stderr or proc.stdout)[-400:]}
+        except subprocess.TimeoutExpired:
+            out[key] = {"error": "timeout after %d s" % budget_s}
+    return out
+
+
 def bench_single(args):
     from cogdl_amd import synth
     from cogdl_amd.operators import spmm as spmm_mod
@@ -219,6 +242,14 @@ def bench_single(args):
     }
     result["gnn_epoch"] = gcn_epoch_ms(gd, rowptr64, colind64, x)
     result["gnn_epoch"]["ms_with_torch_linear"] = gcn_epoch_ms(gd, rowptr64, colind64, x, mfma_linear=False)["ms"]
+    if not args.no_trainer:
+        tr = trainer_epoch()
+        if tr is not None:
+            result["gnn_epoch"]["trainer"] = tr
+            if "train_step_ms_median" in tr.get("gpu", {}):
+                result["gnn_epoch"]["trainer_ms"] = tr["gpu"]["train_step_ms_median"]
+            if "train_step_ms_median" in tr.get("cpu_reference", {}):
+                result["gnn_epoch"]["reference_cpu_trainer_ms"] = tr["cpu_reference"]["train_step_ms_median"]
     if not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(g, x_cpu)
     return result
@@ -238,6 +269,7 @@ def main():
     ap.add_argument("--feat", type=int, default=128)
     ap.add_argument("--topology", default="uniform", choices=["uniform", "rmat"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-trainer", action="store_true", help="skip the reference-Trainer epoch legs (gnn_epoch.trainer_ms)")
     ap.add_argument("--shard-nodes", type=int, default=0, help="N>1: nodes per GPU (default: papers100M/8)")
     ap.add_argument("--shard-degree", type=float, default=0.0, help="N>1: mean in-degree (default 28.8)")
     ap.add_argument("--remote-frac", type=float, default=-1.0,

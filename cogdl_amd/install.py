@@ -36,8 +36,11 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
 _finder = None
 
 
-def install(linear=False):
+def install(linear=False, fused_gat=True):
     """Idempotent.  Returns the list of cogdl module names that are now served by cogdl_amd.
+    fused_gat=True (default) also runs the dispatcher's own `initialize_fused_gat()` (utils/spmm_utils.py:241-248)
+    once cogdl is imported and a GPU is present: nothing in the reference ever calls it, so GATLayer's fused branch
+    (`check_fused_gat()`, layers/gat_layer.py:68) would otherwise stay dead even with a working fused operator.
     linear=True additionally routes torch.nn.functional.linear -- i.e. the unchanged nn.Linear inside every CogDL
     layer -- through cogdl_amd.linear (hand-written MFMA weight gradient for full-graph shapes)."""
     global _finder
@@ -69,6 +72,11 @@ def install(linear=False):
             su.CONFIGS[k] = False
         for k in ("fast_spmm", "csrmhspmm", "csr_edge_softmax", "fused_gat_func", "fast_spmm_cpu"):
             su.CONFIGS[k] = None
+        if fused_gat:
+            import torch
+
+            if torch.cuda.is_available():
+                su.initialize_fused_gat()
     return [_PREFIX + op for op in REPLACED]
 
 
