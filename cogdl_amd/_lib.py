@@ -33,8 +33,8 @@ HIP_SIGNATURES = {
     "cogdl_hip_gather_rows": ([_vp, _vp, _vp, _i64, _i64, _i32, _vp], _i32),
     "cogdl_hip_csr_sddmm": ([_vp] * 5 + [_i64, _i64, _i64, _vp], _i32),
     "cogdl_hip_edge_softmax_workspace_bytes": ([_i64, _i64], _sz),
-    "cogdl_hip_edge_softmax_fwd": ([_vp] * 3 + [_i64, _i64, _i64, _vp, _sz, _vp], _i32),
-    "cogdl_hip_edge_softmax_bwd": ([_vp] * 4 + [_i64, _i64, _i64, _vp, _sz, _vp], _i32),
+    "cogdl_hip_edge_softmax_fwd": ([_vp] * 3 + [_i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
+    "cogdl_hip_edge_softmax_bwd": ([_vp] * 4 + [_i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_mhspmm_workspace_bytes": ([_i64, _i64, _i64, _i32], _sz),
     "cogdl_hip_mhspmm": ([_vp] * 5 + [_i64, _i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_mhspmm_eid": ([_vp] * 6 + [_i64, _i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),

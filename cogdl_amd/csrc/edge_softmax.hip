@@ -665,23 +665,52 @@ static int edge_softmax_dispatch(const int32_t *rowptr, const float *a, const fl
 
 }  // namespace cogdl
 
+// edge_softmax_flat.hip
+namespace cogdl {
+bool es_flat_covers(int64_t h, int dtype, const void *a, const void *g, const void *out);
+size_t es_flat_workspace_bytes(int64_t nnz, int64_t h);
+int es_flat_launch(bool bwd, const int32_t *rowptr, const void *a, const void *g, void *out, int64_t m, int64_t nnz,
+                   int64_t h, int dtype, void *ws, size_t wsb, hipStream_t s);
+}  // namespace cogdl
+
 using namespace cogdl;
+
+// Tuning key 7, bit 2: force the row kernels of this file (experiments / A-B tests of the flat kernel).
+static bool es_use_flat(int64_t h, int dtype, const void *a, const void *g, const void *out, const void *ws) {
+    return ws != nullptr && (g_tuning[kTuneEsScalar] & 4) == 0 && es_flat_covers(h, dtype, a, g, out);
+}
 
 extern "C" size_t cogdl_hip_edge_softmax_workspace_bytes(int64_t nnz, int64_t h) {
     if (nnz <= 0 || h <= 0) return 0;
-    return rowreduce_workspace_bytes(nnz, 2 * h, es_thresh_scale(h));
+    const size_t rows = rowreduce_workspace_bytes(nnz, 2 * h, es_thresh_scale(h));
+    const bool pow2 = (h & (h - 1)) == 0 && h <= kWave;
+    return pow2 ? std::max(rows, es_flat_workspace_bytes(nnz, h)) : rows;
 }
 
-extern "C" int cogdl_hip_edge_softmax_fwd(const int32_t *rowptr, const float *values, float *out, int64_t m,
-                                          int64_t nnz, int64_t h, void *workspace, size_t workspace_bytes,
-                                          void *stream) {
-    return edge_softmax_dispatch<false>(rowptr, values, nullptr, out, m, nnz, h, workspace, workspace_bytes,
-                                        (hipStream_t)stream);
+template <bool BACKWARD>
+static int edge_softmax_entry(const int32_t *rowptr, const void *a, const void *g, void *out, int64_t m, int64_t nnz,
+                              int64_t h, int dtype, void *ws, size_t wsb, hipStream_t s) {
+    if (m < 0 || h < 0 || nnz < 0) return COGDL_HIP_EINVAL;
+    if (dtype != COGDL_HIP_F32 && dtype != COGDL_HIP_F16 && dtype != COGDL_HIP_BF16) return COGDL_HIP_EDTYPE;
+    if (m == 0 || h == 0 || nnz == 0) return COGDL_HIP_OK;
+    if (!rowptr || !a || !out || (BACKWARD && !g)) return COGDL_HIP_EINVAL;
+    if (h > 0x7fffffff || nnz > 0x7fffffff) return COGDL_HIP_ERANGE;
+    if (es_use_flat(h, dtype, a, g, out, ws)) return es_flat_launch(BACKWARD, rowptr, a, g, out, m, nnz, h, dtype, ws, wsb, s);
+    // the row kernels: f32 only (H not a power of two, H > 64, unaligned operands, or no workspace)
+    if (dtype != COGDL_HIP_F32) return COGDL_HIP_EUNSUPPORTED;
+    return edge_softmax_dispatch<BACKWARD>(rowptr, (const float *)a, (const float *)g, (float *)out, m, nnz, h, ws, wsb, s);
 }
 
-extern "C" int cogdl_hip_edge_softmax_bwd(const int32_t *rowptr, const float *softmax, const float *grad,
-                                          float *grad_in, int64_t m, int64_t nnz, int64_t h, void *workspace,
+extern "C" int cogdl_hip_edge_softmax_fwd(const int32_t *rowptr, const void *values, void *out, int64_t m,
+                                          int64_t nnz, int64_t h, int dtype, void *workspace,
                                           size_t workspace_bytes, void *stream) {
-    return edge_softmax_dispatch<true>(rowptr, softmax, grad, grad_in, m, nnz, h, workspace, workspace_bytes,
-                                       (hipStream_t)stream);
+    return edge_softmax_entry<false>(rowptr, values, nullptr, out, m, nnz, h, dtype, workspace, workspace_bytes,
+                                     (hipStream_t)stream);
+}
+
+extern "C" int cogdl_hip_edge_softmax_bwd(const int32_t *rowptr, const void *softmax, const void *grad,
+                                          void *grad_in, int64_t m, int64_t nnz, int64_t h, int dtype,
+                                          void *workspace, size_t workspace_bytes, void *stream) {
+    return edge_softmax_entry<true>(rowptr, softmax, grad, grad_in, m, nnz, h, dtype, workspace, workspace_bytes,
+                                    (hipStream_t)stream);
 }

@@ -1,0 +1,561 @@
+// edge_softmax_flat.hip -- edge_softmax forward / backward as a SEGMENTED softmax over the flat [E*H] value array,
+// gfx950.  Replaces cogdl/operators/edge_softmax/edge_softmax.cu:7-98 (one 32 x H block per row, three passes over the
+// row) for H a power of two <= 64 and f32 / f16 / bf16 values; every other shape keeps the row kernels of
+// edge_softmax.hip.
+//
+// Why flat: a CSR row owns a contiguous run of deg*H values, so the whole operator is a streaming pass over one
+// array with segment boundaries from rowptr.  Work is cut into TILES of a fixed number of elements (not rows):
+//   * every workgroup moves the same bytes, whatever the degree distribution (Reddit-shaped graphs: 82 % of the
+//     edges sit in rows of > 1024 edges, the longest has 10^5);
+//   * global loads and stores are full 16-byte-per-lane vectors, 8 of them in flight per lane;
+//   * the values are read from HBM exactly ONCE and written once (algorithmic bytes E*H*2s forward, E*H*3s backward):
+//     the tile lives in LDS between the statistics and the apply step.
+// Inside a tile (LDS resident): rows that lie completely in the tile are reduced by lane groups (short rows) or by
+// the whole workgroup (long rows).  A row that crosses tile borders is reduced piecewise: every tile publishes the
+// (max, sum) -- backward: the partial <softmax, grad> -- of its piece in a workspace record (write-through stores +
+// flag, MI355X_MICROARCH.md "inter-workgroup visibility" recipe R1), waits for the other pieces of the row, merges
+// all records in tile order (deterministic) and applies the row totals to the piece it still holds in LDS.
+//
+// Progress: tiles are numbered by an atomic ticket, so tile c starts only after every tile < c has started; a piece
+// is published BEFORE its workgroup waits.  A wait therefore only ever needs workgroups to START, and with rows of
+// at most K_max tiles (K_max = 192 <= the number of workgroups resident on 256 CUs) some waiting workgroup can
+// always finish.  Rows longer than K_max tiles never wait: their piece records are produced up front by the init
+// kernel (the same launch that zeroes the ticket and the flags), at the price of one extra read of those rows only.
+// Independently of all that every wait is bounded: on time-out the workgroup recomputes the row statistics from
+// global memory itself (correct under any scheduling, merely slower).
+#include "rowreduce.h"
+
+namespace cogdl {
+namespace esf {
+
+constexpr int kThreads = 256;
+constexpr int kRowChunk = 512;    // rowptr entries staged in LDS per pass over a tile's rows
+constexpr int kKMax = 192;        // longest row (in tiles) that uses the in-launch exchange
+constexpr unsigned kSpinLimit = 1u << 16;
+
+template <bool BWD> struct TileSize { static constexpr int value = BWD ? 4096 : 8192; };  // elements (32 KB of LDS)
+
+__device__ __forceinline__ float es_exp(float x) { return __expf(x); }
+
+struct Params {
+    const int32_t *rowptr;
+    const void *a;       // values (forward) | softmax output (backward)
+    const void *g;       // upstream gradient (backward)
+    void *out;
+    int64_t m, nnz;
+    int h;               // power of two <= 64
+    int tile_e;          // edges per tile = tile elements / h
+    int64_t n_tiles;
+    unsigned *ticket;    // 1 word, zeroed by the init kernel
+    unsigned *flags;     // [n_tiles * 2], zeroed by the init kernel
+    float2 *rec;         // [n_tiles * 2][h]: (max, sum) | (dot, 0)
+    int64_t long_edges;  // rows with more edges are "super-long": records come from the init kernel
+    unsigned spin_limit; // polls of one flag before the wait gives up (tuning key 8; tests force the escape path)
+};
+
+// ---- agent-scope accesses (write-through stores / L1-bypassing loads; see the file header) ---------------------
+__device__ __forceinline__ void st_agent(unsigned *p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned ld_agent(const unsigned *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_rec(float2 *p, float x, float y) {
+    const unsigned long long bits = ((unsigned long long)__float_as_uint(y) << 32) | __float_as_uint(x);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld_rec(const float2 *p) {
+    const unsigned long long bits =
+        __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)bits), __uint_as_float((unsigned)(bits >> 32)));
+}
+
+// (max, sum) pairs: b's elements follow a's.
+__device__ __forceinline__ float2 ms_combine(float2 a, float2 b) {
+    const float mx = fmaxf(a.x, b.x);
+    const float sa = (a.y == 0.f) ? 0.f : a.y * es_exp(a.x - mx);
+    const float sb = (b.y == 0.f) ? 0.f : b.y * es_exp(b.x - mx);
+    return make_float2(mx, sa + sb);
+}
+
+// 256-ary search, whole workgroup: the row that contains edge e (rowptr[r] <= e < rowptr[r+1]), 0 <= e < nnz.
+// Every round is one L2 load per thread and one barrier (3 rounds up to 16 M rows) instead of ~24 dependent loads.
+__device__ __forceinline__ int64_t wg_row_of_edge(const int32_t *__restrict__ rowptr, int64_t m, int64_t e) {
+    int64_t lo = 0, hi = m;  // invariant: rowptr[lo] <= e < rowptr[hi]
+    while (hi - lo > 1) {
+        const int64_t step = (hi - lo + kThreads - 1) / kThreads;
+        const int64_t idx = lo + (int64_t)(threadIdx.x + 1) * step;
+        const int below = (idx < hi && (int64_t)rowptr[idx] <= e) ? 1 : 0;
+        const int cnt = __syncthreads_count(below);  // probes are monotone: the first `cnt` are <= e
+        lo = lo + (int64_t)cnt * step;
+        hi = min(lo + step, hi);
+    }
+    return lo;
+}
+
+// ---- whole-workgroup reduction of one value per thread over the threads that share a head (t % h) ------------------
+// In-wave butterfly over the lane strides >= h, the four wave partials through LDS in wave order.  Result: every
+// thread gets the total of its head.  `red` = 4 * 64 floats.
+template <bool MAX>
+__device__ __forceinline__ float wg_head_reduce(float v, int h, float *red) {
+#pragma unroll
+    for (int s = kWave / 2; s > 0; s >>= 1)
+        if (s >= h) v = MAX ? fmaxf(v, __shfl_xor(v, s, kWave)) : v + __shfl_xor(v, s, kWave);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    __syncthreads();  // the previous use of `red` is over
+    if (lane < h) red[wave * kWave + lane] = v;
+    __syncthreads();
+    const int hd = threadIdx.x & (h - 1);
+    float r = red[hd];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) r = MAX ? fmaxf(r, red[w * kWave + hd]) : r + red[w * kWave + hd];
+    return r;
+}
+
+// Statistics of the LDS span [off, off + cnt) (one row piece; off and cnt multiples of h): thread t walks the
+// elements t, t + 256, ... (head t % h, bank-conflict free).  Forward: the values are replaced by exp(v - max) and
+// (max, sum) is returned; backward: <a, g> is returned in .x.  All threads return the value of head t % h.
+template <bool BWD>
+__device__ __forceinline__ float2 wg_piece_lds(float *tile, const float *tile_g, int off, int cnt, int h, float *red) {
+    const int t = threadIdx.x;
+    if constexpr (BWD) {
+        float dot = 0.f;
+        for (int i = t; i < cnt; i += kThreads) dot = fmaf(tile[off + i], tile_g[off + i], dot);
+        return make_float2(wg_head_reduce<false>(dot, h, red), 0.f);
+    } else {
+        float mx = -INFINITY;
+        for (int i = t; i < cnt; i += kThreads) mx = fmaxf(mx, tile[off + i]);
+        mx = wg_head_reduce<true>(mx, h, red);
+        float sum = 0.f;
+        for (int i = t; i < cnt; i += kThreads) {
+            const float p = es_exp(tile[off + i] - mx);
+            tile[off + i] = p;
+            sum += p;
+        }
+        return make_float2(mx, wg_head_reduce<false>(sum, h, red));
+    }
+}
+
+// The same statistics straight from global memory, elements [lo, hi) of the flat arrays (time-out escape of the
+// exchange and the init kernel's pass over super-long rows).  Nothing is modified.
+template <typename T, bool BWD>
+__device__ __forceinline__ float2 wg_piece_global(const T *__restrict__ a, const T *__restrict__ g, int64_t lo,
+                                                  int64_t hi, int h, float *red) {
+    const int t = threadIdx.x;
+    constexpr int U = 8;
+    if constexpr (BWD) {
+        float dot = 0.f;
+        for (int64_t i = lo + t; i < hi; i += (int64_t)kThreads * U) {
+            float va[U], vg[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t idx = i + (int64_t)u * kThreads;
+                const bool ok = idx < hi;
+                va[u] = ok ? to_f32<T>(a[idx]) : 0.f;
+                vg[u] = ok ? to_f32<T>(g[idx]) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) dot = fmaf(va[u], vg[u], dot);
+        }
+        return make_float2(wg_head_reduce<false>(dot, h, red), 0.f);
+    } else {
+        float mx = -INFINITY, sum = 0.f;  // online (max, sum), one rescale per batch of U
+        for (int64_t i = lo + t; i < hi; i += (int64_t)kThreads * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t idx = i + (int64_t)u * kThreads;
+                v[u] = idx < hi ? to_f32<T>(a[idx]) : -INFINITY;
+            }
+            float bm = v[0];
+#pragma unroll
+            for (int u = 1; u < U; ++u) bm = fmaxf(bm, v[u]);
+            const float mn = fmaxf(mx, bm);
+            float s = 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) s += es_exp(v[u] - mn);
+            sum = ((sum == 0.f) ? 0.f : sum * es_exp(mx - mn)) + s;
+            mx = mn;
+        }
+        const float gm = wg_head_reduce<true>(mx, h, red);
+        const float mine = (sum == 0.f) ? 0.f : sum * es_exp(mx - gm);
+        return make_float2(gm, wg_head_reduce<false>(mine, h, red));
+    }
+}
+
+// Publish the record of (tile, slot): threads 0..h-1 (all in wave 0) store their head's pair write-through, the wave
+// drains its stores, one lane raises the flag.
+__device__ __forceinline__ void publish(const Params &p, int64_t tile, int slot, float2 mine) {
+    if (threadIdx.x < kWave) {
+        if ((int)threadIdx.x < p.h) st_rec(p.rec + (tile * 2 + slot) * p.h + threadIdx.x, mine.x, mine.y);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) st_agent(p.flags + tile * 2 + slot, 1u);
+    }
+}
+
+// Record slot of row [start, end) in tile c (the row is known to intersect c and to extend beyond it).
+__device__ __forceinline__ int slot_of(int64_t start, int64_t c, int tile_e) { return start <= c * tile_e ? 0 : 1; }
+
+// Totals of the row [start, end) that crosses tile borders: wait for the records of all its pieces, merge them in
+// tile order.  Returns, for the head t % h of every thread, (max, sum) | (dot, -).  Returns false on time-out.
+// `mrg` = 256 float2 of LDS.
+template <bool BWD>
+__device__ __forceinline__ bool row_totals(const Params &p, int64_t start, int64_t end, float2 *mrg, float2 &tot) {
+    const int64_t c_a = start / p.tile_e, c_b = (end - 1) / p.tile_e;
+    const int k = (int)(c_b - c_a + 1);
+    const int t = threadIdx.x;
+    bool ok = true;
+    for (int q = t; q < k; q += kThreads) {
+        const int64_t c = c_a + q;
+        const unsigned *f = p.flags + c * 2 + ((q == 0) ? slot_of(start, c, p.tile_e) : 0);
+        unsigned spins = 0;
+        while (ld_agent(f) == 0u) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > p.spin_limit) {
+                ok = false;
+                break;
+            }
+        }
+    }
+    if (!__syncthreads_and(ok ? 1 : 0)) return false;
+    // thread (q0 = t / h, hd = t % h) merges the records q0, q0 + 256/h, ... ; then the 256/h partials in order
+    const int h = p.h, hd = t & (h - 1), q0 = t / h, nq = kThreads / h;
+    float2 acc = BWD ? make_float2(0.f, 0.f) : make_float2(-INFINITY, 0.f);
+    for (int q = q0; q < k; q += nq) {
+        const int64_t c = c_a + q;
+        const int slot = (q == 0) ? slot_of(start, c, p.tile_e) : 0;
+        const float2 r = ld_rec(p.rec + (c * 2 + slot) * h + hd);
+        if constexpr (BWD) acc.x += r.x;
+        else acc = ms_combine(acc, r);
+    }
+    // NB: partials interleave the records (q0, q0+nq, ...): max and sum are order-independent up to rounding and the
+    // interleaving is a fixed function of (k, h), so every tile of the row computes the identical totals.
+    __syncthreads();
+    mrg[t] = acc;
+    __syncthreads();
+    float2 r = mrg[hd];
+    for (int q = 1; q < nq && q < k; ++q) {
+        if constexpr (BWD) r.x += mrg[q * h + hd].x;
+        else r = ms_combine(r, mrg[q * h + hd]);
+    }
+    tot = r;
+    return true;
+}
+
+// ---- rows that lie completely inside the tile and have at most `lthr` edges: one lane group of LPR lanes per row ---
+// rp = LDS copy of rowptr[r0 .. r0 + nrows]; LPR is a multiple of h, so lane l always sees head l % h.
+template <int LPR, bool BWD>
+__device__ __forceinline__ void rows_small(float *tile, const float *tile_g, const int32_t *rp, int nrows, int64_t e0,
+                                           int64_t e1, int h, int lthr) {
+    constexpr int NG = kThreads / LPR;
+    const int grp = threadIdx.x / LPR, l = threadIdx.x % LPR;
+    for (int i = grp; i < nrows; i += NG) {
+        const int64_t start = rp[i], end = rp[i + 1];
+        const int len = (int)(end - start);
+        if (start < e0 || end > e1 || len == 0 || len > lthr) continue;  // (group-uniform)
+        const int base = (int)(start - e0) * h, cnt = len * h;
+        if constexpr (BWD) {
+            float dot = 0.f;
+            for (int j = l; j < cnt; j += LPR) dot = fmaf(tile[base + j], tile_g[base + j], dot);
+#pragma unroll
+            for (int s = LPR / 2; s > 0; s >>= 1)
+                if (s >= h) dot += __shfl_xor(dot, s, kWave);
+            for (int j = l; j < cnt; j += LPR) tile[base + j] = tile[base + j] * (tile_g[base + j] - dot);
+        } else {
+            float mx = -INFINITY;
+            for (int j = l; j < cnt; j += LPR) mx = fmaxf(mx, tile[base + j]);
+#pragma unroll
+            for (int s = LPR / 2; s > 0; s >>= 1)
+                if (s >= h) mx = fmaxf(mx, __shfl_xor(mx, s, kWave));
+            float sum = 0.f;
+            for (int j = l; j < cnt; j += LPR) {
+                const float pe = es_exp(tile[base + j] - mx);
+                tile[base + j] = pe;
+                sum += pe;
+            }
+#pragma unroll
+            for (int s = LPR / 2; s > 0; s >>= 1)
+                if (s >= h) sum += __shfl_xor(sum, s, kWave);
+            const float inv = 1.f / sum;
+            for (int j = l; j < cnt; j += LPR) tile[base + j] *= inv;
+        }
+    }
+}
+
+// ---- 16-byte global vector <-> V floats ------------------------------------------------------------------------
+template <typename T> struct VecOf { static constexpr int V = 16 / sizeof(T); };
+
+template <typename T>
+__device__ __forceinline__ void load16(const T *p, float (&v)[VecOf<T>::V]) {
+    load_vec<T, VecOf<T>::V>(p, v);
+}
+
+// =====================================================================================================================
+// main kernel: one tile per workgroup
+template <typename T, bool BWD>
+__global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
+    constexpr int TILE = TileSize<BWD>::value;
+    constexpr int V = VecOf<T>::V;
+    constexpr int NV = TILE / (kThreads * V);  // 16-byte vectors per thread (per array)
+    __shared__ __attribute__((aligned(16))) float tile[TILE];
+    __shared__ __attribute__((aligned(16))) float tile_gs[BWD ? TILE : 4];
+    __shared__ int32_t rp[kRowChunk + 1];
+    __shared__ float red[4 * kWave];
+    __shared__ float2 mrg[kThreads];
+    __shared__ float2 fac[2][kWave];  // per partial piece (head, tail) and head id: what the store step applies
+    __shared__ int64_t s_tile;
+    constexpr int kMaxLong = 64;
+    __shared__ int s_nlong, s_long[kMaxLong];
+    const int t = threadIdx.x;
+    const T *__restrict__ a = (const T *)p.a;
+    const T *__restrict__ g = (const T *)p.g;
+    T *__restrict__ out = (T *)p.out;
+    const int h = p.h;
+
+    if (t == 0) s_tile = (int64_t)atomicAdd(p.ticket, 1u);
+    __syncthreads();
+    const int64_t c = s_tile;
+    if (c >= p.n_tiles) return;
+    const int64_t e0 = c * p.tile_e, e1 = min(p.nnz, e0 + p.tile_e);
+    const int64_t b0 = e0 * h;
+    const int count = (int)((e1 - e0) * h);
+    const bool full = count == TILE;
+
+    // ---- 1. the tile's values, 16 bytes per lane per load, all loads in flight before anything waits ------------
+    float va[NV][V];
+    float vg[BWD ? NV : 1][V];
+    if (full) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) load16<T>(a + b0 + (int64_t)(j * kThreads + t) * V, va[j]);
+        if constexpr (BWD) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) load16<T>(g + b0 + (int64_t)(j * kThreads + t) * V, vg[j]);
+        }
+    } else {  // the last tile: element-wise guarded
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const int i = (j * kThreads + t) * V + k;
+                va[j][k] = i < count ? to_f32<T>(a[b0 + i]) : 0.f;
+                if constexpr (BWD) vg[j][k] = i < count ? to_f32<T>(g[b0 + i]) : 0.f;
+            }
+    }
+    // ---- 2. the rows of the tile (overlaps the loads) ---------------------------------------------------------------
+    const int64_t r_first = wg_row_of_edge(p.rowptr, p.m, e0);
+    const int64_t r_last = wg_row_of_edge(p.rowptr, p.m, e1 - 1);
+    // ---- 3. registers -> LDS ---------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int k = 0; k < V; k += 4) {
+            *reinterpret_cast<float4 *>(tile + (j * kThreads + t) * V + k) =
+                make_float4(va[j][k], va[j][k + 1], va[j][k + 2], va[j][k + 3]);
+            if constexpr (BWD)
+                *reinterpret_cast<float4 *>(tile_gs + (j * kThreads + t) * V + k) =
+                    make_float4(vg[j][k], vg[j][k + 1], vg[j][k + 2], vg[j][k + 3]);
+        }
+    __syncthreads();
+    const float *tile_g = tile_gs;
+
+    // ---- 4. partial pieces (the row of the first / last edge when it extends beyond the tile) --------------------
+    const int64_t hs = p.rowptr[r_first], he = p.rowptr[r_first + 1];  // head row
+    const int64_t ts = p.rowptr[r_last], te = p.rowptr[r_last + 1];    // tail row (may be the same row)
+    const bool head_partial = hs < e0 || he > e1;
+    const bool tail_partial = (r_last != r_first) && te > e1;
+    const int head_end = head_partial ? (int)(min(he, e1) - e0) * h : 0;  // LDS span [0, head_end)
+    const int tail_begin = tail_partial ? (int)(ts - e0) * h : count;     // LDS span [tail_begin, count)
+    float2 head_piece = make_float2(0.f, 0.f), tail_piece = make_float2(0.f, 0.f);
+    if (head_partial) {
+        head_piece = wg_piece_lds<BWD>(tile, tile_g, 0, head_end, h, red);
+        if (he - hs <= p.long_edges) publish(p, c, 0, head_piece);  // super-long rows: published by the init kernel
+    }
+    if (tail_partial) {
+        tail_piece = wg_piece_lds<BWD>(tile, tile_g, tail_begin, count - tail_begin, h, red);
+        if (te - ts <= p.long_edges) publish(p, c, 1, tail_piece);
+    }
+
+    // ---- 5. rows completely inside the tile ---------------------------------------------------------------------------
+    const int64_t rc0 = r_first + (head_partial ? 1 : 0), rc1 = r_last - (tail_partial ? 1 : 0);  // inclusive range
+    if (rc1 >= rc0) {
+        // lanes per row from the mean row length of this tile: ~8 sequential steps per lane, at least max(8, h) lanes
+        const int64_t nrows_all = rc1 - rc0 + 1;
+        const int mean_elems = (int)min((int64_t)TILE, (int64_t)(tail_begin - head_end) / nrows_all);
+        int lpr = max(8, h);
+        while (lpr < kWave && lpr * 8 < mean_elems) lpr <<= 1;
+        const int lthr = 32 * (lpr / h);  // longer rows: one at a time by the whole workgroup
+        for (int64_t r0 = rc0; r0 <= rc1; r0 += kRowChunk) {
+            const int nrows = (int)min((int64_t)kRowChunk, rc1 - r0 + 1);
+            __syncthreads();
+            if (t == 0) s_nlong = 0;
+            for (int i = t; i <= nrows; i += kThreads) rp[i] = p.rowptr[r0 + i];
+            __syncthreads();
+            switch (lpr) {
+                case 8: rows_small<8, BWD>(tile, tile_g, rp, nrows, e0, e1, h, lthr); break;
+                case 16: rows_small<16, BWD>(tile, tile_g, rp, nrows, e0, e1, h, lthr); break;
+                case 32: rows_small<32, BWD>(tile, tile_g, rp, nrows, e0, e1, h, lthr); break;
+                default: rows_small<64, BWD>(tile, tile_g, rp, nrows, e0, e1, h, lthr); break;
+            }
+            // Long complete rows of this chunk, one at a time by the whole workgroup.  A tile holds fewer than 32 of
+            // them (they have more than lthr >= 32 * max(8, h) / h edges each), so the list cannot overflow.
+            for (int i = t; i < nrows; i += kThreads) {
+                if (rp[i + 1] - rp[i] > lthr) {
+                    const int pos = atomicAdd(&s_nlong, 1);
+                    if (pos < kMaxLong) s_long[pos] = i;
+                }
+            }
+            __syncthreads();
+            const int n_long = min(s_nlong, kMaxLong);
+            for (int q = 0; q < n_long; ++q) {
+                const int i2 = s_long[q];
+                const int off = (int)(rp[i2] - e0) * h, cnt = (rp[i2 + 1] - rp[i2]) * h;
+                const float2 st = wg_piece_lds<BWD>(tile, tile_g, off, cnt, h, red);
+                if constexpr (BWD) {
+                    for (int j = t; j < cnt; j += kThreads) tile[off + j] = tile[off + j] * (tile_g[off + j] - st.x);
+                } else {
+                    const float inv = 1.f / st.y;
+                    for (int j = t; j < cnt; j += kThreads) tile[off + j] *= inv;
+                }
+            }
+        }
+    }
+
+    // ---- 6. row totals of the partial pieces -> the factor the store step applies ------------------------------
+    //   forward : out = p * exp(m_piece - m_row) / s_row          (fac = that product)
+    //   backward: out = a * (g - dot_row)                          (fac = dot_row)
+    const int hd = t & (h - 1);
+    if (head_partial) {
+        float2 tot;
+        if (!row_totals<BWD>(p, hs, he, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
+        if (t < h) fac[0][hd] = BWD ? make_float2(tot.x, 0.f) : make_float2(es_exp(head_piece.x - tot.x) / tot.y, 0.f);
+    }
+    if (tail_partial) {
+        float2 tot;
+        if (!row_totals<BWD>(p, ts, te, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, ts * h, te * h, h, red);
+        if (t < h) fac[1][hd] = BWD ? make_float2(tot.x, 0.f) : make_float2(es_exp(tail_piece.x - tot.x) / tot.y, 0.f);
+    }
+    __syncthreads();
+
+    // ---- 7. LDS -> global, 16 bytes per lane ------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i0 = (j * kThreads + t) * V;
+        float o[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int i = i0 + k;
+            float v = tile[i];
+            if (i < head_end || i >= tail_begin) {
+                const float f = fac[i < head_end ? 0 : 1][i & (h - 1)].x;
+                if constexpr (BWD) v = v * (tile_g[i] - f);
+                else v = v * f;
+            }
+            o[k] = v;
+        }
+        if (full) {
+            store_vec<T, V>(out + b0 + i0, o);
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                if (i0 + k < count) out[b0 + i0 + k] = from_f32<T>(o[k]);
+        }
+    }
+}
+
+// =====================================================================================================================
+// init kernel: zero the ticket and the flags; produce the piece records of super-long rows.
+// Workgroup k owns the tiles [k * K_max, (k+1) * K_max), i.e. the edges [k * L, (k+1) * L) with L = K_max * tile_e.
+// A row of more than L edges contains a multiple of L, so it is the row of the first or of the last edge of some
+// segment: each workgroup checks those two rows and, for a super-long one, computes the statistics of its pieces
+// inside the segment, tile by tile, publishing them exactly where the main kernel looks for them.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(kThreads) void es_flat_init_kernel(const Params p) {
+    __shared__ float red[4 * kWave];
+    const int t = threadIdx.x;
+    const int64_t seg = blockIdx.x;
+    const int64_t c_lo = seg * kKMax, c_hi = min(p.n_tiles, c_lo + kKMax);
+    if (seg == 0 && t == 0) st_agent(p.ticket, 0u);
+    for (int64_t i = c_lo * 2 + t; i < c_hi * 2; i += kThreads) st_agent(p.flags + i, 0u);
+    const int64_t L = (int64_t)kKMax * p.tile_e;
+    if (p.nnz <= L) return;  // no row can be super-long (uniform)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int64_t s_lo = c_lo * p.tile_e, s_hi = min(p.nnz, c_hi * p.tile_e);
+    const int64_t ra = wg_row_of_edge(p.rowptr, p.m, s_lo);
+    const int64_t rb = wg_row_of_edge(p.rowptr, p.m, s_hi - 1);
+    const T *__restrict__ a = (const T *)p.a;
+    const T *__restrict__ g = (const T *)p.g;
+    for (int which = 0; which < 2; ++which) {
+        if (which == 1 && rb == ra) break;
+        const int64_t r = which == 0 ? ra : rb;
+        const int64_t start = p.rowptr[r], end = p.rowptr[r + 1];
+        if (end - start <= p.long_edges) continue;
+        const int64_t lo = max(start, s_lo), hi = min(end, s_hi);
+        for (int64_t c = lo / p.tile_e; c * p.tile_e < hi; ++c) {
+            const int64_t pl = max(lo, c * p.tile_e), ph = min(hi, (c + 1) * p.tile_e);
+            const float2 st = wg_piece_global<T, BWD>(a, g, pl * p.h, ph * p.h, p.h, red);
+            publish(p, c, slot_of(start, c, p.tile_e), st);
+        }
+    }
+}
+
+template <typename T, bool BWD>
+static int launch_typed(const Params &p, hipStream_t s) {
+    const int64_t n_seg = (p.n_tiles + kKMax - 1) / kKMax;
+    if (n_seg > 0x7fffffff || p.n_tiles > 0x7fffffff) return COGDL_HIP_ERANGE;
+    hipLaunchKernelGGL((es_flat_init_kernel<T, BWD>), dim3((unsigned)n_seg), dim3(kThreads), 0, s, p);
+    hipLaunchKernelGGL((es_flat_kernel<T, BWD>), dim3((unsigned)p.n_tiles), dim3(kThreads), 0, s, p);
+    return launch_status();
+}
+
+}  // namespace esf
+
+// ---- interface to edge_softmax.hip ------------------------------------------------------------------------------------
+bool es_flat_covers(int64_t h, int dtype, const void *a, const void *g, const void *out) {
+    if (h < 1 || h > 64 || (h & (h - 1)) != 0) return false;
+    if (dtype != COGDL_HIP_F32 && dtype != COGDL_HIP_F16 && dtype != COGDL_HIP_BF16) return false;
+    return aligned_to(a, 16) && aligned_to(out, 16) && (g == nullptr || aligned_to(g, 16));
+}
+
+static int64_t es_flat_tiles(int64_t nnz, int64_t h, bool bwd) {
+    const int64_t tile_e = (bwd ? esf::TileSize<true>::value : esf::TileSize<false>::value) / h;
+    return (nnz + tile_e - 1) / tile_e;
+}
+
+// [ticket: 256 B][flags: n_tiles * 2 words, padded to 256 B][records: n_tiles * 2 * h float2]
+size_t es_flat_workspace_bytes(int64_t nnz, int64_t h) {
+    const int64_t n_tiles = es_flat_tiles(nnz, h, true);  // the backward's smaller tiles need more of them
+    const size_t flags = ((size_t)n_tiles * 2 * sizeof(unsigned) + 255) / 256 * 256;
+    return 256 + flags + (size_t)n_tiles * 2 * (size_t)h * sizeof(float2);
+}
+
+int es_flat_launch(bool bwd, const int32_t *rowptr, const void *a, const void *g, void *out, int64_t m, int64_t nnz,
+                   int64_t h, int dtype, void *ws, size_t wsb, hipStream_t s) {
+    if (!ws || wsb < es_flat_workspace_bytes(nnz, h)) return COGDL_HIP_EWORKSPACE;
+    if (!aligned_to(ws, 256)) return COGDL_HIP_EALIGN;
+    esf::Params p{};
+    p.rowptr = rowptr;
+    p.a = a;
+    p.g = g;
+    p.out = out;
+    p.m = m;
+    p.nnz = nnz;
+    p.h = (int)h;
+    p.tile_e = (int)((bwd ? esf::TileSize<true>::value : esf::TileSize<false>::value) / h);
+    p.n_tiles = es_flat_tiles(nnz, h, bwd);
+    p.ticket = (unsigned *)ws;
+    p.flags = (unsigned *)((char *)ws + 256);
+    const size_t flags = ((size_t)es_flat_tiles(nnz, h, true) * 2 * sizeof(unsigned) + 255) / 256 * 256;
+    p.rec = (float2 *)((char *)ws + 256 + flags);
+    p.long_edges = (int64_t)esf::kKMax * p.tile_e;
+    p.spin_limit = g_tuning[kTuneEsSpin] > 0 ? (unsigned)g_tuning[kTuneEsSpin] : esf::kSpinLimit;
+    switch (dtype) {
+        case COGDL_HIP_F32: return bwd ? esf::launch_typed<float, true>(p, s) : esf::launch_typed<float, false>(p, s);
+        case COGDL_HIP_F16: return bwd ? esf::launch_typed<__half, true>(p, s) : esf::launch_typed<__half, false>(p, s);
+        case COGDL_HIP_BF16:
+            return bwd ? esf::launch_typed<__hip_bfloat16, true>(p, s) : esf::launch_typed<__hip_bfloat16, false>(p, s);
+        default: return COGDL_HIP_EDTYPE;
+    }
+}
+
+}  // namespace cogdl

@@ -105,6 +105,33 @@ def arxiv_like(seed=0, topology="uniform"):
     return finalize(src, dst, n)
 
 
+REDDIT_NODES, REDDIT_UNDIRECTED = 232_965, 57_307_946
+
+
+def reddit_like(seed=0, device="cpu", norm=None):
+    """BASELINE.json configs[2]: Reddit's shape (SAINT format, cogdl/datasets/saint_data.py:15-64) -- N = 232,965,
+    114,615,892 directed edges after symmetrisation, + one self loop per node = 114,848,857 nnz.  R-MAT pairs are
+    drawn until there are enough distinct undirected pairs, then exactly 57,307,946 of them are kept (seeded
+    selection), so the edge count is Reddit's regardless of how many duplicates R-MAT produced.  Power-law rows: the
+    longest has ~10^5 edges, 82 % of the edges sit in rows of more than 1024.  On a GPU this takes a few seconds (on
+    the CPU ~1 min); the graph depends on (seed, device type)."""
+    n, target = REDDIT_NODES, REDDIT_UNDIRECTED
+    keys = None
+    draw = 0
+    while keys is None or keys.numel() < target:
+        src, dst = rmat_pairs(n, 100_000_000, seed * 7919 + draw, device=device)
+        lo, hi = torch.minimum(src, dst), torch.maximum(src, dst)
+        keep = lo != hi
+        k = torch.unique(lo[keep] * n + hi[keep])
+        del src, dst, lo, hi, keep
+        keys = k if keys is None else torch.unique(torch.cat([keys, k]))
+        draw += 1
+    if keys.numel() > target:
+        g = torch.Generator(device=device).manual_seed(seed + 1)
+        keys = keys[torch.randperm(keys.numel(), generator=g, device=device)[:target]]
+    return finalize(keys // n, keys % n, n, norm=norm)
+
+
 def cora_like(seed=0):
     """Cora shape: N=2,708, 5,278 undirected pairs -> 10,556 directed + 2,708 loops."""
     n = 2_708

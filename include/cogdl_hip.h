@@ -66,7 +66,9 @@ COGDL_API int cogdl_hip_last_hip_error(void);
  * long-row workgroups (default 1024), key 4 = cap on the fused-GAT vector width (0 = widest), key 5 = fused-GAT
  * forward kernel (0 = automatic, 1 = edge-wise online softmax, 2 = chunk-wise softmax where the shape allows),
  * key 6 = csr_spmm/mhspmm vector width cap (negative: force), key 7 = edge_softmax lane width (bit 0: 4-byte lanes in
- * the row kernels, bit 1: 4-byte lanes in the hub-row path; 0 = 16-byte lanes where the layout allows).
+ * the row kernels, bit 1: 4-byte lanes in the hub-row path, bit 2: row kernels instead of the flat streaming kernel;
+ * 0 = flat kernel where it applies, 16-byte lanes where the layout allows), key 8 = polls before the flat edge_softmax
+ * kernel's cross-tile wait gives up and recomputes the row statistics itself (0 = default 65536).
  * Defaults are the measured optima. */
 COGDL_API int cogdl_hip_set_tuning(int key, int value);
 
@@ -138,13 +140,21 @@ COGDL_API int cogdl_hip_csr_sddmm(const int32_t *rowptr, const int32_t *colind, 
  * edge_softmax: per (destination row, head) softmax over the row's edges; values [E,H].
  * Replaces edge_softmax.edge_softmax / edge_softmax_backward
  * (operators/edge_softmax/edge_softmax.cc:16-49, edge_softmax.cu:7-60,63-98).
- * Any H >= 1 (the reference's block (32,H) caps H at 32).
+ * Any H >= 1 (the reference's block (32,H) caps H at 32).  values / softmax / grad / out share the element type
+ * `dtype` (f32, f16, bf16; fp32 arithmetic, rounded once on store).
+ * With a workspace of cogdl_hip_edge_softmax_workspace_bytes(nnz, h) bytes (device, 256-B aligned), H a power of
+ * two <= 64 and 16-byte aligned operands the call is ONE streaming pass (every value read from HBM once, written
+ * once; rows that cross tile borders are combined inside the launch, csrc/edge_softmax_flat.hip): two launches (a
+ * small init kernel + the main kernel), no host synchronisation, hipGraph-capturable.  Other shapes use
+ * row-parallel kernels (f32 only: COGDL_HIP_EUNSUPPORTED for 2-byte types there; without a workspace hub rows are
+ * reduced sequentially).
  * ------------------------------------------------------------------------------------- */
 COGDL_API size_t cogdl_hip_edge_softmax_workspace_bytes(int64_t nnz, int64_t h);
-COGDL_API int cogdl_hip_edge_softmax_fwd(const int32_t *rowptr, const float *values, float *out, int64_t m,
-                               int64_t nnz, int64_t h, void *workspace, size_t workspace_bytes, void *stream);
-COGDL_API int cogdl_hip_edge_softmax_bwd(const int32_t *rowptr, const float *softmax, const float *grad,
-                               float *grad_in, int64_t m, int64_t nnz, int64_t h, void *workspace,
+COGDL_API int cogdl_hip_edge_softmax_fwd(const int32_t *rowptr, const void *values, void *out, int64_t m,
+                               int64_t nnz, int64_t h, int dtype, void *workspace, size_t workspace_bytes,
+                               void *stream);
+COGDL_API int cogdl_hip_edge_softmax_bwd(const int32_t *rowptr, const void *softmax, const void *grad,
+                               void *grad_in, int64_t m, int64_t nnz, int64_t h, int dtype, void *workspace,
                                size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------

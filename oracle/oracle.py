@@ -71,6 +71,7 @@ class _Sigs:
     oracle_sample_adj = ([_vp, _vp, _i64, _vp, _i64, _i64, _i32] + [_vp] * 4 + [_i64, _i64, _vp], _i32)
     oracle_subgraph = ([_vp, _vp, _i64, _vp, _i64] + [_vp] * 3 + [_i64, _vp], _i32)
     oracle_gat_fwd = ([_vp] * 5 + [_f32] + [_vp] * 2 + [_i64] * 3, None)
+    oracle_gat_bwd = ([_vp] * 7 + [_f32] + [_vp] * 7 + [_i64] * 4, None)
     oracle_num_threads = ([], _i32)
 
 
@@ -178,6 +179,25 @@ def gat_fwd(rowptr, colind, h_l, h_r, feat, slope, return_att=False):
     att = np.empty((int(rowptr[v]), h), np.float32) if return_att else None
     lib().oracle_gat_fwd(_p(rowptr), _p(colind), _p(h_l), _p(h_r), _p(feat), float(slope), _p(out), _p(att), v, h, f)
     return (out, att) if return_att else out
+
+
+def gat_bwd(rowptr, colind, h_l, h_r, feat, slope, gout, n_src=None, scales=False):
+    """fp64 gradients of the unfused GAT composition -> (grad_feat [n_src,H,F], grad_h_l [V,H], grad_h_r [n_src,H]);
+    scales=True appends the three sums of absolute terms (the base of a floating-point tolerance)."""
+    rowptr, colind = _np(rowptr, np.int32), _np(colind, np.int32)
+    h_l, h_r, feat, gout = (_np(a, np.float32) for a in (h_l, h_r, feat, gout))
+    v, (ns, h, f) = rowptr.shape[0] - 1, feat.shape
+    n_src = ns if n_src is None else n_src
+    colptr, rowind, _, _ = csr2csc(rowptr, colind, None, n_cols=n_src)
+    grad_feat = np.empty((n_src, h, f), np.float32)
+    grad_l, grad_r = np.empty((v, h), np.float32), np.empty((n_src, h), np.float32)
+    abs_f = np.empty_like(grad_feat) if scales else None
+    abs_l = np.empty_like(grad_l) if scales else None
+    abs_r = np.empty_like(grad_r) if scales else None
+    lib().oracle_gat_bwd(_p(rowptr), _p(colind), _p(colptr), _p(rowind), _p(h_l), _p(h_r), _p(feat), float(slope),
+                         _p(gout), _p(grad_feat), _p(grad_l), _p(grad_r), _p(abs_f), _p(abs_l), _p(abs_r), v, n_src,
+                         h, f)
+    return (grad_feat, grad_l, grad_r, abs_f, abs_l, abs_r) if scales else (grad_feat, grad_l, grad_r)
 
 
 # ---------------------------------------------------------------------------- scatter max

@@ -78,10 +78,11 @@ def test_edge_softmax_reference_golden(golden):
     np.testing.assert_allclose(got, z["softmax"], rtol=2e-5, atol=1e-7)
 
 
-@pytest.fixture(params=[0, 1, 3], ids=["vec4-lanes-auto", "scalar-row-lanes", "scalar-lanes-everywhere"])
+@pytest.fixture(params=[0, 4, 5, 7], ids=["flat-kernel", "row-kernels-vec4-auto", "row-kernels-scalar-rows",
+                                            "row-kernels-scalar-everywhere"])
 def es_lanes(request):
-    """edge_softmax picks 16-byte or 4-byte lanes per shape; tuning key 7: bit 0 forces the 4-byte row kernels,
-    bit 1 the 4-byte hub-row path."""
+    """edge_softmax: the flat streaming kernel (H a power of two <= 64) or the row kernels (everything else; tuning
+    key 7 bit 2 forces them, bit 0 forces their 4-byte row lanes, bit 1 their 4-byte hub-row path)."""
     from cogdl_amd import _lib
 
     _lib.hip().cogdl_hip_set_tuning(7, request.param)
@@ -112,6 +113,94 @@ def test_edge_softmax_fwd_bwd(oracle, es_lanes, h, deg, scale):
     sums = torch.zeros(60, h).index_add_(0, rows, out.detach().cpu())
     nonempty = g.degrees() > 0
     assert torch.allclose(sums[nonempty], torch.ones_like(sums[nonempty]), atol=1e-5)
+
+
+def _softmax_grad_scale(sm, gr, rows_, n, h):
+    dot_abs = torch.zeros(n, h).index_add_(0, rows_, (sm * gr).abs())
+    return (sm * (gr.abs() + dot_abs[rows_])).numpy()
+
+
+# hubs: rows of many tiles of the flat kernel (tile = 8192 / H edges forward, 4096 / H backward), borders aligned or
+# not with tile borders, hubs next to each other, a hub as the last row
+FLAT_HUBS = [((3, 1023), (4, 1025), (17, 9000), (18, 2048), (40, 5)), ((0, 20000),), ((58, 3000), (59, 4100))]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("hubs", FLAT_HUBS, ids=["mixed", "one-huge-first-row", "hubs-at-the-end"])
+@pytest.mark.parametrize("h", [1, 2, 8, 64])
+def test_edge_softmax_flat_kernel_rows_across_tiles(oracle, hubs, h, dtype):
+    """The flat kernel against the oracle on rows that span 1..40 tiles, every I/O dtype (inputs rounded to the dtype
+    first, fp32 arithmetic inside, one rounding on store)."""
+    if h == 64:
+        hubs = tuple((r, min(d, 3000)) for r, d in hubs)
+    g = synth.hub_csr(60, 60, hubs=hubs, seed=h)
+    v = rand(g.nnz, h, seed=3, scale=3.0).to(dtype)
+    gr = rand(g.nnz, h, seed=4).to(dtype)
+    vd = v.to(DEV).requires_grad_()
+    out = csr_edge_softmax(g.rowptr.to(DEV), vd)
+    assert out.dtype == dtype
+    want = oracle.edge_softmax_fwd(g.rowptr, v.float())
+    tol = {torch.float32: (1e-5, 1e-9), torch.bfloat16: (2.0 ** -7, 1e-30), torch.float16: (2.0 ** -10, 1e-7)}[dtype]
+    np.testing.assert_allclose(out.detach().float().cpu().numpy(), want, rtol=tol[0], atol=tol[1])
+    out.backward(gr.to(DEV))
+    sm = out.detach().float().cpu()
+    want_g = oracle.edge_softmax_bwd(g.rowptr, sm, gr.float())
+    rows_ = torch.repeat_interleave(torch.arange(60), g.degrees())
+    scale_g = _softmax_grad_scale(sm, gr.float(), rows_, 60, h)
+    assert vd.grad.dtype == dtype
+    assert np.all(np.abs(vd.grad.float().cpu().numpy() - want_g) <= tol[0] * scale_g + 1e-12)
+    again = csr_edge_softmax(g.rowptr.to(DEV), v.to(DEV))
+    assert torch.equal(again, out.detach())  # deterministic: fixed merge order, no atomics on data
+
+
+@pytest.mark.parametrize("spin", [0, 1], ids=["exchange", "forced-timeout-escape"])
+def test_edge_softmax_flat_kernel_super_long_rows_and_timeout_escape(oracle, spin):
+    """H = 64: a tile is 128 edges, so rows beyond 192 tiles = 24,576 edges take the init kernel's record path (no
+    waiting); tuning key 8 = 1 makes every cross-tile wait give up at once, which exercises the recompute-from-global
+    escape on ordinary multi-tile rows."""
+    from cogdl_amd import _lib
+
+    g = synth.hub_csr(40, 40, hubs=((2, 30000), (3, 26000), (20, 700), (39, 25000)), seed=1)
+    h = 64
+    v = rand(g.nnz, h, seed=5, scale=2.0)
+    gr = rand(g.nnz, h, seed=6)
+    _lib.hip().cogdl_hip_set_tuning(8, spin)
+    try:
+        vd = v.to(DEV).requires_grad_()
+        out = csr_edge_softmax(g.rowptr.to(DEV), vd)
+        out.backward(gr.to(DEV))
+        torch.cuda.synchronize()
+    finally:
+        _lib.hip().cogdl_hip_set_tuning(8, 0)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), oracle.edge_softmax_fwd(g.rowptr, v), rtol=1e-5, atol=1e-9)
+    sm = out.detach().cpu()
+    want_g = oracle.edge_softmax_bwd(g.rowptr, sm, gr)
+    rows_ = torch.repeat_interleave(torch.arange(40), g.degrees())
+    assert np.all(np.abs(vd.grad.cpu().numpy() - want_g) <= 1e-5 * _softmax_grad_scale(sm, gr, rows_, 40, h) + 1e-12)
+
+
+def test_edge_softmax_flat_kernel_many_short_and_empty_rows(oracle):
+    """Tiles with hundreds of rows (more than one rowptr chunk per tile), empty rows, degree-1 rows, H = 1."""
+    gen = torch.Generator().manual_seed(0)
+    deg = torch.randint(0, 4, (40000,), generator=gen)
+    deg[1000:9000] = 0  # a tile border inside a long run of empty rows
+    deg[20000] = 9000
+    rowptr = torch.zeros(40001, dtype=torch.long)
+    torch.cumsum(deg, 0, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    for h in (1, 4):
+        v = rand(nnz, h, seed=h, scale=2.0)
+        out = csr_edge_softmax(rowptr.int().to(DEV), v.to(DEV))
+        np.testing.assert_allclose(out.cpu().numpy(), oracle.edge_softmax_fwd(rowptr.int(), v), rtol=1e-5, atol=1e-9)
+
+
+def test_edge_softmax_bf16_odd_head_count_goes_through_the_row_kernels(oracle):
+    g = synth.random_csr(80, 80, 9, seed=2)
+    v = rand(g.nnz, 3, seed=1).bfloat16()
+    out = csr_edge_softmax(g.rowptr.to(DEV), v.to(DEV))
+    assert out.dtype == torch.bfloat16
+    np.testing.assert_allclose(out.float().cpu().numpy(), oracle.edge_softmax_fwd(g.rowptr, v.float()), rtol=2.0 ** -7,
+                               atol=1e-30)
 
 
 def test_edge_softmax_1d_view_like_dispatcher():
@@ -386,41 +475,6 @@ def test_coo2csr_index_gpu_doc_example_and_errors():
     assert row_ptr.tolist() == [0, 2, 3, 4, 4, 5] and col[perm].tolist() == [1, 3, 3, 1, 2]
     with pytest.raises(_lib.BackendError):
         coo2csr_index(torch.tensor([0, 7], device=DEV), torch.tensor([0, 1], device=DEV), 5)
-
-
-# ------------------------------------------------------------- BASELINE configs[2] at full size (Reddit-shaped)
-def test_full_size_reddit_shaped_gat_properties():
-    """N = 232,965, ~79 M R-MAT edges (hub rows of ~10^5 edges), H = 8 x F = 8 -- too big for the CPU oracle, so
-    size-independent properties: fused == composition of the unfused HIP operators (f32 1e-4, bf16 inputs 2^-7);
-    softmax rows sum to one; the fused output is a convex combination of neighbour rows (bounded by their max);
-    the operator is deterministic run to run."""
-    from cogdl_amd.operators.fused_gat import gat_forward
-
-    n, h, f = 232_965, 8, 8
-    src, dst = synth.rmat_pairs(n, 57_300_000, seed=0, device=DEV)
-    g = synth.finalize(src, dst, n, norm=None)
-    del src, dst
-    assert int(g.degrees().max()) > 50_000
-    gen = torch.Generator(device=DEV).manual_seed(0)
-    ar, ac = (torch.randn(n, h, device=DEV, generator=gen) for _ in range(2))
-    feat = torch.randn(n, h, f, device=DEV, generator=gen)
-    out, emax, esum = gat_forward(ar, ac, g.rowptr, g.colind, 0.2, feat)
-    again, _, _ = gat_forward(ar, ac, g.rowptr, g.colind, 0.2, feat)
-    assert torch.equal(out, again)
-    row = torch.repeat_interleave(torch.arange(n, device=DEV), g.degrees().to(DEV))
-    score = torch.nn.functional.leaky_relu(ar[row] + ac[g.colind.long()], 0.2)
-    att = csr_edge_softmax(g.rowptr, score)
-    sums = torch.zeros(n, h, device=DEV).index_add_(0, row, att)
-    assert torch.allclose(sums, torch.ones_like(sums), atol=2e-4)
-    unfused = mhspmm_raw(g.rowptr, g.colind, att, feat)
-    assert torch.allclose(out, unfused, rtol=1e-4, atol=1e-4)
-    assert float(out.abs().max()) <= float(feat.abs().max()) * (1 + 1e-5)
-    # saved statistics == the row max / sum of exp(score - max) the backward relies on
-    mx = torch.full((n, h), -float("inf"), device=DEV).scatter_reduce(0, row.view(-1, 1).expand_as(score), score, "amax")
-    assert torch.allclose(emax, mx, rtol=0, atol=1e-6)
-    del score, att, sums, unfused, mx
-    outb, _, _ = gat_forward(ar, ac, g.rowptr, g.colind, 0.2, feat.bfloat16())
-    assert torch.allclose(outb.float(), out, rtol=2.0 ** -6, atol=2e-2)
 
 
 def test_gat_bwd_status_codes_distinguish_unsupported_from_invalid():

@@ -149,3 +149,33 @@ def test_message_ops_oracle_bit_exact_vs_reference(golden, oracle):
     out = oracle.src_op_e_aggr("add", "sum", None, z["ef"], z["row"], z["col"], n)
     assert out.tobytes() == z["scatter_add"].tobytes()
     assert not z["scatter_add"][n - 20:].any()  # destinations nobody points at stay zero
+
+
+def test_gat_bwd_oracle_equals_float64_autograd_of_the_unfused_composition(oracle):
+    """oracle_gat_bwd (used as the full-size checker of the fused GAT backward) against torch autograd in float64 through
+    the layer maths of cogdl/layers/gat_layer.py:73-77; also thread-count independent (rows are independent)."""
+    import torch
+
+    from cogdl_amd import synth
+
+    for (m, n_src, h, f, seed) in ((150, 120, 4, 8, 0), (3000, 3000, 8, 8, 1), (90, 200, 1, 41, 2)):
+        g = synth.random_csr(m, n_src, 7, seed=seed, weighted=False)
+        gen = torch.Generator().manual_seed(seed)
+        h_l, h_r = torch.randn(m, h, generator=gen), torch.randn(n_src, h, generator=gen)
+        feat, gout = torch.randn(n_src, h, f, generator=gen), torch.randn(m, h, f, generator=gen)
+        dd = torch.float64
+        l64, r64, f64 = (t.to(dd).requires_grad_() for t in (h_l, h_r, feat))
+        row = torch.repeat_interleave(torch.arange(m), g.degrees())
+        col = g.colind.long()
+        s = torch.nn.functional.leaky_relu(l64[row] + r64[col], 0.2)
+        mx = torch.full((m, h), -1e30, dtype=dd).scatter_reduce(0, row.view(-1, 1).expand_as(s), s, "amax")
+        e = torch.exp(s - mx[row])
+        att = e / torch.zeros(m, h, dtype=dd).index_add_(0, row, e)[row]
+        out = torch.zeros(m, h, f, dtype=dd).index_add_(0, row, att.unsqueeze(-1) * f64[col])
+        out.backward(gout.to(dd))
+        gf, gl, gr = oracle.gat_bwd(g.rowptr, g.colind, h_l, h_r, feat, 0.2, gout, n_src=n_src)
+        np.testing.assert_allclose(gf, f64.grad.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(gl, l64.grad.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(gr, r64.grad.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(oracle.gat_fwd(g.rowptr, g.colind, h_l, h_r, feat, 0.2), out.detach().numpy(),
+                                   rtol=1e-5, atol=1e-6)
