@@ -26,7 +26,7 @@ inline int launch_status() {
 inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 // Run-time tuning knobs (cogdl_hip_set_tuning): experiments without recompiling.
-enum Tuning { kTuneXcdStripe = 0, kTuneLongThresh = 1, kTuneRowSort = 2, kTuneLongGrid = 3, kTuneGatVec = 4, kTuneGatOnline = 5, kTuneSpmmVec = 6, kTuneEsScalar = 7, kTuneEsSpin = 8, kTuneCount = 9 };
+enum Tuning { kTuneXcdStripe = 0, kTuneLongThresh = 1, kTuneRowSort = 2, kTuneLongGrid = 3, kTuneGatVec = 4, kTuneGatOnline = 5, kTuneSpmmVec = 6, kTuneEsScalar = 7, kTuneEsSpin = 8, kTuneEsDebug = 9, kTuneCount = 10 };
 extern int g_tuning[kTuneCount];
 
 // Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8; observed, used for

@@ -51,6 +51,8 @@ struct Params {
     float2 *rec;         // [n_tiles * 2][h]: (max, sum) | (dot, 0)
     int64_t long_edges;  // rows with more edges are "super-long": records come from the init kernel
     unsigned spin_limit; // polls of one flag before the wait gives up (tuning key 8; tests force the escape path)
+    int debug;           // EXPERIMENTS ONLY (tuning key 9): bit 0 tile = blockIdx, bit 1 skip the cross-tile exchange
+                         // (wrong results), bit 2 skip the row search (wrong results), bit 3 skip in-tile processing
 };
 
 // ---- agent-scope accesses (write-through stores / L1-bypassing loads; see the file header) ---------------------
@@ -312,9 +314,11 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
     T *__restrict__ out = (T *)p.out;
     const int h = p.h;
 
-    if (t == 0) s_tile = (int64_t)atomicAdd(p.ticket, 1u);
-    __syncthreads();
-    const int64_t c = s_tile;
+    if (!(p.debug & 1)) {
+        if (t == 0) s_tile = (int64_t)atomicAdd(p.ticket, 1u);
+        __syncthreads();
+    }
+    const int64_t c = (p.debug & 1) ? (int64_t)blockIdx.x : s_tile;
     if (c >= p.n_tiles) return;
     const int64_t e0 = c * p.tile_e, e1 = min(p.nnz, e0 + p.tile_e);
     const int64_t b0 = e0 * h;
@@ -342,8 +346,8 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
             }
     }
     // ---- 2. the rows of the tile (overlaps the loads) ---------------------------------------------------------------
-    const int64_t r_first = wg_row_of_edge(p.rowptr, p.m, e0);
-    const int64_t r_last = wg_row_of_edge(p.rowptr, p.m, e1 - 1);
+    const int64_t r_first = (p.debug & 4) ? 0 : wg_row_of_edge(p.rowptr, p.m, e0);
+    const int64_t r_last = (p.debug & 4) ? 0 : wg_row_of_edge(p.rowptr, p.m, e1 - 1);
     // ---- 3. registers -> LDS ---------------------------------------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < NV; ++j)
@@ -361,8 +365,8 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
     // ---- 4. partial pieces (the row of the first / last edge when it extends beyond the tile) --------------------
     const int64_t hs = p.rowptr[r_first], he = p.rowptr[r_first + 1];  // head row
     const int64_t ts = p.rowptr[r_last], te = p.rowptr[r_last + 1];    // tail row (may be the same row)
-    const bool head_partial = hs < e0 || he > e1;
-    const bool tail_partial = (r_last != r_first) && te > e1;
+    const bool head_partial = (hs < e0 || he > e1) && !(p.debug & 8);
+    const bool tail_partial = (r_last != r_first) && te > e1 && !(p.debug & 8);
     const int head_end = head_partial ? (int)(min(he, e1) - e0) * h : 0;  // LDS span [0, head_end)
     const int tail_begin = tail_partial ? (int)(ts - e0) * h : count;     // LDS span [tail_begin, count)
     float2 head_piece = make_float2(0.f, 0.f), tail_piece = make_float2(0.f, 0.f);
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
 
     // ---- 5. rows completely inside the tile ---------------------------------------------------------------------------
     const int64_t rc0 = r_first + (head_partial ? 1 : 0), rc1 = r_last - (tail_partial ? 1 : 0);  // inclusive range
-    if (rc1 >= rc0) {
+    if (rc1 >= rc0 && !(p.debug & 8)) {
         // lanes per row from the mean row length of this tile: ~8 sequential steps per lane, at least max(8, h) lanes
         const int64_t nrows_all = rc1 - rc0 + 1;
         const int mean_elems = (int)min((int64_t)TILE, (int64_t)(tail_begin - head_end) / nrows_all);
@@ -426,12 +430,14 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
     const int hd = t & (h - 1);
     if (head_partial) {
         float2 tot;
-        if (!row_totals<BWD>(p, hs, he, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
+        if (p.debug & 2) tot = head_piece;
+        else if (!row_totals<BWD>(p, hs, he, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
         if (t < h) fac[0][hd] = BWD ? make_float2(tot.x, 0.f) : make_float2(es_exp(head_piece.x - tot.x) / tot.y, 0.f);
     }
     if (tail_partial) {
         float2 tot;
-        if (!row_totals<BWD>(p, ts, te, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, ts * h, te * h, h, red);
+        if (p.debug & 2) tot = tail_piece;
+        else if (!row_totals<BWD>(p, ts, te, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, ts * h, te * h, h, red);
         if (t < h) fac[1][hd] = BWD ? make_float2(tot.x, 0.f) : make_float2(es_exp(tail_piece.x - tot.x) / tot.y, 0.f);
     }
     __syncthreads();
@@ -549,6 +555,7 @@ int es_flat_launch(bool bwd, const int32_t *rowptr, const void *a, const void *g
     p.rec = (float2 *)((char *)ws + 256 + flags);
     p.long_edges = (int64_t)esf::kKMax * p.tile_e;
     p.spin_limit = g_tuning[kTuneEsSpin] > 0 ? (unsigned)g_tuning[kTuneEsSpin] : esf::kSpinLimit;
+    p.debug = g_tuning[kTuneEsDebug];
     switch (dtype) {
         case COGDL_HIP_F32: return bwd ? esf::launch_typed<float, true>(p, s) : esf::launch_typed<float, false>(p, s);
         case COGDL_HIP_F16: return bwd ? esf::launch_typed<__half, true>(p, s) : esf::launch_typed<__half, false>(p, s);

@@ -148,7 +148,9 @@ def test_edge_softmax_flat_kernel_rows_across_tiles(oracle, hubs, h, dtype):
     rows_ = torch.repeat_interleave(torch.arange(60), g.degrees())
     scale_g = _softmax_grad_scale(sm, gr.float(), rows_, 60, h)
     assert vd.grad.dtype == dtype
-    assert np.all(np.abs(vd.grad.float().cpu().numpy() - want_g) <= tol[0] * scale_g + 1e-12)
+    # (f16: results below 6e-5 are subnormal, spaced 6e-8 apart -- an absolute floor of the representation)
+    floor = 6e-8 if dtype == torch.float16 else 1e-12
+    assert np.all(np.abs(vd.grad.float().cpu().numpy() - want_g) <= tol[0] * scale_g + floor)
     again = csr_edge_softmax(g.rowptr.to(DEV), v.to(DEV))
     assert torch.equal(again, out.detach())  # deterministic: fixed merge order, no atomics on data
 

@@ -125,6 +125,20 @@ def gat_suite(g, tag, h, f, dtypes=(torch.float32, torch.bfloat16), reps=10):
     sm = es_launch("cogdl_hip_edge_softmax_fwd", g.rowptr, att)
     report("edge_softmax_bwd", cfg0, timeit(lambda: es_launch("cogdl_hip_edge_softmax_bwd", g.rowptr, sm, att), reps),
            nnz * h * 12, nnz)
+    if torch.bfloat16 in dtypes:
+        attb, smb = att.bfloat16(), sm.bfloat16()
+        report("edge_softmax_fwd", cfg0 + " bf16", timeit(lambda: es_launch("cogdl_hip_edge_softmax_fwd", g.rowptr, attb), reps),
+               nnz * h * 4 + 4 * (n + 1), nnz)
+        report("edge_softmax_bwd", cfg0 + " bf16",
+               timeit(lambda: es_launch("cogdl_hip_edge_softmax_bwd", g.rowptr, smb, attb), reps), nnz * h * 6, nnz)
+    # A/B: the round-1 row kernels (tuning key 7, bit 2) on the same inputs
+    from cogdl_amd import _lib
+    _lib.hip().cogdl_hip_set_tuning(7, 4)
+    report("edge_softmax_fwd(row kernels)", cfg0, timeit(lambda: es_launch("cogdl_hip_edge_softmax_fwd", g.rowptr, att), reps),
+           nnz * h * 8 + 4 * (n + 1), nnz)
+    report("edge_softmax_bwd(row kernels)", cfg0, timeit(lambda: es_launch("cogdl_hip_edge_softmax_bwd", g.rowptr, sm, att), reps),
+           nnz * h * 12, nnz)
+    _lib.hip().cogdl_hip_set_tuning(7, 0)
     for dt in dtypes:
         s = 4 if dt == torch.float32 else 2
         name = "f32" if dt == torch.float32 else "bf16"
@@ -157,14 +171,24 @@ def gat_suite(g, tag, h, f, dtypes=(torch.float32, torch.bfloat16), reps=10):
     # backward: two passes over the edges (CSR pass for grad_attn_row, CSC pass for grad_feat/grad_attn_col)
     report("gat_bwd(fused, fwd+bwd - fwd)", cfg0 + " f32", t_fb - t_f,
            2 * nnz * (4 + 2 * h * f * 4 + h * 4) + 4 * n * h * f * 4, nnz)
+    if torch.bfloat16 in dtypes:  # configs[2]'s dtype: feat / out / grad read and written as bf16
+        ftb, gb = feat.bfloat16().requires_grad_(), grad.bfloat16()
+
+        def fwd_bwd16():
+            out = FusedGATFunction.apply(ar_g, ac_g, g.rowptr, g.colind, g.rowptr, g.colind, 0.2, ftb)
+            torch.autograd.grad(out, (ar_g, ac_g, ftb), gb)
+
+        t_fb = timeit(fwd_bwd16, reps)
+        t_f = timeit(lambda: gat_forward(ar, ac, g.rowptr, g.colind, 0.2, ftb.detach()), reps)
+        report("gat_bwd(fused, fwd+bwd - fwd)", cfg0 + " bf16", t_fb - t_f,
+               2 * nnz * (4 + 2 * h * f * 2 + h * 4) + 4 * n * h * f * 2, nnz)
 
 
 def reddit():
-    """Reddit-shaped GAT workload (config 3): N=232,965, ~114.6 M edges (RMAT), H=8 x F=8; generated on the GPU."""
-    n = 232_965
-    src, dst = synth.rmat_pairs(n, 57_300_000, seed=0, device=DEV)
-    g = synth.finalize(src, dst, n, norm=None)
-    del src, dst
+    """Reddit-shaped GAT workload (configs[2]): N=232,965, 114,848,857 nnz (R-MAT rows, Reddit's edge count), H=8 x F=8;
+    generated on the GPU."""
+    n = synth.REDDIT_NODES
+    g = synth.reddit_like(seed=0, device=DEV)
     print("reddit-like: N=%d nnz=%d max_deg=%d" % (n, g.nnz, int(g.degrees().max())), flush=True)
     gat_suite(g, "reddit-rmat", 8, 8)
     gat_suite(g, "reddit-rmat", 1, 41, dtypes=(torch.float32,))
