@@ -12,17 +12,25 @@
 //     the tile lives in LDS between the statistics and the apply step.
 // Inside a tile (LDS resident): rows that lie completely in the tile are reduced by lane groups (short rows) or by
 // the whole workgroup (long rows).  A row that crosses tile borders is reduced piecewise: every tile publishes the
-// (max, sum) -- backward: the partial <softmax, grad> -- of its piece in a workspace record (write-through stores +
-// flag, MI355X_MICROARCH.md "inter-workgroup visibility" recipe R1), waits for the other pieces of the row, merges
-// all records in tile order (deterministic) and applies the row totals to the piece it still holds in LDS.
+// (max, sum) -- backward: the partial <softmax, grad> -- of its piece in a workspace record (one self-flagging 8-byte
+// write-through store per head, MI355X_MICROARCH.md "inter-workgroup visibility" recipe R2), reads the records of the
+// other pieces of the row until all are there, merges them in tile order (deterministic) and applies the row totals
+// to the piece it still holds on chip.
 //
-// Progress: tiles are numbered by an atomic ticket, so tile c starts only after every tile < c has started; a piece
-// is published BEFORE its workgroup waits.  A wait therefore only ever needs workgroups to START, and with rows of
-// at most K_max tiles (K_max = 192 <= the number of workgroups resident on 256 CUs) some waiting workgroup can
-// always finish.  Rows longer than K_max tiles never wait: their piece records are produced up front by the init
-// kernel (the same launch that zeroes the ticket and the flags), at the price of one extra read of those rows only.
-// Independently of all that every wait is bounded: on time-out the workgroup recomputes the row statistics from
-// global memory itself (correct under any scheduling, merely slower).
+// Two launches per call.  The INIT kernel zeroes the piece records, computes per tile the rows of its first and last edge
+// (one search per tile, all tiles in parallel -- the main kernel then starts with a 32-byte record instead of two
+// dependent searches) and produces the piece records of "super-long" rows (below).  The MAIN kernel runs one tile per
+// workgroup, tile = blockIdx.  A tile that lies inside ONE row (the common case on hub-heavy graphs) never touches
+// LDS with its values: statistics, exchange and apply work on the registers the loads landed in.
+//
+// Progress: a piece is published BEFORE its workgroup waits, so a wait only needs the other tiles of the row to START.
+// Workgroups start in index order on this hardware (observed, MI355X_MICROARCH.md; not a contract), rows of at most
+// K_max = 192 tiles take part in the exchange, and 192 workgroups always fit on the chip at once -- so in practice no
+// wait outlives the start-up skew of neighbouring workgroups.  CORRECTNESS does not depend on any of this: every
+// wait is bounded, and on time-out the workgroup recomputes the row statistics from global memory itself (right under
+// any scheduling, merely slower; the count of such escapes is kept in the workspace header for the tests).  Rows
+// longer than K_max tiles never wait at all: their piece records come from the init kernel, at the price of one extra
+// read of those rows only.
 #include "rowreduce.h"
 
 namespace cogdl {
@@ -31,11 +39,19 @@ namespace esf {
 constexpr int kThreads = 256;
 constexpr int kRowChunk = 512;    // rowptr entries staged in LDS per pass over a tile's rows
 constexpr int kKMax = 192;        // longest row (in tiles) that uses the in-launch exchange
-constexpr unsigned kSpinLimit = 1u << 16;
+constexpr unsigned kSpinLimit = 1u << 12;
 
 template <bool BWD> struct TileSize { static constexpr int value = BWD ? 4096 : 8192; };  // elements (32 KB of LDS)
 
 __device__ __forceinline__ float es_exp(float x) { return __expf(x); }
+
+// What the main kernel needs to know about its tile, computed once by the init kernel.
+struct __attribute__((aligned(16))) TileInfo {
+    int32_t r_first, r_last;  // rows of the tile's first and last edge
+    int32_t hs, he;           // edge range of row r_first
+    int32_t ts, te;           // edge range of row r_last
+    int32_t pad0, pad1;
+};
 
 struct Params {
     const int32_t *rowptr;
@@ -46,13 +62,15 @@ struct Params {
     int h;               // power of two <= 64
     int tile_e;          // edges per tile = tile elements / h
     int64_t n_tiles;
-    unsigned *ticket;    // 1 word, zeroed by the init kernel
-    unsigned *flags;     // [n_tiles * 2], zeroed by the init kernel
-    float2 *rec;         // [n_tiles * 2][h]: (max, sum) | (dot, 0)
+    unsigned *stats;     // workspace header: [0] = number of timed-out waits (zeroed by the init kernel)
+    TileInfo *tinfo;     // [n_tiles], written by the init kernel
+    float2 *rec;         // [n_tiles * 2][h]: (max, sum) | (dot, 1); zeroed by the init kernel, .y != 0 = published
     int64_t long_edges;  // rows with more edges are "super-long": records come from the init kernel
     unsigned spin_limit; // polls of one flag before the wait gives up (tuning key 8; tests force the escape path)
-    int debug;           // EXPERIMENTS ONLY (tuning key 9): bit 0 tile = blockIdx, bit 1 skip the cross-tile exchange
-                         // (wrong results), bit 2 skip the row search (wrong results), bit 3 skip in-tile processing
+    int debug;           // bit 0 (tuning key 9, timing experiments, results are WRONG): no cross-tile exchange;
+                         // bit 1 (tuning key 8 < 0, tests): every cross-tile wait takes the time-out escape at once
+    int n_seg;           // init kernel: leading workgroups that own a segment of K_max tiles
+    int info_per_wave;   // init kernel: 1 = one wave per tile (64-ary search), 0 = one thread per tile (binary search)
 };
 
 // ---- agent-scope accesses (write-through stores / L1-bypassing loads; see the file header) ---------------------
@@ -185,18 +203,18 @@ __device__ __forceinline__ float2 wg_piece_global(const T *__restrict__ a, const
     }
 }
 
-// Publish the record of (tile, slot): threads 0..h-1 (all in wave 0) store their head's pair write-through, the wave
-// drains its stores, one lane raises the flag.
+// Publish the record of (tile, slot): threads 0..h-1 store their head's pair as ONE aligned 8-byte write-through
+// store.  The record is its own flag ("granule", MI355X_MICROARCH.md recipe R2): the init kernel zeroes every record
+// and a published one never has .y == 0 (forward: .y = sum of exp(v - max) >= 1; backward: .y = 1), so a reader that
+// sees .y != 0 sees the whole record -- no drain of the store queue, no separate flag, no counter.
+__device__ __forceinline__ int slot_of(int64_t start, int64_t c, int tile_e) { return start <= c * tile_e ? 0 : 1; }
+template <bool BWD>
 __device__ __forceinline__ void publish(const Params &p, int64_t tile, int slot, float2 mine) {
-    if (threadIdx.x < kWave) {
-        if ((int)threadIdx.x < p.h) st_rec(p.rec + (tile * 2 + slot) * p.h + threadIdx.x, mine.x, mine.y);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0) st_agent(p.flags + tile * 2 + slot, 1u);
-    }
+    if (p.debug & 1) return;
+    if ((int)threadIdx.x < p.h) st_rec(p.rec + (tile * 2 + slot) * p.h + threadIdx.x, mine.x, BWD ? 1.f : mine.y);
 }
 
-// Record slot of row [start, end) in tile c (the row is known to intersect c and to extend beyond it).
-__device__ __forceinline__ int slot_of(int64_t start, int64_t c, int tile_e) { return start <= c * tile_e ? 0 : 1; }
+// (slot_of: record slot of a row in tile c -- the row is known to intersect c and to extend beyond it.)
 
 // Totals of the row [start, end) that crosses tile borders: wait for the records of all its pieces, merge them in
 // tile order.  Returns, for the head t % h of every thread, (max, sum) | (dot, -).  Returns false on time-out.
@@ -206,32 +224,53 @@ __device__ __forceinline__ bool row_totals(const Params &p, int64_t start, int64
     const int64_t c_a = start / p.tile_e, c_b = (end - 1) / p.tile_e;
     const int k = (int)(c_b - c_a + 1);
     const int t = threadIdx.x;
+    if (p.debug & 1) {
+        tot = BWD ? make_float2(0.f, 0.f) : make_float2(0.f, 1.f);
+        return true;
+    }
+    if (p.debug & 2) {  // tests: take the time-out escape on every wait
+        if (t == 0) atomicAdd(p.stats, 1u);
+        return false;
+    }
+    const int slot_a = slot_of(start, c_a, p.tile_e);
+    // thread (q0 = t / h, hd = t % h) fetches the records q0, q0 + 256/h, ... of its head, 8 loads in flight, and
+    // re-reads only while one of ITS records is still unpublished (.y == 0); then the 256/h partials are merged in
+    // order.  The grouping is a fixed function of (k, h): every tile of the row computes the identical totals.
+    const int h = p.h, hd = t & (h - 1), q0 = t / h, nq = kThreads / h;
+    float2 acc = BWD ? make_float2(0.f, 0.f) : make_float2(-INFINITY, 0.f);
+    constexpr int U = 8;
     bool ok = true;
-    for (int q = t; q < k; q += kThreads) {
-        const int64_t c = c_a + q;
-        const unsigned *f = p.flags + c * 2 + ((q == 0) ? slot_of(start, c, p.tile_e) : 0);
+    for (int qb = q0; qb < k && ok; qb += nq * U) {
+        float2 r[U];
         unsigned spins = 0;
-        while (ld_agent(f) == 0u) {
-            __builtin_amdgcn_s_sleep(8);
+        for (;;) {
+            bool all = true;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = min(qb + u * nq, k - 1);  // clamped: branch-free issue, the surplus is ignored below
+                r[u] = ld_rec(p.rec + ((c_a + q) * 2 + ((q == 0) ? slot_a : 0)) * h + hd);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) all = all && (r[u].y != 0.f);
+            if (all) break;
             if (++spins > p.spin_limit) {
                 ok = false;
                 break;
             }
+            __builtin_amdgcn_s_sleep(8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (qb + u * nq < k) {
+                if constexpr (BWD) acc.x += r[u].x;
+                else acc = ms_combine(acc, r[u]);
+            }
         }
     }
-    if (!__syncthreads_and(ok ? 1 : 0)) return false;
-    // thread (q0 = t / h, hd = t % h) merges the records q0, q0 + 256/h, ... ; then the 256/h partials in order
-    const int h = p.h, hd = t & (h - 1), q0 = t / h, nq = kThreads / h;
-    float2 acc = BWD ? make_float2(0.f, 0.f) : make_float2(-INFINITY, 0.f);
-    for (int q = q0; q < k; q += nq) {
-        const int64_t c = c_a + q;
-        const int slot = (q == 0) ? slot_of(start, c, p.tile_e) : 0;
-        const float2 r = ld_rec(p.rec + (c * 2 + slot) * h + hd);
-        if constexpr (BWD) acc.x += r.x;
-        else acc = ms_combine(acc, r);
+    if (!__syncthreads_and(ok ? 1 : 0)) {
+        if (t == 0) atomicAdd(p.stats, 1u);
+        return false;
     }
-    // NB: partials interleave the records (q0, q0+nq, ...): max and sum are order-independent up to rounding and the
-    // interleaving is a fixed function of (k, h), so every tile of the row computes the identical totals.
     __syncthreads();
     mrg[t] = acc;
     __syncthreads();
@@ -244,43 +283,46 @@ __device__ __forceinline__ bool row_totals(const Params &p, int64_t start, int64
     return true;
 }
 
-// ---- rows that lie completely inside the tile and have at most `lthr` edges: one lane group of LPR lanes per row ---
-// rp = LDS copy of rowptr[r0 .. r0 + nrows]; LPR is a multiple of h, so lane l always sees head l % h.
+// ---- one complete row in LDS, reduced by an aligned group of LPR lanes (LPR a multiple of h: lane l sees head l % h)
+template <int LPR, bool BWD>
+__device__ __forceinline__ void row_in_lds(float *tile, const float *tile_g, int base, int cnt, int l, int h) {
+    if constexpr (BWD) {
+        float dot = 0.f;
+        for (int j = l; j < cnt; j += LPR) dot = fmaf(tile[base + j], tile_g[base + j], dot);
+#pragma unroll
+        for (int s = LPR / 2; s > 0; s >>= 1)
+            if (s >= h) dot += __shfl_xor(dot, s, kWave);
+        for (int j = l; j < cnt; j += LPR) tile[base + j] = tile[base + j] * (tile_g[base + j] - dot);
+    } else {
+        float mx = -INFINITY;
+        for (int j = l; j < cnt; j += LPR) mx = fmaxf(mx, tile[base + j]);
+#pragma unroll
+        for (int s = LPR / 2; s > 0; s >>= 1)
+            if (s >= h) mx = fmaxf(mx, __shfl_xor(mx, s, kWave));
+        float sum = 0.f;
+        for (int j = l; j < cnt; j += LPR) {
+            const float pe = es_exp(tile[base + j] - mx);
+            tile[base + j] = pe;
+            sum += pe;
+        }
+#pragma unroll
+        for (int s = LPR / 2; s > 0; s >>= 1)
+            if (s >= h) sum += __shfl_xor(sum, s, kWave);
+        const float inv = 1.f / sum;
+        for (int j = l; j < cnt; j += LPR) tile[base + j] *= inv;
+    }
+}
+
+// Rows of at most `lthr` edges: one lane group per row.  rp = LDS copy of rowptr[r0 .. r0 + nrows].
 template <int LPR, bool BWD>
 __device__ __forceinline__ void rows_small(float *tile, const float *tile_g, const int32_t *rp, int nrows, int64_t e0,
-                                           int64_t e1, int h, int lthr) {
+                                           int h, int lthr) {
     constexpr int NG = kThreads / LPR;
     const int grp = threadIdx.x / LPR, l = threadIdx.x % LPR;
     for (int i = grp; i < nrows; i += NG) {
-        const int64_t start = rp[i], end = rp[i + 1];
-        const int len = (int)(end - start);
-        if (start < e0 || end > e1 || len == 0 || len > lthr) continue;  // (group-uniform)
-        const int base = (int)(start - e0) * h, cnt = len * h;
-        if constexpr (BWD) {
-            float dot = 0.f;
-            for (int j = l; j < cnt; j += LPR) dot = fmaf(tile[base + j], tile_g[base + j], dot);
-#pragma unroll
-            for (int s = LPR / 2; s > 0; s >>= 1)
-                if (s >= h) dot += __shfl_xor(dot, s, kWave);
-            for (int j = l; j < cnt; j += LPR) tile[base + j] = tile[base + j] * (tile_g[base + j] - dot);
-        } else {
-            float mx = -INFINITY;
-            for (int j = l; j < cnt; j += LPR) mx = fmaxf(mx, tile[base + j]);
-#pragma unroll
-            for (int s = LPR / 2; s > 0; s >>= 1)
-                if (s >= h) mx = fmaxf(mx, __shfl_xor(mx, s, kWave));
-            float sum = 0.f;
-            for (int j = l; j < cnt; j += LPR) {
-                const float pe = es_exp(tile[base + j] - mx);
-                tile[base + j] = pe;
-                sum += pe;
-            }
-#pragma unroll
-            for (int s = LPR / 2; s > 0; s >>= 1)
-                if (s >= h) sum += __shfl_xor(sum, s, kWave);
-            const float inv = 1.f / sum;
-            for (int j = l; j < cnt; j += LPR) tile[base + j] *= inv;
-        }
+        const int len = rp[i + 1] - rp[i];
+        if (len == 0 || len > lthr) continue;  // (group-uniform)
+        row_in_lds<LPR, BWD>(tile, tile_g, (int)(rp[i] - e0) * h, len * h, l, h);
     }
 }
 
@@ -292,6 +334,42 @@ __device__ __forceinline__ void load16(const T *p, float (&v)[VecOf<T>::V]) {
     load_vec<T, VecOf<T>::V>(p, v);
 }
 
+// Reduction of V per-thread slot values over the workgroup, slot k of thread t belonging to head (t*V + k) % h
+// (the register layout of a tile: thread t holds the elements (j*256 + t)*V + k).  On return every slot holds the
+// total of its head.  `red` = 4 * 64 floats.
+template <int V, bool MAX>
+__device__ __forceinline__ void wg_slot_reduce(float (&x)[V], int h, float *red) {
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
+    if (h < V) {  // several slots of one thread share a head: fold them first (slots >= h become copies)
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            if (k >= h) x[k & (h - 1)] = MAX ? fmaxf(x[k & (h - 1)], x[k]) : x[k & (h - 1)] + x[k];
+    }
+    const int period = h > V ? h / V : 1;  // lanes with equal (lane % period) hold the same heads
+#pragma unroll
+    for (int s = kWave / 2; s > 0; s >>= 1) {
+        if (s >= period) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) x[k] = MAX ? fmaxf(x[k], __shfl_xor(x[k], s, kWave)) : x[k] + __shfl_xor(x[k], s, kWave);
+        }
+    }
+    __syncthreads();  // the previous use of `red` is over
+    if (lane < period) {
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            if (k < h) red[wave * kWave + ((lane * V + k) & (h - 1))] = x[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const int hd = (t * V + k) & (h - 1);
+        float r = red[hd];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) r = MAX ? fmaxf(r, red[w * kWave + hd]) : r + red[w * kWave + hd];
+        x[k] = r;
+    }
+}
+
 // =====================================================================================================================
 // main kernel: one tile per workgroup
 template <typename T, bool BWD>
@@ -299,27 +377,21 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
     constexpr int TILE = TileSize<BWD>::value;
     constexpr int V = VecOf<T>::V;
     constexpr int NV = TILE / (kThreads * V);  // 16-byte vectors per thread (per array)
+    constexpr int kMaxLong = 64;
     __shared__ __attribute__((aligned(16))) float tile[TILE];
     __shared__ __attribute__((aligned(16))) float tile_gs[BWD ? TILE : 4];
     __shared__ int32_t rp[kRowChunk + 1];
     __shared__ float red[4 * kWave];
     __shared__ float2 mrg[kThreads];
-    __shared__ float2 fac[2][kWave];  // per partial piece (head, tail) and head id: what the store step applies
-    __shared__ int64_t s_tile;
-    constexpr int kMaxLong = 64;
+    __shared__ float2 pstat[kWave];   // piece statistics per head (register path)
+    __shared__ float fac[2][kWave];   // per partial piece (head, tail) and head id: what the store step applies
     __shared__ int s_nlong, s_long[kMaxLong];
     const int t = threadIdx.x;
     const T *__restrict__ a = (const T *)p.a;
     const T *__restrict__ g = (const T *)p.g;
     T *__restrict__ out = (T *)p.out;
     const int h = p.h;
-
-    if (!(p.debug & 1)) {
-        if (t == 0) s_tile = (int64_t)atomicAdd(p.ticket, 1u);
-        __syncthreads();
-    }
-    const int64_t c = (p.debug & 1) ? (int64_t)blockIdx.x : s_tile;
-    if (c >= p.n_tiles) return;
+    const int64_t c = blockIdx.x;
     const int64_t e0 = c * p.tile_e, e1 = min(p.nnz, e0 + p.tile_e);
     const int64_t b0 = e0 * h;
     const int count = (int)((e1 - e0) * h);
@@ -335,7 +407,7 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) load16<T>(g + b0 + (int64_t)(j * kThreads + t) * V, vg[j]);
         }
-    } else {  // the last tile: element-wise guarded
+    } else {  // the last tile: element-wise guarded (masked elements: 0)
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
@@ -345,10 +417,94 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
                 if constexpr (BWD) vg[j][k] = i < count ? to_f32<T>(g[b0 + i]) : 0.f;
             }
     }
-    // ---- 2. the rows of the tile (overlaps the loads) ---------------------------------------------------------------
-    const int64_t r_first = (p.debug & 4) ? 0 : wg_row_of_edge(p.rowptr, p.m, e0);
-    const int64_t r_last = (p.debug & 4) ? 0 : wg_row_of_edge(p.rowptr, p.m, e1 - 1);
-    // ---- 3. registers -> LDS ---------------------------------------------------------------------------------------------
+    // ---- 2. the rows of the tile (precomputed by the init kernel) ----------------------------------------------
+    const TileInfo ti = p.tinfo[c];
+    const int64_t r_first = ti.r_first, r_last = ti.r_last;
+    const int64_t hs = ti.hs, he = ti.he, ts = ti.ts, te = ti.te;
+
+    if (r_first == r_last) {
+        // ================= the whole tile is one piece of one row: everything stays in registers =================
+        const bool partial = hs < e0 || he > e1;
+        float x[V];
+        float2 piece = make_float2(0.f, 0.f);  // this thread's view: statistics of head t % h (threads < h publish)
+        if constexpr (BWD) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) x[k] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int k = 0; k < V; ++k) x[k] = fmaf(va[j][k], vg[j][k], x[k]);  // masked elements are 0 * 0
+            wg_slot_reduce<V, false>(x, h, red);  // x[k] = <a, g> of head (t*V + k) % h over the tile
+        } else {
+            float mxs[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) mxs[k] = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const bool valid = full || ((j * kThreads + t) * V + k) < count;
+                    mxs[k] = fmaxf(mxs[k], valid ? va[j][k] : -INFINITY);
+                }
+            wg_slot_reduce<V, true>(mxs, h, red);
+#pragma unroll
+            for (int k = 0; k < V; ++k) x[k] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const bool valid = full || ((j * kThreads + t) * V + k) < count;
+                    const float pe = valid ? es_exp(va[j][k] - mxs[k]) : 0.f;
+                    va[j][k] = pe;
+                    x[k] += pe;
+                }
+            wg_slot_reduce<V, false>(x, h, red);  // x[k] = sum of exp(v - max) of its head
+            // hand (max, sum) per head to the threads that publish / finish: slot k of thread t is head (t*V+k) % h
+            if (t * V < h || (h < V && t == 0)) {
+#pragma unroll
+                for (int k = 0; k < V; ++k)
+                    if (t * V + k < h) pstat[t * V + k] = make_float2(mxs[k], x[k]);
+            }
+        }
+        if constexpr (BWD) {
+            if (t * V < h || (h < V && t == 0)) {
+#pragma unroll
+                for (int k = 0; k < V; ++k)
+                    if (t * V + k < h) pstat[t * V + k] = make_float2(x[k], 0.f);
+            }
+        }
+        __syncthreads();
+        if (t < h) piece = pstat[t];
+        if (partial) {
+            if (he - hs <= p.long_edges) publish<BWD>(p, c, 0, piece);  // super-long rows: published by the init kernel
+            float2 tot;
+            if (!row_totals<BWD>(p, hs, he, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
+            if (t < h) fac[0][t] = BWD ? tot.x : es_exp(piece.x - tot.x) / tot.y;
+        } else {
+            if (t < h) fac[0][t] = BWD ? piece.x : 1.f / piece.y;
+        }
+        __syncthreads();
+        float f[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) f[k] = fac[0][(t * V + k) & (h - 1)];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i0 = (j * kThreads + t) * V;
+            float o[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) o[k] = BWD ? va[j][k] * (vg[j][k] - f[k]) : va[j][k] * f[k];
+            if (full) {
+                store_vec<T, V>(out + b0 + i0, o);
+            } else {
+#pragma unroll
+                for (int k = 0; k < V; ++k)
+                    if (i0 + k < count) out[b0 + i0 + k] = from_f32<T>(o[k]);
+            }
+        }
+        return;
+    }
+
+    // ================= several rows in the tile: LDS resident =====================================================
 #pragma unroll
     for (int j = 0; j < NV; ++j)
 #pragma unroll
@@ -362,32 +518,30 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
     __syncthreads();
     const float *tile_g = tile_gs;
 
-    // ---- 4. partial pieces (the row of the first / last edge when it extends beyond the tile) --------------------
-    const int64_t hs = p.rowptr[r_first], he = p.rowptr[r_first + 1];  // head row
-    const int64_t ts = p.rowptr[r_last], te = p.rowptr[r_last + 1];    // tail row (may be the same row)
-    const bool head_partial = (hs < e0 || he > e1) && !(p.debug & 8);
-    const bool tail_partial = (r_last != r_first) && te > e1 && !(p.debug & 8);
-    const int head_end = head_partial ? (int)(min(he, e1) - e0) * h : 0;  // LDS span [0, head_end)
-    const int tail_begin = tail_partial ? (int)(ts - e0) * h : count;     // LDS span [tail_begin, count)
+    // ---- partial pieces: the row of the first edge if it began before the tile, of the last edge if it goes on ----
+    const bool head_partial = hs < e0;
+    const bool tail_partial = te > e1;
+    const int head_end = head_partial ? (int)(he - e0) * h : 0;        // LDS span [0, head_end)
+    const int tail_begin = tail_partial ? (int)(ts - e0) * h : count;  // LDS span [tail_begin, count)
     float2 head_piece = make_float2(0.f, 0.f), tail_piece = make_float2(0.f, 0.f);
     if (head_partial) {
         head_piece = wg_piece_lds<BWD>(tile, tile_g, 0, head_end, h, red);
-        if (he - hs <= p.long_edges) publish(p, c, 0, head_piece);  // super-long rows: published by the init kernel
+        if (he - hs <= p.long_edges) publish<BWD>(p, c, 0, head_piece);
     }
     if (tail_partial) {
         tail_piece = wg_piece_lds<BWD>(tile, tile_g, tail_begin, count - tail_begin, h, red);
-        if (te - ts <= p.long_edges) publish(p, c, 1, tail_piece);
+        if (te - ts <= p.long_edges) publish<BWD>(p, c, 1, tail_piece);
     }
 
-    // ---- 5. rows completely inside the tile ---------------------------------------------------------------------------
+    // ---- rows completely inside the tile ---------------------------------------------------------------------------
     const int64_t rc0 = r_first + (head_partial ? 1 : 0), rc1 = r_last - (tail_partial ? 1 : 0);  // inclusive range
-    if (rc1 >= rc0 && !(p.debug & 8)) {
+    if (rc1 >= rc0) {
         // lanes per row from the mean row length of this tile: ~8 sequential steps per lane, at least max(8, h) lanes
         const int64_t nrows_all = rc1 - rc0 + 1;
         const int mean_elems = (int)min((int64_t)TILE, (int64_t)(tail_begin - head_end) / nrows_all);
         int lpr = max(8, h);
         while (lpr < kWave && lpr * 8 < mean_elems) lpr <<= 1;
-        const int lthr = 32 * (lpr / h);  // longer rows: one at a time by the whole workgroup
+        const int lthr = 32 * (lpr / h);  // longer rows: one wave each
         for (int64_t r0 = rc0; r0 <= rc1; r0 += kRowChunk) {
             const int nrows = (int)min((int64_t)kRowChunk, rc1 - r0 + 1);
             __syncthreads();
@@ -395,13 +549,13 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
             for (int i = t; i <= nrows; i += kThreads) rp[i] = p.rowptr[r0 + i];
             __syncthreads();
             switch (lpr) {
-                case 8: rows_small<8, BWD>(tile, tile_g, rp, nrows, e0, e1, h, lthr); break;
-                case 16: rows_small<16, BWD>(tile, tile_g, rp, nrows, e0, e1, h, lthr); break;
-                case 32: rows_small<32, BWD>(tile, tile_g, rp, nrows, e0, e1, h, lthr); break;
-                default: rows_small<64, BWD>(tile, tile_g, rp, nrows, e0, e1, h, lthr); break;
+                case 8: rows_small<8, BWD>(tile, tile_g, rp, nrows, e0, h, lthr); break;
+                case 16: rows_small<16, BWD>(tile, tile_g, rp, nrows, e0, h, lthr); break;
+                case 32: rows_small<32, BWD>(tile, tile_g, rp, nrows, e0, h, lthr); break;
+                default: rows_small<64, BWD>(tile, tile_g, rp, nrows, e0, h, lthr); break;
             }
-            // Long complete rows of this chunk, one at a time by the whole workgroup.  A tile holds fewer than 32 of
-            // them (they have more than lthr >= 32 * max(8, h) / h edges each), so the list cannot overflow.
+            // Long complete rows of this chunk: one WAVE per row, four at a time, no workgroup barrier.  A tile holds
+            // fewer than 32 of them (more than lthr >= 32 * max(8, h) / h edges each): the list cannot overflow.
             for (int i = t; i < nrows; i += kThreads) {
                 if (rp[i + 1] - rp[i] > lthr) {
                     const int pos = atomicAdd(&s_nlong, 1);
@@ -410,39 +564,29 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
             }
             __syncthreads();
             const int n_long = min(s_nlong, kMaxLong);
-            for (int q = 0; q < n_long; ++q) {
+            for (int q = t >> 6; q < n_long; q += 4) {
                 const int i2 = s_long[q];
-                const int off = (int)(rp[i2] - e0) * h, cnt = (rp[i2 + 1] - rp[i2]) * h;
-                const float2 st = wg_piece_lds<BWD>(tile, tile_g, off, cnt, h, red);
-                if constexpr (BWD) {
-                    for (int j = t; j < cnt; j += kThreads) tile[off + j] = tile[off + j] * (tile_g[off + j] - st.x);
-                } else {
-                    const float inv = 1.f / st.y;
-                    for (int j = t; j < cnt; j += kThreads) tile[off + j] *= inv;
-                }
+                row_in_lds<kWave, BWD>(tile, tile_g, (int)(rp[i2] - e0) * h, (rp[i2 + 1] - rp[i2]) * h, t & (kWave - 1), h);
             }
         }
     }
 
-    // ---- 6. row totals of the partial pieces -> the factor the store step applies ------------------------------
+    // ---- row totals of the partial pieces -> the factor the store step applies ----------------------------------
     //   forward : out = p * exp(m_piece - m_row) / s_row          (fac = that product)
     //   backward: out = a * (g - dot_row)                          (fac = dot_row)
-    const int hd = t & (h - 1);
     if (head_partial) {
         float2 tot;
-        if (p.debug & 2) tot = head_piece;
-        else if (!row_totals<BWD>(p, hs, he, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
-        if (t < h) fac[0][hd] = BWD ? make_float2(tot.x, 0.f) : make_float2(es_exp(head_piece.x - tot.x) / tot.y, 0.f);
+        if (!row_totals<BWD>(p, hs, he, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
+        if (t < h) fac[0][t] = BWD ? tot.x : es_exp(head_piece.x - tot.x) / tot.y;
     }
     if (tail_partial) {
         float2 tot;
-        if (p.debug & 2) tot = tail_piece;
-        else if (!row_totals<BWD>(p, ts, te, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, ts * h, te * h, h, red);
-        if (t < h) fac[1][hd] = BWD ? make_float2(tot.x, 0.f) : make_float2(es_exp(tail_piece.x - tot.x) / tot.y, 0.f);
+        if (!row_totals<BWD>(p, ts, te, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, ts * h, te * h, h, red);
+        if (t < h) fac[1][t] = BWD ? tot.x : es_exp(tail_piece.x - tot.x) / tot.y;
     }
     __syncthreads();
 
-    // ---- 7. LDS -> global, 16 bytes per lane ------------------------------------------------------------------------
+    // ---- LDS -> global, 16 bytes per lane ---------------------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int i0 = (j * kThreads + t) * V;
@@ -452,7 +596,7 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
             const int i = i0 + k;
             float v = tile[i];
             if (i < head_end || i >= tail_begin) {
-                const float f = fac[i < head_end ? 0 : 1][i & (h - 1)].x;
+                const float f = fac[i < head_end ? 0 : 1][i & (h - 1)];
                 if constexpr (BWD) v = v * (tile_g[i] - f);
                 else v = v * f;
             }
@@ -469,19 +613,59 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
 }
 
 // =====================================================================================================================
-// init kernel: zero the ticket and the flags; produce the piece records of super-long rows.
-// Workgroup k owns the tiles [k * K_max, (k+1) * K_max), i.e. the edges [k * L, (k+1) * L) with L = K_max * tile_e.
+// init kernel.  Workgroups [0, n_seg): segment k owns the tiles [k * K_max, (k+1) * K_max), i.e. the edges
+// [k * L, (k+1) * L) with L = K_max * tile_e: it zeroes their piece records and produces the piece records of super-long rows.
 // A row of more than L edges contains a multiple of L, so it is the row of the first or of the last edge of some
-// segment: each workgroup checks those two rows and, for a super-long one, computes the statistics of its pieces
-// inside the segment, tile by tile, publishing them exactly where the main kernel looks for them.
+// segment: each segment checks those two rows and, for a super-long one, computes the statistics of its pieces inside
+// the segment, tile by tile, publishing them exactly where the main kernel looks for them.
+// Workgroups [n_seg, ...): the TileInfo records -- one search per tile edge, a thread (binary search) or a wave
+// (64-ary search: 3 dependent rounds instead of 18, for graphs with few tiles) per tile.
+__device__ __forceinline__ int row_of_edge_wave(const int32_t *__restrict__ rowptr, int64_t m, int64_t e, int lane) {
+    int64_t lo = 0, hi = m;
+    while (hi - lo > 1) {
+        const int64_t step = (hi - lo + kWave - 1) / kWave;
+        const int64_t idx = lo + (int64_t)(lane + 1) * step;
+        const bool below = idx < hi && (int64_t)rowptr[idx] <= e;
+        const int cnt = __popcll(__ballot(below));
+        lo = lo + (int64_t)cnt * step;
+        hi = min(lo + step, hi);
+    }
+    return (int)lo;
+}
+
 template <typename T, bool BWD>
 __global__ __launch_bounds__(kThreads) void es_flat_init_kernel(const Params p) {
     __shared__ float red[4 * kWave];
     const int t = threadIdx.x;
+    if ((int)blockIdx.x >= p.n_seg) {  // ---- tile records
+        const int64_t b = blockIdx.x - p.n_seg;
+        const int64_t c = p.info_per_wave ? b * 4 + (t >> 6) : b * kThreads + t;
+        if (c >= p.n_tiles) return;
+        const int64_t e0 = c * p.tile_e, e1 = min(p.nnz, e0 + p.tile_e);
+        int r_first, r_last;
+        if (p.info_per_wave) {
+            r_first = row_of_edge_wave(p.rowptr, p.m, e0, t & (kWave - 1));
+            r_last = (int64_t)p.rowptr[r_first + 1] >= e1 ? r_first : row_of_edge_wave(p.rowptr, p.m, e1 - 1, t & (kWave - 1));
+            if ((t & (kWave - 1)) != 0) return;
+        } else {
+            r_first = row_of_edge(p.rowptr, p.m, (int)e0);
+            r_last = (int64_t)p.rowptr[r_first + 1] >= e1 ? r_first : row_of_edge(p.rowptr, p.m, (int)(e1 - 1));
+        }
+        TileInfo ti;
+        ti.r_first = r_first;
+        ti.r_last = r_last;
+        ti.hs = p.rowptr[r_first];
+        ti.he = p.rowptr[r_first + 1];
+        ti.ts = p.rowptr[r_last];
+        ti.te = p.rowptr[r_last + 1];
+        ti.pad0 = ti.pad1 = 0;
+        p.tinfo[c] = ti;
+        return;
+    }
     const int64_t seg = blockIdx.x;
     const int64_t c_lo = seg * kKMax, c_hi = min(p.n_tiles, c_lo + kKMax);
-    if (seg == 0 && t == 0) st_agent(p.ticket, 0u);
-    for (int64_t i = c_lo * 2 + t; i < c_hi * 2; i += kThreads) st_agent(p.flags + i, 0u);
+    if (seg == 0 && t == 0) st_agent(p.stats, 0u);
+    for (int64_t i = c_lo * 2 * p.h + t; i < c_hi * 2 * p.h; i += kThreads) st_rec(p.rec + i, 0.f, 0.f);
     const int64_t L = (int64_t)kKMax * p.tile_e;
     if (p.nnz <= L) return;  // no row can be super-long (uniform)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -500,16 +684,19 @@ __global__ __launch_bounds__(kThreads) void es_flat_init_kernel(const Params p) 
         for (int64_t c = lo / p.tile_e; c * p.tile_e < hi; ++c) {
             const int64_t pl = max(lo, c * p.tile_e), ph = min(hi, (c + 1) * p.tile_e);
             const float2 st = wg_piece_global<T, BWD>(a, g, pl * p.h, ph * p.h, p.h, red);
-            publish(p, c, slot_of(start, c, p.tile_e), st);
+            publish<BWD>(p, c, slot_of(start, c, p.tile_e), st);
         }
     }
 }
 
 template <typename T, bool BWD>
-static int launch_typed(const Params &p, hipStream_t s) {
+static int launch_typed(Params &p, hipStream_t s) {
     const int64_t n_seg = (p.n_tiles + kKMax - 1) / kKMax;
-    if (n_seg > 0x7fffffff || p.n_tiles > 0x7fffffff) return COGDL_HIP_ERANGE;
-    hipLaunchKernelGGL((es_flat_init_kernel<T, BWD>), dim3((unsigned)n_seg), dim3(kThreads), 0, s, p);
+    p.info_per_wave = p.n_tiles < 16384 ? 1 : 0;
+    const int64_t n_info = p.info_per_wave ? (p.n_tiles + 3) / 4 : (p.n_tiles + kThreads - 1) / kThreads;
+    if (n_seg + n_info > 0x7fffffff || p.n_tiles > 0x7fffffff) return COGDL_HIP_ERANGE;
+    p.n_seg = (int)n_seg;
+    hipLaunchKernelGGL((es_flat_init_kernel<T, BWD>), dim3((unsigned)(n_seg + n_info)), dim3(kThreads), 0, s, p);
     hipLaunchKernelGGL((es_flat_kernel<T, BWD>), dim3((unsigned)p.n_tiles), dim3(kThreads), 0, s, p);
     return launch_status();
 }
@@ -528,11 +715,13 @@ static int64_t es_flat_tiles(int64_t nnz, int64_t h, bool bwd) {
     return (nnz + tile_e - 1) / tile_e;
 }
 
-// [ticket: 256 B][flags: n_tiles * 2 words, padded to 256 B][records: n_tiles * 2 * h float2]
+// [header: 256 B][tile records: n_tiles * 32 B, padded to 256 B][piece records: n_tiles * 2 * h float2], sized for the
+// backward's smaller tiles (more of them).
+static size_t es_flat_info_bytes(int64_t nnz, int64_t h) {
+    return ((size_t)es_flat_tiles(nnz, h, true) * sizeof(esf::TileInfo) + 255) / 256 * 256;
+}
 size_t es_flat_workspace_bytes(int64_t nnz, int64_t h) {
-    const int64_t n_tiles = es_flat_tiles(nnz, h, true);  // the backward's smaller tiles need more of them
-    const size_t flags = ((size_t)n_tiles * 2 * sizeof(unsigned) + 255) / 256 * 256;
-    return 256 + flags + (size_t)n_tiles * 2 * (size_t)h * sizeof(float2);
+    return 256 + es_flat_info_bytes(nnz, h) + (size_t)es_flat_tiles(nnz, h, true) * 2 * (size_t)h * sizeof(float2);
 }
 
 int es_flat_launch(bool bwd, const int32_t *rowptr, const void *a, const void *g, void *out, int64_t m, int64_t nnz,
@@ -549,13 +738,12 @@ int es_flat_launch(bool bwd, const int32_t *rowptr, const void *a, const void *g
     p.h = (int)h;
     p.tile_e = (int)((bwd ? esf::TileSize<true>::value : esf::TileSize<false>::value) / h);
     p.n_tiles = es_flat_tiles(nnz, h, bwd);
-    p.ticket = (unsigned *)ws;
-    p.flags = (unsigned *)((char *)ws + 256);
-    const size_t flags = ((size_t)es_flat_tiles(nnz, h, true) * 2 * sizeof(unsigned) + 255) / 256 * 256;
-    p.rec = (float2 *)((char *)ws + 256 + flags);
+    p.stats = (unsigned *)ws;
+    p.tinfo = (esf::TileInfo *)((char *)ws + 256);
+    p.rec = (float2 *)((char *)ws + 256 + es_flat_info_bytes(nnz, h));
     p.long_edges = (int64_t)esf::kKMax * p.tile_e;
+    p.debug = (g_tuning[kTuneEsDebug] & 1) | (g_tuning[kTuneEsSpin] < 0 ? 2 : 0);
     p.spin_limit = g_tuning[kTuneEsSpin] > 0 ? (unsigned)g_tuning[kTuneEsSpin] : esf::kSpinLimit;
-    p.debug = g_tuning[kTuneEsDebug];
     switch (dtype) {
         case COGDL_HIP_F32: return bwd ? esf::launch_typed<float, true>(p, s) : esf::launch_typed<float, false>(p, s);
         case COGDL_HIP_F16: return bwd ? esf::launch_typed<__half, true>(p, s) : esf::launch_typed<__half, false>(p, s);

@@ -68,7 +68,9 @@ COGDL_API int cogdl_hip_last_hip_error(void);
  * key 6 = csr_spmm/mhspmm vector width cap (negative: force), key 7 = edge_softmax lane width (bit 0: 4-byte lanes in
  * the row kernels, bit 1: 4-byte lanes in the hub-row path, bit 2: row kernels instead of the flat streaming kernel;
  * 0 = flat kernel where it applies, 16-byte lanes where the layout allows), key 8 = polls before the flat edge_softmax
- * kernel's cross-tile wait gives up and recomputes the row statistics itself (0 = default 65536).
+ * kernel's cross-tile wait gives up and recomputes the row statistics itself (0 = default 4096; negative: every
+ * wait gives up at once -- tests of that escape path), key 9 = timing experiments (bit 0: the flat edge_softmax kernel
+ * skips its cross-tile exchange -- WRONG results).
  * Defaults are the measured optima. */
 COGDL_API int cogdl_hip_set_tuning(int key, int value);
 

@@ -87,6 +87,8 @@ def test_edge_softmax_forward_backward_vs_oracle(oracle, reddit, dtype, tol, sca
     att.backward(grad)
     again = csr_edge_softmax(c.g.rowptr, score)
     assert torch.equal(again, att.detach())  # run-to-run identical: fixed merge order of the tile records
+    from cogdl_amd.operators import edge_softmax as es_mod
+    assert int(es_mod.LAST_WORKSPACE[:4].view(torch.int32)[0]) == 0, "a cross-tile wait timed out (escape path taken)"
     want = oracle.edge_softmax_fwd(c.rowptr, score.float().cpu().numpy())
     got = att.detach().float().cpu().numpy()
     _close(got, want, want, tol, "edge_softmax forward")  # every term is positive: the scale is the value itself

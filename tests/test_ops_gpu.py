@@ -155,10 +155,10 @@ def test_edge_softmax_flat_kernel_rows_across_tiles(oracle, hubs, h, dtype):
     assert torch.equal(again, out.detach())  # deterministic: fixed merge order, no atomics on data
 
 
-@pytest.mark.parametrize("spin", [0, 1], ids=["exchange", "forced-timeout-escape"])
+@pytest.mark.parametrize("spin", [0, -1], ids=["exchange", "forced-timeout-escape"])
 def test_edge_softmax_flat_kernel_super_long_rows_and_timeout_escape(oracle, spin):
     """H = 64: a tile is 128 edges, so rows beyond 192 tiles = 24,576 edges take the init kernel's record path (no
-    waiting); tuning key 8 = 1 makes every cross-tile wait give up at once, which exercises the recompute-from-global
+    waiting); tuning key 8 = -1 makes every cross-tile wait give up at once, which exercises the recompute-from-global
     escape on ordinary multi-tile rows."""
     from cogdl_amd import _lib
 
@@ -172,6 +172,9 @@ def test_edge_softmax_flat_kernel_super_long_rows_and_timeout_escape(oracle, spi
         out = csr_edge_softmax(g.rowptr.to(DEV), vd)
         out.backward(gr.to(DEV))
         torch.cuda.synchronize()
+        from cogdl_amd.operators import edge_softmax as es_mod
+        escapes = int(es_mod.LAST_WORKSPACE[:4].view(torch.int32)[0])  # (of the backward launch, the last one)
+        assert (escapes > 0) == (spin == -1), escapes
     finally:
         _lib.hip().cogdl_hip_set_tuning(8, 0)
     np.testing.assert_allclose(out.detach().cpu().numpy(), oracle.edge_softmax_fwd(g.rowptr, v), rtol=1e-5, atol=1e-9)
