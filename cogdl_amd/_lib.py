@@ -57,6 +57,11 @@ HIP_SIGNATURES = {
     "cogdl_hip_coo2csr_index_workspace_bytes": ([_i64, _i64], _sz),
     "cogdl_hip_sample_adj_workspace_bytes": ([_i64, _i64, _i64], _sz),
     "cogdl_hip_sample_adj": ([_vp, _vp, _i64, _vp, _i64, _i64, _i32, _u64] + [_vp] * 4 + [_i64, _vp, _vp, _sz, _vp], _i32),
+    "cogdl_hip_subgraph_workspace_bytes": ([_i64, _i64], _sz),
+    "cogdl_hip_subgraph": ([_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp], _i32),
+    "cogdl_hip_gather_feature_rows": ([_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp], _i32),
+    "cogdl_hip_gather_feature_rows_i32": ([_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp], _i32),
+    "cogdl_hip_add_rows_at_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp], _i32),
     "cogdl_hip_coo2csr_index": ([_vp, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp], _i32),
 }
 

@@ -120,7 +120,40 @@ def sample_adj_c(indptr, indices, node_idx, num_neighbors, replace, seed=None):
     return out_indptr, out_indices[:ne].clone(), out_nodes[:nn].clone(), out_edges[:ne].clone()
 
 
+def _subgraph_gpu(indptr, indices, node_idx):
+    """Graph on the GPU -> (row_ptr, col, nodes, edges) on the GPU (cogdl_hip_subgraph, csrc/subgraph.hip).  node_idx
+    may arrive on the CPU: Graph.csr_subgraph moves it there (cogdl/data/data.py:853-854) before calling."""
+    dev = indptr.device
+    indptr, indices = indptr.to(torch.long).contiguous(), indices.to(torch.long).contiguous()
+    if not torch.is_tensor(node_idx):
+        node_idx = torch.as_tensor(node_idx, dtype=torch.long)
+    node_idx = node_idx.to(device=dev, dtype=torch.long).contiguous()
+    n, b = indptr.numel() - 1, node_idx.numel()
+    safe = node_idx.clamp(0, max(n - 1, 0))
+    cap_e = int((indptr[safe + 1] - indptr[safe]).sum()) if b and n else 0  # upper bound (ids clamped: the kernel flags bad ones)
+    out_indptr = torch.empty(b + 1, dtype=torch.long, device=dev)
+    out_indices = torch.empty(cap_e, dtype=torch.long, device=dev)
+    out_edges = torch.empty(cap_e, dtype=torch.long, device=dev)
+    counts = torch.empty(2, dtype=torch.long, device=dev)
+    lib = _lib.hip()
+    ws_bytes = lib.cogdl_hip_subgraph_workspace_bytes(b, n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with _lib.on_device(dev):
+        rc = lib.cogdl_hip_subgraph(_lib.ptr(indptr), _lib.ptr(indices), n, _lib.ptr(node_idx), b, _lib.ptr(out_indptr),
+                                    _lib.ptr(out_indices), _lib.ptr(out_edges), cap_e, _lib.ptr(counts), _lib.ptr(ws),
+                                    ws_bytes, _lib.stream_of(indptr))
+    _lib.check(rc, "subgraph")
+    ne, flags = (int(v) for v in counts.tolist())  # the one synchronisation: the output size
+    if flags & 1:
+        raise _lib.BackendError("subgraph: node id out of range [0, %d)" % n)
+    if flags:
+        raise _lib.BackendError("subgraph: %s" % ("neighbour id out of range" if flags & 2 else "capacity exceeded"))
+    return out_indptr, out_indices[:ne], torch.arange(0, b, device=dev), out_edges[:ne]
+
+
 def subgraph_c(indptr, indices, node_idx):
+    if torch.is_tensor(indptr) and indptr.is_cuda:
+        return _subgraph_gpu(indptr, indices, node_idx)
     indptr, indices, node_idx = _i64(indptr), _i64(indices), _i64(node_idx)
     n, b = indptr.numel() - 1, node_idx.numel()
     cap_e = int((indptr[node_idx + 1] - indptr[node_idx]).sum()) if b else 0

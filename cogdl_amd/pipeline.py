@@ -1,0 +1,161 @@
+"""The mini-batch input pipeline of sampled training on the GPU.
+
+The reference samples on the CPU inside DataLoader workers (cogdl/data/sampler.py:62-116 -> Graph.sample_adj ->
+sample.cpp, single-threaded per worker), gathers `x[n_id]` on the host into a fresh tensor and copies every batch to
+the GPU (cogdl/models/nn/graphsage.py:86-99).  Here, for a graph whose structure lives in HBM:
+
+  gather_rows_by_id(src, ids)      x[n_id] as ONE kernel that reads the selected rows wherever they live -- HBM, or
+                                   PINNED host memory read straight over the host link (zero copy: no host-side
+                                   index_select, no staging buffer, no separate H2D copy);
+  BatchPipeline                    sampling (cogdl_hip_sample_adj per hop) + the feature gather of batch i+1 run on a
+                                   side stream while batch i trains on the caller's stream;
+  layerwise_inference              Graphsage.inference (graphsage.py:106-119): layer by layer over ALL nodes with full
+                                   neighbourhoods (sample_adj(-1) on the GPU), features of the current layer gathered
+                                   by the same kernel.
+"""
+import torch
+
+from . import _lib
+from .operators.sample import sample_adj_c
+
+
+def gather_rows_by_id(src, ids, out=None):
+    """out[i] = src[ids[i]] along dim 0.  `src`: a CUDA tensor, or a PINNED CPU tensor (read by the GPU in place);
+    `ids`: CUDA int64 / int32.  Returns a CUDA tensor on ids' device (stream-ordered on its current stream)."""
+    if not ids.is_cuda:
+        raise _lib.BackendError("gather_rows_by_id: ids must live on the GPU (got %s)" % ids.device)
+    dev = ids.device
+    if src.is_cuda:
+        if src.device != dev:
+            raise _lib.BackendError("gather_rows_by_id: src on %s, ids on %s" % (src.device, dev))
+    elif not src.is_pinned():
+        raise _lib.BackendError("gather_rows_by_id: a host-resident source must be pinned (src.pin_memory()) so that the "
+                                "GPU can read it in place; there is no staged-copy fallback")
+    if not src.is_contiguous():
+        raise _lib.BackendError("gather_rows_by_id: src must be contiguous")
+    if ids.dtype not in (torch.int64, torch.int32) or ids.dim() != 1:
+        raise _lib.BackendError("gather_rows_by_id: ids must be a 1-D int64/int32 tensor")
+    ids = ids.contiguous()
+    n, n_src = ids.numel(), src.shape[0]
+    row_elems = src.numel() // max(n_src, 1) if n_src else 0
+    row_bytes = row_elems * src.element_size()
+    if out is None:
+        out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=dev)
+    elif out.shape != (n,) + tuple(src.shape[1:]) or out.dtype != src.dtype or not out.is_contiguous() or out.device != dev:
+        raise _lib.BackendError("gather_rows_by_id: `out` must be a contiguous %s tensor of shape %s on %s"
+                                % (src.dtype, (n,) + tuple(src.shape[1:]), dev))
+    if n == 0 or row_bytes == 0:
+        return out
+    if row_bytes % 4:
+        raise _lib.BackendError("gather_rows_by_id: rows of %d bytes (must be a multiple of 4)" % row_bytes)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    fn = _lib.hip().cogdl_hip_gather_feature_rows if ids.dtype == torch.int64 else _lib.hip().cogdl_hip_gather_feature_rows_i32
+    with _lib.on_device(dev):
+        rc = fn(_lib.ptr(ids), src.data_ptr(), _lib.ptr(out), n, row_bytes, n_src, _lib.ptr(bad),
+                torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "gather_feature_rows")
+    out._cogdl_bad_flag = bad  # checked lazily (BatchPipeline / tests): reading it here would stall the stream
+    return out
+
+
+def check_gather(out):
+    """Raise if the gather that produced `out` met an id outside the source (synchronises)."""
+    bad = getattr(out, "_cogdl_bad_flag", None)
+    if bad is not None and int(bad.item()):
+        raise _lib.BackendError("gather_rows_by_id: an id lies outside the source's rows")
+
+
+def sample_blocks(indptr, indices, seeds, fanouts):
+    """NeighborSampler.sample (cogdl/data/sampler.py:93-116) on the GPU: one sample_adj per hop, outermost hop last;
+    returns (n_id, [((row_ptr, col), n_dst), ...] innermost block first)."""
+    adjs = []
+    batch = seeds
+    for k in fanouts:
+        row_ptr, col, nodes, _ = sample_adj_c(indptr, indices, batch, k, False)
+        adjs.append(((row_ptr, col), batch.numel()))
+        batch = nodes
+    return batch, adjs[::-1]
+
+
+class BatchPipeline:
+    """Iterate over mini-batches (seeds, n_id, adjs, x_batch, y_batch) with the NEXT batch's sampling and feature
+    gather running on a side stream while the caller trains on the current one.
+
+        indptr, indices : CSR of the graph on the GPU (int64)
+        x               : node features, on the GPU or in pinned host memory ([N, F])
+        y               : labels on the GPU (or None)
+        seed_batches    : iterable of 1-D int64 seed tensors on the GPU (distinct ids per batch)
+    The caller must not synchronise the device inside its step (loss.item(), .cpu()) if it wants the overlap."""
+
+    def __init__(self, indptr, indices, x, y, seed_batches, fanouts):
+        self.indptr, self.indices, self.x, self.y = indptr, indices, x, y
+        self.seed_batches, self.fanouts = seed_batches, list(fanouts)
+        self.dev = indptr.device
+        self.side = torch.cuda.Stream(device=self.dev)
+
+    def _prepare(self, seeds):
+        main = torch.cuda.current_stream(self.dev)
+        self.side.wait_stream(main)  # the seeds (and anything they depend on) were produced on the caller's stream
+        with torch.cuda.stream(self.side):
+            n_id, adjs = sample_blocks(self.indptr, self.indices, seeds, self.fanouts)
+            xb = gather_rows_by_id(self.x, n_id)
+            yb = None if self.y is None else self.y.index_select(0, seeds)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        return seeds, n_id, adjs, xb, yb, done
+
+    def __iter__(self):
+        it = iter(self.seed_batches)
+        try:
+            nxt = self._prepare(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            seeds, n_id, adjs, xb, yb, done = nxt
+            main = torch.cuda.current_stream(self.dev)
+            main.wait_event(done)
+            for t in [seeds, n_id, xb] + ([yb] if yb is not None else []) + [b for (blk, _) in adjs for b in blk]:
+                t.record_stream(main)  # allocated on the side stream, consumed on the caller's
+            # the consumer's step is enqueued (asynchronously) between this yield and the next _prepare
+            yield seeds, n_id, adjs, xb, yb
+            try:
+                nxt = self._prepare(next(it))
+            except StopIteration:
+                nxt = None
+
+
+def layerwise_inference(convs, x_all, indptr, indices, batch_size=65536, activation=torch.relu, make_graph=None,
+                        keep_on_host=None):
+    """Graphsage.inference (cogdl/models/nn/graphsage.py:106-119) for a GPU-resident graph: for every layer, for every
+    block of `batch_size` target nodes, the FULL neighbourhood is taken with sample_adj(-1) on the GPU, the current
+    layer's inputs of the block's frontier are gathered with gather_rows_by_id, and `convs[i](make_graph(row_ptr, col),
+    x)[:block]` is evaluated; the activation follows every layer but the last.
+
+    x_all may live on the GPU or in pinned host memory; intermediate layer outputs follow `keep_on_host` (default: the
+    same side as x_all) -- on the host they are written into a pinned buffer, so the next layer reads them zero-copy.
+    `make_graph(row_ptr, col)` builds what the layer takes as its graph argument (default: the tuple; with CogDL:
+    `lambda rp, c: Graph(row_ptr=rp, col=c)`)."""
+    dev = indptr.device
+    n = indptr.numel() - 1
+    if keep_on_host is None:
+        keep_on_host = not x_all.is_cuda
+    make_graph = make_graph or (lambda rp, c: (rp, c))
+    with torch.no_grad():
+        for li, conv in enumerate(convs):
+            out_all = None
+            for start in range(0, n, batch_size):
+                batch = torch.arange(start, min(n, start + batch_size), device=dev)
+                row_ptr, col, nodes, _ = sample_adj_c(indptr, indices, batch, -1, False)
+                x = gather_rows_by_id(x_all, nodes)
+                h = conv(make_graph(row_ptr, col), x)[: batch.numel()]
+                if li != len(convs) - 1 and activation is not None:
+                    h = activation(h)
+                if out_all is None:
+                    shape = (n,) + tuple(h.shape[1:])
+                    out_all = (torch.empty(shape, dtype=h.dtype, pin_memory=True) if keep_on_host
+                               else torch.empty(shape, dtype=h.dtype, device=dev))
+                out_all[start:start + batch.numel()].copy_(h, non_blocking=True)
+            if keep_on_host:
+                torch.cuda.current_stream(dev).synchronize()  # the pinned buffer is complete before it is read again
+            x_all = out_all
+    return x_all

@@ -302,6 +302,41 @@ COGDL_API int cogdl_hip_sample_adj(const int64_t *indptr, const int64_t *indices
                          size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * subgraph on the GPU: the node-induced subgraph of a GPU-resident CSR graph, the contract of sampler.subgraph
+ * (cogdl/operators/sample/sample.cpp:146-188, reached from Graph.csr_subgraph, cogdl/data/data.py:850-872) and of
+ * cogdl_host_subgraph, int64 in and out, device pointers:
+ *   row i of the result = row node_idx[i] restricted to the sources that are in node_idx, relabelled to their
+ *   position in node_idx (a duplicated id keeps its last position), edges in CSR order;
+ *   out_indptr[batch+1], out_indices[E'] (local ids), out_edges[E'] (CSR positions of the kept edges);
+ *   cap_edges >= E' (the summed degree of the selected rows always suffices);
+ *   out_counts (DEVICE int64[2]) = {E', flags}; flags: bit 0 node id out of range, bit 1 neighbour id out of range,
+ *   bit 2 capacity exceeded.  Nothing synchronises.
+ * ------------------------------------------------------------------------------------- */
+COGDL_API size_t cogdl_hip_subgraph_workspace_bytes(int64_t batch, int64_t num_nodes);
+COGDL_API int cogdl_hip_subgraph(const int64_t *indptr, const int64_t *indices, int64_t num_nodes,
+                       const int64_t *node_idx, int64_t batch, int64_t *out_indptr, int64_t *out_indices,
+                       int64_t *out_edges, int64_t cap_edges, int64_t *out_counts, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Row gathers by node id.
+ * gather_feature_rows: out[i,:] = src[ids[i],:], rows of row_bytes bytes (a multiple of 4) -- the mini-batch feature
+ *   gather x[n_id] of the sampling pipeline (cogdl/data/sampler.py:82-116, cogdl/models/nn/graphsage.py:86-99).
+ *   `src` is a device pointer OR a pointer into PINNED host memory (device-mapped): the selected rows are then read
+ *   straight over the host link, overlapping other streams ("zero copy"); `out` is device memory.  ids int64 (what
+ *   the sampler returns) or int32 (_i32).  *bad_flag (device int, may be NULL; the caller zeroes it) gets bit 0 if
+ *   an id lies outside [0, n_src): such rows are skipped.
+ * add_rows_at_f32: out[ids[i],:] += src[i,:] for DISTINCT ids (no atomics): accumulation of returned halo gradients
+ *   in the vertex-sharded SpMM backward (cogdl_amd/dist.py).
+ * ------------------------------------------------------------------------------------- */
+COGDL_API int cogdl_hip_gather_feature_rows(const int64_t *ids, const void *src, void *out, int64_t n,
+                                  int64_t row_bytes, int64_t n_src, int *bad_flag, void *stream);
+COGDL_API int cogdl_hip_gather_feature_rows_i32(const int32_t *ids, const void *src, void *out, int64_t n,
+                                      int64_t row_bytes, int64_t n_src, int *bad_flag, void *stream);
+COGDL_API int cogdl_hip_add_rows_at_f32(const int64_t *ids, const float *src, float *out, int64_t n, int64_t k,
+                              int64_t n_dst, int *bad_flag, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * linear_wgrad: grad_w[out, in] = grad_out[k_rows, out]^T . x[k_rows, in], grad_b[out] = column sums of grad_out
  * (grad_b may be NULL) -- the weight/bias gradient of the `self.linear(x)` inside every CogDL layer
  * (cogdl/layers/gcn_layer.py:52, gat_layer.py:60, sage_layer.py:72; torch.nn.Linear's backward, which torch hands to
