@@ -38,7 +38,7 @@ if has epoch; then
   tail -3 gpurun_out/epoch_probe.log; cat gpurun_out/epoch_breakdown.txt
 fi
 if has e2e; then
-  (echo "# tools/sage_bench.py (configs[3]) and tools/gat_bench.py (configs[2]) on one MI355X"; timeout 400 python tools/sage_bench.py 2>&1 | tail -1; timeout 300 python tools/sage_bench.py --batch 8192 --steps 30 2>&1 | tail -1; timeout 600 python tools/gat_bench.py 2>&1 | tail -5) > gpurun_out/e2e.txt 2>&1
+  (echo "# tools/sage_bench.py (configs[3]) and tools/gat_bench.py (configs[2]) on one MI355X"; timeout 400 python tools/sage_bench.py --inference 2>&1 | tail -1; timeout 300 python tools/sage_bench.py --batch 8192 --steps 30 2>&1 | tail -1; timeout 300 python tools/sage_bench.py --features host 2>&1 | tail -1; timeout 300 python tools/sage_bench.py --features host --pipeline 2>&1 | tail -1; timeout 300 python tools/sage_bench.py --pipeline 2>&1 | tail -1; timeout 300 python tools/sage_bench.py --features host --pipeline --batch 8192 --steps 30 2>&1 | tail -1; timeout 600 python tools/gat_bench.py 2>&1 | tail -5) > gpurun_out/e2e.txt 2>&1
   cat gpurun_out/e2e.txt | cut -c1-300
 fi
 if has sampler; then

@@ -24,8 +24,8 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cogdl_amd import synth  # noqa: E402
-from cogdl_amd.operators.sample import sample_adj_c  # noqa: E402
 from cogdl_amd.operators.spmm import csrspmm  # noqa: E402
+from cogdl_amd.pipeline import BatchPipeline, gather_rows_by_id, layerwise_inference, sample_blocks  # noqa: E402
 
 
 class SageMean(torch.nn.Module):
@@ -56,17 +56,6 @@ class Sage(torch.nn.Module):
         return x
 
 
-def sample_blocks(indptr, indices, seeds, fanout):
-    """NeighborSampler.sample (cogdl/data/sampler.py:93-116): outermost hop last, blocks returned innermost first."""
-    adjs = []
-    batch = seeds
-    for k in fanout:
-        row_ptr, col, nodes, _ = sample_adj_c(indptr, indices, batch, k, False)
-        adjs.append(((row_ptr, col), batch.numel()))
-        batch = nodes
-    return batch, adjs[::-1]
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
@@ -77,6 +66,10 @@ def main():
     ap.add_argument("--feat", type=int, default=100)
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--classes", type=int, default=47)
+    ap.add_argument("--features", default="hbm", choices=["hbm", "host"],
+                    help="host: the feature matrix stays in PINNED host memory and x[n_id] is gathered zero-copy over the host link")
+    ap.add_argument("--pipeline", action="store_true", help="sample + gather batch i+1 on a side stream while batch i trains")
+    ap.add_argument("--inference", action="store_true", help="also time layer-wise full-neighbour inference over all nodes")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
@@ -92,21 +85,28 @@ def main():
     indptr, indices = g.rowptr.long(), g.colind.long()
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
     x_all = torch.randn(n, args.feat, device=dev, generator=gen)
+    if args.features == "host":
+        x_all = x_all.cpu().pin_memory()
     y_all = torch.randint(0, args.classes, (n,), device=dev, generator=gen)
     torch.manual_seed(0)
     model = Sage(args.feat, args.hidden, args.classes).to(dev)
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index]) if world > 1 else model
     opt = torch.optim.Adam(net.parameters(), lr=0.01)
 
-    def step():
-        seeds = torch.randint(0, n, (args.batch,), device=dev, generator=gen).unique()
-        n_id, adjs = sample_blocks(indptr, indices, seeds, [10, 10])
+    def draw_seeds():
+        return torch.randint(0, n, (args.batch,), device=dev, generator=gen).unique()
+
+    def train_on(seeds, n_id, adjs, xb, yb):
         opt.zero_grad(set_to_none=True)
-        out = net(x_all[n_id], adjs)
-        loss = F.cross_entropy(out, y_all[seeds])
+        loss = F.cross_entropy(net(xb, adjs), yb)
         loss.backward()
         opt.step()
         return seeds.numel(), n_id.numel(), sum(b[0][1].numel() for b in adjs)
+
+    def step():
+        seeds = draw_seeds()
+        n_id, adjs = sample_blocks(indptr, indices, seeds, [10, 10])
+        return train_on(seeds, n_id, adjs, gather_rows_by_id(x_all, n_id), y_all[seeds])
 
     net.train()
     for _ in range(args.warmup):
@@ -116,9 +116,17 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     seeds = nodes = edges = 0
-    for _ in range(args.steps):
-        a, b, c = step()
-        seeds, nodes, edges = seeds + a, nodes + b, edges + c
+    if args.pipeline:
+        batches = [draw_seeds() for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for batch in BatchPipeline(indptr, indices, x_all, y_all, batches, [10, 10]):
+            a, b, c = train_on(*batch)
+            seeds, nodes, edges = seeds + a, nodes + b, edges + c
+    else:
+        for _ in range(args.steps):
+            a, b, c = step()
+            seeds, nodes, edges = seeds + a, nodes + b, edges + c
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -134,14 +142,36 @@ def main():
         sample_blocks(indptr, indices, torch.randint(0, n, (args.batch,), device=dev, generator=gen).unique(), [10, 10])
     torch.cuda.synchronize()
     ms_sample = (time.perf_counter() - t1) / 20 * 1e3
+    # the feature gather alone, for a typical frontier
+    n_id, _ = sample_blocks(indptr, indices, draw_seeds(), [10, 10])
+    for _ in range(3):
+        gather_rows_by_id(x_all, n_id)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        gather_rows_by_id(x_all, n_id)
+    torch.cuda.synchronize()
+    ms_gather = (time.perf_counter() - t1) / 20 * 1e3
+    gather_gbs = n_id.numel() * args.feat * 4 / ms_gather / 1e6
+    infer = None
+    if args.inference and rank == 0:
+        model.eval()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        out = layerwise_inference(list(model.convs), x_all, indptr, indices, batch_size=65536)
+        torch.cuda.synchronize()
+        infer = {"s": time.perf_counter() - t1, "nodes": n, "out_shape": list(out.shape),
+                 "what": "Graphsage.inference: 2 layers x all nodes, full neighbourhoods (sample_adj(-1) on the GPU)"}
     if rank == 0:
         print(json.dumps({
             "metric": "GraphSAGE mini-batch training, seed nodes/s (products-shaped graph, fan-out [10,10]) @%d GPU" % world,
             "value": float(tot) / float(dt), "unit": "seed nodes/s", "n_gpus": world, "steps": args.steps,
             "ms_per_step": float(dt) / args.steps * 1e3, "ms_sampling_alone_rank0": ms_sample,
+            "ms_feature_gather_alone_rank0": ms_gather, "feature_gather_GBs": gather_gbs, "layerwise_inference": infer,
             "batch": args.batch, "frontier_nodes_per_step": nodes // args.steps, "sampled_edges_per_step": edges // args.steps,
             "config": {"nodes": n, "nnz": int(g.nnz), "feat": args.feat, "hidden": args.hidden, "classes": args.classes,
-                       "sampler": "cogdl_hip_sample_adj (GPU-resident graph)", "features": "resident in HBM",
+                       "sampler": "cogdl_hip_sample_adj (GPU-resident graph)", "features": "resident in HBM" if args.features == "hbm" else "pinned host memory, zero-copy gather",
+                       "pipeline": "next batch sampled + gathered on a side stream" if args.pipeline else "none",
                        "parallelism": "replicas + DDP all-reduce (RCCL)" if world > 1 else "single GPU"}}))
     if world > 1:
         torch.distributed.destroy_process_group()
