@@ -101,7 +101,7 @@ def load_pmc_traffic(phase="arxiv_uniform_F128"):
         return None
 
 
-def gcn_epoch_ms(gd, rowptr64, colind64, x, reps=20, warmup=5, mfma_linear=True):
+def gcn_epoch_ms(gd, rowptr64, colind64, x, reps=20, warmup=5, mfma_linear=True, captured=False):
     """The 'GNN epoch time' half of BASELINE.json's metric: one full-graph training step (= one epoch) of CogDL's
     default `gcn` model (cogdl/models/nn/gcn.py:26-29: 2 GCNLayers, hidden 64, relu, dropout 0.5; GCNLayer.forward
     = spmm(graph, linear(x)), cogdl/layers/gcn_layer.py:51-53) on the arxiv-shaped graph, 40 classes, Adam(lr 0.01,
@@ -118,9 +118,11 @@ def gcn_epoch_ms(gd, rowptr64, colind64, x, reps=20, warmup=5, mfma_linear=True)
     lin1, lin2 = torch.nn.Linear(f_in, hidden).to(dev), torch.nn.Linear(hidden, classes).to(dev)
     drop = torch.nn.Dropout(0.5)
     params = list(lin1.parameters()) + list(lin2.parameters())
-    opt = torch.optim.Adam(params, lr=0.01, weight_decay=5e-4)
+    opt = torch.optim.Adam(params, lr=0.01, weight_decay=5e-4, capturable=captured)
     y = torch.randint(0, classes, (n,), device=dev)
     train_mask = torch.rand(n, device=dev) < 0.537  # ogbn-arxiv: 90,941 of 169,343 nodes train
+    train_idx = torch.nonzero(train_mask).flatten()  # captured variant: static shapes, no boolean-mask indexing
+    y_train = y[train_idx]
     feats = x.detach()
 
     def step():
@@ -128,10 +130,17 @@ def gcn_epoch_ms(gd, rowptr64, colind64, x, reps=20, warmup=5, mfma_linear=True)
         h = csrspmm(rowptr64.int(), colind64.int(), lin1(feats), gd.weight, True)
         h = drop(torch.relu_(h))
         out = csrspmm(rowptr64.int(), colind64.int(), lin2(h), gd.weight, True)
-        loss = torch.nn.functional.cross_entropy(out[train_mask], y[train_mask])
+        if captured:
+            loss = torch.nn.functional.cross_entropy(out.index_select(0, train_idx), y_train)
+        else:
+            loss = torch.nn.functional.cross_entropy(out[train_mask], y[train_mask])
         loss.backward()
         opt.step()
 
+    if captured:  # the whole step (forward, backward, Adam) as ONE hipGraph launch (cogdl_amd/graphs.py)
+        from cogdl_amd import graphs
+
+        step = graphs.capture(step, warmup=3)
     for _ in range(warmup):
         step()
     ts = []
@@ -242,6 +251,14 @@ def bench_single(args):
     }
     result["gnn_epoch"] = gcn_epoch_ms(gd, rowptr64, colind64, x)
     result["gnn_epoch"]["ms_with_torch_linear"] = gcn_epoch_ms(gd, rowptr64, colind64, x, mfma_linear=False)["ms"]
+    try:
+        cap = gcn_epoch_ms(gd, rowptr64, colind64, x, captured=True)
+        result["gnn_epoch"]["ms_hipgraph"] = cap["ms"]
+        result["gnn_epoch"]["hipgraph"] = ("the same step captured once with cogdl_amd.graphs.capture (index tensor instead of "
+                                           "the boolean mask, capturable Adam) and replayed as one graph launch")
+    except Exception as e:  # a capture failure must not take the bench line down
+        result["gnn_epoch"]["ms_hipgraph"] = None
+        result["gnn_epoch"]["hipgraph_error"] = repr(e)[:300]
     if not args.no_trainer:
         tr = trainer_epoch()
         if tr is not None:

@@ -28,6 +28,7 @@ HIP_SIGNATURES = {
     "cogdl_hip_csr_spmm": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_csr_spmm_acc": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_csr_spmm_variant": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _i32, _vp, _sz, _vp], _i32),
+    "cogdl_hip_csr_spmm_epilogue": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_csr2csc_workspace_bytes": ([_i64, _i64, _i64], _sz),
     "cogdl_hip_csr2csc": ([_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp], _i32),
     "cogdl_hip_gather_rows": ([_vp, _vp, _vp, _i64, _i64, _i32, _vp], _i32),

@@ -20,147 +20,9 @@
 // path (piece sums combined in a FIXED order: deterministic; such rows differ from the reference only by
 // re-association, <= 1e-6 relative).
 // HBM-bound: algorithmic bytes per edge = 4 (colind) + s_w + F*s, per row 4 + F*s.
-#include "rowreduce.h"
+#include "spmm_op.h"
 
 namespace cogdl {
-
-constexpr int kDefaultUnroll = 8;
-
-template <bool EXACT>
-__device__ __forceinline__ float mul_add(float acc, float w, float v) {
-    // The library is compiled with -ffp-contract=off: `acc + w * v` is a rounded multiply
-    // followed by a rounded add, exactly what the reference's x86-64 build executes.
-    if constexpr (EXACT) return acc + w * v;
-    else return fmaf(w, v, acc);
-}
-
-// WMODE: 0 = unweighted (csr_spmm_no_edge_value), 1 = one weight per edge (val, dtype T),
-//        2 = multi-head (mhspmm): x is [N, H, fdim], weight att[e, head] in fp32, head = column / fdim.
-template <typename T, int VEC_, int LPR_, int UNROLL_, int WMODE, bool EXACT>
-struct SpmmOp {
-    static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_;
-    static constexpr bool kReduce = true;
-    static constexpr int kLds = 0;
-    const T *val;      // WMODE 1
-    const float *att;  // WMODE 2: [E, heads]
-    const T *x;
-    T *out;
-    int k;       // feature width (heads * fdim for WMODE 2)
-    int fdim;
-    int acc_mode;  // != 0: out += A x
-    const int32_t *eid;  // WMODE 2: attention row of edge e is att[eid[e]] (a transposed view of A; NULL: att[e])
-
-    struct Ctx {
-        int col0, heads, hd;
-        bool col_ok;
-        const T *xcol;
-    };
-    struct State { float acc[VEC]; };
-    struct LaneVals {
-        float w;
-        int id;
-    };
-    struct Batch {
-        float v[UNROLL][VEC];
-        float w[UNROLL];
-    };
-
-    __device__ __forceinline__ Ctx make_ctx(int l, int tile) const {
-        Ctx c;
-        c.col0 = (tile * LPR + l) * VEC;
-        c.col_ok = c.col0 < k;
-        const int cc = c.col_ok ? c.col0 : 0;  // lanes past the last column read column 0 and never store
-        c.heads = (WMODE == 2) ? k / fdim : 1;
-        c.hd = (WMODE == 2) ? cc / fdim : 0;
-        c.xcol = x + cc;
-        return c;
-    }
-    __device__ __forceinline__ void row_load(Ctx &, int64_t, bool) const {}
-    __device__ __forceinline__ void init_zero(State &s) const {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) s.acc[i] = 0.f;
-    }
-    __device__ __forceinline__ void init(const Ctx &c, State &s, int64_t row, bool ok) const {
-        init_zero(s);
-        if (acc_mode && ok && c.col_ok) load_vec<T, VEC>(out + row * (int64_t)k + c.col0, s.acc);
-    }
-    __device__ __forceinline__ void lane_load(const Ctx &, LaneVals &lv, int64_t e) const {
-        if constexpr (WMODE == 1) lv.w = to_f32<T>(val[e]);
-        if constexpr (WMODE == 2) lv.id = eid ? eid[e] : 0;
-    }
-    __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t e, const LaneVals &lv,
-                                          int sub, int jj) const {
-        if constexpr (WMODE == 1) b.w[u] = group_bcast<LPR>(lv.w, sub, jj);
-        else if constexpr (WMODE == 2) {  // 4*H-byte run per edge
-            const int64_t arow = eid ? (int64_t)group_bcast<LPR>(lv.id, sub, jj) : e;
-            b.w[u] = att[arow * c.heads + c.hd];
-        }
-        else b.w[u] = 1.f;
-        load_vec<T, VEC>(c.xcol + (int64_t)col * k, b.v[u]);
-    }
-    // Strictly in CSR order.  acc + 0*0 == acc exactly (acc is never -0), so masked slots are no-ops;
-    // selecting v (not only w) to zero keeps inf/nan out.
-    __device__ __forceinline__ void apply(const Ctx &, State &s, const Batch &b, int u, bool valid, int64_t,
-                                          int) const {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            const float vv = valid ? b.v[u][i] : 0.f;
-            if constexpr (WMODE != 0) s.acc[i] = mul_add<EXACT>(s.acc[i], valid ? b.w[u] : 0.f, vv);
-            else s.acc[i] = s.acc[i] + vv;
-        }
-    }
-    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
-    __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
-    __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
-    __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
-        if (ok && c.col_ok) store_vec<T, VEC>(out + row * (int64_t)k + c.col0, s.acc);
-    }
-    __device__ __forceinline__ void pack(const State &s, float (&rec)[kRec]) const {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) rec[i] = s.acc[i];
-    }
-    __device__ __forceinline__ void unpack(State &s, const float (&rec)[kRec]) const {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) s.acc[i] = rec[i];
-    }
-    __device__ __forceinline__ void merge(const Ctx &, State &a, const State &b) const {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) a.acc[i] += b.acc[i];
-    }
-};
-
-template <typename T>
-struct SpmmArgs {
-    const int32_t *rowptr;
-    const int32_t *colind;
-    const T *val;
-    const float *att;
-    const T *x;
-    T *out;
-    int64_t m, nnz;
-    int k, fdim, acc_mode;
-    const int32_t *eid;
-};
-
-template <typename T, int VEC, int LPR, int UNROLL, int WMODE, bool EXACT>
-static int launch_spmm(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) {
-    SpmmOp<T, VEC, LPR, UNROLL, WMODE, EXACT> op{a.val, a.att, a.x, a.out, a.k, a.fdim, a.acc_mode, a.eid};
-    const int64_t tiles = ((int64_t)a.k + (int64_t)LPR * VEC - 1) / ((int64_t)LPR * VEC);
-    return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, tiles, ws, wsb, s);
-}
-
-// (VEC, LPR) choice: as many lanes per row as the row has VEC-wide columns (whole-wave rows are the
-// fastest: scalar column broadcast, no inter-row divergence inside a wave), VEC as small as that allows.
-template <typename T, int VEC, int WMODE>
-static int dispatch_lpr(const SpmmArgs<T> &a, int lpr, void *ws, size_t wsb, hipStream_t s) {
-    switch (lpr) {
-        case 4: return launch_spmm<T, VEC, 4, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
-        case 8: return launch_spmm<T, VEC, 8, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
-        case 16: return launch_spmm<T, VEC, 16, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
-        case 32: return launch_spmm<T, VEC, 32, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
-        default: return launch_spmm<T, VEC, 64, kDefaultUnroll, WMODE, true>(a, ws, wsb, s);
-    }
-}
 
 // Vector width and lanes per row.  Every lane's VEC columns must stay inside one row (k % VEC == 0), inside
 // one head for mhspmm (fdim % VEC == 0), and be naturally aligned.  Measured on MI355X (arxiv-shaped uniform and
@@ -197,26 +59,11 @@ RowGeometry spmm_geometry(int64_t k, int64_t unit, int elem_bytes, int align) {
     return g;
 }
 
-static int pointer_alignment(const void *a, const void *b) {
-    const uintptr_t v = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b);
-    return (v % 16 == 0) ? 16 : (v % 8 == 0) ? 8 : (v % 4 == 0) ? 4 : 2;
-}
-
-template <typename T, int WMODE>
-static int spmm_auto(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) {
-    const RowGeometry g = spmm_geometry(a.k, (WMODE == 2) ? a.fdim : a.k, (int)sizeof(T), pointer_alignment(a.x, a.out));
-    switch (g.vec) {
-        case 4: return dispatch_lpr<T, 4, WMODE>(a, g.lpr, ws, wsb, s);
-        case 2: return dispatch_lpr<T, 2, WMODE>(a, g.lpr, ws, wsb, s);
-        default: return dispatch_lpr<T, 1, WMODE>(a, g.lpr, ws, wsb, s);
-    }
-}
-
 template <typename T>
 static int spmm_typed(const int32_t *rowptr, const int32_t *colind, const void *val, const void *x, void *out,
                       int64_t m, int64_t k, int64_t nnz, int acc_mode, void *ws, size_t wsb, hipStream_t s) {
     if (!aligned_to(x, sizeof(T)) || !aligned_to(out, sizeof(T))) return COGDL_HIP_EALIGN;
-    SpmmArgs<T> a{rowptr, colind, (const T *)val, nullptr, (const T *)x, (T *)out, m, nnz, (int)k, (int)k, acc_mode};
+    SpmmArgs<T> a{rowptr, colind, (const T *)val, nullptr, (const T *)x, (T *)out, m, nnz, (int)k, (int)k, acc_mode, nullptr, {}};
     return val ? spmm_auto<T, 1>(a, ws, wsb, s) : spmm_auto<T, 0>(a, ws, wsb, s);
 }
 
@@ -248,7 +95,7 @@ static int mhspmm_typed(const int32_t *rowptr, const int32_t *colind, const floa
                         const void *feat, void *out, int64_t v, int64_t h, int64_t f, int64_t nnz, void *ws, size_t wsb,
                         hipStream_t s) {
     if (!aligned_to(feat, sizeof(T)) || !aligned_to(out, sizeof(T))) return COGDL_HIP_EALIGN;
-    SpmmArgs<T> a{rowptr, colind, nullptr, att, (const T *)feat, (T *)out, v, nnz, (int)(h * f), (int)f, 0, eid};
+    SpmmArgs<T> a{rowptr, colind, nullptr, att, (const T *)feat, (T *)out, v, nnz, (int)(h * f), (int)f, 0, eid, {}};
     return spmm_auto<T, 2>(a, ws, wsb, s);
 }
 
@@ -322,7 +169,7 @@ extern "C" int cogdl_hip_csr_spmm_variant(const int32_t *rowptr, const int32_t *
     if (dtype != COGDL_HIP_F32 || !val) return COGDL_HIP_EDTYPE;
     if (k % 4 != 0 || !aligned_to(x, 16) || !aligned_to(out, 16)) return COGDL_HIP_EALIGN;
     hipStream_t s = (hipStream_t)stream;
-    SpmmArgs<float> a{rowptr, colind, (const float *)val, nullptr, (const float *)x, (float *)out, m, nnz, (int)k, (int)k, 0};
+    SpmmArgs<float> a{rowptr, colind, (const float *)val, nullptr, (const float *)x, (float *)out, m, nnz, (int)k, (int)k, 0, nullptr, {}};
     // The variants may need more workspace than the automatic geometry: only pass it on when it is big enough.
 #define V(id, VEC, LPR, UNR, EX)                                                                                   \
     case id: {                                                                                                     \

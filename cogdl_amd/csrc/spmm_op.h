@@ -1,0 +1,190 @@
+// spmm_op.h -- the csr_spmm / mhspmm functor over the row-reduce engine and its dispatch (shared by spmm.hip and
+// spmm_epilogue.hip, which instantiate it without / with the fused normalisation epilogue).
+#pragma once
+#include "rowreduce.h"
+
+namespace cogdl {
+
+constexpr int kDefaultUnroll = 8;
+
+template <bool EXACT>
+__device__ __forceinline__ float mul_add(float acc, float w, float v) {
+    // The library is compiled with -ffp-contract=off: `acc + w * v` is a rounded multiply
+    // followed by a rounded add, exactly what the reference's x86-64 build executes.
+    if constexpr (EXACT) return acc + w * v;
+    else return fmaf(w, v, acc);
+}
+
+// WMODE: 0 = unweighted (csr_spmm_no_edge_value), 1 = one weight per edge (val, dtype T),
+//        2 = multi-head (mhspmm): x is [N, H, fdim], weight att[e, head] in fp32, head = column / fdim.
+// Fused epilogue (EPI): out[i,:] = act( dst_scale[i] * sum_e val[e] * (src_scale[col[e]] * x[col[e],:]) + bias ) --
+// the two broadcast multiplies CogDL's dispatcher wraps around the kernel (out_norm * x before, in_norm * x after:
+// cogdl/utils/spmm_utils.py:99-109) and the layer's activation, applied where the operands already are.  Every
+// product is a separately rounded fp32 multiply, in the reference's order: bit-identical to the unfused composition.
+struct SpmmEpilogue {
+    const float *src_scale;  // [n_src] or NULL
+    const float *dst_scale;  // [m] or NULL
+    const float *bias;       // [k] or NULL
+    int act;                 // 0 = none, 1 = relu
+};
+
+template <typename T, int VEC_, int LPR_, int UNROLL_, int WMODE, bool EXACT, bool EPI = false>
+struct SpmmOp {
+    static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_;
+    static constexpr bool kReduce = true;
+    static constexpr int kLds = 0;
+    const T *val;      // WMODE 1
+    const float *att;  // WMODE 2: [E, heads]
+    const T *x;
+    T *out;
+    int k;       // feature width (heads * fdim for WMODE 2)
+    int fdim;
+    int acc_mode;  // != 0: out += A x
+    const int32_t *eid;  // WMODE 2: attention row of edge e is att[eid[e]] (a transposed view of A; NULL: att[e])
+    SpmmEpilogue epi;    // EPI only
+
+    struct Ctx {
+        int col0, heads, hd;
+        bool col_ok;
+        const T *xcol;
+    };
+    struct State { float acc[VEC]; };
+    struct LaneVals {
+        float w;
+        int id;
+    };
+    struct Batch {
+        float v[UNROLL][VEC];
+        float w[UNROLL];
+        float s[EPI ? UNROLL : 1];
+    };
+
+    __device__ __forceinline__ Ctx make_ctx(int l, int tile) const {
+        Ctx c;
+        c.col0 = (tile * LPR + l) * VEC;
+        c.col_ok = c.col0 < k;
+        const int cc = c.col_ok ? c.col0 : 0;  // lanes past the last column read column 0 and never store
+        c.heads = (WMODE == 2) ? k / fdim : 1;
+        c.hd = (WMODE == 2) ? cc / fdim : 0;
+        c.xcol = x + cc;
+        return c;
+    }
+    __device__ __forceinline__ void row_load(Ctx &, int64_t, bool) const {}
+    __device__ __forceinline__ void init_zero(State &s) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.acc[i] = 0.f;
+    }
+    __device__ __forceinline__ void init(const Ctx &c, State &s, int64_t row, bool ok) const {
+        init_zero(s);
+        if (acc_mode && ok && c.col_ok) load_vec<T, VEC>(out + row * (int64_t)k + c.col0, s.acc);
+    }
+    __device__ __forceinline__ void lane_load(const Ctx &, LaneVals &lv, int64_t e) const {
+        if constexpr (WMODE == 1) lv.w = to_f32<T>(val[e]);
+        if constexpr (WMODE == 2) lv.id = eid ? eid[e] : 0;
+    }
+    __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t e, const LaneVals &lv,
+                                          int sub, int jj) const {
+        if constexpr (WMODE == 1) b.w[u] = group_bcast<LPR>(lv.w, sub, jj);
+        else if constexpr (WMODE == 2) {  // 4*H-byte run per edge
+            const int64_t arow = eid ? (int64_t)group_bcast<LPR>(lv.id, sub, jj) : e;
+            b.w[u] = att[arow * c.heads + c.hd];
+        }
+        else b.w[u] = 1.f;
+        if constexpr (EPI) b.s[u] = epi.src_scale ? epi.src_scale[col] : 1.f;
+        load_vec<T, VEC>(c.xcol + (int64_t)col * k, b.v[u]);
+    }
+    // Strictly in CSR order.  acc + 0*0 == acc exactly (acc is never -0), so masked slots are no-ops;
+    // selecting v (not only w) to zero keeps inf/nan out.
+    __device__ __forceinline__ void apply(const Ctx &, State &s, const Batch &b, int u, bool valid, int64_t,
+                                          int) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float vv = valid ? b.v[u][i] : 0.f;
+            if constexpr (EPI) vv = valid ? b.s[u] * b.v[u][i] : 0.f;  // (out_norm * x)[col, :], rounded like the reference's product
+            if constexpr (WMODE != 0) s.acc[i] = mul_add<EXACT>(s.acc[i], valid ? b.w[u] : 0.f, vv);
+            else s.acc[i] = s.acc[i] + vv;
+        }
+    }
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
+    __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
+    __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
+    __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
+        if (!(ok && c.col_ok)) return;
+        if constexpr (EPI) {
+            float o[VEC];
+            const float d = epi.dst_scale ? epi.dst_scale[row] : 1.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float v = epi.dst_scale ? d * s.acc[i] : s.acc[i];
+                if (epi.bias) v = v + epi.bias[c.col0 + i];
+                o[i] = (epi.act == 1) ? fmaxf(v, 0.f) : v;
+            }
+            store_vec<T, VEC>(out + row * (int64_t)k + c.col0, o);
+        } else {
+            store_vec<T, VEC>(out + row * (int64_t)k + c.col0, s.acc);
+        }
+    }
+    __device__ __forceinline__ void pack(const State &s, float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) rec[i] = s.acc[i];
+    }
+    __device__ __forceinline__ void unpack(State &s, const float (&rec)[kRec]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.acc[i] = rec[i];
+    }
+    __device__ __forceinline__ void merge(const Ctx &, State &a, const State &b) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) a.acc[i] += b.acc[i];
+    }
+};
+
+template <typename T>
+struct SpmmArgs {
+    const int32_t *rowptr;
+    const int32_t *colind;
+    const T *val;
+    const float *att;
+    const T *x;
+    T *out;
+    int64_t m, nnz;
+    int k, fdim, acc_mode;
+    const int32_t *eid;
+    SpmmEpilogue epi;
+};
+
+template <typename T, int VEC, int LPR, int UNROLL, int WMODE, bool EXACT, bool EPI = false>
+static int launch_spmm(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) {
+    SpmmOp<T, VEC, LPR, UNROLL, WMODE, EXACT, EPI> op{a.val, a.att, a.x, a.out, a.k, a.fdim, a.acc_mode, a.eid, a.epi};
+    const int64_t tiles = ((int64_t)a.k + (int64_t)LPR * VEC - 1) / ((int64_t)LPR * VEC);
+    return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, tiles, ws, wsb, s);
+}
+
+// (VEC, LPR) choice: as many lanes per row as the row has VEC-wide columns (whole-wave rows are the
+// fastest: scalar column broadcast, no inter-row divergence inside a wave), VEC as small as that allows.
+template <typename T, int VEC, int WMODE, bool EPI = false>
+static int dispatch_lpr(const SpmmArgs<T> &a, int lpr, void *ws, size_t wsb, hipStream_t s) {
+    switch (lpr) {
+        case 4: return launch_spmm<T, VEC, 4, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
+        case 8: return launch_spmm<T, VEC, 8, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
+        case 16: return launch_spmm<T, VEC, 16, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
+        case 32: return launch_spmm<T, VEC, 32, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
+        default: return launch_spmm<T, VEC, 64, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
+    }
+}
+
+static int pointer_alignment(const void *a, const void *b) {
+    const uintptr_t v = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b);
+    return (v % 16 == 0) ? 16 : (v % 8 == 0) ? 8 : (v % 4 == 0) ? 4 : 2;
+}
+
+template <typename T, int WMODE, bool EPI = false>
+static int spmm_auto(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) {
+    const RowGeometry g = spmm_geometry(a.k, (WMODE == 2) ? a.fdim : a.k, (int)sizeof(T), pointer_alignment(a.x, a.out));
+    switch (g.vec) {
+        case 4: return dispatch_lpr<T, 4, WMODE, EPI>(a, g.lpr, ws, wsb, s);
+        case 2: return dispatch_lpr<T, 2, WMODE, EPI>(a, g.lpr, ws, wsb, s);
+        default: return dispatch_lpr<T, 1, WMODE, EPI>(a, g.lpr, ws, wsb, s);
+    }
+}
+
+}  // namespace cogdl

@@ -1,0 +1,56 @@
+"""Opt-in replacement of CogDL's `spmm` DISPATCHER (cogdl/utils/spmm_utils.py:85-123) that folds the two broadcast
+multiplies it wraps around the kernel into the kernel.  `install(fused_norm=True)` rebinds
+`cogdl.utils.spmm_utils.spmm` (and every module that imported it by name) to `spmm` below; everything the fused
+operator does not cover -- CPU tensors, half precision, ActNN, GRB adjacency shortcuts -- is forwarded to the
+reference's own function, unchanged.
+
+Which graphs benefit: those that carry their normalisation as `out_norm` / `in_norm` vectors instead of baked-in edge
+weights, i.e. CSR-only graphs (cogdl/data/data.py:240-258) -- in practice every block `Graph.sample_adj` returns, after
+the `row_norm()` MeanAggregator applies (layers/sage_layer.py:8-12).
+"""
+import sys
+
+import torch
+
+from .operators.spmm import csrspmm_fused
+
+_orig = {}  # module name -> the reference's spmm
+
+
+def make_spmm(reference_spmm):
+    def spmm(graph, x, actnn=False, fast_spmm=None, fast_spmm_cpu=None):
+        in_norm, out_norm = getattr(graph, "in_norm", None), getattr(graph, "out_norm", None)
+        fusable = (torch.is_tensor(x) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and not actnn
+                   and (in_norm is not None or out_norm is not None)
+                   and getattr(graph, "grb_adj", None) is None)
+        if not fusable:
+            return reference_spmm(graph, x, actnn=actnn, fast_spmm=fast_spmm, fast_spmm_cpu=fast_spmm_cpu)
+        return csrspmm_fused(graph.row_indptr.int(), graph.col_indices.int(), x, graph.raw_edge_weight, out_norm,
+                             in_norm)
+
+    spmm.__doc__ = "cogdl_amd fused-normalisation front of cogdl.utils.spmm_utils.spmm"
+    spmm._cogdl_amd_fused = True
+    return spmm
+
+
+def install():
+    su = sys.modules.get("cogdl.utils.spmm_utils")
+    if su is None:
+        return False
+    if getattr(su.spmm, "_cogdl_amd_fused", False):
+        return True
+    reference_spmm = su.spmm
+    fused = make_spmm(reference_spmm)
+    for name, mod in list(sys.modules.items()):
+        if name.startswith("cogdl") and mod is not None and getattr(mod, "spmm", None) is reference_spmm:
+            _orig[name] = reference_spmm
+            mod.spmm = fused
+    return True
+
+
+def uninstall():
+    for name, fn in _orig.items():
+        mod = sys.modules.get(name)
+        if mod is not None:
+            mod.spmm = fn
+    _orig.clear()

@@ -1,0 +1,59 @@
+"""HIP-graph capture of a training step (SURVEY.md section 8f rank 3 / round-1 verdict item 6): a full-graph GNN
+epoch is ~100 short kernels, i.e. bound by the host's launch rate, not by the GPU.  The C ABI neither allocates nor
+synchronises, so a whole step -- forward, backward, optimizer -- can be captured once and replayed as ONE graph launch.
+
+    step = cogdl_amd.graphs.capture(train_step)      # train_step(): no arguments, reads/writes persistent tensors
+    for epoch in range(n): step()
+
+What the helper takes care of (torch.cuda.CUDAGraph does the capture itself):
+  * the graph-plan lookups of the backward passes (cached transposes, keyed on a structure hash that has to be read on
+    the host) are recorded during an eager run and replayed from that record while capturing (cogdl_amd.plan.PlanTape);
+  * warm-up runs on a side stream, as torch's capture rules ask, so that every lazily created piece of state
+    (plans, memoised transposed weights, cuBLAS/hipBLASLt workspaces, optimizer state) exists before the capture.
+What the step must respect: static shapes and addresses (index with precomputed index tensors, not boolean masks), no
+host synchronisation (`.item()`, `.cpu()`, printing a loss), an optimizer created with `capturable=True`.
+"""
+import torch
+
+from . import plan as _plan
+
+
+class CapturedStep:
+    def __init__(self, graph, outputs):
+        self.graph, self.outputs = graph, outputs
+
+    def __call__(self):
+        self.graph.replay()
+        return self.outputs
+
+
+def capture(step, warmup=3, pool=None):
+    """Run `step()` `warmup` times eagerly (side stream), record its plan lookups, capture it, return a callable that
+    replays the captured graph and returns the (static) outputs of the captured call."""
+    if warmup < 1:
+        raise ValueError("at least one eager run is needed to record the plan lookups")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    tape = _plan.PlanTape()
+    with torch.cuda.stream(side):
+        for i in range(warmup):
+            if i == warmup - 1:
+                _plan.set_tape(tape)
+            try:
+                step()
+            finally:
+                _plan.set_tape(None)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    tape.mode, tape.pos = "replay", 0
+    graph = torch.cuda.CUDAGraph()
+    _plan.set_tape(tape)
+    try:
+        with torch.cuda.graph(graph, pool=pool):
+            outputs = step()
+    finally:
+        _plan.set_tape(None)
+    if tape.pos != len(tape.plans):
+        raise RuntimeError("hipGraph capture: the captured step used %d of the %d recorded plan lookups"
+                           % (tape.pos, len(tape.plans)))
+    return CapturedStep(graph, outputs)

@@ -36,8 +36,10 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
 _finder = None
 
 
-def install(linear=False, fused_gat=True):
+def install(linear=False, fused_gat=True, fused_norm=False):
     """Idempotent.  Returns the list of cogdl module names that are now served by cogdl_amd.
+    fused_norm=True rebinds the dispatcher function `cogdl.utils.spmm_utils.spmm` itself (opt-in: that is no longer the
+    unchanged dispatcher) to cogdl_amd.fused.spmm, which folds `out_norm * x` / `in_norm * x` into the kernel.
     fused_gat=True (default) also runs the dispatcher's own `initialize_fused_gat()` (utils/spmm_utils.py:241-248)
     once cogdl is imported and a GPU is present: nothing in the reference ever calls it, so GATLayer's fused branch
     (`check_fused_gat()`, layers/gat_layer.py:68) would otherwise stay dead even with a working fused operator.
@@ -66,6 +68,10 @@ def install(linear=False, fused_gat=True):
         from . import linear as _linear
 
         _linear.install()
+    if fused_norm:
+        from . import fused as _fused
+
+        _fused.install()
     su = sys.modules.get("cogdl.utils.spmm_utils")
     if su is not None:  # force the dispatcher to re-resolve the callables
         for k in ("spmm_flag", "mh_spmm_flag", "fused_gat_flag", "spmm_cpu_flag"):
@@ -100,6 +106,8 @@ def _rebind_graph_build():
 def uninstall():
     if "cogdl_amd.linear" in sys.modules:
         sys.modules["cogdl_amd.linear"].uninstall()
+    if "cogdl_amd.fused" in sys.modules:
+        sys.modules["cogdl_amd.fused"].uninstall()
     for name in _COO2CSR_HOLDERS:
         mod = sys.modules.get(name)
         if mod is not None and hasattr(mod, "_cogdl_amd_orig_coo2csr_index"):

@@ -124,6 +124,76 @@ class SPMMFunction(torch.autograd.Function):
         return None, None, grad_feat, grad_w, None
 
 
+def csr_spmm_epilogue_raw(rowptr, colind, val, x, src_scale=None, dst_scale=None, bias=None, relu=False,
+                          split_long_rows=True):
+    """One cogdl_hip_csr_spmm_epilogue launch: relu?( dst_scale * (A (src_scale * x)) + bias ), fp32, no autograd."""
+    dev = _lib.require_cuda(rowptr, colind, val, x, src_scale, dst_scale, bias)
+    _check_csr(rowptr, colind, x)
+    if x.dtype != torch.float32:
+        raise _lib.BackendError("the fused epilogue is fp32 (got %s)" % x.dtype)
+    x, rowptr, colind = x.contiguous(), rowptr.contiguous(), colind.contiguous()
+    m, k, nnz = rowptr.numel() - 1, x.shape[1], colind.numel()
+
+    def vec(t, n, what):
+        if t is None:
+            return None
+        t = t.reshape(-1).float().contiguous()
+        if t.numel() != n:
+            raise _lib.BackendError("%s has %d entries, expected %d" % (what, t.numel(), n))
+        return t
+
+    val = vec(val, nnz, "csr_data")
+    src_scale, dst_scale, bias = vec(src_scale, x.shape[0], "out_norm"), vec(dst_scale, m, "in_norm"), vec(bias, k, "bias")
+    out = torch.empty((m, k), dtype=torch.float32, device=dev)
+    ws, ws_bytes = (_lib.workspace("cogdl_hip_csr_spmm_workspace_bytes", dev, nnz, k, 0) if split_long_rows else (None, 0))
+    with _lib.on_device(dev):
+        rc = _lib.hip().cogdl_hip_csr_spmm_epilogue(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(val), _lib.ptr(x),
+                                                    _lib.ptr(out), m, k, nnz, 0, _lib.ptr(src_scale), _lib.ptr(dst_scale),
+                                                    _lib.ptr(bias), 1 if relu else 0, _lib.ptr(ws), ws_bytes,
+                                                    _lib.stream_of(x))
+    _lib.check(rc, "csr_spmm_epilogue")
+    return out
+
+
+class FusedSPMMFunction(torch.autograd.Function):
+    """y = relu?( in_norm * (A (out_norm * x)) + bias ) in one kernel (forward) and
+    grad_x = out_norm * (A^T (in_norm * (grad_y * [y > 0]))) in one kernel (backward: the same epilogue kernel on the
+    cached transpose with the two norm vectors swapped).  Norms and edge weights are constants of the graph (no
+    gradient), as in CogDL's dispatcher (cogdl/utils/spmm_utils.py:98-109)."""
+
+    @staticmethod
+    def forward(ctx, rowptr, colind, feat, edge_weight_csr, out_norm, in_norm, bias, relu):
+        rowptr, colind = _lib.csr_structure(rowptr, colind)
+        _check_csr(rowptr, colind, feat)
+        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None
+        out = csr_spmm_epilogue_raw(rowptr, colind, edge_weight_csr, feat, out_norm, in_norm, bias, relu)
+        ctx.n_src, ctx.relu, ctx.has_bias = feat.shape[0], bool(relu), bias is not None
+        ctx.save_for_backward(rowptr, colind, edge_weight_csr, out_norm, in_norm, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        rowptr, colind, w, out_norm, in_norm, out = ctx.saved_tensors
+        g = grad_out.contiguous()
+        if ctx.relu:
+            g = g * (out > 0).to(g.dtype)
+        grad_feat = grad_bias = None
+        if ctx.has_bias and ctx.needs_input_grad[6]:
+            grad_bias = g.sum(0)
+        if ctx.needs_input_grad[2]:
+            plan = PLANS.get(ctx.fp, rowptr, colind, ctx.n_src)
+            w_t = plan.transposed_values(w) if w is not None else None
+            grad_feat = csr_spmm_epilogue_raw(plan.colptr, plan.rowind, w_t, g, in_norm, out_norm, None, False,
+                                              split_long_rows=plan.has_hub_columns())
+        return None, None, grad_feat, None, None, None, grad_bias, None
+
+
+def csrspmm_fused(rowptr, colind, x, csr_data=None, out_norm=None, in_norm=None, bias=None, relu=False):
+    """relu?( in_norm * csrspmm(rowptr, colind, out_norm * x, csr_data) + bias ) as one operator (fp32).  out_norm:
+    [N_src] or [N_src, 1], in_norm: [M] or [M, 1] (Graph.out_norm / Graph.in_norm, cogdl/data/data.py:240-258)."""
+    return FusedSPMMFunction.apply(rowptr, colind, x, csr_data, out_norm, in_norm, bias, relu)
+
+
 def csrspmm(rowptr, colind, x, csr_data, sym=False, actnn=False):
     if actnn:
         raise _lib.BackendError("actnn=True needs the ActNN quantiser (third_party/actnn is an empty submodule "

@@ -124,6 +124,25 @@ def _reap_pending():
     _PENDING[:] = still
 
 
+class PlanTape:
+    """hipGraph capture support.  While a stream is being captured nothing may be read back on the host, so the
+    structure hash cannot key the plan lookup.  cogdl_amd.graphs.capture() therefore runs the step eagerly first in
+    RECORD mode (every plan lookup of the step is appended to the tape, in call order) and then captures it in REPLAY
+    mode (lookups are served from the tape in the same order, fingerprints are not computed): the captured step must
+    issue the same operator sequence as the recorded one -- which graph capture requires anyway."""
+
+    def __init__(self):
+        self.plans, self.pos, self.mode = [], 0, "record"
+
+
+_TAPE = None
+
+
+def set_tape(tape):
+    global _TAPE
+    _TAPE = tape
+
+
 class Fingerprint:
     """A structure hash in flight: the kernel writes its per-workgroup partials straight into pinned host memory
     (device-visible on ROCm: no memset, no device-to-host copy kernel); an event guards them.  Buffers and events are
@@ -134,6 +153,11 @@ class Fingerprint:
     def __init__(self, rowptr, colind, n_cols):
         dev = rowptr.device
         m, nnz = rowptr.numel() - 1, colind.numel()
+        self.meta = (dev.index, m, nnz, int(n_cols))
+        self._key = None
+        self.host = self.event = None
+        if _TAPE is not None and _TAPE.mode == "replay":
+            return  # capturing: the plan comes from the tape, nothing is hashed
         _reap_pending()
         pool = _PINNED_POOL.get(dev.index)
         if pool:
@@ -148,8 +172,6 @@ class Fingerprint:
                                                       self.host.data_ptr(), stream.cuda_stream)
             _lib.check(rc, "csr_fingerprint")
             self.event.record(stream)
-        self.meta = (dev.index, m, nnz, int(n_cols))
-        self._key = None
 
     def key(self):
         if self._key is None:
@@ -161,6 +183,8 @@ class Fingerprint:
         # Back to the pool once the kernel that writes the buffer is known to be done; otherwise the pair is parked
         # on _PENDING (keeping the pinned block allocated) until a later call finds its event complete.
         try:
+            if self.host is None:
+                return
             dev_index = self.meta[0]
             if self._key is not None or self.event.query():
                 pool = _PINNED_POOL.setdefault(dev_index, [])
@@ -183,6 +207,23 @@ class PlanCache:
         self.misses = 0
 
     def get(self, fingerprint, rowptr, colind, n_cols):
+        tape = _TAPE
+        if tape is not None and tape.mode == "replay":
+            if tape.pos >= len(tape.plans):
+                raise _lib.BackendError("hipGraph capture: the captured step looks up more graph plans than the recorded one")
+            plan = tape.plans[tape.pos]
+            tape.pos += 1
+            if (plan.m, plan.nnz, plan.n_cols) != fingerprint.meta[1:]:
+                raise _lib.BackendError("hipGraph capture: the captured step's operator sequence differs from the "
+                                        "recorded one (plan %d: %s vs %s)" % (tape.pos - 1, (plan.m, plan.nnz, plan.n_cols),
+                                                                               fingerprint.meta[1:]))
+            return plan
+        plan = self._lookup(fingerprint, rowptr, colind, n_cols)
+        if tape is not None:
+            tape.plans.append(plan)
+        return plan
+
+    def _lookup(self, fingerprint, rowptr, colind, n_cols):
         key = fingerprint.key()
         plan = self.lru.get(key)
         if plan is not None:

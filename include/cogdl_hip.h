@@ -110,6 +110,23 @@ COGDL_API int cogdl_hip_csr_spmm_variant(const int32_t *rowptr, const int32_t *c
                                int variant, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * csr_spmm with a fused normalisation / bias / activation epilogue (fp32):
+ *   out[i,:] = act( dst_scale[i] * sum_e val[e] * (src_scale[colind[e]] * x[colind[e],:]) + bias[:] )
+ * i.e. the GPU branch of cogdl.utils.spmm_utils.spmm for a graph that carries its normalisation as out_norm / in_norm
+ * vectors (utils/spmm_utils.py:98-109: `x = out_norm * x`, kernel, `x = in_norm * x` -- CSR-only graphs such as sampled
+ * blocks after row_norm(), cogdl/data/data.py:240-258) plus the bias / ReLU a layer applies behind it
+ * (layers/gcn_layer.py:51-64), in ONE pass: no scaled copy of x, no second and third sweep over the output.
+ * src_scale [n_src], dst_scale [m], bias [k] are fp32 device vectors, each may be NULL; act: 0 none, 1 ReLU; val may be
+ * NULL (unweighted).  Every product is a separately rounded fp32 multiply in the reference's order: bit-identical to
+ * the unfused composition for rows up to the long-row threshold.  Workspace: as cogdl_hip_csr_spmm (same query).
+ * Returns COGDL_HIP_EUNSUPPORTED for dtype != COGDL_HIP_F32 (callers compose the unfused operators).
+ * ------------------------------------------------------------------------------------- */
+COGDL_API int cogdl_hip_csr_spmm_epilogue(const int32_t *rowptr, const int32_t *colind, const void *val, const void *x,
+                                void *out, int64_t m, int64_t k, int64_t nnz, int dtype, const float *src_scale,
+                                const float *dst_scale, const float *bias, int act, void *workspace,
+                                size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * csr2csc: stable transpose of the CSR structure.
  * Replaces spmm.csr2csc (operators/spmm/spmm.cpp:72-90 -> cusparseCsr2cscEx2 ALG1,
  * spmm_kernel.cu:514-532,596-614) and mhtranspose.csr2csc (mhTranspose.cu:51-111).

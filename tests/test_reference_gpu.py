@@ -113,6 +113,19 @@ assert torch.isfinite(o).all() and torch.isfinite(xs.grad).all()
 import cogdl.layers.sage_layer as sl
 report["sage_layer"] = "ok"
 
+# ---- 2d. opt-in fused dispatcher front (install(fused_norm=True)): in_norm folded into the kernel, same SAGELayer output
+import cogdl_amd
+cogdl_amd.install(fused_norm=True)
+import cogdl.layers.sage_layer as sage_mod
+assert getattr(spmm_utils.spmm, "_cogdl_amd_fused", False) and getattr(sage_mod.spmm, "_cogdl_amd_fused", False)
+with torch.no_grad():
+    out_f = sage(block.to(DEV), T(z["x_src"]).to(DEV))
+np.testing.assert_allclose(out_f.cpu().numpy(), z["out"], rtol=1e-4, atol=1e-5)
+import cogdl_amd.fused
+cogdl_amd.fused.uninstall()
+assert not getattr(spmm_utils.spmm, "_cogdl_amd_fused", False)
+report["fused_norm"] = "ok"
+
 # ---- 3. experiment() through the reference's Trainer on cuda:0 (configs[0] shape, then configs[1] shape)
 before = calls["spmm"]
 ds = refpkg.cora_like(seed=0)
