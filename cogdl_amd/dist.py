@@ -12,13 +12,15 @@ Layout (1-D row partition, one process per GPU, torch.distributed over RCCL/xGMI
     "sorted by id" is "sorted by owner"); int32 indices stay valid at papers100M scale because both
     tables are shard-local (SURVEY.md section 7, int32 limits).
 Forward per call:
-    1. gather the rows other ranks asked for            x[send_idx]                       (current stream)
-    2. all-to-all the halo rows                         RCCL, asynchronous                (comm stream)
-    3. Y  = A_loc . X_local                             overlaps with 2                   (current stream)
-    4. Y += A_rem . halo                                after 2 completes (cogdl_hip_csr_spmm_acc)
+    1. gather the rows other ranks asked for            cogdl_hip_gather_feature_rows     (compute stream)
+    2. all-to-all the halo rows                         RCCL, on an explicit COMM stream behind an event
+    3. Y  = A_loc . X_local                             overlaps with 2                   (compute stream)
+    4. Y += A_rem . halo                                after the comm stream's event (cogdl_hip_csr_spmm_acc)
 Backward is the transposed pattern: G_halo = A_rem^T . G (sent back with the reverse all-to-all,
-overlapped with A_loc^T . G) and accumulated into the owners' rows in a fixed rank order
-(deterministic: the row lists of one peer are unique, peers are applied in rank order).
+overlapped with A_loc^T . G) and accumulated into the owners' rows by ONE kernel: the returned rows are
+summed per owner row through a selection matrix S (S[r, j] = 1 iff returned row j belongs to local row r;
+built once per shard, its entries in peer order), i.e. G_x += S . back with cogdl_hip_csr_spmm_acc --
+deterministic (fixed order per row), no atomics, no per-peer launches.
 xGMI is point-to-point: the all-to-all drives all 7 links of a GPU at once (one send/recv pair per
 peer), which is why the exchange is an all-to-all and not a ring all-gather of X.
 
@@ -40,6 +42,11 @@ class HipBackend:
         from .operators.spmm import csr_spmm_raw
 
         return csr_spmm_raw(rowptr, colind, val, x, out=out)
+
+    def gather(self, x, idx):
+        from .pipeline import gather_rows_by_id
+
+        return gather_rows_by_id(x.detach(), idx)
 
     def transpose(self, rowptr, colind, val, n_cols):
         from .plan import csr2csc, gather_rows
@@ -147,7 +154,13 @@ class ShardedCSR:
         send_ids, _ = exchange_rows(halo_ids, self.recv_counts, self.send_counts, group)
         self.send_idx = (send_ids - lo).long()  # local row ids, grouped by requesting rank
         assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_local)
+        # Selection matrix of the backward accumulation: row r lists the positions j of `back` (= of send_idx) that
+        # belong to local row r, in peer order (stable sort) -> gx += S . back is one deterministic csr_spmm_acc.
+        order = torch.sort(self.send_idx, stable=True).indices
+        self.sel_rowptr = _csr_from_sorted_rows(self.send_idx[order], self.n_local).int()
+        self.sel_colind = order.int()
         self._t_loc = self._t_rem = None
+        self._comm = None  # explicit communication stream (GPU shards), created on first use
 
     # transposes for the backward pass, built on first use
     def transposed(self):
@@ -160,14 +173,36 @@ class ShardedCSR:
         return self.n_halo * feat * elem
 
 
+def _exchange_overlapped(sh, send, send_counts, recv_counts):
+    """The halo all-to-all on the shard's COMM stream, ordered behind everything enqueued on the compute stream so
+    far (event) -- returns (recv, done) where done() makes the compute stream wait for the exchange.  The local-block
+    SpMM the caller enqueues in between overlaps with it.  CPU / gloo shards (tests) exchange synchronously."""
+    if not send.is_cuda or dist.get_backend(sh.group) != "nccl":
+        recv, work = exchange_rows(send, send_counts, recv_counts, sh.group, async_op=True)
+        return recv, work.wait
+    if sh._comm is None:
+        sh._comm = torch.cuda.Stream(device=send.device)
+    compute = torch.cuda.current_stream(send.device)
+    ready = torch.cuda.Event()
+    ready.record(compute)
+    with torch.cuda.stream(sh._comm):
+        sh._comm.wait_event(ready)
+        recv, _ = exchange_rows(send, send_counts, recv_counts, sh.group, async_op=False)
+        finished = torch.cuda.Event()
+        finished.record(sh._comm)
+    send.record_stream(sh._comm)
+    recv.record_stream(compute)
+    return recv, lambda: compute.wait_event(finished)
+
+
 class _ShardedSpMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, sh):
         be = sh.backend
-        send = x.index_select(0, sh.send_idx)
-        halo, work = exchange_rows(send, sh.send_counts, sh.recv_counts, sh.group, async_op=True)
+        send = be.gather(x, sh.send_idx) if hasattr(be, "gather") else x.index_select(0, sh.send_idx)
+        halo, done = _exchange_overlapped(sh, send, sh.send_counts, sh.recv_counts)
         y = be.spmm(sh.rowptr_loc, sh.colind_loc, sh.w_loc, x)  # overlaps with the all-to-all
-        work.wait()
+        done()
         if sh.n_halo:
             y = be.spmm(sh.rowptr_rem, sh.colind_rem, sh.w_rem, halo, out=y)
         ctx.sh = sh
@@ -180,18 +215,11 @@ class _ShardedSpMM(torch.autograd.Function):
         g = g.contiguous()
         (cp_l, ri_l, w_l), (cp_r, ri_r, w_r) = sh.transposed()
         g_halo = be.spmm(cp_r, ri_r, w_r, g) if sh.n_halo else g.new_zeros((0, g.shape[1]))
-        back, work = exchange_rows(g_halo, sh.recv_counts, sh.send_counts, sh.group, async_op=True)
+        back, done = _exchange_overlapped(sh, g_halo, sh.recv_counts, sh.send_counts)
         gx = be.spmm(cp_l, ri_l, w_l, g)  # overlaps with the reverse all-to-all
-        work.wait()
-        off = 0
-        for q in range(sh.world):  # fixed peer order => deterministic
-            n = sh.send_counts[q]
-            if n:
-                # The rows one peer asked for are unique, so "add" is gather + add + scatter: no atomics (torch's
-                # index_add_ would issue one fp32 atomic per element -- ~30 G atomics/s on MI355X, 10x slower).
-                idx = sh.send_idx[off:off + n]
-                gx.index_copy_(0, idx, gx.index_select(0, idx) + back[off:off + n])
-            off += n
+        done()
+        if back.shape[0]:
+            gx = be.spmm(sh.sel_rowptr, sh.sel_colind, None, back, out=gx)  # gx += S . back: fixed order, one launch
         return gx, None
 
 
@@ -211,25 +239,32 @@ def _papers_like_shard(rank, world, shard_nodes, degree, remote_frac, seed, devi
     sources uniform over the whole owner shard (no reuse: the halo then approaches one row per remote EDGE);
     together with remote_frac = (world-1)/world that is a random partition of a structureless graph, the worst case
     for a 1-D partition.  Self loop appended, row-normalised weights."""
-    g = torch.Generator(device="cpu").manual_seed(seed * 1000003 + rank)
-    nnz = int(shard_nodes * degree)
+    gdev = torch.device(device)
+    g = torch.Generator(device=gdev).manual_seed(seed * 1000003 + rank)  # generated where it is used: a true
+    nnz = int(shard_nodes * degree)                                       # papers100M shard is 4e8 edges per GPU
     lo = rank * shard_nodes
-    rows = torch.randint(0, shard_nodes, (nnz,), generator=g)
-    cols = torch.randint(0, shard_nodes, (nnz,), generator=g)  # offset inside a shard
+
+    def randint(high):
+        return torch.randint(0, high, (nnz,), generator=g, device=gdev)
+
+    rows = randint(shard_nodes)
+    cols = randint(shard_nodes)  # offset inside a shard
     if world > 1:
-        is_remote = torch.rand(nnz, generator=g) < remote_frac
-        other = torch.randint(0, world - 1, (nnz,), generator=g)
+        is_remote = torch.rand(nnz, generator=g, device=gdev) < remote_frac
+        other = randint(world - 1)
         other = other + (other >= rank).long()  # uniform over the other shards
         owner = torch.where(is_remote, other, torch.full_like(other, rank))
+        del is_remote, other
     else:
-        owner = torch.zeros(nnz, dtype=torch.long)
+        owner = torch.zeros(nnz, dtype=torch.long, device=gdev)
     if world > 1 and halo_frac > 0:
         pool = max(1, int(halo_frac * shard_nodes / (world - 1)))
         slot = (rank - owner - 1) % world  # 0 .. world-2 for owner != rank: this rank's slice of the owner's boundary
-        boundary = slot * pool + torch.randint(0, pool, (nnz,), generator=g)
+        boundary = slot * pool + randint(pool)
         cols = torch.where(owner != rank, boundary, cols)
+        del slot, boundary
     cols = cols + owner * shard_nodes
-    rows, cols = rows.to(device), cols.to(device)
+    del owner
     rows = torch.cat([rows, torch.arange(shard_nodes, device=device)])
     cols = torch.cat([cols, torch.arange(lo, lo + shard_nodes, device=device)])
     order = torch.sort(rows, stable=True).indices
@@ -238,6 +273,14 @@ def _papers_like_shard(rank, world, shard_nodes, degree, remote_frac, seed, devi
     deg = (rowptr[1:] - rowptr[:-1]).float()
     w = (1.0 / deg)[rows]
     return rowptr, cols, w
+
+
+def _rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:
+        return None
 
 
 def bench_sharded_spmm(args):
@@ -251,7 +294,10 @@ def bench_sharded_spmm(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    shard_nodes = args.shard_nodes or 111_059_956 // 8 // 8  # 1/8 of a papers100M 8-way shard per GPU
+    # Weak scaling with the TRUE papers100M shard per GPU: 111,059,956 nodes / 8 = 13.9 M rows, ~4.1e8 edges, X = 7.1 GB
+    # per GPU -- at N = 8 this is the whole graph (3.3e9 edges: beyond what int32 CSR indices can address on ONE GPU,
+    # which is why the single-GPU leg of the curve cannot be the unsharded graph and the scaling is weak, not strong).
+    shard_nodes = args.shard_nodes or 111_059_956 // 8
     degree = args.shard_degree or 28.8                         # 3.2e9 symmetrised edges / 111e6 nodes
     f = args.feat
     remote_frac = args.remote_frac if args.remote_frac >= 0 else 0.1
@@ -318,6 +364,9 @@ def bench_sharded_spmm(args):
                        "halo_frac": halo_frac, "halo_rows_rank0": sh.n_halo,
                        "parallelism": "vertex-shard x%d, RCCL all-to-all halo exchange overlapped with local SpMM" % world},
             "halo_GB_per_step_all_ranks": float(halo_gb) * 2 / 1e9,
+            "n_ranks_seen": dist.get_world_size(), "rccl_version": _rccl_version(),
+            "exchange": "all_to_all_single on an explicit comm stream (event-ordered), gather = cogdl_hip_gather_feature_rows, "
+                        "backward accumulation = one csr_spmm_acc over the selection matrix",
             "local_block_spmm_ms_rank0": loc_ms,
             "local_block_GEdges_s_rank0": sh.nnz_local / (loc_ms * 1e-3) / 1e9,
         }

@@ -105,3 +105,92 @@ def test_papers_like_shard_generator_shape():
     rowptr, cols, _ = _papers_like_shard(0, world, s, deg, 0.1, 0, "cpu", halo_frac=0.0)
     remote = (cols // s) != 0
     assert torch.unique(cols[remote]).numel() > 0.6 * int(remote.sum())
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3]: GraphSAGE replicas, one process per device, gradients all-reduced by torch DDP
+# (cogdl/trainer/trainer.py:291-303).  World size 2 over gloo on CPU: every rank samples its own seeds with the host
+# sampler (libcogdl_host, HIP-free), runs a 2-layer mean-aggregator SAGE step; after the step the replicas hold identical
+# parameters, equal to ONE process stepping on the average of the two ranks' losses.
+class _CpuSage(torch.nn.Module):
+    def __init__(self, f, hidden, classes):
+        super().__init__()
+        self.fc1, self.fc2 = torch.nn.Linear(2 * f, hidden), torch.nn.Linear(2 * hidden, classes)
+
+    @staticmethod
+    def _mean(block, x):
+        row_ptr, col = block
+        deg = row_ptr[1:] - row_ptr[:-1]
+        row = torch.repeat_interleave(torch.arange(deg.numel()), deg)
+        agg = torch.zeros(deg.numel(), x.shape[1]).index_add_(0, row, x[col])
+        return agg / deg.clamp(min=1).float().view(-1, 1)
+
+    def forward(self, x, adjs):
+        (b1, n1), (b2, n2) = adjs
+        h = torch.relu(self.fc1(torch.cat([x, self._mean(b1, x)], 1))[:n1])
+        return self.fc2(torch.cat([h, self._mean(b2, h)], 1))[:n2]
+
+
+def _sage_batch(indptr, indices, seeds, seed):
+    from cogdl_amd.operators.sample import sample_adj_c
+
+    adjs, batch = [], seeds
+    for hop, k in enumerate((4, 4)):
+        rp, col, nodes, _ = sample_adj_c(indptr, indices, batch, k, False, seed=seed * 10 + hop)
+        if rp.numel() - 1 < nodes.numel():  # the padding Graph.sample_adj applies (data/data.py:828-830)
+            rp = torch.cat([rp, rp[-1].repeat(nodes.numel() - rp.numel() + 1)])
+        adjs.append(((rp, col), batch.numel()))
+        batch = nodes
+    return batch, adjs[::-1]
+
+
+def _sage_problem():
+    from cogdl_amd import synth
+
+    g = synth.scaled(400, 8, seed=1, norm=None, self_loops=False)
+    x = torch.randn(400, 6, generator=torch.Generator().manual_seed(2))
+    y = torch.randint(0, 3, (400,), generator=torch.Generator().manual_seed(3))
+    seeds = [torch.arange(0, 32), torch.arange(100, 132)]
+    return g.rowptr.long(), g.colind.long(), x, y, seeds
+
+
+def _sage_loss(model, indptr, indices, x, y, seeds, seed):
+    n_id, adjs = _sage_batch(indptr, indices, seeds, seed)
+    return torch.nn.functional.cross_entropy(model(x[n_id], adjs), y[seeds])
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        indptr, indices, x, y, seeds = _sage_problem()
+        torch.manual_seed(0)
+        model = _CpuSage(6, 8, 3)
+        ddp = torch.nn.parallel.DistributedDataParallel(model)
+        opt = torch.optim.SGD(ddp.parameters(), lr=0.1)
+        for it in range(2):
+            opt.zero_grad()
+            _sage_loss(ddp, indptr, indices, x, y, seeds[rank], seed=rank + 10 * it).backward()  # all-reduce inside
+            opt.step()
+        torch.save([p.detach().clone() for p in model.parameters()], os.path.join(out_dir, "p%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sage_replicas_ddp_world2(tmp_path):
+    mp.spawn(_ddp_worker, args=(2, 29731, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = (torch.load(os.path.join(str(tmp_path), "p%d.pt" % r)) for r in range(2))
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)  # replicas stay in lock step
+    indptr, indices, x, y, seeds = _sage_problem()
+    torch.manual_seed(0)
+    model = _CpuSage(6, 8, 3)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    for it in range(2):
+        opt.zero_grad()
+        loss = sum(_sage_loss(model, indptr, indices, x, y, seeds[r], seed=r + 10 * it) for r in range(2)) / 2
+        loss.backward()
+        opt.step()
+    for a, b in zip(p0, model.parameters()):
+        np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=1e-5, atol=1e-6)
