@@ -86,21 +86,30 @@ def install(linear=False, fused_gat=True, fused_norm=False):
     return [_PREFIX + op for op in REPLACED]
 
 
-# modules that hold `coo2csr_index` by name (cogdl/utils/graph_utils.py:133 defines it; data.py:11 and utils.py:16 import it)
-_COO2CSR_HOLDERS = ("cogdl.utils.graph_utils", "cogdl.utils.utils", "cogdl.utils", "cogdl.data.data")
+
+
+_GRAPH_BUILD_NAMES = ("coo2csr_index", "add_remaining_self_loops", "symmetric_normalization", "row_normalization")
 
 
 def _rebind_graph_build():
-    """CSR construction stays on the GPU.  Effective for the CogDL modules already imported; call
-    install() again after `import cogdl` if it ran before (install() is idempotent)."""
-    from .graph_build import coo2csr_index
+    """CSR construction, self loops and normalisation stay on the GPU (cogdl_amd/graph_build.py; CPU
+    tensors keep the reference's arithmetic).  Every cogdl module that holds one of the helpers by name is rebound
+    (`from cogdl.utils import ...` copies the reference); effective for the modules already imported -- call install()
+    again after `import cogdl` if it ran before (install() is idempotent)."""
+    from . import graph_build
 
-    for name in _COO2CSR_HOLDERS:
-        mod = sys.modules.get(name)
-        if mod is not None and hasattr(mod, "coo2csr_index"):
-            if not hasattr(mod, "_cogdl_amd_orig_coo2csr_index"):
-                mod._cogdl_amd_orig_coo2csr_index = mod.coo2csr_index
-            mod.coo2csr_index = coo2csr_index
+    for name, mod in list(sys.modules.items()):
+        if mod is None or not (name == "cogdl" or name.startswith("cogdl.")):
+            continue
+        for fn in _GRAPH_BUILD_NAMES:
+            cur = getattr(mod, fn, None)
+            if cur is None or getattr(cur, "__module__", "") == "cogdl_amd.graph_build":
+                continue
+            if getattr(cur, "__module__", "") != "cogdl.utils.graph_utils":
+                continue
+            saved = mod.__dict__.setdefault("_cogdl_amd_orig_graph_build", {})
+            saved.setdefault(fn, cur)
+            setattr(mod, fn, getattr(graph_build, fn))
 
 
 def uninstall():
@@ -108,11 +117,10 @@ def uninstall():
         sys.modules["cogdl_amd.linear"].uninstall()
     if "cogdl_amd.fused" in sys.modules:
         sys.modules["cogdl_amd.fused"].uninstall()
-    for name in _COO2CSR_HOLDERS:
-        mod = sys.modules.get(name)
-        if mod is not None and hasattr(mod, "_cogdl_amd_orig_coo2csr_index"):
-            mod.coo2csr_index = mod._cogdl_amd_orig_coo2csr_index
-            del mod._cogdl_amd_orig_coo2csr_index
+    for name, mod in list(sys.modules.items()):
+        if mod is not None and (name == "cogdl" or name.startswith("cogdl.")):
+            for fn, orig in mod.__dict__.pop("_cogdl_amd_orig_graph_build", {}).items():
+                setattr(mod, fn, orig)
     pkg = sys.modules.get("cogdl.operators")
     if pkg is not None:
         for attr, orig in pkg.__dict__.pop("_cogdl_amd_orig_ops", {}).items():

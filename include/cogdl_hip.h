@@ -319,6 +319,26 @@ COGDL_API int cogdl_hip_sample_adj(const int64_t *indptr, const int64_t *indices
                          size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Graph preprocessing on the GPU (what cogdl.data.Graph does once per graph before its first SpMM), int64 COO in and out:
+ * add_remaining_self_loops (cogdl/utils/graph_utils.py:40-70 via Adjacency.add_remaining_self_loops,
+ *   cogdl/data/data.py:175-191): existing self loops are dropped, one loop per node is appended behind the kept edges
+ *   (which keep their order); a node that had loops keeps the weight of its LAST one, the others get fill_value;
+ *   val == NULL means unit weights.  Outputs hold nnz + num_nodes entries; *out_count (device) = the number written.
+ * coo_norm_weights (graph_utils.py:72-89, degrees as in :10-17 = edges per row): mode 0 (sym)
+ *   out[e] = d^-1/2[col[e]] * val[e] * d^-1/2[row[e]], mode 1 (row) out[e] = val[e] / d[row[e]]; 1/0 -> 0.
+ * *bad_flag (device int, zeroed by the caller) gets bit 0 if an index lies outside [0, num_nodes).
+ * ------------------------------------------------------------------------------------- */
+COGDL_API size_t cogdl_hip_add_remaining_self_loops_workspace_bytes(int64_t nnz, int64_t num_nodes);
+COGDL_API int cogdl_hip_add_remaining_self_loops(const int64_t *row, const int64_t *col, const float *val, int64_t nnz,
+                                       int64_t num_nodes, float fill_value, int64_t *out_row, int64_t *out_col,
+                                       float *out_val, int64_t *out_count, int *bad_flag, void *workspace,
+                                       size_t workspace_bytes, void *stream);
+COGDL_API size_t cogdl_hip_coo_norm_weights_workspace_bytes(int64_t num_nodes);
+COGDL_API int cogdl_hip_coo_norm_weights(const int64_t *row, const int64_t *col, const float *val, int64_t nnz,
+                               int64_t num_nodes, int mode, float *out, int *bad_flag, void *workspace,
+                               size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * subgraph on the GPU: the node-induced subgraph of a GPU-resident CSR graph, the contract of sampler.subgraph
  * (cogdl/operators/sample/sample.cpp:146-188, reached from Graph.csr_subgraph, cogdl/data/data.py:850-872) and of
  * cogdl_host_subgraph, int64 in and out, device pointers:

@@ -508,3 +508,36 @@ def test_gat_bwd_status_codes_distinguish_unsupported_from_invalid():
     assert call(8, 8, null_feat=True) == 1
     assert lib.cogdl_hip_strerror(7) == b"shape not covered by this entry point"
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------- graph preprocessing on the GPU
+@pytest.mark.parametrize("n,e,weighted", [(50, 300, True), (2000, 30000, False), (7, 0, True), (300, 5000, True)])
+def test_add_remaining_self_loops_and_normalisation_gpu_equal_the_reference_expressions(n, e, weighted):
+    """cogdl_amd.graph_build on GPU tensors (HIP kernels) against the same functions on CPU tensors, which execute the
+    reference's own torch expressions (cogdl/utils/graph_utils.py:40-89)."""
+    from cogdl_amd import graph_build as gb
+
+    gen = torch.Generator().manual_seed(n + e)
+    row, col = torch.randint(0, n, (e,), generator=gen), torch.randint(0, n, (e,), generator=gen)
+    if e:
+        row[::7] = col[::7]  # plenty of self loops, some nodes with several
+    w = torch.rand(e, generator=gen) + 0.5 if weighted else None
+    (r_c, c_c), w_c = gb.add_remaining_self_loops((row, col), w, 1, n)
+    (r_g, c_g), w_g = gb.add_remaining_self_loops((row.to(DEV), col.to(DEV)), None if w is None else w.to(DEV), 1, n)
+    assert r_g.is_cuda and torch.equal(r_g.cpu(), r_c) and torch.equal(c_g.cpu(), c_c)
+    # a node with several loops: index_put keeps one of them (unspecified which) -- compare everything but those nodes' weight
+    loops = row == col
+    multi = torch.bincount(row[loops], minlength=n) > 1
+    same = torch.ones_like(w_c, dtype=torch.bool)
+    same[r_c.numel() - n:][multi] = False
+    assert torch.equal(w_g.cpu()[same], w_c[same])
+    for fn in (gb.symmetric_normalization, gb.row_normalization):
+        want = fn(n, r_c, c_c, w_c)
+        got = fn(n, r_g, c_g, w_g.clone() if weighted else None).cpu()
+        if not weighted:
+            want = fn(n, r_c, c_c, None)
+        ok = torch.ones_like(want, dtype=torch.bool)
+        ok[r_c.numel() - n:][multi] = False
+        np.testing.assert_allclose(got[ok].numpy(), want[ok].numpy(), rtol=2e-6, atol=0)
+    with pytest.raises(Exception):
+        gb.symmetric_normalization(n, torch.tensor([0, n], device=DEV), torch.tensor([0, 0], device=DEV))
