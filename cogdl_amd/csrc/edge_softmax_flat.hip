@@ -25,8 +25,8 @@
 //
 // Progress: a piece is published BEFORE its workgroup waits, so a wait only needs the other tiles of the row to START.
 // Workgroups start in index order on this hardware (observed, MI355X_MICROARCH.md; not a contract), rows of at most
-// K_max = 192 tiles take part in the exchange, and 192 workgroups always fit on the chip at once -- so in practice no
-// wait outlives the start-up skew of neighbouring workgroups.  CORRECTNESS does not depend on any of this: every
+// K_max = 512 tiles take part in the exchange, and more workgroups than that are resident at once (4 per CU x 256 CUs)
+// -- so in practice no wait outlives the start-up skew of neighbouring workgroups.  CORRECTNESS does not depend on any of this: every
 // wait is bounded, and on time-out the workgroup recomputes the row statistics from global memory itself (right under
 // any scheduling, merely slower; the count of such escapes is kept in the workspace header for the tests).  Rows
 // longer than K_max tiles never wait at all: their piece records come from the init kernel, at the price of one extra
@@ -38,7 +38,7 @@ namespace esf {
 
 constexpr int kThreads = 256;
 constexpr int kRowChunk = 512;    // rowptr entries staged in LDS per pass over a tile's rows
-constexpr int kKMax = 192;        // longest row (in tiles) that uses the in-launch exchange
+constexpr int kKMax = 512;        // longest row (in tiles) that uses the in-launch exchange
 constexpr unsigned kSpinLimit = 1u << 12;
 
 template <bool BWD> struct TileSize { static constexpr int value = BWD ? 4096 : 8192; };  // elements (32 KB of LDS)

@@ -157,12 +157,12 @@ def test_edge_softmax_flat_kernel_rows_across_tiles(oracle, hubs, h, dtype):
 
 @pytest.mark.parametrize("spin", [0, -1], ids=["exchange", "forced-timeout-escape"])
 def test_edge_softmax_flat_kernel_super_long_rows_and_timeout_escape(oracle, spin):
-    """H = 64: a tile is 128 edges, so rows beyond 192 tiles = 24,576 edges take the init kernel's record path (no
-    waiting); tuning key 8 = -1 makes every cross-tile wait give up at once, which exercises the recompute-from-global
+    """H = 64: a tile is 128 edges (64 backward), so rows beyond 512 tiles = 65,536 (32,768) edges take the init kernel's
+    record path (no waiting); tuning key 8 = -1 makes every cross-tile wait give up at once, which exercises the recompute-from-global
     escape on ordinary multi-tile rows."""
     from cogdl_amd import _lib
 
-    g = synth.hub_csr(40, 40, hubs=((2, 30000), (3, 26000), (20, 700), (39, 25000)), seed=1)
+    g = synth.hub_csr(40, 40, hubs=((2, 70000), (3, 36000), (20, 700), (39, 66000)), seed=1)
     h = 64
     v = rand(g.nnz, h, seed=5, scale=2.0)
     gr = rand(g.nnz, h, seed=6)

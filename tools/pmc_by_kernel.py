@@ -40,7 +40,11 @@ for path in sorted(glob.glob(os.path.join(root, prefix + "*", "**", "*counter_co
 mean = lambda l: sum(l) / len(l) if l else None  # noqa: E731
 out = {"source": "rocprofv3 --kernel-trace --pmc <counter> (one pass per counter), workload tools/pmc_probe_es.py",
        "calibration": {}, "kernels": {}}
-f, w = mean(calib["FETCH_SIZE"]), mean(calib["WRITE_SIZE"])
+def big(lst):  # the 1 GiB copies only (other, small device copies of the probe also run the copy kernel)
+    return [v for v in lst if v >= 0.5 * max(lst)] if lst else lst
+
+
+f, w = mean(big(calib["FETCH_SIZE"])), mean(big(calib["WRITE_SIZE"]))
 if f:
     out["calibration"]["fetch_bytes_per_unit"] = GIB / f
 if w:
