@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[2] end to end (a profile, not bench.py's contract line): one full-graph training step of
 CogDL's GAT (cogdl/models/nn/gat.py: GATLayer(602 -> 8 x 8 heads, ELU) + GATLayer(64 -> 41 x 1 head); GATLayer.forward,
-cogdl/layers/gat_layer.py:59-86) on the Reddit-shaped graph (232,965 nodes, ~79 M edges after coalescing), fp32, through
-the operators a CogDL layer would call:
+cogdl/layers/gat_layer.py:59-86) on the Reddit-shaped graph at its TRUE size (232,965 nodes, 114,848,857 nnz), in fp32
+and in bf16 (configs[2]'s dtype: torch.autocast(bfloat16) around the forward, fp32 master weights -- the layer's matmul
+yields bf16 features, which fused_gat_func / csrmhspmm read and write natively), through the operators a CogDL layer
+would call:
   fused    attn_drop = 0:   fused_gat_func                      (gat_layer.py:68-70)
   unfused  attn_drop = 0.5 (the model's default): leaky_relu(h_l[row] + h_r[col]) -> csr_edge_softmax -> dropout ->
            csrmhspmm        (gat_layer.py:72-77; the gathers / leaky_relu / dropout are torch's)
@@ -51,25 +53,27 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     args = ap.parse_args()
     n, feats, classes = 232_965, 602, 41
-    src, dst = synth.rmat_pairs(n, 57_300_000, seed=0, device=DEV)
-    gr = synth.finalize(src, dst, n, norm=None)
-    del src, dst
+    gr = synth.reddit_like(seed=0, device=DEV)
     deg = (gr.rowptr[1:] - gr.rowptr[:-1]).long()
     g = (gr.rowptr, gr.colind, torch.repeat_interleave(torch.arange(n, device=DEV), deg))
     x = torch.randn(n, feats, device=DEV)
     y = torch.randint(0, classes, (n,), device=DEV)
     mask = torch.rand(n, device=DEV) < 0.66  # Reddit: 153,431 of 232,965 nodes train
     res = {"graph": {"nodes": n, "nnz": int(gr.nnz), "max_degree": int(deg.max())}}
-    for name, p in (("fused (attn_drop 0)", 0.0), ("unfused (attn_drop 0.5, model default)", 0.5)):
+    for name, p, amp in (("fused (attn_drop 0) f32", 0.0, None), ("fused (attn_drop 0) bf16", 0.0, torch.bfloat16),
+                         ("unfused (attn_drop 0.5, model default) f32", 0.5, None),
+                         ("unfused (attn_drop 0.5, model default) bf16", 0.5, torch.bfloat16)):
         torch.manual_seed(0)
         l1, l2 = GatLayer(feats, 8, 8, p).to(DEV), GatLayer(64, classes, 1, p).to(DEV)
         opt = torch.optim.Adam(list(l1.parameters()) + list(l2.parameters()), lr=0.005)
 
         def step():
             opt.zero_grad(set_to_none=True)
-            h = F.elu(l1(g, F.dropout(x, 0.6, True)))
-            out = l2(g, F.dropout(h, 0.6, True))
-            F.cross_entropy(out[mask], y[mask]).backward()
+            with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+                h = F.elu(l1(g, F.dropout(x, 0.6, True)))
+                out = l2(g, F.dropout(h, 0.6, True))
+                loss = F.cross_entropy(out[mask].float(), y[mask])
+            loss.backward()
             opt.step()
 
         for _ in range(2):
@@ -82,7 +86,7 @@ def main():
         ms = (time.perf_counter() - t0) / args.steps * 1e3
         res[name] = {"ms_per_epoch": ms, "GEdges_per_s_both_layers_fwd_bwd": 4 * gr.nnz / ms / 1e6,
                      "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}
-        print("%-42s %8.1f ms per full-graph training step" % (name, ms), flush=True)
+        print("%-46s %8.1f ms per full-graph training step" % (name, ms), flush=True)
         del l1, l2, opt
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
