@@ -1,5 +1,16 @@
 """Drop-in for cogdl/operators/scatter_max.py: `scatter_max(rowptr, colind, feat)` -> [M, F]
-(operators/scatter_max.py:17-37), used by MaxAggregator (cogdl/layers/sage_layer.py:21-29)."""
+(operators/scatter_max.py:17-37), used by MaxAggregator (cogdl/layers/sage_layer.py:21-29).
+
+Two result conventions:
+  * default: the true segment maximum (rows whose values are all negative get their real maximum; an empty row gives 0);
+  * reference-exact (`scatter_max(..., reference_exact=True)` or COGDL_AMD_SCATTER_MAX_REFERENCE=1): what the reference's
+    CUDA kernel returns -- its accumulator starts at FLT_MIN, the smallest positive normal float
+    (operators/scatter_max/scatter_max.cu:16), so every non-empty row's result is max(FLT_MIN, true maximum), and
+    where nothing exceeds FLT_MIN the argmax is undefined there (here: -1, no gradient flows).  The two agree whenever
+    a row's maximum exceeds FLT_MIN.
+"""
+import os
+
 import torch
 
 from .. import _lib
@@ -58,12 +69,19 @@ def scatter_max_bp_csc(colptr, rowind, grad, max_id, n_src):
     return out
 
 
+FLT_MIN = 1.1754943508222875e-38
+
+
 class ScatterMaxFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rowptr, colind, feat):
+    def forward(ctx, rowptr, colind, feat, reference_exact=False):
         rowptr, colind = _lib.csr_structure(rowptr, colind)
         ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None  # before the kernel
         out, max_id = scatter_max_fp(rowptr, colind, feat)
+        if reference_exact:  # acc = FLT_MIN; if (acc < B) {acc = B; max_id = cid}  (scatter_max.cu:16-23)
+            below = ((rowptr[1:] > rowptr[:-1]).view(-1, 1)) & ~(out > FLT_MIN)
+            out = torch.where(below, torch.full_like(out, FLT_MIN), out)
+            max_id = torch.where(below, torch.full_like(max_id, -1), max_id)
         ctx.save_for_backward(max_id, rowptr, colind)
         ctx.n_src = feat.shape[0]
         return out
@@ -73,8 +91,10 @@ class ScatterMaxFunction(torch.autograd.Function):
         max_id, rowptr, colind = ctx.saved_tensors
         # the cached transpose of the structure (the plan SpMM's backward uses, too) turns the scatter into a gather
         plan = PLANS.get(ctx.fp, rowptr, colind, ctx.n_src)
-        return None, None, scatter_max_bp_csc(plan.colptr, plan.rowind, grad, max_id, ctx.n_src)
+        return None, None, scatter_max_bp_csc(plan.colptr, plan.rowind, grad, max_id, ctx.n_src), None
 
 
-def scatter_max(rowptr, colind, feat):
-    return ScatterMaxFunction.apply(rowptr, colind, feat)
+def scatter_max(rowptr, colind, feat, reference_exact=None):
+    if reference_exact is None:
+        reference_exact = os.environ.get("COGDL_AMD_SCATTER_MAX_REFERENCE", "0") == "1"
+    return ScatterMaxFunction.apply(rowptr, colind, feat, bool(reference_exact))

@@ -541,3 +541,23 @@ def test_add_remaining_self_loops_and_normalisation_gpu_equal_the_reference_expr
         np.testing.assert_allclose(got[ok].numpy(), want[ok].numpy(), rtol=2e-6, atol=0)
     with pytest.raises(Exception):
         gb.symmetric_normalization(n, torch.tensor([0, n], device=DEV), torch.tensor([0, 0], device=DEV))
+
+
+def test_scatter_max_reference_exact_mode(oracle):
+    """reference_exact=True reproduces the reference kernel's FLT_MIN start value (scatter_max.cu:16): rows whose values
+    are all <= FLT_MIN return FLT_MIN (and route no gradient); everything else is the true maximum."""
+    g = synth.random_csr(200, 150, 6, seed=4, weighted=False)
+    x = rand(150, 32, seed=9)
+    x[:, :8] = -x[:, :8].abs()  # columns where every value is negative
+    want, want_id = oracle.scatter_max_fwd(g.rowptr, g.colind, x, quirk=True)
+    xd = x.to(DEV).requires_grad_()
+    out = scatter_max(g.rowptr.to(DEV), g.colind.to(DEV), xd, reference_exact=True)
+    assert out.detach().cpu().numpy().tobytes() == want.tobytes()
+    out.sum().backward()
+    routed = torch.zeros(150, 32)
+    ok = torch.from_numpy(want_id) >= 0
+    rows, cols = torch.nonzero(ok, as_tuple=True)
+    routed.index_put_((torch.from_numpy(want_id)[ok].long(), cols), torch.ones(int(ok.sum())), accumulate=True)
+    assert torch.equal(xd.grad.cpu(), routed)
+    true_max = scatter_max(g.rowptr.to(DEV), g.colind.to(DEV), x.to(DEV))  # default: the real maximum
+    assert float(true_max[:, :8][g.degrees() > 0].max()) < 0
