@@ -283,46 +283,42 @@ __device__ __forceinline__ bool row_totals(const Params &p, int64_t start, int64
     return true;
 }
 
-// ---- one complete row in LDS, reduced by an aligned group of LPR lanes (LPR a multiple of h: lane l sees head l % h)
-template <int LPR, bool BWD>
-__device__ __forceinline__ void row_in_lds(float *tile, const float *tile_g, int base, int cnt, int l, int h) {
+// ---- one complete row in LDS, reduced by an aligned group of `lpr` lanes (a power of two, a multiple of h: lane l sees
+// head l % h).  The group size is a run-time value: one copy of this code serves every row length (seven unrolled
+// instantiations had grown the forward kernel to ~80 KB of instructions, beyond the instruction cache).
+template <bool BWD>
+__device__ __forceinline__ void row_in_lds(float *tile, const float *tile_g, int base, int cnt, int l, int lpr, int h) {
     if constexpr (BWD) {
         float dot = 0.f;
-        for (int j = l; j < cnt; j += LPR) dot = fmaf(tile[base + j], tile_g[base + j], dot);
-#pragma unroll
-        for (int s = LPR / 2; s > 0; s >>= 1)
-            if (s >= h) dot += __shfl_xor(dot, s, kWave);
-        for (int j = l; j < cnt; j += LPR) tile[base + j] = tile[base + j] * (tile_g[base + j] - dot);
+        for (int j = l; j < cnt; j += lpr) dot = fmaf(tile[base + j], tile_g[base + j], dot);
+        for (int s = lpr >> 1; s >= h; s >>= 1) dot += __shfl_xor(dot, s, kWave);
+        for (int j = l; j < cnt; j += lpr) tile[base + j] = tile[base + j] * (tile_g[base + j] - dot);
     } else {
         float mx = -INFINITY;
-        for (int j = l; j < cnt; j += LPR) mx = fmaxf(mx, tile[base + j]);
-#pragma unroll
-        for (int s = LPR / 2; s > 0; s >>= 1)
-            if (s >= h) mx = fmaxf(mx, __shfl_xor(mx, s, kWave));
+        for (int j = l; j < cnt; j += lpr) mx = fmaxf(mx, tile[base + j]);
+        for (int s = lpr >> 1; s >= h; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s, kWave));
         float sum = 0.f;
-        for (int j = l; j < cnt; j += LPR) {
+        for (int j = l; j < cnt; j += lpr) {
             const float pe = es_exp(tile[base + j] - mx);
             tile[base + j] = pe;
             sum += pe;
         }
-#pragma unroll
-        for (int s = LPR / 2; s > 0; s >>= 1)
-            if (s >= h) sum += __shfl_xor(sum, s, kWave);
+        for (int s = lpr >> 1; s >= h; s >>= 1) sum += __shfl_xor(sum, s, kWave);
         const float inv = 1.f / sum;
-        for (int j = l; j < cnt; j += LPR) tile[base + j] *= inv;
+        for (int j = l; j < cnt; j += lpr) tile[base + j] *= inv;
     }
 }
 
 // Rows of at most `lthr` edges: one lane group per row.  rp = LDS copy of rowptr[r0 .. r0 + nrows].
-template <int LPR, bool BWD>
+template <bool BWD>
 __device__ __forceinline__ void rows_small(float *tile, const float *tile_g, const int32_t *rp, int nrows, int64_t e0,
-                                           int h, int lthr) {
-    constexpr int NG = kThreads / LPR;
-    const int grp = threadIdx.x / LPR, l = threadIdx.x % LPR;
-    for (int i = grp; i < nrows; i += NG) {
+                                           int h, int lpr, int lthr) {
+    const int ng = kThreads / lpr;
+    const int grp = threadIdx.x / lpr, l = threadIdx.x & (lpr - 1);
+    for (int i = grp; i < nrows; i += ng) {
         const int len = rp[i + 1] - rp[i];
         if (len == 0 || len > lthr) continue;  // (group-uniform)
-        row_in_lds<LPR, BWD>(tile, tile_g, (int)(rp[i] - e0) * h, len * h, l, h);
+        row_in_lds<BWD>(tile, tile_g, (int)(rp[i] - e0) * h, len * h, l, lpr, h);
     }
 }
 
@@ -377,7 +373,7 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
     constexpr int TILE = TileSize<BWD>::value;
     constexpr int V = VecOf<T>::V;
     constexpr int NV = TILE / (kThreads * V);  // 16-byte vectors per thread (per array)
-    constexpr int kMaxLong = 64;
+    constexpr int kMaxLong = 256;
     __shared__ __attribute__((aligned(16))) float tile[TILE];
     __shared__ __attribute__((aligned(16))) float tile_gs[BWD ? TILE : 4];
     __shared__ int32_t rp[kRowChunk + 1];
@@ -385,6 +381,7 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
     __shared__ float2 mrg[kThreads];
     __shared__ float2 pstat[kWave];   // piece statistics per head (register path)
     __shared__ float fac[2][kWave];   // per partial piece (head, tail) and head id: what the store step applies
+    __shared__ float facm[2][kWave];  // forward, short straddling rows: the row maximum
     __shared__ int s_nlong, s_long[kMaxLong];
     const int t = threadIdx.x;
     const T *__restrict__ a = (const T *)p.a;
@@ -523,12 +520,32 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
     const bool tail_partial = te > e1;
     const int head_end = head_partial ? (int)(he - e0) * h : 0;        // LDS span [0, head_end)
     const int tail_begin = tail_partial ? (int)(ts - e0) * h : count;  // LDS span [tail_begin, count)
+    // A SHORT row that straddles a tile border (at most a quarter of a tile: it touches exactly two tiles) is not
+    // exchanged at all: both tiles read the whole row from global memory (a few hundred bytes beyond their own tile,
+    // L2-hot because the neighbour loads them at the same time) and compute the identical statistics independently --
+    // one read instead of publish + poll + merge, and no waiting on another workgroup.  On low-degree graphs
+    // (arxiv-shaped: 15 edges per row) every tile border is of this kind.
+    const int64_t halo_max = p.tile_e / 4;
+    const bool head_halo = head_partial && (he - hs) <= halo_max;
+    const bool tail_halo = tail_partial && (te - ts) <= halo_max;
     float2 head_piece = make_float2(0.f, 0.f), tail_piece = make_float2(0.f, 0.f);
-    if (head_partial) {
+    if (head_halo) {
+        const float2 tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
+        if (t < h) {
+            fac[0][t] = BWD ? tot.x : 1.f / tot.y;
+            facm[0][t] = tot.x;
+        }
+    } else if (head_partial) {
         head_piece = wg_piece_lds<BWD>(tile, tile_g, 0, head_end, h, red);
         if (he - hs <= p.long_edges) publish<BWD>(p, c, 0, head_piece);
     }
-    if (tail_partial) {
+    if (tail_halo) {
+        const float2 tot = wg_piece_global<T, BWD>(a, g, ts * h, te * h, h, red);
+        if (t < h) {
+            fac[1][t] = BWD ? tot.x : 1.f / tot.y;
+            facm[1][t] = tot.x;
+        }
+    } else if (tail_partial) {
         tail_piece = wg_piece_lds<BWD>(tile, tile_g, tail_begin, count - tail_begin, h, red);
         if (te - ts <= p.long_edges) publish<BWD>(p, c, 1, tail_piece);
     }
@@ -536,10 +553,12 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
     // ---- rows completely inside the tile ---------------------------------------------------------------------------
     const int64_t rc0 = r_first + (head_partial ? 1 : 0), rc1 = r_last - (tail_partial ? 1 : 0);  // inclusive range
     if (rc1 >= rc0) {
-        // lanes per row from the mean row length of this tile: ~8 sequential steps per lane, at least max(8, h) lanes
+        // lanes per row from the mean row length of this tile: ~8 sequential steps per lane, at least h lanes (one
+        // per head: short rows then need no cross-lane reduction at all, and a workgroup keeps 256 / h rows in flight
+        // -- with 8+ lanes per 15-element row the dependent shuffle chains of a few rows were all a wave had to do)
         const int64_t nrows_all = rc1 - rc0 + 1;
         const int mean_elems = (int)min((int64_t)TILE, (int64_t)(tail_begin - head_end) / nrows_all);
-        int lpr = max(8, h);
+        int lpr = h;
         while (lpr < kWave && lpr * 8 < mean_elems) lpr <<= 1;
         const int lthr = 32 * (lpr / h);  // longer rows: one wave each
         for (int64_t r0 = rc0; r0 <= rc1; r0 += kRowChunk) {
@@ -548,14 +567,9 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
             if (t == 0) s_nlong = 0;
             for (int i = t; i <= nrows; i += kThreads) rp[i] = p.rowptr[r0 + i];
             __syncthreads();
-            switch (lpr) {
-                case 8: rows_small<8, BWD>(tile, tile_g, rp, nrows, e0, h, lthr); break;
-                case 16: rows_small<16, BWD>(tile, tile_g, rp, nrows, e0, h, lthr); break;
-                case 32: rows_small<32, BWD>(tile, tile_g, rp, nrows, e0, h, lthr); break;
-                default: rows_small<64, BWD>(tile, tile_g, rp, nrows, e0, h, lthr); break;
-            }
-            // Long complete rows of this chunk: one WAVE per row, four at a time, no workgroup barrier.  A tile holds
-            // fewer than 32 of them (more than lthr >= 32 * max(8, h) / h edges each): the list cannot overflow.
+            rows_small<BWD>(tile, tile_g, rp, nrows, e0, h, lpr, lthr);
+            // Long complete rows of this chunk: one WAVE per row, four at a time, no workgroup barrier.  A tile holds at
+            // most TILE / h / 33 <= 248 of them (more than lthr >= 32 edges each): the list cannot overflow.
             for (int i = t; i < nrows; i += kThreads) {
                 if (rp[i + 1] - rp[i] > lthr) {
                     const int pos = atomicAdd(&s_nlong, 1);
@@ -566,7 +580,7 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
             const int n_long = min(s_nlong, kMaxLong);
             for (int q = t >> 6; q < n_long; q += 4) {
                 const int i2 = s_long[q];
-                row_in_lds<kWave, BWD>(tile, tile_g, (int)(rp[i2] - e0) * h, (rp[i2 + 1] - rp[i2]) * h, t & (kWave - 1), h);
+                row_in_lds<BWD>(tile, tile_g, (int)(rp[i2] - e0) * h, (rp[i2 + 1] - rp[i2]) * h, t & (kWave - 1), kWave, h);
             }
         }
     }
@@ -574,12 +588,13 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
     // ---- row totals of the partial pieces -> the factor the store step applies ----------------------------------
     //   forward : out = p * exp(m_piece - m_row) / s_row          (fac = that product)
     //   backward: out = a * (g - dot_row)                          (fac = dot_row)
-    if (head_partial) {
+    //   (short straddling rows, forward: the span still holds the raw values: out = exp(v - m_row) / s_row)
+    if (head_partial && !head_halo) {
         float2 tot;
         if (!row_totals<BWD>(p, hs, he, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
         if (t < h) fac[0][t] = BWD ? tot.x : es_exp(head_piece.x - tot.x) / tot.y;
     }
-    if (tail_partial) {
+    if (tail_partial && !tail_halo) {
         float2 tot;
         if (!row_totals<BWD>(p, ts, te, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, ts * h, te * h, h, red);
         if (t < h) fac[1][t] = BWD ? tot.x : es_exp(tail_piece.x - tot.x) / tot.y;
@@ -596,9 +611,10 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
             const int i = i0 + k;
             float v = tile[i];
             if (i < head_end || i >= tail_begin) {
-                const float f = fac[i < head_end ? 0 : 1][i & (h - 1)];
+                const int which = i < head_end ? 0 : 1;
+                const float f = fac[which][i & (h - 1)];
                 if constexpr (BWD) v = v * (tile_g[i] - f);
-                else v = v * f;
+                else v = (which == 0 ? head_halo : tail_halo) ? es_exp(v - facm[which][i & (h - 1)]) * f : v * f;
             }
             o[k] = v;
         }
