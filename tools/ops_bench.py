@@ -70,6 +70,14 @@ def arxiv():
             report("csr_spmm", cfg, timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x)),
                    nnz * (8 + f * 4) + n * (4 + f * 4), nnz)
             if f in (64, 128):
+                from cogdl_amd.operators.spmm import csr_spmm_epilogue_raw
+                on, inn = torch.rand(n, 1, device=DEV) + 0.5, torch.rand(n, 1, device=DEV) + 0.5
+                report("csr_spmm_epilogue(norms+relu)", cfg,
+                       timeit(lambda: csr_spmm_epilogue_raw(g.rowptr, g.colind, g.weight, x, on, inn, None, True)),
+                       nnz * (12 + f * 4) + n * (8 + f * 4), nnz)
+                report("  unfused: out_norm*x, spmm, in_norm*., relu", cfg,
+                       timeit(lambda: torch.relu(inn * csr_spmm_raw(g.rowptr, g.colind, g.weight, on * x))),
+                       nnz * (12 + f * 4) + n * (8 + f * 4), nnz)
                 report("csr_spmm(unweighted)", cfg, timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, None, x)),
                        nnz * (4 + f * 4) + n * (4 + f * 4), nnz)
                 xb = x.bfloat16()
