@@ -70,7 +70,7 @@ struct RowGeometry {
     int vec, lpr;
     int64_t tiles;
 };
-RowGeometry spmm_geometry(int64_t k, int64_t unit, int elem_bytes, int align);
+RowGeometry spmm_geometry(int64_t k, int64_t unit, int elem_bytes, int align, bool narrow_groups = false);
 
 struct RowSched {
     const int32_t *rowptr;
@@ -225,7 +225,8 @@ __device__ __forceinline__ void reduce_edges(const Op &op, typename Op::Ctx &ctx
 template <class Op>
 __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSched &s, float *op_lds) {
     constexpr int LPR = Op::LPR;
-    constexpr int G = 256 / LPR;  // groups per workgroup
+    constexpr int RPW = kWave / LPR;   // lane groups per wave; LPR need not divide 64 (e.g. 10 lanes for a 160-byte
+    constexpr int G = RPW * 4;         // row): the last 64 % LPR lanes of every wave then idle ("lane_on" below)
     constexpr int NREC = Op::kReduce ? Op::kRec : 1;
     __shared__ float red[Op::kReduce ? G : 1][NREC][LPR];
     __shared__ int32_t tbl[kMaxChunksPerBlock + 1];
@@ -239,7 +240,8 @@ __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSche
     const int lane = threadIdx.x & (kWave - 1);
     const int sub = lane / LPR;
     const int l = lane % LPR;
-    const int g = (threadIdx.x >> 6) * (kWave / LPR) + sub;
+    const bool lane_on = (kWave % LPR == 0) || sub < RPW;
+    const int g = (threadIdx.x >> 6) * RPW + sub;
     typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
     for (int t = 0; t < n; ++t) {
         const int64_t c = c_begin + t;
@@ -249,6 +251,7 @@ __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSche
             if (!decode_piece(lr, s.rowptr, tbl, c, t, slot, row, lo, hi)) continue;
             const int per = (hi - lo + G - 1) / G;  // contiguous slices
             int sb = min(lo + g * per, hi), se = min(sb + per, hi);
+            if (!lane_on) sb = se = hi;
             if constexpr (LPR == kWave) {  // one wave per slice: keep the loop bounds scalar
                 sb = __builtin_amdgcn_readfirstlane(sb);
                 se = __builtin_amdgcn_readfirstlane(se);
@@ -260,8 +263,10 @@ __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSche
             if constexpr (Op::kReduce) {
                 float rec[NREC];
                 op.pack(st, rec);
+                if (lane_on) {
 #pragma unroll
-                for (int i = 0; i < NREC; ++i) red[g][i][l] = rec[i];
+                    for (int i = 0; i < NREC; ++i) red[g][i][l] = rec[i];
+                }
                 __syncthreads();
                 if (g == 0) {
                     for (int q = 1; q < G; ++q) {  // fixed order: group 0, 1, 2, ...
@@ -336,10 +341,11 @@ __global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const 
     if (rb < 0) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    const int sub = lane / LPR;
     const int l = lane % LPR;
+    const bool lane_on = (kWave % LPR == 0) || lane / LPR < RPW;  // LPR not dividing 64: the trailing lanes idle
+    const int sub = lane_on ? lane / LPR : 0;
     int64_t row = rb * GPB + wave * RPW + sub;
-    bool ok = row < s.m;
+    bool ok = lane_on && row < s.m;
     int start = 0, end = 0;
     if (ok) {
         start = s.rowptr[row];
@@ -354,7 +360,11 @@ __global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const 
         // sequentially by one group in CSR order (bit-identical results).
         if (g_sort_rows(s)) {
             int mine;
-            if (deal_rows_by_length<GPB>(wave * RPW + sub, l == 0, ok, start, end, mine)) row = rb * GPB + mine;
+            if (deal_rows_by_length<GPB>(wave * RPW + sub, lane_on && l == 0, ok, start, end, mine)) row = rb * GPB + mine;
+            if (!lane_on) {
+                ok = false;
+                start = end = 0;
+            }
         }
     }
     if constexpr (LPR == kWave) {  // whole wave on one row: make the loop bounds scalar
@@ -375,7 +385,8 @@ __global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const 
 template <class Op>
 __global__ __launch_bounds__(256) void rowreduce_combine_kernel(const Op op, const RowSched s) {
     constexpr int LPR = Op::LPR;
-    constexpr int G = 256 / LPR;
+    constexpr int RPW = kWave / LPR;
+    constexpr int G = RPW * 4;
     constexpr int NREC = Op::kRec;
     __shared__ int32_t tbl[kMaxChunksPerBlock + 1];
     const LongRows &lr = s.lr;
@@ -390,12 +401,13 @@ __global__ __launch_bounds__(256) void rowreduce_combine_kernel(const Op op, con
     const int lane = threadIdx.x & (kWave - 1);
     const int sub = lane / LPR;
     const int l = lane % LPR;
-    const int g = (threadIdx.x >> 6) * (kWave / LPR) + sub;
+    const bool lane_on = (kWave % LPR == 0) || sub < RPW;
+    const int g = (threadIdx.x >> 6) * RPW + sub;
     typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
     for (int t0 = 0; t0 < n; t0 += G) {
         const int t = t0 + g;
         const int64_t c = c_begin + t;
-        int32_t row = (t < n) ? tbl[t] : -1;
+        int32_t row = (lane_on && t < n) ? tbl[t] : -1;
         int start = 0, end = 0;
         if (row >= 0) {
             start = s.rowptr[row];

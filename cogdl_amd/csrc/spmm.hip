@@ -34,7 +34,7 @@ namespace cogdl {
 //   * rows of >= 512 B (fp32 F >= 128) use 8-byte lanes so that a whole wave (or two) shares a row: scalar column
 //     broadcast, no intra-wave length divergence (fp32 F=256: 390 -> 359 us with two column tiles per row).
 // `align` = guaranteed alignment in bytes of x and out (the workspace query assumes 16: allocator memory).
-RowGeometry spmm_geometry(int64_t k, int64_t unit, int elem_bytes, int align) {
+RowGeometry spmm_geometry(int64_t k, int64_t unit, int elem_bytes, int align, bool narrow_groups) {
     const int maxv = std::min(4, 16 / elem_bytes);
     auto legal = [&](int v) { return v <= maxv && unit % v == 0 && align % (v * elem_bytes) == 0; };
     int vec = 1;
@@ -52,6 +52,14 @@ RowGeometry spmm_geometry(int64_t k, int64_t unit, int elem_bytes, int align) {
     const int64_t need = (k + vec - 1) / vec;
     int lpr = 4;
     while (lpr < kWave && lpr < need) lpr <<= 1;
+    // Rows whose lane count is 5/8 or 3/4 of a power of two (F = 40 fp32: 10 sixteen-byte lanes) would leave 25-37 % of
+    // every row group idle; a group of exactly `need` lanes packs floor(64 / need) rows into a wave instead (60 of 64
+    // lanes busy, 6 / 5 / 3 rows per wave instead of 4 / 4 / 2).  Measured on MI355X (arxiv-shaped graphs, fp32): R-MAT
+    // F=40 136 -> 120 us, F=48 126 -> 113 us, F=80 168 -> 138 us (more rows per wave = better balance on skewed
+    // degrees); uniform degrees: +-0 .. -4 % (those are bound by the per-row latency chain, not by lanes -- F=20 takes
+    // 68 us where F=40 takes 99 us).  Groups of 5 / 6 lanes (F=20 / 24) gained nothing.  csr_spmm only; tuning key
+    // 6 == -99 switches it off for A-B runs.
+    if (narrow_groups && g_tuning[kTuneSpmmVec] != -99 && (need == 10 || need == 12 || need == 20)) lpr = (int)need;
     RowGeometry g;
     g.vec = vec;
     g.lpr = lpr;
@@ -107,8 +115,10 @@ using namespace cogdl;
 
 extern "C" size_t cogdl_hip_csr_spmm_workspace_bytes(int64_t nnz, int64_t k, int dtype) {
     if (nnz <= 0 || k <= 0) return 0;
-    const RowGeometry g = spmm_geometry(k, k, elem_bytes_of(dtype), 16);
-    return rowreduce_workspace_bytes(nnz, g.tiles * g.vec * g.lpr);
+    const RowGeometry g = spmm_geometry(k, k, elem_bytes_of(dtype), 16, true);
+    // (the epilogue entry keeps power-of-two groups, which never need less: sized for the larger of the two)
+    const RowGeometry g2 = spmm_geometry(k, k, elem_bytes_of(dtype), 16, false);
+    return std::max(rowreduce_workspace_bytes(nnz, g.tiles * g.vec * g.lpr), rowreduce_workspace_bytes(nnz, g2.tiles * g2.vec * g2.lpr));
 }
 
 extern "C" size_t cogdl_hip_mhspmm_workspace_bytes(int64_t nnz, int64_t h, int64_t f, int dtype) {

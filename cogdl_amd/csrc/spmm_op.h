@@ -163,6 +163,14 @@ static int launch_spmm(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s
 // fastest: scalar column broadcast, no inter-row divergence inside a wave), VEC as small as that allows.
 template <typename T, int VEC, int WMODE, bool EPI = false>
 static int dispatch_lpr(const SpmmArgs<T> &a, int lpr, void *ws, size_t wsb, hipStream_t s) {
+    if constexpr (WMODE != 2 && !EPI) {  // lane groups that do not divide the wave (spmm_geometry: narrow_groups)
+        switch (lpr) {
+            case 10: return launch_spmm<T, VEC, 10, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
+            case 12: return launch_spmm<T, VEC, 12, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
+            case 20: return launch_spmm<T, VEC, 20, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
+            default: break;
+        }
+    }
     switch (lpr) {
         case 4: return launch_spmm<T, VEC, 4, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
         case 8: return launch_spmm<T, VEC, 8, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
@@ -179,7 +187,8 @@ static int pointer_alignment(const void *a, const void *b) {
 
 template <typename T, int WMODE, bool EPI = false>
 static int spmm_auto(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) {
-    const RowGeometry g = spmm_geometry(a.k, (WMODE == 2) ? a.fdim : a.k, (int)sizeof(T), pointer_alignment(a.x, a.out));
+    const RowGeometry g = spmm_geometry(a.k, (WMODE == 2) ? a.fdim : a.k, (int)sizeof(T), pointer_alignment(a.x, a.out),
+                                        WMODE != 2 && !EPI);
     switch (g.vec) {
         case 4: return dispatch_lpr<T, 4, WMODE, EPI>(a, g.lpr, ws, wsb, s);
         case 2: return dispatch_lpr<T, 2, WMODE, EPI>(a, g.lpr, ws, wsb, s);

@@ -65,7 +65,7 @@ COGDL_API int cogdl_hip_last_hip_error(void);
  * inside a workgroup (default 0: rows dealt by decreasing length), key 3 = cap on the number of
  * long-row workgroups (default 1024), key 4 = cap on the fused-GAT vector width (0 = widest), key 5 = fused-GAT
  * forward kernel (0 = automatic, 1 = edge-wise online softmax, 2 = chunk-wise softmax where the shape allows),
- * key 6 = csr_spmm/mhspmm vector width cap (negative: force), key 7 = edge_softmax lane width (bit 0: 4-byte lanes in
+ * key 6 = csr_spmm/mhspmm vector width cap (negative: force; -99: power-of-two lane groups only), key 7 = edge_softmax lane width (bit 0: 4-byte lanes in
  * the row kernels, bit 1: 4-byte lanes in the hub-row path, bit 2: row kernels instead of the flat streaming kernel;
  * 0 = flat kernel where it applies, 16-byte lanes where the layout allows), key 8 = polls before the flat edge_softmax
  * kernel's cross-tile wait gives up and recomputes the row statistics itself (0 = default 4096; negative: every
