@@ -88,6 +88,41 @@ tdeg = torch.zeros(100).scatter_add_(0, trow, torch.ones(200))
 tinv = tdeg.pow(-1); tinv[torch.isinf(tinv)] = 0
 assert (cops.s_mul_e_mean(tg, tg.x, ea) == want * tinv.view(-1, 1)).all()
 assert (cops.s_sub_t(tg, tg.x) == tg.x[tcol] - tg.x[trow]).all()
+# 7. opt-in fused dispatcher front: CPU tensors / graphs without norm vectors are forwarded to the reference's own spmm
+cogdl_amd.install(fused_norm=True)
+import cogdl.layers.sage_layer as sage_mod
+assert getattr(spmm_utils.spmm, "_cogdl_amd_fused", False) and getattr(sage_mod.spmm, "_cogdl_amd_fused", False)
+with torch.no_grad():
+    y2 = spmm_utils.spmm(g, x.detach())
+assert torch.equal(y2, y)
+nodes_b, block = g.sample_adj(torch.tensor([1, 2, 3]), -1)
+block.row_norm()                                             # CSR-only graph: in_norm vector (data.py:248-252)
+assert block.in_norm is not None
+xb = torch.randn(nodes_b.numel(), 5)
+with torch.no_grad():
+    agg = sage_mod.spmm(block, xb)                           # CPU tensor -> the reference's path, in_norm applied there
+deg = (block.row_indptr[1:] - block.row_indptr[:-1]).float()
+want_b = torch.zeros(nodes_b.numel(), 5).index_add_(
+    0, torch.repeat_interleave(torch.arange(deg.numel()), deg.long()), xb[block.col_indices])
+want_b = want_b / deg.clamp(min=1).view(-1, 1)
+assert torch.allclose(agg, want_b, rtol=1e-5, atol=1e-6)
+import cogdl_amd.fused
+cogdl_amd.fused.uninstall()
+assert not getattr(spmm_utils.spmm, "_cogdl_amd_fused", False) and not getattr(sage_mod.spmm, "_cogdl_amd_fused", False)
+
+# 8. the graph-preprocessing helpers are rebound everywhere they are held by name; CPU tensors keep the reference's results
+import cogdl.utils.graph_utils as gu
+for fn in ("add_remaining_self_loops", "symmetric_normalization", "row_normalization", "coo2csr_index"):
+    assert getattr(gu, fn).__module__ == "cogdl_amd.graph_build", fn
+assert cogdl.utils.row_normalization.__module__ == "cogdl_amd.graph_build"
+orig = gu._cogdl_amd_orig_graph_build
+r0, c0 = torch.randint(0, 50, (2, 400))
+w0 = torch.rand(400)
+(ra, ca), wa = gu.add_remaining_self_loops((r0, c0), w0, 1, 50)
+(rb, cb), wb = orig["add_remaining_self_loops"]((r0, c0), w0, 1, 50)
+assert torch.equal(ra, rb) and torch.equal(ca, cb) and torch.equal(wa, wb)
+assert torch.equal(gu.symmetric_normalization(50, ra, ca, wa), orig["symmetric_normalization"](50, rb, cb, wb))
+assert torch.equal(gu.row_normalization(50, ra, ca, wa), orig["row_normalization"](50, rb, cb, wb))
 shutil.rmtree(scratch, ignore_errors=True)
 print("INSTALL-OK", served)
 '''
