@@ -7,6 +7,8 @@
 
 #include "../../include/cogdl_hip.h"
 
+#include <algorithm>
+
 namespace cogdl {
 
 constexpr int kWave = 64;   // CDNA wavefront width, hard-coded on purpose (gfx950 only)
@@ -24,6 +26,20 @@ inline int launch_status() {
 }
 
 inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// Stream-ordered fill of 32-bit words.  A kernel, not hipMemsetAsync: inside a captured hipGraph the small memsets of
+// this library did not take effect on replay on ROCm 7.2 (measured: a 4-byte flag word kept the bytes of whatever had
+// owned the pool block before); a kernel node replays like every other launch.
+template <int UNUSED = 0>
+__global__ void fill_u32_kernel(uint32_t *__restrict__ p, uint32_t v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+inline hipError_t fill_u32_async(void *p, uint32_t v, size_t n_words, hipStream_t s) {
+    if (n_words == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((n_words + 255) / 256, 4096);
+    hipLaunchKernelGGL(fill_u32_kernel<0>, dim3(blocks), dim3(256), 0, s, (uint32_t *)p, v, n_words);
+    return hipGetLastError();
+}
 
 // Run-time tuning knobs (cogdl_hip_set_tuning): experiments without recompiling.
 enum Tuning { kTuneXcdStripe = 0, kTuneLongThresh = 1, kTuneRowSort = 2, kTuneLongGrid = 3, kTuneGatVec = 4, kTuneGatOnline = 5, kTuneSpmmVec = 6, kTuneEsScalar = 7, kTuneEsSpin = 8, kTuneEsDebug = 9, kTuneCount = 10 };

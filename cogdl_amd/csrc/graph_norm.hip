@@ -113,7 +113,7 @@ extern "C" int cogdl_hip_coo_norm_weights(const int64_t *row, const int64_t *col
     if (workspace_bytes < cogdl_hip_coo_norm_weights_workspace_bytes(num_nodes)) return COGDL_HIP_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     int32_t *deg = (int32_t *)workspace;
-    hipError_t e = hipMemsetAsync(deg, 0, (size_t)std::max<int64_t>(num_nodes, 1) * 4, s);
+    hipError_t e = fill_u32_async(deg, 0u, (size_t)std::max<int64_t>(num_nodes, 1), s);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
         return COGDL_HIP_ELAUNCH;
@@ -153,7 +153,7 @@ extern "C" int cogdl_hip_add_remaining_self_loops(const int64_t *row, const int6
     size_t scan_t = 0;
     (void)rocprim::exclusive_scan(nullptr, scan_t, (int32_t *)nullptr, (int64_t *)nullptr, int64_t(0), (size_t)(nnz + 1),
                                   rocprim::plus<int64_t>(), nullptr);
-    hipError_t e = hipMemsetAsync(loop_src, 0xff, (size_t)std::max<int64_t>(num_nodes, 1) * 4, s);
+    hipError_t e = fill_u32_async(loop_src, 0xffffffffu, (size_t)std::max<int64_t>(num_nodes, 1), s);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
         return COGDL_HIP_ELAUNCH;

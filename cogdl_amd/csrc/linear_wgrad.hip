@@ -277,8 +277,8 @@ extern "C" int cogdl_hip_linear_wgrad_f32(const float *x, const float *grad_out,
     if (in_features > 0x7fffffff / 64 || out_features > 0x7fffffff / 64) return COGDL_HIP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
     if (k_rows == 0) {  // empty reduction: zeros
-        hipError_t e = hipMemsetAsync(grad_w, 0, (size_t)in_features * out_features * sizeof(float), s);
-        if (e == hipSuccess && grad_b) e = hipMemsetAsync(grad_b, 0, (size_t)out_features * sizeof(float), s);
+        hipError_t e = fill_u32_async(grad_w, 0u, (size_t)in_features * out_features, s);
+        if (e == hipSuccess && grad_b) e = fill_u32_async(grad_b, 0u, (size_t)out_features, s);
         if (e != hipSuccess) {
             g_last_hip_error = (int)e;
             return COGDL_HIP_ELAUNCH;

@@ -47,13 +47,21 @@ __device__ __forceinline__ int64_t count_for(int64_t deg, int64_t k, int replace
 }
 
 // flags: bit 0 = a seed outside [0, num_nodes), bit 1 = a neighbour id outside, bit 2 = output capacity exceeded
+// `batch_count` (device, may be NULL): how many of the `batch` seed slots are in use -- the padded entry point
+// samples into buffers of a FIXED capacity, so that a whole mini-batch step can be captured in a hipGraph.
+__device__ __forceinline__ int64_t valid_seeds(const int64_t *batch_count, int64_t batch) {
+    if (!batch_count) return batch;
+    const int64_t v = *batch_count;
+    return v < 0 ? 0 : (v > batch ? batch : v);
+}
+
 __global__ void sample_counts_kernel(const int64_t *__restrict__ indptr, const int64_t *__restrict__ node_idx,
-                                     int64_t batch, int64_t num_nodes, int64_t k, int replace,
-                                     int32_t *__restrict__ cnt, int *__restrict__ flags) {
+                                     int64_t batch, const int64_t *__restrict__ batch_count, int64_t num_nodes, int64_t k,
+                                     int replace, int32_t *__restrict__ cnt, int *__restrict__ flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > batch) return;
     int32_t c = 0;
-    if (i < batch) {
+    if (i < valid_seeds(batch_count, batch)) {
         const int64_t s = node_idx[i];
         if (s < 0 || s >= num_nodes) atomicOr(flags, 1);
         else c = (int32_t)count_for(indptr[s + 1] - indptr[s], k, replace);
@@ -64,16 +72,26 @@ __global__ void sample_counts_kernel(const int64_t *__restrict__ indptr, const i
 __global__ __launch_bounds__(256) void sample_pick_kernel(const int64_t *__restrict__ indptr,
                                                           const int64_t *__restrict__ indices,
                                                           const int64_t *__restrict__ node_idx, int64_t batch,
+                                                          const int64_t *__restrict__ batch_count,
                                                           int64_t num_nodes, int64_t k, int replace, uint64_t seed,
+                                                          const uint64_t *__restrict__ seed_dev,
                                                           const int64_t *__restrict__ out_indptr,
                                                           int64_t *__restrict__ out_edges, uint32_t *__restrict__ keys,
-                                                          int64_t cap_edges, int *__restrict__ flags) {
+                                                          uint32_t pad_key, int64_t cap_edges, int *__restrict__ flags) {
     __shared__ int32_t chosen_all[4][kSampleMaxK];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
     if (i >= batch) return;
+    if (i >= valid_seeds(batch_count, batch)) {  // an unused seed slot: sorts last, gets no local id
+        if (lane == 0) keys[i] = pad_key;
+        return;
+    }
+    if (seed_dev) seed += *seed_dev;  // (a captured graph re-reads it on every replay; `seed` then is a per-call offset)
     const int64_t s = node_idx[i];
-    if (s < 0 || s >= num_nodes) return;  // flagged by the count kernel; its count is 0
+    if (s < 0 || s >= num_nodes) {  // flagged by the count kernel; its count is 0
+        if (lane == 0) keys[i] = pad_key;
+        return;
+    }
     if (lane == 0) keys[i] = (uint32_t)s;
     const int64_t start = indptr[s], deg = indptr[s + 1] - start;
     const int64_t off = out_indptr[i], cnt = out_indptr[i + 1] - off;
@@ -116,12 +134,23 @@ __global__ __launch_bounds__(256) void sample_pick_kernel(const int64_t *__restr
 }
 
 // Unused tail of the sequence (capacity > actual number of picks): a key above every node id, so it sorts last.
-__global__ void sample_pad_kernel(const int64_t *__restrict__ out_indptr, int64_t batch, int64_t cap_edges,
-                                  uint32_t *__restrict__ keys, uint32_t pad_key) {
+// `padded`: the unused tails of the outputs get benign values too -- out_indices / out_edges 0 (a valid id / position),
+// out_indptr[batch+1 .. batch+cap_edges] = E' (rows without edges) -- so that the block is a well-formed CSR of the
+// full capacity whatever was sampled.
+__global__ void sample_pad_kernel(int64_t *__restrict__ out_indptr, int64_t batch, int64_t cap_edges,
+                                  uint32_t *__restrict__ keys, uint32_t pad_key, int padded,
+                                  int64_t *__restrict__ out_indices, int64_t *__restrict__ out_edges) {
     const int64_t total = out_indptr[batch];
-    for (int64_t j = total + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cap_edges;
-         j += (int64_t)gridDim.x * blockDim.x)
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = total + t0; j < cap_edges; j += stride) {
         keys[batch + j] = pad_key;
+        if (padded) {
+            out_indices[j] = 0;
+            out_edges[j] = 0;
+        }
+    }
+    if (padded)
+        for (int64_t j = t0; j < cap_edges; j += stride) out_indptr[batch + 1 + j] = total;
 }
 
 // sorted order j: first[pos[j]] = is this the first occurrence of its node in Q; head[j] = j for run heads, else 0
@@ -144,8 +173,9 @@ __global__ void sample_relabel_kernel(const uint32_t *__restrict__ skeys, const 
                                       const int32_t *__restrict__ head_of, int64_t len, int64_t batch,
                                       uint32_t pad_key, const int64_t *__restrict__ out_indptr,
                                       int64_t *__restrict__ out_indices, int64_t *__restrict__ out_nodes,
-                                      int64_t *__restrict__ out_counts, const int *__restrict__ flags) {
+                                      int64_t *__restrict__ out_counts, const int *__restrict__ flags, int padded) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (padded && j < len && j >= (int64_t)rank[len - 1] + first[len - 1]) out_nodes[j] = 0;  // unused slots: a valid id
     if (j == 0) {
         out_counts[0] = (int64_t)rank[len - 1] + first[len - 1];  // nodes
         out_counts[1] = out_indptr[batch];                        // edges
@@ -213,11 +243,11 @@ extern "C" size_t cogdl_hip_sample_adj_workspace_bytes(int64_t batch, int64_t ca
     return carve(nullptr, batch, cap_edges, num_nodes).total;
 }
 
-extern "C" int cogdl_hip_sample_adj(const int64_t *indptr, const int64_t *indices, int64_t num_nodes,
-                                    const int64_t *node_idx, int64_t batch, int64_t num_neighbors, int replace,
-                                    uint64_t seed, int64_t *out_indptr, int64_t *out_indices, int64_t *out_nodes,
-                                    int64_t *out_edges, int64_t cap_edges, int64_t *out_counts, void *workspace,
-                                    size_t workspace_bytes, void *stream) {
+static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_t num_nodes, const int64_t *node_idx,
+                           int64_t batch, const int64_t *batch_count, int64_t num_neighbors, int replace, uint64_t seed,
+                           const uint64_t *seed_dev, int padded, int64_t *out_indptr, int64_t *out_indices,
+                           int64_t *out_nodes, int64_t *out_edges, int64_t cap_edges, int64_t *out_counts,
+                           void *workspace, size_t workspace_bytes, void *stream) {
     if (batch < 0 || cap_edges < 0 || num_nodes < 0 || !out_indptr || !out_counts || !workspace) return COGDL_HIP_EINVAL;
     if (batch > 0 && (!indptr || !node_idx || !out_nodes)) return COGDL_HIP_EINVAL;
     if (cap_edges > 0 && (!indices || !out_indices || !out_edges)) return COGDL_HIP_EINVAL;
@@ -233,23 +263,24 @@ extern "C" int cogdl_hip_sample_adj(const int64_t *indptr, const int64_t *indice
         g_last_hip_error = (int)e;
         return COGDL_HIP_ELAUNCH;
     };
-    hipError_t e = hipMemsetAsync(w.flags, 0, sizeof(int), s);
+    hipError_t e = fill_u32_async(w.flags, 0u, 1, s);
     if (e != hipSuccess) return fail(e);
     hipLaunchKernelGGL(sample_counts_kernel, dim3((unsigned)((batch + 256) / 256)), dim3(256), 0, s, indptr, node_idx, batch,
-                       num_nodes, num_neighbors, replace, w.cnt, w.flags);
+                       batch_count, num_nodes, num_neighbors, replace, w.cnt, w.flags);
     size_t tb = w.temp_bytes;
     e = rocprim::exclusive_scan(w.temp, tb, w.cnt, out_indptr, int64_t(0), (size_t)(batch + 1), rocprim::plus<int64_t>(), s);
     if (e != hipSuccess) return fail(e);
     if (len == 0) {
-        e = hipMemsetAsync(out_counts, 0, 3 * sizeof(int64_t), s);
+        e = fill_u32_async(out_counts, 0u, 6, s);
         return e == hipSuccess ? launch_status() : fail(e);
     }
     if (batch > 0)
         hipLaunchKernelGGL(sample_pick_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, s, indptr, indices, node_idx,
-                           batch, num_nodes, num_neighbors, replace, seed, out_indptr, out_edges, w.keys, cap_edges, w.flags);
+                           batch, batch_count, num_nodes, num_neighbors, replace, seed, seed_dev, out_indptr, out_edges, w.keys,
+                           pad_key, cap_edges, w.flags);
     if (cap_edges > 0)
         hipLaunchKernelGGL(sample_pad_kernel, dim3((unsigned)std::min<int64_t>((cap_edges + 255) / 256, 1024)), dim3(256), 0, s,
-                           out_indptr, batch, cap_edges, w.keys, pad_key);
+                           out_indptr, batch, cap_edges, w.keys, pad_key, padded, out_indices, out_edges);
     rocprim::counting_iterator<int32_t> iota(0);
     tb = w.temp_bytes;
     e = rocprim::radix_sort_pairs(w.temp, tb, w.keys, w.skeys, iota, w.spos, (size_t)len, 0u,
@@ -264,6 +295,27 @@ extern "C" int cogdl_hip_sample_adj(const int64_t *indptr, const int64_t *indice
     e = rocprim::inclusive_scan(w.temp, tb, w.head, w.head_of, (size_t)len, MaxOp(), s);
     if (e != hipSuccess) return fail(e);
     hipLaunchKernelGGL(sample_relabel_kernel, dim3(blocks), dim3(256), 0, s, w.skeys, w.spos, w.first, w.rank, w.head_of, len,
-                       batch, pad_key, out_indptr, out_indices, out_nodes, out_counts, w.flags);
+                       batch, pad_key, out_indptr, out_indices, out_nodes, out_counts, w.flags, padded);
     return launch_status();
+}
+
+extern "C" int cogdl_hip_sample_adj(const int64_t *indptr, const int64_t *indices, int64_t num_nodes,
+                                    const int64_t *node_idx, int64_t batch, int64_t num_neighbors, int replace,
+                                    uint64_t seed, int64_t *out_indptr, int64_t *out_indices, int64_t *out_nodes,
+                                    int64_t *out_edges, int64_t cap_edges, int64_t *out_counts, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    return sample_adj_impl(indptr, indices, num_nodes, node_idx, batch, nullptr, num_neighbors, replace, seed, nullptr, 0,
+                           out_indptr, out_indices, out_nodes, out_edges, cap_edges, out_counts, workspace,
+                           workspace_bytes, stream);
+}
+
+extern "C" int cogdl_hip_sample_adj_padded(const int64_t *indptr, const int64_t *indices, int64_t num_nodes,
+                                           const int64_t *node_idx, int64_t batch, const int64_t *batch_count,
+                                           int64_t num_neighbors, int replace, uint64_t seed, const uint64_t *seed_dev,
+                                           int64_t *out_indptr, int64_t *out_indices, int64_t *out_nodes,
+                                           int64_t *out_edges, int64_t cap_edges, int64_t *out_counts, void *workspace,
+                                           size_t workspace_bytes, void *stream) {
+    return sample_adj_impl(indptr, indices, num_nodes, node_idx, batch, batch_count, num_neighbors, replace, seed, seed_dev,
+                           1, out_indptr, out_indices, out_nodes, out_edges, cap_edges, out_counts, workspace,
+                           workspace_bytes, stream);
 }

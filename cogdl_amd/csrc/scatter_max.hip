@@ -298,7 +298,7 @@ extern "C" int cogdl_hip_scatter_max_bwd(const float *grad, const int32_t *max_i
     hipStream_t s = (hipStream_t)stream;
     if (n_src > 0 && k > 0) {
         if (!grad_src) return COGDL_HIP_EINVAL;
-        hipError_t e = hipMemsetAsync(grad_src, 0, (size_t)n_src * (size_t)k * sizeof(float), s);
+        hipError_t e = fill_u32_async(grad_src, 0u, (size_t)n_src * (size_t)k, s);
         if (e != hipSuccess) {
             g_last_hip_error = (int)e;
             return COGDL_HIP_ELAUNCH;

@@ -138,9 +138,9 @@ extern "C" int cogdl_hip_subgraph(const int64_t *indptr, const int64_t *indices,
         g_last_hip_error = (int)e;
         return COGDL_HIP_ELAUNCH;
     };
-    hipError_t e = hipMemsetAsync(w.flags, 0, sizeof(int), s);
+    hipError_t e = fill_u32_async(w.flags, 0u, 1, s);
     if (e != hipSuccess) return fail(e);
-    e = hipMemsetAsync(w.assoc, 0xff, (size_t)std::max<int64_t>(num_nodes, 1) * 4, s);  // -1 everywhere
+    e = fill_u32_async(w.assoc, 0xffffffffu, (size_t)std::max<int64_t>(num_nodes, 1), s);  // -1 everywhere
     if (e != hipSuccess) return fail(e);
     if (batch > 0)
         hipLaunchKernelGGL(subgraph_assoc_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, s, node_idx, batch,

@@ -194,9 +194,38 @@ extern "C" size_t cogdl_hip_csr2csc_workspace_bytes(int64_t m, int64_t n_cols, i
            align_up((size_t)((nnz >> kCoarseShift) + 2) * sizeof(int32_t), 256) + 256;
 }
 
+// Fixed-capacity blocks (sample_adj_padded): colind holds `nnz` slots of which only the first rowptr[m] are edges.  The
+// surplus gets the key n_cols -- behind every real column, so colptr[n_cols] = rowptr[m] and no column reaches it.
+__global__ void padded_keys_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind, int64_t m,
+                                   int64_t nnz, uint32_t n_cols, uint32_t *__restrict__ keys) {
+    const int64_t valid = rowptr[m];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x)
+        keys[e] = e < valid ? (uint32_t)colind[e] : n_cols;
+}
+
+extern "C" size_t cogdl_hip_csr2csc_padded_workspace_bytes(int64_t m, int64_t n_cols, int64_t nnz) {
+    return cogdl_hip_csr2csc_workspace_bytes(m, n_cols + 1, nnz) + align_up((size_t)std::max<int64_t>(nnz, 0) * sizeof(uint32_t), 256);
+}
+
+static int csr2csc_impl(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols, int64_t nnz,
+                        int32_t *colptr, int32_t *rowind, int32_t *perm, void *workspace, size_t workspace_bytes,
+                        void *stream, bool padded);
+
+extern "C" int cogdl_hip_csr2csc_padded(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols,
+                                        int64_t nnz, int32_t *colptr, int32_t *rowind, int32_t *perm, void *workspace,
+                                        size_t workspace_bytes, void *stream) {
+    return csr2csc_impl(rowptr, colind, m, n_cols, nnz, colptr, rowind, perm, workspace, workspace_bytes, stream, true);
+}
+
 extern "C" int cogdl_hip_csr2csc(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols,
                                  int64_t nnz, int32_t *colptr, int32_t *rowind, int32_t *perm, void *workspace,
                                  size_t workspace_bytes, void *stream) {
+    return csr2csc_impl(rowptr, colind, m, n_cols, nnz, colptr, rowind, perm, workspace, workspace_bytes, stream, false);
+}
+
+static int csr2csc_impl(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols, int64_t nnz,
+                        int32_t *colptr, int32_t *rowind, int32_t *perm, void *workspace, size_t workspace_bytes,
+                        void *stream, bool padded) {
     if (m < 0 || n_cols < 0 || nnz < 0 || !colptr) return COGDL_HIP_EINVAL;
     if (nnz > 0x7fffffff) return COGDL_HIP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
@@ -205,14 +234,25 @@ extern "C" int cogdl_hip_csr2csc(const int32_t *rowptr, const int32_t *colind, i
         return launch_status();
     }
     if (!rowptr || !colind || !rowind || !perm || !workspace) return COGDL_HIP_EINVAL;
-    if (workspace_bytes < cogdl_hip_csr2csc_workspace_bytes(m, n_cols, nnz)) return COGDL_HIP_EWORKSPACE;
+    if (workspace_bytes < (padded ? cogdl_hip_csr2csc_padded_workspace_bytes(m, n_cols, nnz)
+                                  : cogdl_hip_csr2csc_workspace_bytes(m, n_cols, nnz)))
+        return COGDL_HIP_EWORKSPACE;
     if (!aligned_to(workspace, 256)) return COGDL_HIP_EALIGN;
+    if (padded && (m == 0 || n_cols >= 0x7fffffff)) return COGDL_HIP_ERANGE;
+    const uint32_t *keys_in = (const uint32_t *)colind;
+    if (padded) {  // (the key buffer sits in front of the ordinary layout)
+        uint32_t *keys = (uint32_t *)workspace;
+        workspace = (char *)workspace + align_up((size_t)nnz * sizeof(uint32_t), 256);
+        hipLaunchKernelGGL(padded_keys_kernel, dim3((unsigned)std::min<int64_t>((nnz + 255) / 256, 4096)), dim3(256), 0, s,
+                           rowptr, colind, m, nnz, (uint32_t)n_cols, keys);
+        keys_in = keys;
+    }
     uint32_t *keys_sorted = (uint32_t *)workspace;
     char *temp = (char *)workspace + align_up((size_t)nnz * sizeof(uint32_t), 256);
     size_t temp_bytes = 0;
-    const unsigned bits = key_bits(n_cols);
+    const unsigned bits = key_bits(padded ? n_cols + 1 : n_cols);
     (void)sort_pairs(nullptr, temp_bytes, nullptr, nullptr, nullptr, nnz, bits, nullptr);
-    hipError_t e = sort_pairs(temp, temp_bytes, (const uint32_t *)colind, keys_sorted, perm, nnz, bits, s);
+    hipError_t e = sort_pairs(temp, temp_bytes, keys_in, keys_sorted, perm, nnz, bits, s);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
         return COGDL_HIP_ELAUNCH;
@@ -273,7 +313,7 @@ extern "C" int cogdl_hip_coo2csr_index(const int64_t *row, int64_t nnz, int64_t 
     if (nnz > 0 && (!row || !perm || !workspace)) return COGDL_HIP_EINVAL;
     if (workspace_bytes < cogdl_hip_coo2csr_index_workspace_bytes(nnz, num_nodes)) return COGDL_HIP_EWORKSPACE;
     if (nnz > 0 && !aligned_to(workspace, 256)) return COGDL_HIP_EALIGN;
-    hipError_t e = hipMemsetAsync(bad_flag, 0, sizeof(int), s);
+    hipError_t e = fill_u32_async(bad_flag, 0u, 1, s);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
         return COGDL_HIP_ELAUNCH;

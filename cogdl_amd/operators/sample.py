@@ -91,6 +91,45 @@ def _sample_adj_gpu(indptr, indices, node_idx, num_neighbors, replace, seed):
     return out_indptr, out_indices[:ne], out_nodes[:nn], out_edges[:ne]
 
 
+def sample_adj_padded(indptr, indices, node_idx, num_neighbors, replace=False, seed=0, seed_dev=None, count=None):
+    """sample_adj into buffers of FIXED capacity (GPU graphs only): no size depends on what was sampled and nothing
+    synchronises, so the call can sit inside a captured hipGraph (cogdl_amd.graphs.capture / torch.cuda.graph).
+
+        node_idx : [B] int64 seed slots, of which `count` (a device int64 scalar tensor; None = all B) are in use
+        seed_dev : device int64 scalar tensor added to `seed` on the device at every launch (a captured step bumps it
+                   in place between replays); None = `seed` alone
+    Returns (row_ptr [B + B*k + 1], col [B*k], nodes [B + B*k], edges [B*k], counts [3] = {N', E', flags}) -- all on the
+    GPU, the unused tails filled as cogdl_hip_sample_adj_padded documents (empty rows, index 0).  The valid prefix is
+    exactly what sample_adj_c returns for the same seed."""
+    dev = indptr.device
+    if not (torch.is_tensor(indptr) and indptr.is_cuda):
+        raise _lib.BackendError("sample_adj_padded: the graph must live on the GPU")
+    num_neighbors = int(num_neighbors)
+    if num_neighbors < 0:
+        raise _lib.BackendError("sample_adj_padded: a fixed capacity needs num_neighbors >= 0")
+    for name, t in (("indptr", indptr), ("indices", indices), ("node_idx", node_idx)):
+        if t.dtype != torch.long or not t.is_contiguous() or t.device != dev:
+            raise _lib.BackendError("sample_adj_padded: %s must be a contiguous int64 tensor on %s" % (name, dev))
+    n, b = indptr.numel() - 1, node_idx.numel()
+    cap_e = b * num_neighbors
+    out_indptr = torch.empty(b + cap_e + 1, dtype=torch.long, device=dev)
+    out_indices = torch.empty(cap_e, dtype=torch.long, device=dev)
+    out_nodes = torch.empty(b + cap_e, dtype=torch.long, device=dev)
+    out_edges = torch.empty(cap_e, dtype=torch.long, device=dev)
+    counts = torch.empty(3, dtype=torch.long, device=dev)
+    lib = _lib.hip()
+    ws_bytes = lib.cogdl_hip_sample_adj_workspace_bytes(b, cap_e, n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with _lib.on_device(dev):
+        rc = lib.cogdl_hip_sample_adj_padded(_lib.ptr(indptr), _lib.ptr(indices), n, _lib.ptr(node_idx), b,
+                                             _lib.ptr(count), num_neighbors, int(bool(replace)), int(seed),
+                                             _lib.ptr(seed_dev), _lib.ptr(out_indptr), _lib.ptr(out_indices),
+                                             _lib.ptr(out_nodes), _lib.ptr(out_edges), cap_e, _lib.ptr(counts),
+                                             _lib.ptr(ws), ws_bytes, _lib.stream_of(indptr))
+    _lib.check(rc, "sample_adj_padded")
+    return out_indptr, out_indices, out_nodes, out_edges, counts
+
+
 def sample_adj_c(indptr, indices, node_idx, num_neighbors, replace, seed=None):
     if torch.is_tensor(indptr) and indptr.is_cuda:
         return _sample_adj_gpu(indptr, indices, node_idx, num_neighbors, replace, seed)

@@ -17,7 +17,7 @@ import os
 import torch
 
 from .. import _lib
-from ..plan import PLANS, Fingerprint, gather_rows
+from ..plan import PLANS, Fingerprint, csr2csc, gather_rows
 
 _lib.hip()  # fail at import if the HIP library is missing (no silent `csrspmm = None`)
 
@@ -162,10 +162,11 @@ class FusedSPMMFunction(torch.autograd.Function):
     gradient), as in CogDL's dispatcher (cogdl/utils/spmm_utils.py:98-109)."""
 
     @staticmethod
-    def forward(ctx, rowptr, colind, feat, edge_weight_csr, out_norm, in_norm, bias, relu):
+    def forward(ctx, rowptr, colind, feat, edge_weight_csr, out_norm, in_norm, bias, relu, transient=False):
         rowptr, colind = _lib.csr_structure(rowptr, colind)
         _check_csr(rowptr, colind, feat)
-        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None
+        ctx.transient = bool(transient)
+        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] and not transient else None
         out = csr_spmm_epilogue_raw(rowptr, colind, edge_weight_csr, feat, out_norm, in_norm, bias, relu)
         ctx.n_src, ctx.relu, ctx.has_bias = feat.shape[0], bool(relu), bias is not None
         ctx.save_for_backward(rowptr, colind, edge_weight_csr, out_norm, in_norm, out if relu else None)
@@ -181,17 +182,34 @@ class FusedSPMMFunction(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[6]:
             grad_bias = g.sum(0)
         if ctx.needs_input_grad[2]:
-            plan = PLANS.get(ctx.fp, rowptr, colind, ctx.n_src)
-            w_t = plan.transposed_values(w) if w is not None else None
+            if ctx.transient:  # a structure that is never seen again: transposed here, nothing hashed or cached or read back
+                plan = csr2csc(rowptr, colind, ctx.n_src, padded=True)
+                w_t = gather_rows(plan.perm, w.detach()) if w is not None else None
+                hubs = True
+            else:
+                plan = PLANS.get(ctx.fp, rowptr, colind, ctx.n_src)
+                w_t = plan.transposed_values(w) if w is not None else None
+                hubs = plan.has_hub_columns()
             grad_feat = csr_spmm_epilogue_raw(plan.colptr, plan.rowind, w_t, g, in_norm, out_norm, None, False,
-                                              split_long_rows=plan.has_hub_columns())
-        return None, None, grad_feat, None, None, None, grad_bias, None
+                                              split_long_rows=hubs)
+        return None, None, grad_feat, None, None, None, grad_bias, None, None
 
 
 def csrspmm_fused(rowptr, colind, x, csr_data=None, out_norm=None, in_norm=None, bias=None, relu=False):
     """relu?( in_norm * csrspmm(rowptr, colind, out_norm * x, csr_data) + bias ) as one operator (fp32).  out_norm:
     [N_src] or [N_src, 1], in_norm: [M] or [M, 1] (Graph.out_norm / Graph.in_norm, cogdl/data/data.py:240-258)."""
     return FusedSPMMFunction.apply(rowptr, colind, x, csr_data, out_norm, in_norm, bias, relu)
+
+
+def csrspmm_block(rowptr, colind, x, csr_data=None, in_norm=None):
+    """in_norm * (A x) for a SAMPLED block (fp32): a structure that changes with every mini-batch, so the backward
+    transposes it on the spot instead of hashing it into the plan cache (no structure hash, no pinned read-back, no
+    host synchronisation anywhere -- the call can be captured in a hipGraph, and the transposes of a million
+    mini-batches do not pile up in the cache).  `rowptr` may describe fewer edges than `colind` holds
+    (rowptr[-1] <= len(colind): the fixed-capacity blocks of sample_adj_padded); the surplus entries are ignored in both
+    directions (they only cost time).
+    in_norm = 1 / in-degree gives the mean aggregator (Graph.row_norm, cogdl/data/data.py:240-258)."""
+    return FusedSPMMFunction.apply(rowptr, colind, x, csr_data, None, in_norm, None, False, True)
 
 
 def csrspmm(rowptr, colind, x, csr_data, sym=False, actnn=False):

@@ -16,7 +16,7 @@ the GPU (cogdl/models/nn/graphsage.py:86-99).  Here, for a graph whose structure
 import torch
 
 from . import _lib
-from .operators.sample import sample_adj_c
+from .operators.sample import sample_adj_c, sample_adj_padded
 
 
 def gather_rows_by_id(src, ids, out=None):
@@ -75,6 +75,31 @@ def sample_blocks(indptr, indices, seeds, fanouts):
         adjs.append(((row_ptr, col), batch.numel()))
         batch = nodes
     return batch, adjs[::-1]
+
+
+HOP_SEED_STRIDE = 0x9E3779B97F4A7C15  # the hops of one batch draw from seeds this far apart
+
+
+def sample_blocks_padded(indptr, indices, seeds, fanouts, seed=0, seed_dev=None):
+    """sample_blocks with every size fixed by (len(seeds), fanouts) -- nothing depends on what was sampled, nothing
+    synchronises: the form a captured step needs (cogdl_amd.graphs.capture).  Hop h samples len(seeds_h) * fanout_h
+    edge slots for its seed slots (of which the previous hop's device-side node count are in use).
+
+    Returns (n_id, adjs, counts): n_id [cap] (unused slots hold id 0), adjs = [((row_ptr, col), n_dst_slots), ...]
+    innermost block first exactly like sample_blocks -- row_ptr is padded to ALL node slots of the block, col holds
+    local ids (< the number of nodes in use) with the unused slots set to 0 behind row_ptr[-1] --, and counts = the
+    per-hop device tensors {nodes, edges, flags} (first hop first) for whoever wants to look (that read synchronises).
+    The in-use prefix of every output equals sample_blocks' result for the same per-hop seeds."""
+    adjs, counts = [], []
+    batch, count = seeds, None
+    for hop, k in enumerate(fanouts):
+        hop_seed = (int(seed) + hop * HOP_SEED_STRIDE) % (1 << 64)
+        row_ptr, col, nodes, _, cnt = sample_adj_padded(indptr, indices, batch, k, False, seed=hop_seed, seed_dev=seed_dev,
+                                                         count=count)
+        adjs.append(((row_ptr, col), batch.numel()))
+        counts.append(cnt)
+        batch, count = nodes, cnt[0:1]
+    return batch, adjs[::-1], counts
 
 
 class BatchPipeline:

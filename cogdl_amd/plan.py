@@ -66,8 +66,9 @@ def tensor_key(t):
     return (t.data_ptr(), t._version, t.dtype, tuple(t.shape), tuple(t.stride()), t.device.index)
 
 
-def csr2csc(rowptr, colind, n_cols=None):
-    """Stable transpose of the structure -> CscPlan (device tensors, int32)."""
+def csr2csc(rowptr, colind, n_cols=None, padded=False):
+    """Stable transpose of the structure -> CscPlan (device tensors, int32).  padded: `colind` is a fixed-capacity
+    buffer of which only the first rowptr[-1] entries (read on the device) are edges (cogdl_hip_csr2csc_padded)."""
     dev = _lib.require_cuda(rowptr, colind)
     m = rowptr.numel() - 1
     nnz = colind.numel()
@@ -76,11 +77,13 @@ def csr2csc(rowptr, colind, n_cols=None):
     rowind = torch.empty(nnz, dtype=torch.int32, device=dev)
     perm = torch.empty(nnz, dtype=torch.int32, device=dev)
     lib = _lib.hip()
-    ws_bytes = lib.cogdl_hip_csr2csc_workspace_bytes(m, n_cols, nnz)
+    query, fn = ((lib.cogdl_hip_csr2csc_padded_workspace_bytes, lib.cogdl_hip_csr2csc_padded) if padded
+                 else (lib.cogdl_hip_csr2csc_workspace_bytes, lib.cogdl_hip_csr2csc))
+    ws_bytes = query(m, n_cols, nnz)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     with _lib.on_device(dev):
-        rc = lib.cogdl_hip_csr2csc(_lib.ptr(rowptr), _lib.ptr(colind), m, n_cols, nnz, _lib.ptr(colptr),
-                                   _lib.ptr(rowind), _lib.ptr(perm), _lib.ptr(ws), ws_bytes, _lib.stream_of(rowptr))
+        rc = fn(_lib.ptr(rowptr), _lib.ptr(colind), m, n_cols, nnz, _lib.ptr(colptr), _lib.ptr(rowind), _lib.ptr(perm),
+                _lib.ptr(ws), ws_bytes, _lib.stream_of(rowptr))
     _lib.check(rc, "csr2csc")
     return CscPlan(colptr, rowind, perm, m, n_cols, nnz)
 

@@ -140,6 +140,13 @@ COGDL_API size_t cogdl_hip_csr2csc_workspace_bytes(int64_t m, int64_t n_cols, in
 COGDL_API int cogdl_hip_csr2csc(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols,
                       int64_t nnz, int32_t *colptr, int32_t *rowind, int32_t *perm,
                       void *workspace, size_t workspace_bytes, void *stream);
+/* The same for a fixed-capacity block (cogdl_hip_sample_adj_padded): colind holds `nnz` slots, the first rowptr[m]
+ * (read on the device) are edges, the rest is ignored -- colptr[n_cols] = rowptr[m]; rowind / perm hold that many
+ * meaningful entries (the tail is unspecified but in range).  Launch shapes depend on the capacity only. */
+COGDL_API size_t cogdl_hip_csr2csc_padded_workspace_bytes(int64_t m, int64_t n_cols, int64_t nnz);
+COGDL_API int cogdl_hip_csr2csc_padded(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols,
+                             int64_t nnz, int32_t *colptr, int32_t *rowind, int32_t *perm, void *workspace,
+                             size_t workspace_bytes, void *stream);
 
 /* out[i, 0:h] = src[perm[i], 0:h]  (elem_bytes in {2,4}).
  * Replaces mhtranspose.mhtranspose (operators/spmm/mhTranspose.cu:6-49) and the value leg
@@ -317,6 +324,25 @@ COGDL_API int cogdl_hip_sample_adj(const int64_t *indptr, const int64_t *indices
                          uint64_t seed, int64_t *out_indptr, int64_t *out_indices, int64_t *out_nodes,
                          int64_t *out_edges, int64_t cap_edges, int64_t *out_counts, void *workspace,
                          size_t workspace_bytes, void *stream);
+
+/* sample_adj into buffers of a FIXED capacity, for mini-batch steps captured in a hipGraph (every launch shape is a
+ * function of the capacities, never of what was sampled):
+ *   batch        = the number of seed SLOTS; *batch_count (device, NULL = all) of them are in use -- hop 2 passes hop 1's
+ *                  out_nodes with out_counts[0] as its count;
+ *   seed_dev     = device pointer to the RNG seed, NULL = none: the draws use seed + *seed_dev, so the caller bumps the
+ *                  device word between replays and tells the hops of one batch apart by the immediate `seed`;
+ *   out_indptr   holds batch + cap_edges + 1 entries: rows beyond the seeds in use are empty (= E'), so the block is a
+ *                  well-formed CSR over all batch + cap_edges possible nodes (the padding of cogdl/data/data.py:828-830
+ *                  at full capacity);
+ *   out_indices / out_edges beyond E' are 0, out_nodes beyond N' are 0 (valid ids: a feature gather over the whole
+ *                  capacity reads row 0 for them).
+ * Everything else as cogdl_hip_sample_adj (same workspace query). */
+COGDL_API int cogdl_hip_sample_adj_padded(const int64_t *indptr, const int64_t *indices, int64_t num_nodes,
+                                const int64_t *node_idx, int64_t batch, const int64_t *batch_count,
+                                int64_t num_neighbors, int replace, uint64_t seed, const uint64_t *seed_dev,
+                                int64_t *out_indptr, int64_t *out_indices, int64_t *out_nodes, int64_t *out_edges,
+                                int64_t cap_edges, int64_t *out_counts, void *workspace, size_t workspace_bytes,
+                                void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Graph preprocessing on the GPU (what cogdl.data.Graph does once per graph before its first SpMM), int64 COO in and out:

@@ -1,0 +1,214 @@
+"""Fixed-capacity sampled blocks and the captured mini-batch step (BASELINE.json configs[3]):
+cogdl_hip_sample_adj_padded against cogdl_hip_sample_adj, cogdl_hip_csr2csc_padded / csrspmm_block against the ordinary
+operators on the trimmed block, and a whole GraphSAGE step replayed as one hipGraph against the same step run eagerly
+and against the reference-shaped (unpadded, synchronising) step."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cogdl_amd import _lib, graphs, synth
+from cogdl_amd.operators.sample import sample_adj_c, sample_adj_padded
+from cogdl_amd.operators.spmm import csrspmm, csrspmm_block
+from cogdl_amd.pipeline import HOP_SEED_STRIDE, gather_rows_by_id, sample_blocks_padded
+from cogdl_amd.plan import csr2csc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _graph(n, deg, seed, topology="rmat"):
+    g = synth.scaled(n, deg, seed=seed, topology=topology, norm=None, self_loops=False)
+    return g.rowptr.long().to(DEV), g.colind.long().to(DEV)
+
+
+@pytest.mark.parametrize("k,replace", [(10, False), (3, False), (5, True), (0, False)])
+@pytest.mark.parametrize("in_use", [None, 37, 0])
+def test_sample_adj_padded_prefix_equals_sample_adj_and_tails_are_benign(k, replace, in_use):
+    indptr, indices = _graph(4000, 9, seed=k)
+    gen = torch.Generator().manual_seed(5)
+    seeds = torch.randperm(4000, generator=gen)[:100].to(DEV)
+    count = None if in_use is None else torch.tensor([in_use], device=DEV)
+    seed_dev = torch.tensor([41], device=DEV)
+    row_ptr, col, nodes, edges, counts = sample_adj_padded(indptr, indices, seeds, k, replace, seed=1000, seed_dev=seed_dev,
+                                                           count=count)
+    b = 100 if in_use is None else in_use
+    nn, ne, flags = counts.tolist()
+    assert flags == 0
+    assert row_ptr.numel() == 100 + 100 * k + 1 and col.numel() == 100 * k and nodes.numel() == 100 + 100 * k
+    w_rp, w_col, w_nodes, w_edges = sample_adj_c(indptr, indices, seeds[:b], k, replace, seed=1041)
+    assert nn == w_nodes.numel() and ne == w_col.numel()
+    assert torch.equal(row_ptr[: nn + 1], w_rp) and torch.equal(col[:ne], w_col)
+    assert torch.equal(nodes[:nn], w_nodes) and torch.equal(edges[:ne], w_edges)
+    # tails: empty rows, index 0 everywhere
+    assert bool((row_ptr[nn:] == ne).all()) and bool((col[ne:] == 0).all()) and bool((nodes[nn:] == 0).all())
+    assert bool((edges[ne:] == 0).all())
+
+
+def test_sample_adj_padded_rejects_what_has_no_fixed_capacity():
+    indptr, indices = _graph(100, 4, seed=1)
+    seeds = torch.arange(10, device=DEV)
+    with pytest.raises(_lib.BackendError):
+        sample_adj_padded(indptr, indices, seeds, -1)
+    with pytest.raises(_lib.BackendError):
+        sample_adj_padded(indptr.cpu(), indices.cpu(), seeds.cpu(), 3)
+    _, _, _, _, counts = sample_adj_padded(indptr, indices, torch.tensor([3, 100], device=DEV), 3)
+    assert int(counts[2]) & 1  # a seed outside the graph is flagged, not fatal on the device
+
+
+@pytest.mark.parametrize("surplus", [0, 1, 777])
+def test_csr2csc_padded_ignores_the_slots_behind_the_last_row(surplus):
+    g = synth.random_csr(300, 500, 7, seed=surplus)
+    rp, ci = g.rowptr.to(DEV), g.colind.to(DEV)
+    junk = torch.randint(0, 500, (surplus,), dtype=torch.int32, device=DEV)
+    want = csr2csc(rp, ci, 500)
+    got = csr2csc(rp, torch.cat([ci, junk]), 500, padded=True)
+    nnz = ci.numel()
+    assert torch.equal(got.colptr, want.colptr)
+    assert torch.equal(got.rowind[:nnz], want.rowind) and torch.equal(got.perm[:nnz], want.perm)
+    assert int(got.rowind.max()) < 300 and int(got.rowind.min()) >= 0  # the tail stays in range
+
+
+@pytest.mark.parametrize("f", [100, 128, 47])
+def test_csrspmm_block_on_a_padded_block_equals_csrspmm_on_the_trimmed_one(oracle, f):
+    indptr, indices = _graph(20000, 12, seed=f)
+    seeds = torch.randperm(20000, device=DEV)[:256]
+    row_ptr, col, nodes, _, counts = sample_adj_padded(indptr, indices, seeds, 10, seed=f)
+    nn, ne, flags = counts.tolist()
+    assert flags == 0 and ne < col.numel()  # (there IS a surplus: low-degree seeds, duplicates)
+    n_dst, n_src_cap = 256, nodes.numel()
+    rp = row_ptr[: n_dst + 1].int()
+    deg = (rp[1:] - rp[:-1])
+    inv = 1.0 / deg.clamp(min=1).float()
+    x = torch.randn(n_src_cap, f, device=DEV, requires_grad=True)
+    out = csrspmm_block(rp, col.int(), x, None, inv)
+    gr = torch.randn_like(out)
+    out.backward(gr)
+    # the ordinary operator on the trimmed block, weights = 1 / in-degree per edge (Graph.row_norm)
+    x2 = x.detach().clone().requires_grad_()
+    w = torch.repeat_interleave(inv, deg.long())
+    want = csrspmm(rp, col[:ne].int(), x2, w)
+    want.backward(gr)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), x2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert bool((x.grad[nn:] == 0).all())  # node slots not in use receive nothing
+    # and against the CPU oracle
+    ref = oracle.csr_spmm(rp.cpu(), col[:ne].int().cpu(), w.cpu(), x.detach().cpu())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+
+
+def _models():
+    from tools.sage_bench import Sage
+
+    torch.manual_seed(0)
+    a = Sage(32, 64, 7).to(DEV)
+    return a, copy.deepcopy(a)
+
+
+def test_captured_graphsage_step_equals_the_eager_step_and_the_reference_shaped_step():
+    n, b, fan = 30000, 128, [10, 10]
+    indptr, indices = _graph(n, 14, seed=3)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    x_all = torch.randn(n, 32, device=DEV, generator=gen)
+    y_all = torch.randint(0, 7, (n,), device=DEV, generator=gen)
+    order = torch.randperm(n, device=DEV, generator=gen)
+    m_cap, m_eag = _models()
+    m_cap.eval(), m_eag.eval()  # (dropout off: the three paths must agree number for number)
+
+    def make_step(model, seeds_buf, seed_dev, opt):
+        def step():
+            n_id, adjs, counts = sample_blocks_padded(indptr, indices, seeds_buf, fan, seed=77, seed_dev=seed_dev)
+            xb = gather_rows_by_id(x_all, n_id)
+            opt.zero_grad(set_to_none=True)
+            loss = F.cross_entropy(model.forward_padded(xb, adjs), y_all.index_select(0, seeds_buf))
+            loss.backward()
+            opt.step()
+            seed_dev.add_(1)
+            return loss, counts
+        return step
+
+    # ---- the reference-shaped step on the same draws: unpadded blocks (sizes read back), csrspmm + plan cache
+    ref_model = copy.deepcopy(m_eag)
+    seeds0 = order[:b].clone()
+    batch, adjs = seeds0, []
+    for hop, k in enumerate(fan):
+        rp, col, nodes, _ = sample_adj_c(indptr, indices, batch, k, False, seed=(77 + hop * HOP_SEED_STRIDE) % (1 << 64))
+        adjs.append(((rp, col), batch.numel()))
+        batch = nodes
+    ref_loss = F.cross_entropy(ref_model(x_all[batch], adjs[::-1]), y_all[seeds0])
+    ref_loss.backward()
+
+    # ---- eager padded steps
+    buf_e, sd_e = order[:b].clone(), torch.zeros(1, dtype=torch.long, device=DEV)
+    opt_e = torch.optim.Adam(m_eag.parameters(), lr=0.01, capturable=True)
+    step_e = make_step(m_eag, buf_e, sd_e, opt_e)
+    first_grads = None
+    eager_losses = []
+    for i in range(4):
+        buf_e.copy_(order[i * b:(i + 1) * b])
+        loss, counts = step_e()
+        assert int(counts[0][2]) == 0 and int(counts[1][2]) == 0
+        eager_losses.append(float(loss.detach()))
+        if i == 0:
+            first_grads = [p.grad.clone() for p in m_eag.parameters()]
+    assert abs(eager_losses[0] - float(ref_loss)) <= 1e-5 * max(1.0, abs(float(ref_loss)))
+    for g_pad, p_ref in zip(first_grads, ref_model.parameters()):
+        np.testing.assert_allclose(g_pad.cpu().numpy(), p_ref.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+    # ---- the same four steps as replays of one captured graph.  capture() runs the step 3 + 1 times while it warms
+    # up and records (weights and seed counter move): both are put back before the comparison starts.
+    buf_c, sd_c = order[:b].clone(), torch.zeros(1, dtype=torch.long, device=DEV)
+    opt_c = torch.optim.Adam(m_cap.parameters(), lr=0.01, capturable=True)
+    init = copy.deepcopy(m_cap.state_dict())
+    replay = graphs.capture(make_step(m_cap, buf_c, sd_c, opt_c), warmup=3)
+    m_cap.load_state_dict(init)
+    for st in opt_c.state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                v.zero_()
+    sd_c.zero_()
+    cap_losses = []
+    for i in range(4):
+        buf_c.copy_(order[i * b:(i + 1) * b])
+        loss, counts = replay()
+        cap_losses.append(float(loss.detach()))
+    np.testing.assert_allclose(cap_losses, eager_losses, rtol=1e-6)
+    for pc, pe in zip(m_cap.parameters(), m_eag.parameters()):
+        np.testing.assert_allclose(pc.detach().cpu().numpy(), pe.detach().cpu().numpy(), rtol=1e-5, atol=1e-7)
+    assert int(sd_c) == 4
+
+
+def test_captured_step_in_training_mode_keeps_the_sampler_flags_clean():
+    """Dropout masks (bytes of 0x01) and the sampler's scratch share the graph's memory pool: the flag word of every
+    replay must still start from zero (it is cleared by a kernel node; small hipMemsetAsync nodes did not replay)."""
+    n, b = 30000, 256
+    indptr, indices = _graph(n, 14, seed=4)
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    x_all = torch.randn(n, 32, device=DEV, generator=gen)
+    y_all = torch.randint(0, 7, (n,), device=DEV, generator=gen)
+    order = torch.randperm(n, device=DEV, generator=gen)
+    model, _ = _models()
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+    seeds_buf, seed_dev = order[:b].clone(), torch.zeros(1, dtype=torch.long, device=DEV)
+
+    def step():
+        n_id, adjs, counts = sample_blocks_padded(indptr, indices, seeds_buf, [10, 10], seed=5, seed_dev=seed_dev)
+        opt.zero_grad(set_to_none=True)
+        loss = F.cross_entropy(model.forward_padded(gather_rows_by_id(x_all, n_id), adjs), y_all.index_select(0, seeds_buf))
+        loss.backward()
+        opt.step()
+        seed_dev.add_(1)
+        return loss, counts
+
+    replay = graphs.capture(step, warmup=3)
+    seen = set()
+    for i in range(6):
+        seeds_buf.copy_(order[i * b:(i + 1) * b])
+        loss, counts = replay()
+        assert int(counts[0][2]) == 0 and int(counts[1][2]) == 0, (i, counts)
+        assert bool(torch.isfinite(loss))
+        seen.add((int(counts[0][0]), int(counts[1][0])))
+    assert len(seen) > 1  # different seeds and a moving RNG seed: the replays sample different frontiers

@@ -24,8 +24,10 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cogdl_amd import synth  # noqa: E402
-from cogdl_amd.operators.spmm import csrspmm  # noqa: E402
-from cogdl_amd.pipeline import BatchPipeline, gather_rows_by_id, layerwise_inference, sample_blocks  # noqa: E402
+from cogdl_amd import graphs  # noqa: E402
+from cogdl_amd.operators.spmm import csrspmm, csrspmm_block  # noqa: E402
+from cogdl_amd.pipeline import (BatchPipeline, gather_rows_by_id, layerwise_inference, sample_blocks,  # noqa: E402
+                                sample_blocks_padded)
 
 
 class SageMean(torch.nn.Module):
@@ -42,6 +44,16 @@ class SageMean(torch.nn.Module):
         h = csrspmm(row_ptr.int(), col.int(), x, w)  # the .int() copies CogDL's dispatcher makes (spmm_utils.py:106)
         return self.fc(torch.cat([x, h], dim=-1))
 
+    def forward_padded(self, block, n_dst, x):
+        """The same layer on a fixed-capacity block (sample_blocks_padded), for the n_dst target slots only (the
+        caller keeps just those rows anyway, graphsage.py:99): the mean is the SpMM's in_norm epilogue, the block's
+        transpose for the backward is taken on the spot (csrspmm_block) -- every shape is static, nothing syncs."""
+        row_ptr, col = block
+        rp = row_ptr[: n_dst + 1].int()
+        deg = rp[1:] - rp[:-1]
+        h = csrspmm_block(rp, col.int(), x, None, 1.0 / deg.clamp(min=1).float())
+        return self.fc(torch.cat([x[:n_dst], h], dim=-1))
+
 
 class Sage(torch.nn.Module):
     def __init__(self, feats, hidden, classes):
@@ -54,6 +66,57 @@ class Sage(torch.nn.Module):
             if i != len(adjs) - 1:
                 x = F.dropout(F.relu(x), p=0.5, training=self.training)
         return x
+
+    def forward_padded(self, x, adjs):
+        for i, (block, n_dst) in enumerate(adjs):
+            x = self.convs[i].forward_padded(block, n_dst, x)
+            if i != len(adjs) - 1:
+                x = F.dropout(F.relu(x), p=0.5, training=self.training)
+        return x
+
+
+def captured_training(args, dev, n, indptr, indices, x_all, y_all, model, gen):
+    """--captured: the whole mini-batch step -- both sampling hops, the feature gather, forward, backward, Adam -- as ONE
+    hipGraph launch per step.  Every buffer has the capacity B * (1 + 10) * (1 + 10) node slots; the RNG seed lives in
+    device memory and is bumped inside the graph; the seeds of a step are copied into a static buffer before the replay."""
+    b = args.batch
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+    order = torch.randperm(n, device=dev, generator=gen)  # distinct seeds per batch, as a DataLoader over the train set gives
+    seeds_buf = order[:b].clone()
+    seed_dev = torch.zeros(1, dtype=torch.long, device=dev)
+
+    def step():
+        n_id, adjs, counts = sample_blocks_padded(indptr, indices, seeds_buf, [10, 10], seed=20240, seed_dev=seed_dev)
+        xb = gather_rows_by_id(x_all, n_id)
+        opt.zero_grad(set_to_none=True)
+        loss = F.cross_entropy(model.forward_padded(xb, adjs), y_all.index_select(0, seeds_buf))
+        loss.backward()
+        opt.step()
+        seed_dev.add_(1)
+        return loss, counts
+
+    model.train()
+    replay = graphs.capture(step, warmup=3)
+    n_batches = n // b
+    for i in range(args.warmup):
+        seeds_buf.copy_(order[(i % n_batches) * b:(i % n_batches + 1) * b])
+        replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nodes = torch.zeros((), dtype=torch.long, device=dev)
+    edges = torch.zeros((), dtype=torch.long, device=dev)
+    for i in range(args.steps):
+        k = (args.warmup + i) % n_batches
+        seeds_buf.copy_(order[k * b:(k + 1) * b])
+        loss, counts = replay()
+        nodes += counts[-1][0]
+        edges += counts[0][1] + counts[1][1]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    flags = int(counts[0][2]) | int(counts[1][2])
+    if flags or not bool(torch.isfinite(loss)):
+        raise SystemExit("captured step: sampler flags %d, loss %s" % (flags, float(loss)))
+    return dt, b * args.steps, int(nodes), int(edges)
 
 
 def main():
@@ -69,6 +132,8 @@ def main():
     ap.add_argument("--features", default="hbm", choices=["hbm", "host"],
                     help="host: the feature matrix stays in PINNED host memory and x[n_id] is gathered zero-copy over the host link")
     ap.add_argument("--pipeline", action="store_true", help="sample + gather batch i+1 on a side stream while batch i trains")
+    ap.add_argument("--captured", action="store_true",
+                    help="fixed-capacity blocks, the whole step (sampling included) replayed as one hipGraph (single GPU)")
     ap.add_argument("--inference", action="store_true", help="also time layer-wise full-neighbour inference over all nodes")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -109,14 +174,20 @@ def main():
         return train_on(seeds, n_id, adjs, gather_rows_by_id(x_all, n_id), y_all[seeds])
 
     net.train()
-    for _ in range(args.warmup):
-        step()
+    if not args.captured:
+        for _ in range(args.warmup):
+            step()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     seeds = nodes = edges = 0
-    if args.pipeline:
+    if args.captured:
+        if world > 1:
+            raise SystemExit("--captured is the single-GPU step (DDP's bucketed all-reduce is not captured here)")
+        secs, seeds, nodes, edges = captured_training(args, dev, n, indptr, indices, x_all, y_all, model, gen)
+        t0 = time.perf_counter() - secs
+    elif args.pipeline:
         batches = [draw_seeds() for _ in range(args.steps)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -171,7 +242,8 @@ def main():
             "batch": args.batch, "frontier_nodes_per_step": nodes // args.steps, "sampled_edges_per_step": edges // args.steps,
             "config": {"nodes": n, "nnz": int(g.nnz), "feat": args.feat, "hidden": args.hidden, "classes": args.classes,
                        "sampler": "cogdl_hip_sample_adj (GPU-resident graph)", "features": "resident in HBM" if args.features == "hbm" else "pinned host memory, zero-copy gather",
-                       "pipeline": "next batch sampled + gathered on a side stream" if args.pipeline else "none",
+                       "pipeline": ("whole step (2 sampling hops, gather, fwd, bwd, Adam) = one hipGraph replay over fixed-capacity blocks" if args.captured
+                                    else "next batch sampled + gathered on a side stream" if args.pipeline else "none"),
                        "parallelism": "replicas + DDP all-reduce (RCCL)" if world > 1 else "single GPU"}}))
     if world > 1:
         torch.distributed.destroy_process_group()
