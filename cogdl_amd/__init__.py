@@ -8,3 +8,4 @@ operators underneath CogDL's unchanged dispatcher (cogdl/utils/spmm_utils.py) an
 __version__ = "0.1.0"
 
 from .install import install, uninstall  # noqa: F401
+from .plan import transient_structures  # noqa: F401

@@ -17,6 +17,7 @@ import os
 import torch
 
 from .. import _lib
+from .. import plan as _plan
 from ..plan import PLANS, Fingerprint, csr2csc, gather_rows
 
 _lib.hip()  # fail at import if the HIP library is missing (no silent `csrspmm = None`)
@@ -102,7 +103,8 @@ class SPMMFunction(torch.autograd.Function):
         # kernel, not behind the SpMM).
         rowptr, colind = _lib.csr_structure(rowptr, colind)  # validated + contiguous before anything reads raw pointers
         _check_csr(rowptr, colind, feat)
-        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None
+        ctx.transient = _plan.transient()
+        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] and not ctx.transient else None
         out = csr_spmm_raw(rowptr, colind, edge_weight_csr, feat)
         need_w = edge_weight_csr is not None and ctx.needs_input_grad[3]
         ctx.n_src = feat.shape[0]
@@ -116,9 +118,15 @@ class SPMMFunction(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         grad_feat = grad_w = None
         if ctx.needs_input_grad[2]:
-            plan = PLANS.get(ctx.fp, rowptr, colind, ctx.n_src)
-            w_t = plan.transposed_values(w) if w is not None else None
-            grad_feat = csr_spmm_raw(plan.colptr, plan.rowind, w_t, grad_out, split_long_rows=plan.has_hub_columns())
+            if ctx.transient:  # (plan.transient_structures: a one-off structure, transposed here, nothing cached or read back)
+                plan = csr2csc(rowptr, colind, ctx.n_src, padded=True)
+                w_t = gather_rows(plan.perm, w.detach()) if w is not None else None
+                hubs = True
+            else:
+                plan = PLANS.get(ctx.fp, rowptr, colind, ctx.n_src)
+                w_t = plan.transposed_values(w) if w is not None else None
+                hubs = plan.has_hub_columns()
+            grad_feat = csr_spmm_raw(plan.colptr, plan.rowind, w_t, grad_out, split_long_rows=hubs)
         if w is not None and ctx.needs_input_grad[3]:
             grad_w = csr_sddmm_raw(rowptr, colind, grad_out, feat.detach()).to(w.dtype)
         return None, None, grad_feat, grad_w, None
@@ -165,8 +173,8 @@ class FusedSPMMFunction(torch.autograd.Function):
     def forward(ctx, rowptr, colind, feat, edge_weight_csr, out_norm, in_norm, bias, relu, transient=False):
         rowptr, colind = _lib.csr_structure(rowptr, colind)
         _check_csr(rowptr, colind, feat)
-        ctx.transient = bool(transient)
-        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] and not transient else None
+        ctx.transient = bool(transient) or _plan.transient()
+        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] and not ctx.transient else None
         out = csr_spmm_epilogue_raw(rowptr, colind, edge_weight_csr, feat, out_norm, in_norm, bias, relu)
         ctx.n_src, ctx.relu, ctx.has_bias = feat.shape[0], bool(relu), bias is not None
         ctx.save_for_backward(rowptr, colind, edge_weight_csr, out_norm, in_norm, out if relu else None)

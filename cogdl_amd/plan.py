@@ -15,6 +15,7 @@ perm[j] is the CSR position of CSC entry j, so per-call edge values are moved wi
 gather.  The cache holds 8 bytes per edge; eviction is by byte budget.
 """
 import collections
+import contextlib
 import os
 
 import torch
@@ -144,6 +145,29 @@ _TAPE = None
 def set_tape(tape):
     global _TAPE
     _TAPE = tape
+
+
+_TRANSIENT = 0
+
+
+@contextlib.contextmanager
+def transient_structures():
+    """Inside this context the SpMM operators treat every CSR structure they are called with as one they will never
+    see again -- the sampled blocks of mini-batch training: nothing is hashed, cached or read back; a backward pass
+    transposes its structure on the spot (cogdl_hip_csr2csc_padded, so `colind` may be a fixed-capacity buffer with
+    unused slots behind rowptr[-1]).  That makes a whole sampled step free of host synchronisation (capturable in a
+    hipGraph) and keeps a million one-off transposes out of the plan cache.  The mode is latched per call in forward:
+    the backward of a call made inside the context is transient wherever it runs."""
+    global _TRANSIENT
+    _TRANSIENT += 1
+    try:
+        yield
+    finally:
+        _TRANSIENT -= 1
+
+
+def transient():
+    return _TRANSIENT > 0
 
 
 class Fingerprint:

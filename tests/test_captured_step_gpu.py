@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from cogdl_amd import _lib, graphs, synth
 from cogdl_amd.operators.sample import sample_adj_c, sample_adj_padded
 from cogdl_amd.operators.spmm import csrspmm, csrspmm_block
-from cogdl_amd.pipeline import HOP_SEED_STRIDE, gather_rows_by_id, sample_blocks_padded
+from cogdl_amd.pipeline import CapturedMiniBatchStep, HOP_SEED_STRIDE, gather_rows_by_id, sample_blocks_padded
 from cogdl_amd.plan import csr2csc
 
 pytestmark = pytest.mark.gpu
@@ -153,6 +153,7 @@ def test_captured_graphsage_step_equals_the_eager_step_and_the_reference_shaped_
         eager_losses.append(float(loss.detach()))
         if i == 0:
             first_grads = [p.grad.clone() for p in m_eag.parameters()]
+    ref_loss = ref_loss.detach()
     assert abs(eager_losses[0] - float(ref_loss)) <= 1e-5 * max(1.0, abs(float(ref_loss)))
     for g_pad, p_ref in zip(first_grads, ref_model.parameters()):
         np.testing.assert_allclose(g_pad.cpu().numpy(), p_ref.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
@@ -192,23 +193,115 @@ def test_captured_step_in_training_mode_keeps_the_sampler_flags_clean():
     model, _ = _models()
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
-    seeds_buf, seed_dev = order[:b].clone(), torch.zeros(1, dtype=torch.long, device=DEV)
-
-    def step():
-        n_id, adjs, counts = sample_blocks_padded(indptr, indices, seeds_buf, [10, 10], seed=5, seed_dev=seed_dev)
-        opt.zero_grad(set_to_none=True)
-        loss = F.cross_entropy(model.forward_padded(gather_rows_by_id(x_all, n_id), adjs), y_all.index_select(0, seeds_buf))
-        loss.backward()
-        opt.step()
-        seed_dev.add_(1)
-        return loss, counts
-
-    replay = graphs.capture(step, warmup=3)
+    step = CapturedMiniBatchStep(indptr, indices, x_all, y_all, model.forward_padded, opt, order[:b], [10, 10], seed=5)
     seen = set()
     for i in range(6):
-        seeds_buf.copy_(order[i * b:(i + 1) * b])
-        loss, counts = replay()
-        assert int(counts[0][2]) == 0 and int(counts[1][2]) == 0, (i, counts)
+        loss = step(order[i * b:(i + 1) * b])
+        step.check()
         assert bool(torch.isfinite(loss))
-        seen.add((int(counts[0][0]), int(counts[1][0])))
+        seen.add((int(step.counts[0][0]), int(step.counts[1][0])))
     assert len(seen) > 1  # different seeds and a moving RNG seed: the replays sample different frontiers
+    assert int(step.seed_dev) == 3 + 6  # 3 warm-up runs (the capture pass records, it does not execute) + 6 replays
+
+
+REFERENCE_SCRIPT = r'''
+import copy, json, sys
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT)
+from tools import refpkg
+refpkg.setup(install=True)
+import torch
+import torch.nn.functional as F
+import cogdl_amd
+from cogdl.data import Graph
+from cogdl.models.nn.graphsage import Graphsage
+from cogdl_amd import graphs, synth
+from cogdl_amd.operators.sample import sample_adj_c
+from cogdl_amd.pipeline import CapturedMiniBatchStep, HOP_SEED_STRIDE, gather_rows_by_id, sample_blocks_padded
+
+DEV = "cuda:0"
+n, b, fan = 30000, 128, [10, 10]
+g = synth.scaled(n, 14, seed=3, topology="rmat", norm=None, self_loops=False)
+indptr, indices = g.rowptr.long().to(DEV), g.colind.long().to(DEV)
+gen = torch.Generator(device=DEV).manual_seed(1)
+x_all = torch.randn(n, 32, device=DEV, generator=gen)
+y_all = torch.randint(0, 7, (n,), device=DEV, generator=gen)
+order = torch.randperm(n, device=DEV, generator=gen)
+torch.manual_seed(0)
+model = Graphsage(32, 7, [64], 2, fan, 0.5, "mean").to(DEV).eval()   # the reference's class, unchanged
+twin = copy.deepcopy(model)
+
+def adjs_of(blocks):   # what NeighborSampler hands the model (cogdl/data/sampler.py:105-116): (n_id, Graph, size)
+    # (unit weights given explicitly, one per edge SLOT: left to itself Adjacency.get_weight sizes them by
+    #  row_ptr[-1], cogdl/data/data.py:158-159,330-331 -- a host read, and fewer than the block has slots)
+    return [(None, Graph(row_ptr=rp, col=col, edge_weight=torch.ones(col.numel(), device=DEV)), (rp.numel() - 1, n_dst))
+            for (rp, col), n_dst in blocks]
+
+def make_step(net, seeds_buf, seed_dev, opt):
+    def step():
+        with cogdl_amd.transient_structures():
+            n_id, blocks, counts = sample_blocks_padded(indptr, indices, seeds_buf, fan, seed=77, seed_dev=seed_dev)
+            opt.zero_grad(set_to_none=True)
+            loss = F.cross_entropy(net(gather_rows_by_id(x_all, n_id), adjs_of(blocks)), y_all.index_select(0, seeds_buf))
+            loss.backward()
+            opt.step()
+            seed_dev.add_(1)
+        return loss, counts
+    return step
+
+# reference-shaped step on the same draws (unpadded blocks, plan cache, sizes read back on the host)
+ref = copy.deepcopy(model)
+seeds0, batch, blocks = order[:b].clone(), order[:b].clone(), []
+for hop, k in enumerate(fan):
+    rp, col, nodes, _ = sample_adj_c(indptr, indices, batch, k, False, seed=(77 + hop * HOP_SEED_STRIDE) % (1 << 64))
+    blocks.append(((rp, col), batch.numel()))
+    batch = nodes
+ref_loss = F.cross_entropy(ref(x_all[batch], adjs_of(blocks[::-1])), y_all[seeds0])
+
+buf_e, sd_e = order[:b].clone(), torch.zeros(1, dtype=torch.long, device=DEV)
+step_e = make_step(twin, buf_e, sd_e, torch.optim.Adam(twin.parameters(), lr=0.01, capturable=True))
+eager = []
+for i in range(4):
+    buf_e.copy_(order[i * b:(i + 1) * b])
+    loss, counts = step_e()
+    assert int(counts[0][2]) == 0 and int(counts[1][2]) == 0
+    eager.append(float(loss.detach()))
+
+buf_c, sd_c = order[:b].clone(), torch.zeros(1, dtype=torch.long, device=DEV)
+opt_c = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+init = copy.deepcopy(model.state_dict())
+replay = graphs.capture(make_step(model, buf_c, sd_c, opt_c), warmup=3)
+model.load_state_dict(init)
+for st in opt_c.state.values():
+    for v in st.values():
+        if torch.is_tensor(v):
+            v.zero_()
+sd_c.zero_()
+captured = []
+for i in range(4):
+    buf_c.copy_(order[i * b:(i + 1) * b])
+    loss, counts = replay()
+    captured.append(float(loss.detach()))
+print("REPORT " + json.dumps({"ref_loss": float(ref_loss), "eager": eager, "captured": captured}))
+'''
+
+
+def test_reference_graphsage_model_trains_in_a_captured_step():
+    """The reference's unchanged Graphsage / SAGELayer / MeanAggregator / Graph classes (staged package) on fixed-capacity
+    blocks inside cogdl_amd.transient_structures(): eager == one hipGraph replay per step == the reference-shaped step."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from tools import refpkg
+
+    if not refpkg.available():
+        pytest.skip("the reference package is not staged (make -C oracle ref)")
+    res = subprocess.run([sys.executable, "-c", REFERENCE_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    rep = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("REPORT ")][-1][7:])
+    assert abs(rep["eager"][0] - rep["ref_loss"]) <= 1e-5 * max(1.0, abs(rep["ref_loss"]))
+    np.testing.assert_allclose(rep["captured"], rep["eager"], rtol=1e-6)

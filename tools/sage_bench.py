@@ -24,10 +24,9 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cogdl_amd import synth  # noqa: E402
-from cogdl_amd import graphs  # noqa: E402
 from cogdl_amd.operators.spmm import csrspmm, csrspmm_block  # noqa: E402
-from cogdl_amd.pipeline import (BatchPipeline, gather_rows_by_id, layerwise_inference, sample_blocks,  # noqa: E402
-                                sample_blocks_padded)
+from cogdl_amd.pipeline import (BatchPipeline, CapturedMiniBatchStep, gather_rows_by_id,  # noqa: E402
+                                layerwise_inference, sample_blocks)
 
 
 class SageMean(torch.nn.Module):
@@ -77,45 +76,30 @@ class Sage(torch.nn.Module):
 
 def captured_training(args, dev, n, indptr, indices, x_all, y_all, model, gen):
     """--captured: the whole mini-batch step -- both sampling hops, the feature gather, forward, backward, Adam -- as ONE
-    hipGraph launch per step.  Every buffer has the capacity B * (1 + 10) * (1 + 10) node slots; the RNG seed lives in
-    device memory and is bumped inside the graph; the seeds of a step are copied into a static buffer before the replay."""
+    hipGraph launch per step (cogdl_amd.pipeline.CapturedMiniBatchStep).  Every buffer has the capacity
+    B * (1 + 10) * (1 + 10) node slots; the seeds of a step are copied into a static buffer before the replay."""
     b = args.batch
     opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
     order = torch.randperm(n, device=dev, generator=gen)  # distinct seeds per batch, as a DataLoader over the train set gives
-    seeds_buf = order[:b].clone()
-    seed_dev = torch.zeros(1, dtype=torch.long, device=dev)
-
-    def step():
-        n_id, adjs, counts = sample_blocks_padded(indptr, indices, seeds_buf, [10, 10], seed=20240, seed_dev=seed_dev)
-        xb = gather_rows_by_id(x_all, n_id)
-        opt.zero_grad(set_to_none=True)
-        loss = F.cross_entropy(model.forward_padded(xb, adjs), y_all.index_select(0, seeds_buf))
-        loss.backward()
-        opt.step()
-        seed_dev.add_(1)
-        return loss, counts
-
     model.train()
-    replay = graphs.capture(step, warmup=3)
+    step = CapturedMiniBatchStep(indptr, indices, x_all, y_all, model.forward_padded, opt, order[:b], [10, 10], seed=20240)
     n_batches = n // b
     for i in range(args.warmup):
-        seeds_buf.copy_(order[(i % n_batches) * b:(i % n_batches + 1) * b])
-        replay()
+        step(order[(i % n_batches) * b:(i % n_batches + 1) * b])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     nodes = torch.zeros((), dtype=torch.long, device=dev)
     edges = torch.zeros((), dtype=torch.long, device=dev)
     for i in range(args.steps):
         k = (args.warmup + i) % n_batches
-        seeds_buf.copy_(order[k * b:(k + 1) * b])
-        loss, counts = replay()
-        nodes += counts[-1][0]
-        edges += counts[0][1] + counts[1][1]
+        loss = step(order[k * b:(k + 1) * b])
+        nodes += step.counts[-1][0]
+        edges += step.counts[0][1] + step.counts[1][1]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    flags = int(counts[0][2]) | int(counts[1][2])
-    if flags or not bool(torch.isfinite(loss)):
-        raise SystemExit("captured step: sampler flags %d, loss %s" % (flags, float(loss)))
+    step.check()
+    if not bool(torch.isfinite(loss)):
+        raise SystemExit("captured step: loss %s" % float(loss))
     return dt, b * args.steps, int(nodes), int(edges)
 
 
