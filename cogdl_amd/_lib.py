@@ -66,6 +66,7 @@ HIP_SIGNATURES = {
     "cogdl_hip_add_remaining_self_loops": ([_vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp], _i32),
     "cogdl_hip_coo_norm_weights_workspace_bytes": ([_i64], _sz),
     "cogdl_hip_coo_norm_weights": ([_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _sz, _vp], _i32),
+    "cogdl_hip_block_prepare": ([_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp], _i32),
     "cogdl_hip_subgraph_workspace_bytes": ([_i64, _i64], _sz),
     "cogdl_hip_subgraph": ([_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp], _i32),
     "cogdl_hip_gather_feature_rows": ([_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp], _i32),

@@ -169,3 +169,36 @@ extern "C" int cogdl_hip_add_remaining_self_loops(const int64_t *row, const int6
                        num_nodes, keep, pos, loop_src, fill_value, out_row, out_col, out_val, out_count);
     return launch_status();
 }
+
+// ---- a sampled block as the SpMM wants it, in ONE launch ------------------------------------------------------------
+// The sampler speaks int64 (the reference's contract); the SpMM wants int32 indices, and the mean aggregator
+// 1 / in-degree per row (Graph.row_norm, cogdl/data/data.py:240-258: 1/0 -> 0; a row without edges aggregates nothing
+// either way).  Eager torch needs ~7 short kernels per block for this (two .int() copies, a slice copy, the degree
+// difference, clamp, float, reciprocal) -- in a captured mini-batch step every one of them is a dependent graph node.
+namespace cogdl {
+__global__ void block_prepare_kernel(const int64_t *__restrict__ row_ptr, const int64_t *__restrict__ col, int64_t n_rows,
+                                     int64_t n_slots, int32_t *__restrict__ rowptr32, int32_t *__restrict__ col32,
+                                     float *__restrict__ inv_deg) {
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = t0; i < n_slots; i += stride) col32[i] = (int32_t)col[i];
+    for (int64_t i = t0; i <= n_rows; i += stride) {
+        const int64_t a = row_ptr[i];
+        rowptr32[i] = (int32_t)a;
+        if (inv_deg && i < n_rows) {
+            const int64_t d = row_ptr[i + 1] - a;
+            inv_deg[i] = d > 0 ? 1.f / (float)d : 0.f;
+        }
+    }
+}
+}  // namespace cogdl
+
+extern "C" int cogdl_hip_block_prepare(const int64_t *row_ptr, const int64_t *col, int64_t n_rows, int64_t n_slots,
+                                       int32_t *rowptr32, int32_t *col32, float *inv_deg, void *stream) {
+    if (n_rows < 0 || n_slots < 0 || !row_ptr || !rowptr32) return COGDL_HIP_EINVAL;
+    if (n_slots > 0 && (!col || !col32)) return COGDL_HIP_EINVAL;
+    if (n_slots > 0x7fffffff || n_rows > 0x7ffffffe) return COGDL_HIP_ERANGE;
+    const int64_t work = std::max(n_slots, n_rows + 1);
+    hipLaunchKernelGGL(block_prepare_kernel, dim3((unsigned)std::min<int64_t>((work + 255) / 256, 4096)), dim3(256), 0,
+                       (hipStream_t)stream, row_ptr, col, n_rows, n_slots, rowptr32, col32, inv_deg);
+    return launch_status();
+}

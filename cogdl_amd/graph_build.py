@@ -132,3 +132,27 @@ def row_normalization(num_nodes, row, col, val=None):
         dinv[torch.isinf(dinv)] = 0
         return val * dinv[row]
     return _norm_weights(num_nodes, row, col, val, 1, "row_normalization")
+
+
+def block_for_spmm(row_ptr, col, n_rows=None, mean=True):
+    """A sampled block (int64 row_ptr / col on the GPU, as sample_adj_c / sample_adj_padded return it) -> (rowptr int32
+    [n_rows + 1], col int32, in_norm float32 [n_rows] | None) in ONE launch (cogdl_hip_block_prepare): the two .int()
+    copies of the dispatcher (cogdl/utils/spmm_utils.py:106) and, with `mean`, the 1 / in-degree vector of
+    Graph.row_norm() (cogdl/data/data.py:240-258; 0 for a row without edges).  n_rows < the block's rows keeps only the
+    target rows (graphsage.py:99 drops the others after the layer anyway)."""
+    dev = _lib.require_cuda(row_ptr, col)
+    if row_ptr.dtype != torch.long or col.dtype != torch.long:
+        raise _lib.BackendError("block_for_spmm expects the sampler's int64 row_ptr / col (got %s / %s)"
+                                % (row_ptr.dtype, col.dtype))
+    row_ptr, col = row_ptr.contiguous(), col.contiguous()
+    m = row_ptr.numel() - 1 if n_rows is None else int(n_rows)
+    if m < 0 or m > row_ptr.numel() - 1:
+        raise _lib.BackendError("block_for_spmm: n_rows = %d outside the block's %d rows" % (m, row_ptr.numel() - 1))
+    rp32 = torch.empty(m + 1, dtype=torch.int32, device=dev)
+    col32 = torch.empty(col.numel(), dtype=torch.int32, device=dev)
+    inv = torch.empty(m, dtype=torch.float32, device=dev) if mean else None
+    with _lib.on_device(dev):
+        rc = _lib.hip().cogdl_hip_block_prepare(_lib.ptr(row_ptr), _lib.ptr(col), m, col.numel(), _lib.ptr(rp32),
+                                                _lib.ptr(col32), _lib.ptr(inv), _lib.stream_of(row_ptr))
+    _lib.check(rc, "block_prepare")
+    return rp32, col32, inv

@@ -364,6 +364,14 @@ COGDL_API int cogdl_hip_coo_norm_weights(const int64_t *row, const int64_t *col,
                                int64_t num_nodes, int mode, float *out, int *bad_flag, void *workspace,
                                size_t workspace_bytes, void *stream);
 
+/* block_prepare: a sampled block (int64, as sample_adj returns it) as the SpMM takes it, in one launch:
+ *   rowptr32[0..n_rows] = row_ptr[0..n_rows], col32[0..n_slots) = col[0..n_slots) narrowed to int32, and (inv_deg != NULL)
+ *   inv_deg[r] = 1 / (row_ptr[r+1] - row_ptr[r]), 0 for a row without edges -- the in_norm of Graph.row_norm()
+ *   (cogdl/data/data.py:240-258), i.e. the mean aggregator's weights.  n_rows may be smaller than the block's row count
+ *   (only the target rows are aggregated), n_slots is the capacity of col (>= row_ptr[n_rows]). */
+COGDL_API int cogdl_hip_block_prepare(const int64_t *row_ptr, const int64_t *col, int64_t n_rows, int64_t n_slots,
+                            int32_t *rowptr32, int32_t *col32, float *inv_deg, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * subgraph on the GPU: the node-induced subgraph of a GPU-resident CSR graph, the contract of sampler.subgraph
  * (cogdl/operators/sample/sample.cpp:146-188, reached from Graph.csr_subgraph, cogdl/data/data.py:850-872) and of

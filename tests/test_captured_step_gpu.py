@@ -99,6 +99,25 @@ def test_csrspmm_block_on_a_padded_block_equals_csrspmm_on_the_trimmed_one(oracl
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("n_rows", [None, 100, 0])
+def test_block_for_spmm_equals_the_torch_expressions(n_rows):
+    from cogdl_amd.graph_build import block_for_spmm
+
+    indptr, indices = _graph(5000, 6, seed=2)
+    row_ptr, col, nodes, _, counts = sample_adj_padded(indptr, indices, torch.arange(300, device=DEV), 4, seed=9)
+    rp, c32, inv = block_for_spmm(row_ptr, col, n_rows)
+    m = row_ptr.numel() - 1 if n_rows is None else n_rows
+    assert rp.dtype == torch.int32 and c32.dtype == torch.int32 and inv.dtype == torch.float32
+    assert torch.equal(rp, row_ptr[: m + 1].int()) and torch.equal(c32, col.int())
+    deg = (row_ptr[1:m + 1] - row_ptr[:m]).float()
+    want = torch.pow(deg, -1)
+    want[torch.isinf(want)] = 0  # Adjacency.generate_normalization("row"), cogdl/data/data.py:250-252
+    assert torch.equal(inv, want)
+    assert block_for_spmm(row_ptr, col, n_rows, mean=False)[2] is None
+    with pytest.raises(_lib.BackendError):
+        block_for_spmm(row_ptr.int(), col, n_rows)
+
+
 def _models():
     from tools.sage_bench import Sage
 

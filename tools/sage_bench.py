@@ -24,6 +24,7 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cogdl_amd import synth  # noqa: E402
+from cogdl_amd.graph_build import block_for_spmm  # noqa: E402
 from cogdl_amd.operators.spmm import csrspmm, csrspmm_block  # noqa: E402
 from cogdl_amd.pipeline import (BatchPipeline, CapturedMiniBatchStep, gather_rows_by_id,  # noqa: E402
                                 layerwise_inference, sample_blocks)
@@ -47,10 +48,8 @@ class SageMean(torch.nn.Module):
         """The same layer on a fixed-capacity block (sample_blocks_padded), for the n_dst target slots only (the
         caller keeps just those rows anyway, graphsage.py:99): the mean is the SpMM's in_norm epilogue, the block's
         transpose for the backward is taken on the spot (csrspmm_block) -- every shape is static, nothing syncs."""
-        row_ptr, col = block
-        rp = row_ptr[: n_dst + 1].int()
-        deg = rp[1:] - rp[:-1]
-        h = csrspmm_block(rp, col.int(), x, None, 1.0 / deg.clamp(min=1).float())
+        rp, col, inv_deg = block_for_spmm(block[0], block[1], n_dst)  # int32 indices + 1 / in-degree: one launch
+        h = csrspmm_block(rp, col, x, None, inv_deg)
         return self.fc(torch.cat([x[:n_dst], h], dim=-1))
 
 
@@ -79,7 +78,7 @@ def captured_training(args, dev, n, indptr, indices, x_all, y_all, model, gen):
     hipGraph launch per step (cogdl_amd.pipeline.CapturedMiniBatchStep).  Every buffer has the capacity
     B * (1 + 10) * (1 + 10) node slots; the seeds of a step are copied into a static buffer before the replay."""
     b = args.batch
-    opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True, fused=True)  # one kernel per step, not ~10
     order = torch.randperm(n, device=dev, generator=gen)  # distinct seeds per batch, as a DataLoader over the train set gives
     model.train()
     step = CapturedMiniBatchStep(indptr, indices, x_all, y_all, model.forward_padded, opt, order[:b], [10, 10], seed=20240)
