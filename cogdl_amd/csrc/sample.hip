@@ -21,6 +21,11 @@
 
 namespace cogdl {
 
+// The fixed-capacity entry point must be capturable in a hipGraph at ANY size: rocPRIM switches from merge sort to
+// onesweep above 1 M keys, and onesweep clears its histograms / look-back state with hipMemsetAsync -- memset nodes that
+// were seen not to replay (common.h: fill_u32_async).  Padded mode keeps the merge sort at every size.
+using CapturableSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                        rocprim::default_config, (size_t)1 << 40>;
 constexpr int kSampleMaxK = 1024;  // without replacement: chosen set of one seed lives in LDS
 
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -207,6 +212,11 @@ static SampleWs carve(void *base, int64_t batch, int64_t cap_edges, int64_t num_
     rocprim::counting_iterator<int32_t> iota(0);
     (void)rocprim::radix_sort_pairs(nullptr, sort_t, (uint32_t *)nullptr, (uint32_t *)nullptr, iota, (int32_t *)nullptr,
                                     (size_t)std::max<int64_t>(len, 1), 0u, sample_key_bits(num_nodes) + 1, nullptr);
+    size_t sort_m = 0;
+    (void)rocprim::radix_sort_pairs<CapturableSortConfig>(nullptr, sort_m, (uint32_t *)nullptr, (uint32_t *)nullptr, iota,
+                                                          (int32_t *)nullptr, (size_t)std::max<int64_t>(len, 1), 0u,
+                                                          sample_key_bits(num_nodes) + 1, nullptr);
+    sort_t = std::max(sort_t, sort_m);
     (void)rocprim::exclusive_scan(nullptr, scan_t, (int32_t *)nullptr, (int32_t *)nullptr, int32_t(0),
                                   (size_t)std::max<int64_t>(len, 1), rocprim::plus<int32_t>(), nullptr);
     (void)rocprim::exclusive_scan(nullptr, scan64_t, (int32_t *)nullptr, (int64_t *)nullptr, int64_t(0),
@@ -283,8 +293,10 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
                            out_indptr, batch, cap_edges, w.keys, pad_key, padded, out_indices, out_edges);
     rocprim::counting_iterator<int32_t> iota(0);
     tb = w.temp_bytes;
-    e = rocprim::radix_sort_pairs(w.temp, tb, w.keys, w.skeys, iota, w.spos, (size_t)len, 0u,
-                                  sample_key_bits(num_nodes) + 1, s);
+    e = padded ? rocprim::radix_sort_pairs<CapturableSortConfig>(w.temp, tb, w.keys, w.skeys, iota, w.spos, (size_t)len, 0u,
+                                                                 sample_key_bits(num_nodes) + 1, s)
+               : rocprim::radix_sort_pairs(w.temp, tb, w.keys, w.skeys, iota, w.spos, (size_t)len, 0u,
+                                           sample_key_bits(num_nodes) + 1, s);
     if (e != hipSuccess) return fail(e);
     const unsigned blocks = (unsigned)((len + 255) / 256);
     hipLaunchKernelGGL(sample_mark_kernel, dim3(blocks), dim3(256), 0, s, w.skeys, w.spos, len, pad_key, w.first, w.head);

@@ -25,9 +25,16 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // (Tried: a 9-bit-digit onesweep configuration -- two passes instead of three for column ids of up to 18 bits.  With 512
 // bins the default rank algorithm needs 262 KB of LDS; the `match` algorithm fits but runs each pass slower: 4.6 ms vs
 // 3.7 ms for the whole transpose of the Reddit-shaped graph.  rocPRIM's tuned default stays.)
+// capturable: the merge sort at every size -- above 1 M keys rocPRIM's default is onesweep, whose hipMemsetAsync calls
+// become memset nodes in a captured hipGraph, and those were seen not to replay (common.h: fill_u32_async).
+using CapturableSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                        rocprim::default_config, (size_t)1 << 40>;
 static hipError_t sort_pairs(void *temp, size_t &temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
-                             int32_t *perm_out, int64_t nnz, unsigned bits, hipStream_t s) {
+                             int32_t *perm_out, int64_t nnz, unsigned bits, hipStream_t s, bool capturable = false) {
     rocprim::counting_iterator<int32_t> iota(0);
+    if (capturable)
+        return rocprim::radix_sort_pairs<CapturableSortConfig>(temp, temp_bytes, keys_in, keys_out, iota, perm_out,
+                                                               (size_t)nnz, 0u, bits, s);
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, iota, perm_out, (size_t)nnz, 0u, bits, s);
 }
 
@@ -204,7 +211,15 @@ __global__ void padded_keys_kernel(const int32_t *__restrict__ rowptr, const int
 }
 
 extern "C" size_t cogdl_hip_csr2csc_padded_workspace_bytes(int64_t m, int64_t n_cols, int64_t nnz) {
-    return cogdl_hip_csr2csc_workspace_bytes(m, n_cols + 1, nnz) + align_up((size_t)std::max<int64_t>(nnz, 0) * sizeof(uint32_t), 256);
+    size_t extra = 0;  // the merge sort's scratch where it exceeds the default algorithm's
+    if (nnz > 0) {
+        size_t t_default = 0, t_merge = 0;
+        (void)sort_pairs(nullptr, t_default, nullptr, nullptr, nullptr, nnz, key_bits(n_cols + 1), nullptr);
+        (void)sort_pairs(nullptr, t_merge, nullptr, nullptr, nullptr, nnz, key_bits(n_cols + 1), nullptr, true);
+        if (t_merge > t_default) extra = align_up(t_merge - t_default, 256);
+    }
+    return cogdl_hip_csr2csc_workspace_bytes(m, n_cols + 1, nnz) + extra +
+           align_up((size_t)std::max<int64_t>(nnz, 0) * sizeof(uint32_t), 256);
 }
 
 static int csr2csc_impl(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols, int64_t nnz,
@@ -251,8 +266,8 @@ static int csr2csc_impl(const int32_t *rowptr, const int32_t *colind, int64_t m,
     char *temp = (char *)workspace + align_up((size_t)nnz * sizeof(uint32_t), 256);
     size_t temp_bytes = 0;
     const unsigned bits = key_bits(padded ? n_cols + 1 : n_cols);
-    (void)sort_pairs(nullptr, temp_bytes, nullptr, nullptr, nullptr, nnz, bits, nullptr);
-    hipError_t e = sort_pairs(temp, temp_bytes, keys_in, keys_sorted, perm, nnz, bits, s);
+    (void)sort_pairs(nullptr, temp_bytes, nullptr, nullptr, nullptr, nnz, bits, nullptr, padded);
+    hipError_t e = sort_pairs(temp, temp_bytes, keys_in, keys_sorted, perm, nnz, bits, s, padded);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
         return COGDL_HIP_ELAUNCH;

@@ -118,6 +118,41 @@ def test_block_for_spmm_equals_the_torch_expressions(n_rows):
         block_for_spmm(row_ptr.int(), col, n_rows)
 
 
+def test_padded_sampler_and_transpose_replay_correctly_above_a_million_slots():
+    """Above 1 M keys rocPRIM's default sort is onesweep, which clears its state with hipMemsetAsync (memset nodes do not
+    replay reliably): the fixed-capacity entry points keep the merge sort, so a captured graph stays right at any size."""
+    n = 400000
+    indptr, indices = _graph(n, 12, seed=8)
+    seeds = torch.randperm(n, device=DEV)[:120000]
+    sd = torch.zeros(1, dtype=torch.long, device=DEV)
+
+    def work():
+        row_ptr, col, nodes, edges, counts = sample_adj_padded(indptr, indices, seeds, 10, seed=3, seed_dev=sd)
+        plan = csr2csc(row_ptr[: seeds.numel() + 1].int(), col.int(), nodes.numel(), padded=True)
+        return row_ptr, col, nodes, edges, counts, plan.colptr, plan.rowind, plan.perm
+
+    want = [t.clone() for t in work()]
+    assert want[1].numel() == 1200000 and int(want[4][2]) == 0
+    ne = int(want[4][1])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        work()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        got = work()
+    poison = torch.ones(64 << 20, dtype=torch.bool, device=DEV)  # (whatever the allocator hands out next is not zero)
+    del poison
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        for name, a, b in zip("row_ptr col nodes edges counts colptr".split(), got, want):
+            assert torch.equal(a, b), name
+        assert torch.equal(got[6][:ne], want[6][:ne]) and torch.equal(got[7][:ne], want[7][:ne])
+
+
 def _models():
     from tools.sage_bench import Sage
 
