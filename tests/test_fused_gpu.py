@@ -128,12 +128,24 @@ def _gcn_step_factory(seed, n=20000, f=32, hidden=16, classes=5):
     return step, params
 
 
-def test_hip_graph_capture_of_a_gcn_training_step_equals_eager():
-    step_e, params_e = _gcn_step_factory(0)
-    losses_e = [float(step_e()) for _ in range(3 + 4)]  # capture() runs 3 eager warm-up steps before replaying
-    step_c, params_c = _gcn_step_factory(0)
-    captured = graphs.capture(step_c, warmup=3)
-    losses_c = [float(captured()) for _ in range(4)]
+@pytest.mark.parametrize("mfma_linear", [False, True], ids=["torch-linear", "mfma-linear"])
+def test_hip_graph_capture_of_a_gcn_training_step_equals_eager(mfma_linear):
+    """(mfma-linear: the split-K weight gradient zeroes its accumulator first -- by a kernel node, common.h
+    fill_u32_async; a memset node that does not replay would make the replays accumulate into stale gradients.)"""
+    from cogdl_amd import linear as cogdl_linear
+
+    if mfma_linear:
+        cogdl_linear.install()
+    try:
+        step_e, params_e = _gcn_step_factory(0)
+        losses_e = [float(step_e()) for _ in range(3 + 4)]  # capture() runs 3 eager warm-up steps before replaying
+        step_c, params_c = _gcn_step_factory(0)
+        captured = graphs.capture(step_c, warmup=3)
+        poison = torch.ones(32 << 20, dtype=torch.bool, device=DEV)
+        del poison
+        losses_c = [float(captured()) for _ in range(4)]
+    finally:
+        cogdl_linear.uninstall()
     np.testing.assert_allclose(losses_c, losses_e[3:], rtol=1e-5)
     for a, b in zip(params_c, params_e):
         np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-4, atol=1e-6)
