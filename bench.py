@@ -270,7 +270,33 @@ def bench_single(args):
                 result["gnn_epoch"]["reference_cpu_trainer_ms"] = tr["cpu_reference"]["train_step_ms_median"]
     if not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(g, x_cpu)
+    if not args.no_shard_base:
+        result["weak_scaling_base"] = shard_base()
     return result
+
+
+def shard_base(budget_s=200):
+    """`weak_scaling_base`: the N > 1 lines of this bench measure configs[4] (one papers100M-sized shard per GPU, weak
+    scaling), a different workload from this N = 1 line (configs[1]).  So that the N > 1 values have a like-for-like
+    one-GPU base, the same sharded code path is run here at world size 1 on the same shard (child interpreter, RCCL
+    process group of one rank): its GEdges/s is what N x perfect scaling multiplies."""
+    import subprocess
+
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK=os.environ.get("LOCAL_RANK", "0"),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("COGDL_AMD_BASE_PORT", "29547"))
+    try:
+        proc = subprocess.run([sys.executable, os.path.abspath(__file__), "--sharded", "--steps", "10", "--warmup", "2"],
+                              capture_output=True, text=True, timeout=budget_s, env=env)
+        line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+        if not line:
+            return {"error": (proc.stderr or proc.stdout)[-300:]}
+        r = json.loads(line[-1])
+        return {"what": "vertex-sharded csr_spmm fwd+bwd at world size 1 on one papers100M-sized shard (the per-GPU work "
+                        "of the N > 1 lines)", "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                "steps": r["steps"], "nodes_per_gpu": r["config"]["nodes_per_gpu"], "nnz": r["config"]["nnz_global"],
+                "local_block_GEdges_s": r.get("local_block_GEdges_s_rank0")}
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after %d s" % budget_s}
 
 
 def bench_sharded(args):
@@ -288,6 +314,8 @@ def main():
     ap.add_argument("--topology", default="uniform", choices=["uniform", "rmat"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-trainer", action="store_true", help="skip the reference-Trainer epoch legs (gnn_epoch.trainer_ms)")
+    ap.add_argument("--no-shard-base", action="store_true", help="skip the weak_scaling_base leg (the sharded path at world size 1)")
+    ap.add_argument("--sharded", action="store_true", help="run the N>1 workload (vertex-sharded SpMM) even at world size 1")
     ap.add_argument("--shard-nodes", type=int, default=0, help="N>1: nodes per GPU (default: papers100M/8)")
     ap.add_argument("--shard-degree", type=float, default=0.0, help="N>1: mean in-degree (default 28.8)")
     ap.add_argument("--remote-frac", type=float, default=-1.0,
@@ -299,7 +327,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.sharded:
         result = bench_sharded(args)
     else:
         result = bench_single(args)

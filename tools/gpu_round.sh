@@ -24,7 +24,7 @@ if has bench; then
 fi
 if has prof; then
   rm -rf gpurun_out/prof_kt
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_kt" -o kt -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu) > gpurun_out/bench_prof.log 2>&1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_kt" -o kt -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu --no-shard-base) > gpurun_out/bench_prof.log 2>&1
   find gpurun_out/prof_kt -name "*stats*" | head; 
 fi
 if has ops; then
