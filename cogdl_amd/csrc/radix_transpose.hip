@@ -1,0 +1,388 @@
+// radix_transpose.hip -- csr2csc as a hand-written LSD radix sort for gfx950 (replaces the
+// reference's cusparseCsr2cscEx2, cogdl/operators/spmm/spmm_kernel.cu:514-532, and this library's earlier rocPRIM
+// pipeline of transpose.hip, which stays selectable through tuning key 10).
+//
+// What is sorted: the nnz edge slots by column id, stably (a column's edges keep their CSR = row order), carrying TWO
+// payloads per edge -- its CSR position e (-> perm) and its row (-> rowind).  The row is found once, in the first pass,
+// where e is still sequential: every row that starts inside a tile drops its id at its first slot in LDS and a running
+// maximum spreads it -- no search per edge; the earlier pipeline looked the row of every perm[j] up afterwards, 0.6 ms of
+// random reads on the Reddit-shaped graph.
+//
+// Digits of up to 9 bits (512 bins): column ids of up to 18 bits -- every graph of BASELINE.json's configs[0..3] -- take
+// TWO passes where rocPRIM's onesweep takes three 8-bit ones.  One pass = three kernels, no atomics on global memory, no
+// memset, no look-back spinning (=> deterministic, and capturable in a hipGraph at any size):
+//   upsweep    per tile of 8192 slots: digit histogram -> table[digit][tile]
+//   scan       exclusive scan of the table in digit-major order (rocPRIM): where tile t's run of digit d starts
+//   downsweep  per tile: stable rank of every slot inside the tile (per wave: lanes with the same digit found with
+//              ballots, a running per-wave counter per digit in LDS; waves own contiguous quarters of the tile), the tile
+//              is reordered by digit through LDS, then written out as runs of equal digits (64 B on average at 512
+//              bins / 8192 slots; hub columns give long runs).  Keys and the two payloads take turns in one 32 KB LDS
+//              buffer: 45 KB per workgroup, 3 workgroups per CU.
+// Traffic per slot: 4 (upsweep) + 4 + 12 (first downsweep) + 4 + 12 + 12 (second) = 48 B against 16 B algorithmic.
+#include "common.h"
+
+#include <rocprim/device/device_scan.hpp>
+
+namespace cogdl {
+namespace rt {
+
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / kWave;  // 8
+constexpr int kTile = 8192;
+constexpr int kPerWave = kTile / kWaves;  // contiguous slots of one wave
+constexpr int kRows = kPerWave / kWave;   // 16 wave-rows of 64 slots
+constexpr int kMaxBits = 9;
+constexpr int kMaxBins = 1 << kMaxBits;
+static_assert(kMaxBins == kThreads, "one thread per digit in the downsweep's run layout");
+
+static size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct Params {
+    // first pass: keys = colind (slots >= valid get pad_key), payloads are generated; later passes: the three arrays
+    const int32_t *colind;
+    const int32_t *rowptr;
+    const uint32_t *keys_in;
+    const int32_t *e_in, *row_in;
+    uint32_t *keys_out;
+    int32_t *e_out, *row_out;
+    uint32_t *table;        // upsweep: raw counts out; downsweep: scanned offsets in
+    int32_t *tile_rows;     // [2 * n_tiles]: the rows of every tile's first and last slot (written by the first upsweep)
+    int64_t m, nnz, n_tiles;
+    uint32_t pad_key;
+    int shift, bits, padded;
+};
+
+__device__ __forceinline__ int64_t rt_row_search(const int32_t *__restrict__ rowptr, int64_t lo, int64_t hi, int64_t e) {
+    while (hi - lo > 1) {  // invariant: rowptr[lo] <= e (< rowptr[hi] where hi < m + 1); empty rows share offsets
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)rowptr[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// lanes (among `valid` ones) whose digit equals this lane's.  Per bit: x = 0 / ~0 (signed 1-bit extract), the ballot of
+// the bit, and peers &= ~(ballot ^ x) on both halves (v_xnor + v_and): 6 vector instructions per bit.
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, int bits, bool valid) {
+    const uint64_t v = __ballot(valid);
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    for (int b = 0; b < bits; ++b) {
+        const int32_t x = __builtin_amdgcn_sbfe((int32_t)d, (uint32_t)b, 1u);
+        const uint64_t mset = __ballot(x != 0);
+        lo &= ~((uint32_t)mset ^ (uint32_t)x);
+        hi &= ~((uint32_t)(mset >> 32) ^ (uint32_t)x);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <bool FIRST>
+__device__ __forceinline__ uint32_t load_key(const Params &p, int64_t i, int64_t valid) {
+    if constexpr (FIRST) return i < valid ? (uint32_t)p.colind[i] : p.pad_key;
+    else return p.keys_in[i];
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kThreads) void rt_upsweep_kernel(const Params p) {
+    __shared__ uint32_t hist[kWaves][kMaxBins];
+    const int t = threadIdx.x, lane = t & (kWave - 1), w = t >> 6;
+    const int nbins = 1 << p.bits;
+    for (int i = t; i < kWaves * kMaxBins; i += kThreads) (&hist[0][0])[i] = 0;
+    const int64_t tile = blockIdx.x;
+    const int64_t base = tile * kTile + (int64_t)w * kPerWave;
+    const int64_t valid = (FIRST && p.padded) ? (int64_t)p.rowptr[p.m] : p.nnz;
+    uint32_t key[kRows];
+#pragma unroll
+    for (int j = 0; j < kRows; ++j) {
+        const int64_t i = base + j * kWave + lane;
+        key[j] = i < p.nnz ? load_key<FIRST>(p, i, valid) : 0u;
+    }
+    __syncthreads();
+    const uint32_t mask = (uint32_t)nbins - 1u;
+    // counting only: order does not matter, so plain LDS atomics on the wave's private histogram (integer adds: the
+    // result is deterministic); the ballot-based matching of the downsweep costs ~75 vector instructions per 64 slots
+#pragma unroll
+    for (int j = 0; j < kRows; ++j) {
+        const int64_t i = base + j * kWave + lane;
+        if (i < p.nnz) atomicAdd(&hist[w][(key[j] >> p.shift) & mask], 1u);
+    }
+    if constexpr (FIRST) {  // two lanes of two different waves look the tile's boundary rows up for the downsweep
+        if (t == 0 || t == kWave) {
+            const int64_t e = t == 0 ? tile * kTile : min(p.nnz, (tile + 1) * kTile) - 1;
+            p.tile_rows[2 * tile + (t == 0 ? 0 : 1)] = (int32_t)rt_row_search(p.rowptr, 0, p.m, e);
+        }
+    }
+    __syncthreads();
+    for (int d = t; d < nbins; d += kThreads) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int ww = 0; ww < kWaves; ++ww) c += hist[ww][d];
+        p.table[(int64_t)d * p.n_tiles + tile] = c;
+    }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params p) {
+    __shared__ __attribute__((aligned(16))) uint32_t buf[kTile];
+    __shared__ uint32_t cnt[kWaves][kMaxBins];  // per wave: running count, then the wave's start inside the digit's run
+    __shared__ uint32_t dstart[kMaxBins];       // where the digit's run starts in the reordered tile
+    __shared__ uint32_t delta[kMaxBins];        // output position = delta[digit] + position in the reordered tile
+    __shared__ uint32_t wsum[kWaves];
+    const int t = threadIdx.x, lane = t & (kWave - 1), w = t >> 6;
+    const int nbins = 1 << p.bits;
+    const uint32_t mask = (uint32_t)nbins - 1u;
+    for (int i = t; i < kWaves * kMaxBins; i += kThreads) (&cnt[0][0])[i] = 0;
+    const int64_t tile = blockIdx.x;
+    const int64_t tile0 = tile * kTile;
+    const int n_here = (int)min((int64_t)kTile, p.nnz - tile0);
+    const int l0 = w * kPerWave + lane;  // local slot of wave-row 0; wave-row j: l0 + 64 * j
+
+    // ---- everything this tile reads from global memory is requested up front: keys, and (later passes) both payloads
+    uint32_t key[kRows];
+    int32_t pe[FIRST ? 1 : kRows], pr[kRows];
+    if constexpr (FIRST) {
+        const int32_t *__restrict__ src = p.colind + tile0;
+        int valid = n_here;
+        if (p.padded) valid = (int)max((int64_t)0, min((int64_t)n_here, (int64_t)p.rowptr[p.m] - tile0));
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) {
+            const int l = l0 + j * kWave;
+            key[j] = l < valid ? (uint32_t)src[l] : p.pad_key;
+        }
+    } else {
+        const uint32_t *__restrict__ ksrc = p.keys_in + tile0;
+        const int32_t *__restrict__ esrc = p.e_in + tile0, *__restrict__ rsrc = p.row_in + tile0;
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) {
+            const int l = l0 + j * kWave;
+            const bool ok = l < n_here;
+            key[j] = ok ? ksrc[l] : 0u;
+            pe[j] = ok ? esrc[l] : 0;
+            pr[j] = ok ? rsrc[l] : 0;
+        }
+    }
+    // ---- first pass: the row of every slot.  The slots are consecutive CSR positions: every row that STARTS inside
+    // the tile drops its (relative) id at its first slot, a running maximum spreads it over the row -- no search.
+    if constexpr (FIRST) {
+        const int r_first = p.tile_rows[2 * tile], r_last = p.tile_rows[2 * tile + 1];
+        for (int i = t; i < kTile; i += kThreads) buf[i] = 0;
+        __syncthreads();
+        for (int r = r_first + 1 + t; r <= r_last; r += kThreads) {
+            const int64_t pos = (int64_t)p.rowptr[r] - tile0;  // (> 0: r_first is the LAST row that starts at or before tile0)
+            if (pos < n_here) atomicMax(&buf[pos], (uint32_t)(r - r_first));  // empty rows share a slot: the last one owns it
+        }
+        __syncthreads();
+        uint32_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) {
+            uint32_t v = buf[l0 + j * kWave];
+#pragma unroll
+            for (int sft = 1; sft < kWave; sft <<= 1) {
+                const uint32_t u = __shfl_up(v, sft, kWave);
+                if (lane >= sft) v = max(v, u);
+            }
+            v = max(v, carry);
+            carry = __shfl(v, kWave - 1, kWave);
+            pr[j] = (int32_t)v;
+        }
+        if (lane == 0) wsum[w] = carry;
+        __syncthreads();
+        uint32_t prev = 0;
+        for (int ww = 0; ww < w; ++ww) prev = max(prev, wsum[ww]);
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) pr[j] = r_first + (int32_t)max((uint32_t)pr[j], prev);
+    }
+    __syncthreads();
+    // ---- stable rank inside the wave's part: (same digit in earlier wave-rows) + (same digit in lower lanes)
+    uint16_t rank[kRows];
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < kRows; ++j) {
+        const bool ok = l0 + j * kWave < n_here;
+        const uint32_t d = (key[j] >> p.shift) & mask;
+        const uint64_t peers = match_digit(d, p.bits, ok);
+        const int lower = __popcll(peers & lt);
+        const uint32_t before = cnt[w][d];      // (LDS operations of a wave complete in order: read, then the leader's write)
+        rank[j] = (uint16_t)(before + lower);
+        if (ok && lower == 0) cnt[w][d] = before + (uint32_t)__popcll(peers);
+    }
+    __syncthreads();
+    // ---- per digit: total of the tile, each wave's start inside the run; runs laid out in digit order
+    uint32_t tot = 0;  // thread t owns digit t (kThreads == kMaxBins)
+    uint32_t gb = 0;
+    if (t < nbins) {
+#pragma unroll
+        for (int ww = 0; ww < kWaves; ++ww) {
+            const uint32_t c = cnt[ww][t];
+            cnt[ww][t] = tot;
+            tot += c;
+        }
+        gb = p.table[(int64_t)t * p.n_tiles + tile];
+    }
+    uint32_t incl = tot;  // exclusive scan of the totals over the digits
+#pragma unroll
+    for (int sft = 1; sft < kWave; sft <<= 1) {
+        const uint32_t v = __shfl_up(incl, sft, kWave);
+        if (lane >= sft) incl += v;
+    }
+    __syncthreads();  // (wsum is reused)
+    if (lane == kWave - 1) wsum[w] = incl;
+    __syncthreads();
+    uint32_t off = incl - tot;
+    for (int ww = 0; ww < w; ++ww) off += wsum[ww];
+    if (t < nbins) {
+        dstart[t] = off;
+        delta[t] = gb - off;  // (mod 2^32)
+    }
+    __syncthreads();
+    // ---- position of every slot in the reordered tile (in place of its rank)
+    uint16_t (&spos)[kRows] = rank;
+#pragma unroll
+    for (int j = 0; j < kRows; ++j) {
+        const uint32_t d = (key[j] >> p.shift) & mask;
+        spos[j] = (uint16_t)(dstart[d] + cnt[w][d] + rank[j]);
+    }
+    // ---- keys through LDS -> runs of equal digits in the output; remember where each reordered slot goes
+#pragma unroll
+    for (int j = 0; j < kRows; ++j)
+        if (l0 + j * kWave < n_here) buf[spos[j]] = key[j];
+    __syncthreads();
+    uint32_t gpos[kRows];  // (nnz < 2^31)
+#pragma unroll
+    for (int q = 0; q < kRows; ++q) {
+        const int sidx = q * kThreads + t;
+        gpos[q] = 0;
+        if (sidx < n_here) {
+            const uint32_t k = buf[sidx];
+            gpos[q] = delta[(k >> p.shift) & mask] + (uint32_t)sidx;
+            p.keys_out[gpos[q]] = k;
+        }
+    }
+    __syncthreads();
+    // ---- payload 1: the CSR position
+#pragma unroll
+    for (int j = 0; j < kRows; ++j) {
+        const int l = l0 + j * kWave;
+        if (l < n_here) buf[spos[j]] = FIRST ? (uint32_t)(tile0 + l) : (uint32_t)pe[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kRows; ++q)
+        if (q * kThreads + t < n_here) p.e_out[gpos[q]] = (int32_t)buf[q * kThreads + t];
+    __syncthreads();
+    // ---- payload 2: the row
+#pragma unroll
+    for (int j = 0; j < kRows; ++j)
+        if (l0 + j * kWave < n_here) buf[spos[j]] = (uint32_t)pr[j];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kRows; ++q)
+        if (q * kThreads + t < n_here) p.row_out[gpos[q]] = (int32_t)buf[q * kThreads + t];
+}
+
+struct Geometry {
+    int bits, n_pass, dbits;
+    int64_t n_tiles, table_len;
+    size_t scan_temp, off_table, off_scanned, off_temp, off_sets, set_bytes, off_keys_final, off_tile_rows, total;
+    int n_sets;
+};
+
+static unsigned bits_for(int64_t n_keys) {  // enough bits for key values 0 .. n_keys - 1
+    unsigned b = 1;
+    while (b < 32 && (int64_t(1) << b) < n_keys) ++b;
+    return b;
+}
+
+static Geometry geometry(int64_t n_cols, int64_t nnz, bool padded) {
+    Geometry g{};
+    g.bits = (int)bits_for(padded ? n_cols + 1 : n_cols);
+    g.n_pass = (g.bits + kMaxBits - 1) / kMaxBits;
+    g.dbits = (g.bits + g.n_pass - 1) / g.n_pass;
+    g.n_tiles = (nnz + kTile - 1) / kTile;
+    g.table_len = g.n_tiles << g.dbits;
+    size_t st = 0;
+    (void)rocprim::exclusive_scan(nullptr, st, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u,
+                                  (size_t)std::max<int64_t>(g.table_len, 1), rocprim::plus<uint32_t>(), nullptr);
+    g.scan_temp = st;
+    g.n_sets = std::min(g.n_pass - 1, 2);
+    g.set_bytes = 3 * up256((size_t)nnz * 4);
+    size_t o = 0;
+    g.off_table = o;
+    o += up256((size_t)g.table_len * 4);
+    g.off_scanned = o;
+    o += up256((size_t)g.table_len * 4);
+    g.off_temp = o;
+    o += up256(g.scan_temp);
+    g.off_keys_final = o;
+    o += up256((size_t)nnz * 4);
+    g.off_tile_rows = o;
+    o += up256((size_t)g.n_tiles * 8);
+    g.off_sets = o;
+    o += (size_t)g.n_sets * g.set_bytes;
+    g.total = o + 256;
+    return g;
+}
+
+}  // namespace rt
+
+size_t radix_transpose_workspace_bytes(int64_t n_cols, int64_t nnz, bool padded) {
+    if (nnz <= 0) return 256;
+    return rt::geometry(n_cols, nnz, padded).total;
+}
+
+// -> keys_sorted (inside the workspace, returned through *keys_sorted_out), perm, rowind.  nnz > 0, m > 0.
+int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols, int64_t nnz, bool padded,
+                    int32_t *rowind, int32_t *perm, void *workspace, const uint32_t **keys_sorted_out, hipStream_t s) {
+    using namespace rt;
+    const Geometry g = geometry(n_cols, nnz, padded);
+    if (g.n_tiles > 0x7fffffff || g.table_len > 0x7fffffff) return COGDL_HIP_ERANGE;
+    char *ws = (char *)workspace;
+    uint32_t *table = (uint32_t *)(ws + g.off_table), *scanned = (uint32_t *)(ws + g.off_scanned);
+    void *temp = ws + g.off_temp;
+    uint32_t *keys_final = (uint32_t *)(ws + g.off_keys_final);
+    auto set_ptr = [&](int idx, int which) { return ws + g.off_sets + (size_t)idx * g.set_bytes + (size_t)which * up256((size_t)nnz * 4); };
+    Params p{};
+    p.colind = colind;
+    p.rowptr = rowptr;
+    p.m = m;
+    p.nnz = nnz;
+    p.n_tiles = g.n_tiles;
+    p.pad_key = (uint32_t)n_cols;
+    p.tile_rows = (int32_t *)(ws + g.off_tile_rows);
+    p.padded = padded ? 1 : 0;
+    p.bits = g.dbits;
+    for (int pass = 0; pass < g.n_pass; ++pass) {
+        const bool first = pass == 0, last = pass == g.n_pass - 1;
+        p.shift = pass * g.dbits;
+        if (!first) {
+            const int src = (pass - 1) % 2;
+            p.keys_in = (const uint32_t *)set_ptr(src, 0);
+            p.e_in = (const int32_t *)set_ptr(src, 1);
+            p.row_in = (const int32_t *)set_ptr(src, 2);
+        }
+        if (last) {
+            p.keys_out = keys_final;
+            p.e_out = perm;
+            p.row_out = rowind;
+        } else {
+            const int dst = pass % 2;
+            p.keys_out = (uint32_t *)set_ptr(dst, 0);
+            p.e_out = (int32_t *)set_ptr(dst, 1);
+            p.row_out = (int32_t *)set_ptr(dst, 2);
+        }
+        p.table = table;
+        if (first) hipLaunchKernelGGL(rt_upsweep_kernel<true>, dim3((unsigned)g.n_tiles), dim3(kThreads), 0, s, p);
+        else hipLaunchKernelGGL(rt_upsweep_kernel<false>, dim3((unsigned)g.n_tiles), dim3(kThreads), 0, s, p);
+        size_t tb = g.scan_temp;
+        hipError_t e = rocprim::exclusive_scan(temp, tb, table, scanned, 0u, (size_t)g.table_len, rocprim::plus<uint32_t>(), s);
+        if (e != hipSuccess) {
+            g_last_hip_error = (int)e;
+            return COGDL_HIP_ELAUNCH;
+        }
+        p.table = scanned;
+        if (first) hipLaunchKernelGGL(rt_downsweep_kernel<true>, dim3((unsigned)g.n_tiles), dim3(kThreads), 0, s, p);
+        else hipLaunchKernelGGL(rt_downsweep_kernel<false>, dim3((unsigned)g.n_tiles), dim3(kThreads), 0, s, p);
+    }
+    *keys_sorted_out = keys_final;
+    return launch_status();
+}
+
+}  // namespace cogdl

@@ -21,14 +21,44 @@ def rand(*shape, seed=0, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------ csr2csc
-@pytest.mark.parametrize("m,n_cols,deg", [(40, 25, 6), (1, 1, 1), (300, 5000, 3), (2000, 2000, 30), (17, 9, 0)])
-def test_csr2csc_bit_exact(oracle, m, n_cols, deg):
+@pytest.fixture(params=[1, 2], ids=["rocprim-pipeline", "radix-transpose"])
+def csc_algo(request):
+    """csr2csc's two implementations (tuning key 10; the default picks by size): the rocPRIM sort + row look-up and the
+    hand-written two-payload radix sort (csrc/radix_transpose.hip)."""
+    from cogdl_amd import _lib
+
+    _lib.hip().cogdl_hip_set_tuning(10, request.param)
+    yield request.param
+    _lib.hip().cogdl_hip_set_tuning(10, 0)
+
+
+# (n_cols: 1 / 2 / 3 radix passes of <= 9 bits; nnz: less than a tile, a partial last tile, many tiles)
+@pytest.mark.parametrize("m,n_cols,deg", [(40, 25, 6), (1, 1, 1), (300, 5000, 3), (2000, 2000, 30), (17, 9, 0),
+                                          (5000, 300, 9), (3000, 600000, 30), (40000, 40000, 2), (8192, 512, 1)])
+def test_csr2csc_bit_exact(oracle, csc_algo, m, n_cols, deg):
     g = synth.random_csr(m, n_cols, deg, seed=m + deg)
     plan = csr2csc(g.rowptr.to(DEV), g.colind.to(DEV), n_cols)
     colptr, rowind, _, perm = oracle.csr2csc(g.rowptr, g.colind, None, n_cols=n_cols)
     assert np.array_equal(plan.colptr.cpu().numpy(), colptr)
     assert np.array_equal(plan.rowind.cpu().numpy(), rowind)
     assert np.array_equal(plan.perm.cpu().numpy(), perm)
+
+
+def test_csr2csc_hub_rows_hub_columns_and_runs_of_empty_rows(oracle, csc_algo):
+    """Rows of tens of thousands of edges (many tiles of one row), a column that receives a third of all edges (one
+    digit dominating every tile), thousands of empty rows in a row (all starting at the same slot)."""
+    g = synth.hub_csr(9000, 7000, base_deg=2, hubs=((3, 30000), (4, 9000), (8000, 20000)), seed=5, weighted=False)
+    colind = g.colind.clone()
+    colind[::3] = 77
+    deg = (g.rowptr[1:] - g.rowptr[:-1]).clone()
+    rowptr = g.rowptr.clone()
+    rowptr[1000:6001] = rowptr[1000]  # rows 1000..5999 lose their edges to row 999: 5000 empty rows in a row
+    plan = csr2csc(rowptr.to(DEV), colind.to(DEV), 7000)
+    colptr, rowind, _, perm = oracle.csr2csc(rowptr, colind, None, n_cols=7000)
+    assert np.array_equal(plan.colptr.cpu().numpy(), colptr)
+    assert np.array_equal(plan.rowind.cpu().numpy(), rowind)
+    assert np.array_equal(plan.perm.cpu().numpy(), perm)
+    assert int(deg.sum()) == colind.numel()
 
 
 def test_csr2csc_full_size_roundtrip():

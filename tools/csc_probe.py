@@ -1,9 +1,38 @@
-import os, sys, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-from cogdl_amd import synth
-from cogdl_amd.plan import csr2csc
-for g in (synth.arxiv_like(seed=0, topology="rmat").to("cuda:0"), synth.reddit_like(seed=0, device="cuda:0")):
-    for _ in range(3):
-        csr2csc(g.rowptr, g.colind, g.num_nodes)
-    torch.cuda.synchronize()
-    print("done", g.nnz, flush=True)
+#!/usr/bin/env python3
+"""csr2csc: the hand-written radix transpose (tuning key 10 = 0) against the rocPRIM pipeline (= 1): equality of the
+plans and kernel time, arxiv-shaped / Reddit-shaped / products-shaped graphs and a sampled block."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from cogdl_amd import _lib, synth  # noqa: E402
+from cogdl_amd.plan import csr2csc  # noqa: E402
+from tools.ops_bench import timeit  # noqa: E402
+
+lib = _lib.hip()
+DEV = "cuda:0"
+
+
+def graphs():
+    yield "arxiv-rmat", synth.arxiv_like(seed=0, topology="rmat").to(DEV)
+    yield "arxiv-uniform", synth.arxiv_like(seed=0, topology="uniform").to(DEV)
+    yield "block-60k", synth.random_csr(11264, 124000, 5, seed=1, weighted=False).to(DEV)
+    yield "reddit", synth.reddit_like(seed=0, device=DEV)
+
+
+for name, g in graphs():
+    n_cols = g.n_cols
+    plans = {}
+    for algo in (1, 2):
+        lib.cogdl_hip_set_tuning(10, algo)
+        plans[algo] = csr2csc(g.rowptr, g.colind, n_cols)
+        ms = timeit(lambda: csr2csc(g.rowptr, g.colind, n_cols), 10)
+        nnz = g.colind.numel()
+        print("%-14s nnz %10d  %-9s %9.1f us  (%5.1f %% of 16 B/edge at 8 TB/s)" % (
+            name, nnz, "rocPRIM" if algo == 1 else "radix", ms * 1e3, 16 * nnz / (ms * 1e-3) / 8e12 * 100), flush=True)
+    lib.cogdl_hip_set_tuning(10, 0)
+    a, b = plans[2], plans[1]
+    same = torch.equal(a.colptr, b.colptr) and torch.equal(a.rowind, b.rowind) and torch.equal(a.perm, b.perm)
+    print("%-14s plans identical: %s" % (name, same), flush=True)
