@@ -36,3 +36,4 @@ for name, g in graphs():
     a, b = plans[2], plans[1]
     same = torch.equal(a.colptr, b.colptr) and torch.equal(a.rowind, b.rowind) and torch.equal(a.perm, b.perm)
     print("%-14s plans identical: %s" % (name, same), flush=True)
+
