@@ -1,7 +1,8 @@
 // transpose.hip -- csr2csc (stable CSR transpose) and row gathers for gfx950.
 // Replaces the reference's cuSPARSE call (cogdl/operators/spmm/spmm_kernel.cu:514-532,
 // cusparseCsr2cscEx2 ALG1: handle created per call and leaked, cudaMalloc/cudaFree per call)
-// with an allocation-free, stream-ordered, deterministic pipeline:
+// From 256 k edge slots on the transpose is the hand-written two-payload radix sort of radix_transpose.hip; below that
+// (and under tuning key 10 = 1) this file's allocation-free, stream-ordered, deterministic rocPRIM pipeline:
 //   1. stable LSD radix sort of (key = colind[e], value = e) restricted to the
 //      ceil(log2(n_cols)) significant key bits (rocPRIM device primitive, header-only) -> perm
 //   2. colptr from the sorted keys by boundary detection (no atomics)
