@@ -74,7 +74,9 @@ def node_dataset(num_nodes, num_pairs, num_features, num_classes, seed=0, sparse
         mask = torch.zeros(num_nodes, dtype=torch.bool)
         mask[perm[lo:hi]] = True
         setattr(g, name, mask)
-    return NodeDataset(data=g, metric="accuracy")
+    # (the dataset class saves itself to `path` when it is built: a scratch file, not ./data.pt in the caller's directory)
+    path = os.path.join(tempfile.mkdtemp(prefix="cogdl_ds_"), "data.pt")
+    return NodeDataset(path=path, data=g, metric="accuracy")
 
 
 def cora_like(seed=0):
