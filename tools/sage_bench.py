@@ -23,7 +23,7 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cogdl_amd import synth  # noqa: E402
+from cogdl_amd import synth, transient_structures  # noqa: E402
 from cogdl_amd.graph_build import block_for_spmm  # noqa: E402
 from cogdl_amd.operators.spmm import csrspmm, csrspmm_block  # noqa: E402
 from cogdl_amd.pipeline import (BatchPipeline, CapturedMiniBatchStep, gather_rows_by_id,  # noqa: E402
@@ -146,8 +146,9 @@ def main():
 
     def train_on(seeds, n_id, adjs, xb, yb):
         opt.zero_grad(set_to_none=True)
-        loss = F.cross_entropy(net(xb, adjs), yb)
-        loss.backward()
+        with transient_structures():  # sampled blocks never repeat: transposed on the spot, not hashed into the plan cache
+            loss = F.cross_entropy(net(xb, adjs), yb)
+            loss.backward()
         opt.step()
         return seeds.numel(), n_id.numel(), sum(b[0][1].numel() for b in adjs)
 
