@@ -370,6 +370,13 @@ def bench_sharded_spmm(args):
             "local_block_spmm_ms_rank0": loc_ms,
             "local_block_GEdges_s_rank0": sh.nnz_local / (loc_ms * 1e-3) / 1e9,
         }
+        # the dominant kernel of a step: csr_spmm over the rank's local block (SURVEY.md section 8d's formula), timed
+        # above with HIP events on its own; X (7.1 GB per shard) is far beyond the caches, so this IS HBM traffic
+        b_alg = sh.nnz_local * (4 + 4 + f * 4) + shard_nodes * (4 + f * 4)
+        result["roofline"] = {"bound": "hbm", "kernel": "rowreduce_main_kernel<SpmmOp<float,...>> on the local block A_pp (rank 0)",
+                              "achieved": b_alg / (loc_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                              "frac": b_alg / (loc_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                              "algorithmic_bytes_per_launch": b_alg}
     dist.barrier()
     dist.destroy_process_group()
     return result
