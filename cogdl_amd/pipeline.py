@@ -118,12 +118,39 @@ class CapturedMiniBatchStep:
                           takes `[(None, Graph(row_ptr=rp, col=col, edge_weight=ones(len(col))), (len(rp) - 1, n))]`
         optimizer       : created with capturable=True
         initial_seeds   : [batch_size] distinct node ids; the warm-up runs of the capture are REAL training steps on them
+        process_group   : replicas (configs[3]: every rank holds the graph and draws its own seeds): the gradients are
+                          averaged over the group INSIDE the captured step -- one flat all-reduce (RCCL) between
+                          backward and the optimizer, what torch DDP does with its buckets (cogdl/trainer/
+                          trainer.py:291-303), as a node of the same graph; `params` = the tensors to average
+                          (default: every parameter the optimizer holds)
     Every step: `loss = step(seeds)` copies the seeds into the static buffer and replays (the returned loss tensor is
     static too: read it when you need it, not every step).  The RNG seed lives in device memory and advances inside the
     graph.  All operators run in plan.transient_structures() mode: nothing is hashed, cached or read back."""
 
-    def __init__(self, indptr, indices, x, y, forward, optimizer, initial_seeds, fanouts, loss_fn=None, seed=0, warmup=3):
+    def __init__(self, indptr, indices, x, y, forward, optimizer, initial_seeds, fanouts, loss_fn=None, seed=0, warmup=3,
+                 process_group=None, params=None):
         import torch.nn.functional as F
+
+        if process_group is not None:
+            import torch.distributed as dist
+
+            world = dist.get_world_size(process_group)
+            if params is None:
+                params = [q for grp in optimizer.param_groups for q in grp["params"]]
+            params = [q for q in params if q.requires_grad]
+
+            def average_gradients():
+                flat = torch.cat([q.grad.reshape(-1) for q in params])
+                dist.all_reduce(flat, group=process_group)
+                flat.div_(world)
+                off = 0
+                for q in params:
+                    n = q.numel()
+                    q.grad.copy_(flat[off:off + n].view_as(q.grad))
+                    off += n
+        else:
+            def average_gradients():
+                pass
 
         self.seeds = initial_seeds.to(device=indptr.device, dtype=torch.long).contiguous().clone()
         self.seed_dev = torch.zeros(1, dtype=torch.long, device=indptr.device)
@@ -138,6 +165,7 @@ class CapturedMiniBatchStep:
                 optimizer.zero_grad(set_to_none=True)
                 loss = loss_fn(forward(xb, blocks), y.index_select(0, self.seeds))
                 loss.backward()
+                average_gradients()
                 optimizer.step()
                 self.seed_dev.add_(1)
             return loss.detach(), counts

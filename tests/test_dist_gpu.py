@@ -129,3 +129,37 @@ def test_two_ranks_on_one_gpu_hip_kernels_with_halo(tmp_path, oracle):
         np.testing.assert_allclose(z["gx"], want_gx[lo:hi], rtol=1e-5, atol=1e-5)
         halo += int(z["n_halo"])
     assert halo > 0
+
+
+def test_captured_minibatch_step_with_the_gradient_all_reduce_inside_the_graph(rccl_world1):
+    """configs[3] replicas: CapturedMiniBatchStep(process_group=...) puts one flat RCCL all-reduce of the gradients
+    between backward and the optimizer INSIDE the captured hipGraph.  With the one rank this box has the average is
+    the identity: the replays must equal those of the step captured without a group, number for number."""
+    import copy
+
+    from cogdl_amd.pipeline import CapturedMiniBatchStep
+    from tools.sage_bench import Sage
+
+    n, b = 20000, 128
+    g = synth.scaled(n, 12, seed=6, topology="rmat", norm=None, self_loops=False)
+    indptr, indices = g.rowptr.long().to(DEV), g.colind.long().to(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x_all = torch.randn(n, 32, device=DEV, generator=gen)
+    y_all = torch.randint(0, 7, (n,), device=DEV, generator=gen)
+    order = torch.randperm(n, device=DEV, generator=gen)
+    torch.manual_seed(0)
+    m_a = Sage(32, 64, 7).to(DEV).eval()
+    m_b = copy.deepcopy(m_a)
+    losses = []
+    for model, group in ((m_a, None), (m_b, dist.group.WORLD)):
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+        step = CapturedMiniBatchStep(indptr, indices, x_all, y_all, model.forward_padded, opt, order[:b], [10, 10], seed=1,
+                                     process_group=group)
+        out = []
+        for i in range(4):
+            out.append(float(step(order[(i + 1) * b:(i + 2) * b])))
+        step.check()
+        losses.append(out)
+    np.testing.assert_allclose(losses[1], losses[0], rtol=1e-6)
+    for pa, pb in zip(m_a.parameters(), m_b.parameters()):
+        np.testing.assert_allclose(pb.detach().cpu().numpy(), pa.detach().cpu().numpy(), rtol=1e-5, atol=1e-7)

@@ -73,7 +73,7 @@ class Sage(torch.nn.Module):
         return x
 
 
-def captured_training(args, dev, n, indptr, indices, x_all, y_all, model, gen):
+def captured_training(args, dev, n, indptr, indices, x_all, y_all, model, gen, group=None):
     """--captured: the whole mini-batch step -- both sampling hops, the feature gather, forward, backward, Adam -- as ONE
     hipGraph launch per step (cogdl_amd.pipeline.CapturedMiniBatchStep).  Every buffer has the capacity
     B * (1 + 10) * (1 + 10) node slots; the seeds of a step are copied into a static buffer before the replay."""
@@ -81,7 +81,8 @@ def captured_training(args, dev, n, indptr, indices, x_all, y_all, model, gen):
     opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True, fused=True)  # one kernel per step, not ~10
     order = torch.randperm(n, device=dev, generator=gen)  # distinct seeds per batch, as a DataLoader over the train set gives
     model.train()
-    step = CapturedMiniBatchStep(indptr, indices, x_all, y_all, model.forward_padded, opt, order[:b], [10, 10], seed=20240)
+    step = CapturedMiniBatchStep(indptr, indices, x_all, y_all, model.forward_padded, opt, order[:b], [10, 10], seed=20240 + int(os.environ.get("RANK", 0)),
+                                 process_group=group)  # replicas: the gradient all-reduce is a node of the captured graph
     n_batches = n // b
     for i in range(args.warmup):
         step(order[(i % n_batches) * b:(i % n_batches + 1) * b])
@@ -167,9 +168,8 @@ def main():
     t0 = time.perf_counter()
     seeds = nodes = edges = 0
     if args.captured:
-        if world > 1:
-            raise SystemExit("--captured is the single-GPU step (DDP's bucketed all-reduce is not captured here)")
-        secs, seeds, nodes, edges = captured_training(args, dev, n, indptr, indices, x_all, y_all, model, gen)
+        secs, seeds, nodes, edges = captured_training(args, dev, n, indptr, indices, x_all, y_all, model, gen,
+                                                      torch.distributed.group.WORLD if world > 1 else None)
         t0 = time.perf_counter() - secs
     elif args.pipeline:
         batches = [draw_seeds() for _ in range(args.steps)]
