@@ -343,7 +343,7 @@ int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int
                     int32_t *rowind, int32_t *perm, void *workspace, const uint32_t **keys_sorted_out, hipStream_t s) {
     using namespace rt;
     const Geometry g = geometry(n_cols, nnz, padded);
-    if (g.n_tiles > 0x7fffffff || g.table_len > 0x7fffffff) return COGDL_HIP_ERANGE;
+    if (g.n_tiles > 0x7fffffff || g.table_len > 0x7fffffff || m > 0x7fff0000) return COGDL_HIP_ERANGE;  // (int row loops)
     char *ws = (char *)workspace;
     uint32_t *table = (uint32_t *)(ws + g.off_table), *scanned = (uint32_t *)(ws + g.off_scanned);
     void *temp = ws + g.off_temp;

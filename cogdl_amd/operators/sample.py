@@ -110,6 +110,10 @@ def sample_adj_padded(indptr, indices, node_idx, num_neighbors, replace=False, s
     for name, t in (("indptr", indptr), ("indices", indices), ("node_idx", node_idx)):
         if t.dtype != torch.long or not t.is_contiguous() or t.device != dev:
             raise _lib.BackendError("sample_adj_padded: %s must be a contiguous int64 tensor on %s" % (name, dev))
+    for name, t in (("count", count), ("seed_dev", seed_dev)):  # read as 8-byte words on the device
+        if t is not None and (not torch.is_tensor(t) or t.dtype != torch.long or t.device != dev or t.numel() < 1
+                              or not t.is_contiguous()):
+            raise _lib.BackendError("sample_adj_padded: %s must be an int64 tensor on %s (a device scalar)" % (name, dev))
     n, b = indptr.numel() - 1, node_idx.numel()
     cap_e = b * num_neighbors
     out_indptr = torch.empty(b + cap_e + 1, dtype=torch.long, device=dev)

@@ -54,6 +54,10 @@ def test_sample_adj_padded_rejects_what_has_no_fixed_capacity():
         sample_adj_padded(indptr, indices, seeds, -1)
     with pytest.raises(_lib.BackendError):
         sample_adj_padded(indptr.cpu(), indices.cpu(), seeds.cpu(), 3)
+    with pytest.raises(_lib.BackendError):
+        sample_adj_padded(indptr, indices, seeds, 3, count=torch.tensor([5], dtype=torch.int32, device=DEV))
+    with pytest.raises(_lib.BackendError):
+        sample_adj_padded(indptr, indices, seeds, 3, seed_dev=torch.tensor([5]))  # a host tensor
     _, _, _, _, counts = sample_adj_padded(indptr, indices, torch.tensor([3, 100], device=DEV), 3)
     assert int(counts[2]) & 1  # a seed outside the graph is flagged, not fatal on the device
 
