@@ -60,3 +60,21 @@ def test_record_then_replay_in_order(monkeypatch):
             cache.get(_FP(10, 30, 10, 111), None, None, 10)
     finally:
         plan.set_tape(None)
+
+
+def test_transient_structures_context_nests_and_resets():
+    from cogdl_amd import plan, transient_structures
+
+    assert not plan.transient()
+    with transient_structures():
+        assert plan.transient()
+        with transient_structures():
+            assert plan.transient()
+        assert plan.transient()
+    assert not plan.transient()
+    try:
+        with transient_structures():
+            raise ValueError("boom")
+    except ValueError:
+        pass
+    assert not plan.transient()  # left on the exception path too
