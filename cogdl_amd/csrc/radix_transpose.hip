@@ -18,11 +18,14 @@
 //              is reordered by digit through LDS, then written out as runs of equal digits (64 B on average at 512
 //              bins / 8192 slots; hub columns give long runs).  Keys and the two payloads take turns in one 32 KB LDS
 //              buffer: 45 KB per workgroup, 3 workgroups per CU.
-// Traffic per slot: 4 (upsweep) + 4 + 12 (first downsweep) + 4 + 12 + 12 (second) = 48 B against 16 B algorithmic.
-// Measured on the Reddit-shaped graph (114.8 M slots, 2 passes): 2.38 ms, of which the ballot matching is ~0.1 ms and
+// Traffic per slot: 4 (upsweep) + 4 + 12 (first downsweep) + 4 + 12 + 12 (second) = 48 B against 16 B algorithmic
+// (36 B with the packed intermediate records of the two-pass case, see rt_downsweep_kernel).
+// Measured on the Reddit-shaped graph (114.8 M slots, 2 passes, before the XCD-contiguous tile order): 2.38 ms, of which the ballot matching is ~0.1 ms and
 // the two payload arrays ~0.9 ms -- the scatter of 64-byte runs over the whole output (every run lands in a different
 // DRAM page) is what bounds a pass, not the instruction count: 4096-slot tiles (more workgroups in flight, 32-byte runs)
-// are slower (2.89 ms), 16384-slot tiles (128-byte runs, one workgroup per CU) the same (2.34 ms).
+// are slower (2.89 ms), 16384-slot tiles (128-byte runs, one workgroup per CU) the same (2.34 ms).  Dropping one staged
+// array AND two global stores (packed records) gains only 3 %: a staging round costs its two 8-wave barriers, not its
+// bytes -- with 2 workgroups per CU little else runs while a workgroup waits.
 #include "common.h"
 
 #include <rocprim/device/device_scan.hpp>
@@ -54,6 +57,7 @@ struct Params {
     int64_t m, nnz, n_tiles;
     uint32_t pad_key;
     int shift, bits, padded;
+    int row_bits;           // packed records: word = (remaining key digits << row_bits) | row
 };
 
 __device__ __forceinline__ int64_t rt_row_search(const int32_t *__restrict__ rowptr, int64_t lo, int64_t hi, int64_t e) {
@@ -84,7 +88,7 @@ __device__ __forceinline__ uint32_t load_key(const Params &p, int64_t i, int64_t
     else return p.keys_in[i];
 }
 
-template <bool FIRST>
+template <bool FIRST, bool IN_PACKED = false>
 __global__ __launch_bounds__(kThreads) void rt_upsweep_kernel(const Params p) {
     __shared__ uint32_t hist[kWaves][kMaxBins];
     const int t = threadIdx.x, lane = t & (kWave - 1), w = t >> 6;
@@ -97,7 +101,8 @@ __global__ __launch_bounds__(kThreads) void rt_upsweep_kernel(const Params p) {
 #pragma unroll
     for (int j = 0; j < kRows; ++j) {
         const int64_t i = base + j * kWave + lane;
-        key[j] = i < p.nnz ? load_key<FIRST>(p, i, valid) : 0u;
+        if constexpr (IN_PACKED) key[j] = i < p.nnz ? ((uint32_t)p.row_in[i] >> p.row_bits) : 0u;  // (shift = 0)
+        else key[j] = i < p.nnz ? load_key<FIRST>(p, i, valid) : 0u;
     }
     __syncthreads();
     const uint32_t mask = (uint32_t)nbins - 1u;
@@ -123,8 +128,15 @@ __global__ __launch_bounds__(kThreads) void rt_upsweep_kernel(const Params p) {
     }
 }
 
-template <bool FIRST>
+// PACK = 0: records are three arrays (key, e, row) on both sides.  Two-pass sorts (column ids of <= 18 bits) use the
+// PACKED intermediate record instead -- after the first pass only the key's second digit is still needed, and it fits
+// one word together with the row: (digit << row_bits) | row --
+//   PACK = 1 (first pass):  writes (e, word); the keys go through LDS only to place the slots, not to memory;
+//   PACK = 2 (second pass): reads (e, word); one LDS round carries digit and row together, so the pass stages and
+//                           writes two arrays (rowind, perm) and no sorted keys (colptr comes from rt_colptr_perm).
+template <bool FIRST, int PACK = 0>
 __global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params p) {
+    static_assert(PACK == 0 || (FIRST ? PACK == 1 : PACK == 2), "packed out in the first pass, packed in in the second");
     __shared__ __attribute__((aligned(16))) uint32_t buf[kTile];
     __shared__ uint32_t cnt[kWaves][kMaxBins];  // per wave: running count, then the wave's start inside the digit's run
     __shared__ uint32_t dstart[kMaxBins];       // where the digit's run starts in the reordered tile
@@ -156,6 +168,18 @@ __global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params 
         for (int j = 0; j < kRows; ++j) {
             const int l = l0 + j * kWave;
             key[j] = l < valid ? (uint32_t)src[l] : p.pad_key;
+        }
+    } else if constexpr (PACK == 2) {
+        const int32_t *__restrict__ esrc = p.e_in + tile0, *__restrict__ wsrc = p.row_in + tile0;
+        const uint32_t row_mask = (1u << p.row_bits) - 1u;
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) {
+            const int l = l0 + j * kWave;
+            const bool ok = l < n_here;
+            const uint32_t wd = ok ? (uint32_t)wsrc[l] : 0u;
+            key[j] = wd >> p.row_bits;  // (the digit of this pass; p.shift = 0)
+            pr[j] = (int32_t)(wd & row_mask);
+            pe[j] = ok ? esrc[l] : 0;
         }
     } else {
         const uint32_t *__restrict__ ksrc = p.keys_in + tile0;
@@ -252,8 +276,12 @@ __global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params 
     }
     // ---- keys through LDS -> runs of equal digits in the output; remember where each reordered slot goes
 #pragma unroll
-    for (int j = 0; j < kRows; ++j)
-        if (l0 + j * kWave < n_here) buf[spos[j]] = key[j];
+    for (int j = 0; j < kRows; ++j) {
+        if (l0 + j * kWave < n_here) {
+            if constexpr (PACK == 2) buf[spos[j]] = (key[j] << p.row_bits) | (uint32_t)pr[j];  // digit and row in one round
+            else buf[spos[j]] = key[j];
+        }
+    }
     __syncthreads();
     uint32_t gpos[kRows];  // (nnz < 2^31)
 #pragma unroll
@@ -262,8 +290,13 @@ __global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params 
         gpos[q] = 0;
         if (sidx < n_here) {
             const uint32_t k = buf[sidx];
-            gpos[q] = delta[(k >> p.shift) & mask] + (uint32_t)sidx;
-            p.keys_out[gpos[q]] = k;
+            if constexpr (PACK == 2) {
+                gpos[q] = delta[(k >> p.row_bits) & mask] + (uint32_t)sidx;
+                p.row_out[gpos[q]] = (int32_t)(k & ((1u << p.row_bits) - 1u));
+            } else {
+                gpos[q] = delta[(k >> p.shift) & mask] + (uint32_t)sidx;
+                if constexpr (PACK == 0) p.keys_out[gpos[q]] = k;
+            }
         }
     }
     __syncthreads();
@@ -277,15 +310,50 @@ __global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params 
 #pragma unroll
     for (int q = 0; q < kRows; ++q)
         if (q * kThreads + t < n_here) p.e_out[gpos[q]] = (int32_t)buf[q * kThreads + t];
+    if constexpr (PACK == 2) return;  // (the row went out with the digit)
     __syncthreads();
-    // ---- payload 2: the row
+    // ---- payload 2: the row (packed: with the key's remaining digit above it)
 #pragma unroll
-    for (int j = 0; j < kRows; ++j)
-        if (l0 + j * kWave < n_here) buf[spos[j]] = (uint32_t)pr[j];
+    for (int j = 0; j < kRows; ++j) {
+        if (l0 + j * kWave < n_here) {
+            if constexpr (PACK == 1) buf[spos[j]] = ((key[j] >> p.bits) << p.row_bits) | (uint32_t)pr[j];
+            else buf[spos[j]] = (uint32_t)pr[j];
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < kRows; ++q)
         if (q * kThreads + t < n_here) p.row_out[gpos[q]] = (int32_t)buf[q * kThreads + t];
+}
+
+// colptr without the sorted keys (packed sorts do not write them): colptr[c] = the first position j whose column
+// colind[perm[j]] is >= c -- one binary search per column through perm (<= 2^18 columns x ~27 steps x 2 loads).
+__global__ void rt_colptr_perm_kernel(const int32_t *__restrict__ colind, const int32_t *__restrict__ perm,
+                                      const int32_t *__restrict__ rowptr, int64_t m, int padded, int64_t nnz,
+                                      int64_t n_cols, int32_t *__restrict__ colptr) {
+    const int64_t valid = padded ? (int64_t)rowptr[m] : nnz;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c <= n_cols; c += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo = 0, hi = nnz;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            const int64_t e = perm[mid];
+            const int64_t key = e < valid ? (int64_t)colind[e] : n_cols;
+            if (key < c) lo = mid + 1; else hi = mid;
+        }
+        colptr[c] = (int32_t)lo;
+    }
+}
+
+__global__ void rt_colptr_sorted_kernel(const uint32_t *__restrict__ keys, int32_t *__restrict__ colptr, int64_t nnz,
+                                        int64_t n_cols) {
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c <= n_cols; c += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo = 0, hi = nnz;  // first position whose key >= c
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)keys[mid] < c) lo = mid + 1; else hi = mid;
+        }
+        colptr[c] = (int32_t)lo;
+    }
 }
 
 struct Geometry {
@@ -338,11 +406,15 @@ size_t radix_transpose_workspace_bytes(int64_t n_cols, int64_t nnz, bool padded)
     return rt::geometry(n_cols, nnz, padded).total;
 }
 
-// -> keys_sorted (inside the workspace, returned through *keys_sorted_out), perm, rowind.  nnz > 0, m > 0.
+// -> colptr, rowind, perm.  nnz > 0, m > 0.
 int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols, int64_t nnz, bool padded,
-                    int32_t *rowind, int32_t *perm, void *workspace, const uint32_t **keys_sorted_out, hipStream_t s) {
+                    int32_t *colptr, int32_t *rowind, int32_t *perm, void *workspace, hipStream_t s) {
     using namespace rt;
     const Geometry g = geometry(n_cols, nnz, padded);
+    const int row_bits = (int)bits_for(m);
+    // (packed records from 16 M slots on: below that the per-column searches of rt_colptr_perm cost more than the one
+    //  staged array they save -- arxiv-shaped, 2.5 M slots: 125 vs 117 us; Reddit-shaped, 115 M: 2.00 vs 2.06 ms)
+    const bool packed = g.n_pass == 2 && row_bits + g.dbits <= 32 && (nnz >= (int64_t(1) << 24) || g_tuning[kTuneCsr2csc] == 3);
     if (g.n_tiles > 0x7fffffff || g.table_len > 0x7fffffff || m > 0x7fff0000) return COGDL_HIP_ERANGE;  // (int row loops)
     char *ws = (char *)workspace;
     uint32_t *table = (uint32_t *)(ws + g.off_table), *scanned = (uint32_t *)(ws + g.off_scanned);
@@ -359,6 +431,7 @@ int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int
     p.tile_rows = (int32_t *)(ws + g.off_tile_rows);
     p.padded = padded ? 1 : 0;
     p.bits = g.dbits;
+    p.row_bits = row_bits;
     for (int pass = 0; pass < g.n_pass; ++pass) {
         const bool first = pass == 0, last = pass == g.n_pass - 1;
         p.shift = pass * g.dbits;
@@ -379,8 +452,10 @@ int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int
             p.row_out = (int32_t *)set_ptr(dst, 2);
         }
         p.table = table;
-        if (first) hipLaunchKernelGGL(rt_upsweep_kernel<true>, dim3((unsigned)g.n_tiles), dim3(kThreads), 0, s, p);
-        else hipLaunchKernelGGL(rt_upsweep_kernel<false>, dim3((unsigned)g.n_tiles), dim3(kThreads), 0, s, p);
+        if (packed && !first) p.shift = 0;  // (the packed word holds the remaining digit at its bottom)
+        if (first) hipLaunchKernelGGL((rt_upsweep_kernel<true, false>), dim3((unsigned)g.n_tiles), dim3(kThreads), 0, s, p);
+        else if (packed) hipLaunchKernelGGL((rt_upsweep_kernel<false, true>), dim3((unsigned)g.n_tiles), dim3(kThreads), 0, s, p);
+        else hipLaunchKernelGGL((rt_upsweep_kernel<false, false>), dim3((unsigned)g.n_tiles), dim3(kThreads), 0, s, p);
         size_t tb = g.scan_temp;
         hipError_t e = rocprim::exclusive_scan(temp, tb, table, scanned, 0u, (size_t)g.table_len, rocprim::plus<uint32_t>(), s);
         if (e != hipSuccess) {
@@ -389,10 +464,20 @@ int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int
         }
         p.table = scanned;
         const unsigned dgrid = (unsigned)(((g.n_tiles + kXcds - 1) / kXcds) * kXcds);  // (XCD-contiguous tile ranges)
-        if (first) hipLaunchKernelGGL(rt_downsweep_kernel<true>, dim3(dgrid), dim3(kThreads), 0, s, p);
-        else hipLaunchKernelGGL(rt_downsweep_kernel<false>, dim3(dgrid), dim3(kThreads), 0, s, p);
+        if (packed) {
+            if (first) hipLaunchKernelGGL((rt_downsweep_kernel<true, 1>), dim3(dgrid), dim3(kThreads), 0, s, p);
+            else hipLaunchKernelGGL((rt_downsweep_kernel<false, 2>), dim3(dgrid), dim3(kThreads), 0, s, p);
+        } else {
+            if (first) hipLaunchKernelGGL((rt_downsweep_kernel<true, 0>), dim3(dgrid), dim3(kThreads), 0, s, p);
+            else hipLaunchKernelGGL((rt_downsweep_kernel<false, 0>), dim3(dgrid), dim3(kThreads), 0, s, p);
+        }
     }
-    *keys_sorted_out = keys_final;
+    const unsigned cb = (unsigned)std::min<int64_t>((n_cols + 256) / 256, 1 << 20);
+    if (packed)
+        hipLaunchKernelGGL(rt_colptr_perm_kernel, dim3(cb), dim3(256), 0, s, colind, perm, rowptr, m, padded ? 1 : 0, nnz,
+                           n_cols, colptr);
+    else
+        hipLaunchKernelGGL(rt_colptr_sorted_kernel, dim3(cb), dim3(256), 0, s, keys_final, colptr, nnz, n_cols);
     return launch_status();
 }
 

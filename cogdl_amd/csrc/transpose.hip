@@ -196,7 +196,7 @@ using namespace cogdl;
 namespace cogdl {  // radix_transpose.hip
 size_t radix_transpose_workspace_bytes(int64_t n_cols, int64_t nnz, bool padded);
 int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols, int64_t nnz, bool padded,
-                    int32_t *rowind, int32_t *perm, void *workspace, const uint32_t **keys_sorted_out, hipStream_t s);
+                    int32_t *colptr, int32_t *rowind, int32_t *perm, void *workspace, hipStream_t s);
 }
 
 static size_t rocprim_csr2csc_bytes(int64_t n_cols, int64_t nnz) {
@@ -268,14 +268,9 @@ static int csr2csc_impl(const int32_t *rowptr, const int32_t *colind, int64_t m,
     if (padded && (m == 0 || n_cols >= 0x7fffffff)) return COGDL_HIP_ERANGE;
     // The hand-written sort (radix_transpose.hip) from 256 k edge slots on: below that a transpose is a dozen launches
     // either way and rocPRIM's merge sort has the shorter ones (51 k slots: 67 vs 82 us; 2.5 M: 198 vs 117 us).
-    const bool radix = g_tuning[kTuneCsr2csc] == 2 || (g_tuning[kTuneCsr2csc] == 0 && nnz >= (1 << 18));
+    const bool radix = g_tuning[kTuneCsr2csc] >= 2 || (g_tuning[kTuneCsr2csc] == 0 && nnz >= (1 << 18));
     if (radix && m > 0) {
-        const uint32_t *sorted = nullptr;
-        const int rc = radix_transpose(rowptr, colind, m, n_cols, nnz, padded, rowind, perm, workspace, &sorted, s);
-        if (rc != COGDL_HIP_OK) return rc;
-        const unsigned cb = (unsigned)std::min<int64_t>((n_cols + 256) / 256, 1 << 20);
-        hipLaunchKernelGGL(colptr_from_sorted_keys, dim3(cb), dim3(256), 0, s, sorted, colptr, nnz, n_cols);
-        return launch_status();
+        return radix_transpose(rowptr, colind, m, n_cols, nnz, padded, colptr, rowind, perm, workspace, s);
     }
     const uint32_t *keys_in = (const uint32_t *)colind;
     if (padded) {  // (the key buffer sits in front of the ordinary layout)

@@ -71,7 +71,8 @@ COGDL_API int cogdl_hip_last_hip_error(void);
  * kernel's cross-tile wait gives up and recomputes the row statistics itself (0 = default 4096; negative: every
  * wait gives up at once -- tests of that escape path), key 9 = timing experiments (bit 0: the flat edge_softmax kernel
  * skips its cross-tile exchange -- WRONG results), key 10 = csr2csc algorithm (0 = automatic: the hand-written
- * two-payload radix sort from 256 k edge slots on, 1 = always the rocPRIM sort + row look-up pipeline, 2 = always the radix sort).
+ * two-payload radix sort from 256 k edge slots on, 1 = always the rocPRIM sort + row look-up pipeline, 2 = always the radix sort, 3 = the radix sort with packed
+ * intermediate records wherever two passes suffice -- by default only from 16 M slots on).
  * Defaults are the measured optima. */
 COGDL_API int cogdl_hip_set_tuning(int key, int value);
 

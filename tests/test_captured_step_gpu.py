@@ -62,7 +62,7 @@ def test_sample_adj_padded_rejects_what_has_no_fixed_capacity():
     assert int(counts[2]) & 1  # a seed outside the graph is flagged, not fatal on the device
 
 
-@pytest.mark.parametrize("algo", [1, 2], ids=["rocprim-pipeline", "radix-transpose"])
+@pytest.mark.parametrize("algo", [1, 2, 3], ids=["rocprim-pipeline", "radix-transpose", "radix-transpose-packed-records"])
 @pytest.mark.parametrize("surplus", [0, 1, 777, 20000])
 def test_csr2csc_padded_ignores_the_slots_behind_the_last_row(surplus, algo):
     _lib.hip().cogdl_hip_set_tuning(10, algo)

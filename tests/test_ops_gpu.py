@@ -21,7 +21,7 @@ def rand(*shape, seed=0, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------ csr2csc
-@pytest.fixture(params=[1, 2], ids=["rocprim-pipeline", "radix-transpose"])
+@pytest.fixture(params=[1, 2, 3], ids=["rocprim-pipeline", "radix-transpose", "radix-transpose-packed-records"])
 def csc_algo(request):
     """csr2csc's two implementations (tuning key 10; the default picks by size): the rocPRIM sort + row look-up and the
     hand-written two-payload radix sort (csrc/radix_transpose.hip)."""
