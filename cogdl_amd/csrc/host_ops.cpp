@@ -153,39 +153,20 @@ int cogdl_host_coo2csr_index(const int64_t *row, int64_t nnz, int64_t num_nodes,
     return COGDL_HOST_OK;
 }
 
-int cogdl_host_sample_adj(const int64_t *indptr, const int64_t *indices, int64_t num_nodes, const int64_t *node_idx,
-                          int64_t batch, int64_t num_neighbors, int replace, uint64_t seed, int64_t *out_indptr,
-                          int64_t *out_indices, int64_t *out_nodes, int64_t *out_edges, int64_t cap_edges,
-                          int64_t cap_nodes, int64_t *out_counts) {
-    if (!indptr || !out_indptr || !out_counts || batch < 0 || num_nodes < 0 || (batch > 0 && !node_idx))
-        return COGDL_HOST_EINVAL;
-    if (!in_range(node_idx, batch, num_nodes)) return COGDL_HOST_ERANGE;
-    if (batch > cap_nodes) return COGDL_HOST_ECAP;
-
-    // local id of every global node: -1 = not seen yet (out_nodes doubles as the list of touched entries)
-    LocalIds ids(num_nodes, out_nodes);
-    std::vector<int64_t> &local = ids.map;
-    for (int64_t i = 0; i < batch; ++i) {
-        local[(size_t)node_idx[i]] = i;
-        out_nodes[i] = node_idx[i];
-    }
-    int64_t n_nodes = batch, n_edges = 0;
-    ids.n_touched = batch;
-    // Every sampled edge costs three dependent random reads (indptr[seed], indices[edge], the id map): at products scale
-    // each is a cache miss, and a one-seed-at-a-time loop pays them serially (~100 ns each).  The seeds are therefore
-    // processed in blocks of kBlock with one pass per dependent level, each pass prefetching what the next one reads,
-    // so the misses of a block overlap.  Picks, their order and the relabelling are exactly those of the plain loop.
+// The picks of seeds [s0, s1): edge positions -> out_edges, the neighbours' GLOBAL ids -> out_indices, both at the
+// offsets out_indptr holds already.  Every sampled edge costs two dependent random reads here (indptr[seed],
+// indices[edge]): the seeds go in blocks of kBlock with one pass per level, each pass prefetching what the next one
+// reads, so that the misses of a block overlap.  Pure function of (seed word, seed row): threads can split the seeds
+// any way they like.  Returns false on a neighbour id outside the graph.
+static bool sample_picks(const int64_t *indptr, const int64_t *indices, int64_t num_nodes, const int64_t *node_idx,
+                         int64_t s0, int64_t s1, int64_t num_neighbors, int replace, uint64_t seed,
+                         const int64_t *out_indptr, int64_t *out_indices, int64_t *out_edges) {
     constexpr int64_t kBlock = 256;
-    thread_local std::vector<int64_t> blk_edge, blk_src, blk_cnt;
     std::vector<int64_t> pick;
-    out_indptr[0] = 0;
-    for (int64_t b0 = 0; b0 < batch; b0 += kBlock) {
-        const int64_t b1 = std::min(batch, b0 + kBlock);
+    for (int64_t b0 = s0; b0 < s1; b0 += kBlock) {
+        const int64_t b1 = std::min(s1, b0 + kBlock);
         for (int64_t i = b0; i < b1; ++i) __builtin_prefetch(indptr + node_idx[i]);
-        // level 1: row extents -> picks (edge positions), prefetch the neighbour ids
-        blk_edge.clear();
-        blk_cnt.assign((size_t)(b1 - b0), 0);
-        for (int64_t i = b0; i < b1; ++i) {
+        for (int64_t i = b0; i < b1; ++i) {  // level 1: row extents -> picks (edge positions), prefetch the neighbour ids
             const int64_t begin = indptr[node_idx[i]];
             const int64_t deg = indptr[node_idx[i] + 1] - begin;
             SplitMix64 rng(stream_seed(seed, (uint64_t)i));  // per-seed stream: result independent of batching
@@ -198,41 +179,102 @@ int cogdl_host_sample_adj(const int64_t *indptr, const int64_t *indices, int64_t
             } else {
                 sample_without_replacement(deg, num_neighbors, rng, pick);
             }
-            blk_cnt[(size_t)(i - b0)] = (int64_t)pick.size();
-            for (int64_t q : pick) {
-                blk_edge.push_back(begin + q);
-                __builtin_prefetch(indices + begin + q);
+            int64_t *dst = out_edges + out_indptr[i];
+            for (size_t q = 0; q < pick.size(); ++q) {
+                dst[q] = begin + pick[q];
+                __builtin_prefetch(indices + begin + pick[q]);
             }
         }
-        if (n_edges + (int64_t)blk_edge.size() > cap_edges) return COGDL_HOST_ECAP;
-        // level 2: neighbour ids, prefetch their id-map entries
-        blk_src.resize(blk_edge.size());
-        for (size_t e = 0; e < blk_edge.size(); ++e) {
-            const int64_t src = indices[blk_edge[e]];
-            if (src < 0 || src >= num_nodes) return COGDL_HOST_ERANGE;
-            blk_src[e] = src;
-            __builtin_prefetch(&local[(size_t)src], 1);
+        for (int64_t e = out_indptr[b0]; e < out_indptr[b1]; ++e) {  // level 2: the neighbour ids
+            const int64_t src = indices[out_edges[e]];
+            if (src < 0 || src >= num_nodes) return false;
+            out_indices[e] = src;
         }
-        // level 3: relabel in discovery order
-        size_t e = 0;
-        for (int64_t i = b0; i < b1; ++i) {
-            for (int64_t c = 0; c < blk_cnt[(size_t)(i - b0)]; ++c, ++e) {
-                int64_t &id = local[(size_t)blk_src[e]];
-                if (id < 0) {
-                    if (n_nodes >= cap_nodes) return COGDL_HOST_ECAP;
-                    id = n_nodes;
-                    out_nodes[n_nodes++] = blk_src[e];
-                    ids.n_touched = n_nodes;
-                }
-                out_indices[n_edges] = id;
-                out_edges[n_edges++] = blk_edge[e];
-            }
-            out_indptr[i + 1] = n_edges;
+    }
+    return true;
+}
+
+static int64_t sample_count(int64_t deg, int64_t num_neighbors, int replace) {
+    if (num_neighbors < 0) return deg;
+    if (replace) return deg > 0 ? num_neighbors : 0;
+    return std::min(deg, num_neighbors);
+}
+
+int cogdl_host_sample_adj_mt(const int64_t *indptr, const int64_t *indices, int64_t num_nodes, const int64_t *node_idx,
+                             int64_t batch, int64_t num_neighbors, int replace, uint64_t seed, int64_t *out_indptr,
+                             int64_t *out_indices, int64_t *out_nodes, int64_t *out_edges, int64_t cap_edges,
+                             int64_t cap_nodes, int64_t *out_counts, int nthreads) {
+    if (!indptr || !out_indptr || !out_counts || batch < 0 || num_nodes < 0 || (batch > 0 && !node_idx))
+        return COGDL_HOST_EINVAL;
+    if (!in_range(node_idx, batch, num_nodes)) return COGDL_HOST_ERANGE;
+    if (batch > cap_nodes) return COGDL_HOST_ECAP;
+    // Three phases.  (1) how many edges every seed contributes -> out_indptr (one random read per seed, prefetched);
+    // (2) the picks and the neighbours' global ids, written at their final offsets -- independent per seed, split over
+    // `nthreads` OpenMP threads (nthreads = 1, what DataLoader workers get, never enters a parallel region);
+    // (3) relabelling in discovery order, sequential by definition (the third dependent random read, the id map).
+    // Picks, their order and the relabelling are exactly those of the one-seed-at-a-time loop of sample.cpp.
+    constexpr int64_t kAhead = 16;
+    out_indptr[0] = 0;
+    for (int64_t i = 0; i < batch; ++i) {
+        if (i + kAhead < batch) __builtin_prefetch(indptr + node_idx[i + kAhead]);
+        const int64_t s = node_idx[i];
+        out_indptr[i + 1] = out_indptr[i] + sample_count(indptr[s + 1] - indptr[s], num_neighbors, replace);
+    }
+    const int64_t n_edges = out_indptr[batch];
+    if (n_edges > cap_edges) return COGDL_HOST_ECAP;
+    // a thread per ~4096 sampled edges at most; seeds split at equal-edge boundaries
+    int t = (int)std::min<int64_t>(std::max(nthreads, 1), std::max<int64_t>(1, n_edges / 4096));
+    if (t <= 1) {
+        if (!sample_picks(indptr, indices, num_nodes, node_idx, 0, batch, num_neighbors, replace, seed, out_indptr,
+                          out_indices, out_edges))
+            return COGDL_HOST_ERANGE;
+    } else {
+        std::vector<int64_t> cut((size_t)t + 1, batch);
+        cut[0] = 0;
+        for (int k = 1; k < t; ++k)
+            cut[(size_t)k] = std::upper_bound(out_indptr, out_indptr + batch + 1, n_edges * k / t) - out_indptr - 1;
+        std::vector<char> ok((size_t)t, 1);
+        // OpenMP, not std::thread: the caller is a torch process whose OpenMP workers spin for a while after every
+        // parallel torch operator -- fresh threads would fight them for the cores (measured: 2 std::threads made a
+        // two-hop batch 3x SLOWER inside a torch loop), the OpenMP runtime hands the region to those same workers.
+#pragma omp parallel for num_threads(t) schedule(static, 1)
+        for (int k = 0; k < t; ++k)
+            ok[(size_t)k] = sample_picks(indptr, indices, num_nodes, node_idx, cut[(size_t)k], cut[(size_t)k + 1],
+                                         num_neighbors, replace, seed, out_indptr, out_indices, out_edges);
+        for (char v : ok)
+            if (!v) return COGDL_HOST_ERANGE;
+    }
+    // local id of every global node: -1 = not seen yet (out_nodes doubles as the list of touched entries)
+    LocalIds ids(num_nodes, out_nodes);
+    std::vector<int64_t> &local = ids.map;
+    for (int64_t i = 0; i < batch; ++i) {
+        local[(size_t)node_idx[i]] = i;
+        out_nodes[i] = node_idx[i];
+    }
+    int64_t n_nodes = batch;
+    ids.n_touched = batch;
+    for (int64_t e = 0; e < n_edges; ++e) {
+        if (e + kAhead < n_edges) __builtin_prefetch(&local[(size_t)out_indices[e + kAhead]], 1);
+        int64_t &id = local[(size_t)out_indices[e]];
+        if (id < 0) {
+            if (n_nodes >= cap_nodes) return COGDL_HOST_ECAP;
+            id = n_nodes;
+            out_nodes[n_nodes++] = out_indices[e];
+            ids.n_touched = n_nodes;
         }
+        out_indices[e] = id;
     }
     out_counts[0] = n_nodes;
     out_counts[1] = n_edges;
     return COGDL_HOST_OK;
+}
+
+int cogdl_host_sample_adj(const int64_t *indptr, const int64_t *indices, int64_t num_nodes, const int64_t *node_idx,
+                          int64_t batch, int64_t num_neighbors, int replace, uint64_t seed, int64_t *out_indptr,
+                          int64_t *out_indices, int64_t *out_nodes, int64_t *out_edges, int64_t cap_edges,
+                          int64_t cap_nodes, int64_t *out_counts) {
+    return cogdl_host_sample_adj_mt(indptr, indices, num_nodes, node_idx, batch, num_neighbors, replace, seed, out_indptr,
+                                    out_indices, out_nodes, out_edges, cap_edges, cap_nodes, out_counts, 1);
 }
 
 int cogdl_host_subgraph(const int64_t *indptr, const int64_t *indices, int64_t num_nodes, const int64_t *node_idx,

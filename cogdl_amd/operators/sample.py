@@ -11,6 +11,8 @@ Semantics follow cogdl/operators/sample/sample.cpp; differences:
   * random modes draw from an explicit, reproducible generator: the seed is taken from torch's
     CPU generator (so `torch.manual_seed` controls sampling) instead of unseeded libc rand().
 """
+import os
+
 import torch
 
 from .. import _lib
@@ -91,6 +93,16 @@ def _sample_adj_gpu(indptr, indices, node_idx, num_neighbors, replace, seed):
     return out_indptr, out_indices[:ne], out_nodes[:nn], out_edges[:ne]
 
 
+def _sampler_threads():
+    """Host threads for the pick phase of the host sampler: COGDL_AMD_SAMPLER_THREADS, else torch's intra-op thread
+    count capped at 16 -- which is 1 inside DataLoader workers (torch sets it so), where the workers are the
+    parallelism; the library itself uses fewer for small batches (one thread per ~4096 sampled edges)."""
+    env = os.environ.get("COGDL_AMD_SAMPLER_THREADS")
+    if env:
+        return max(1, int(env))
+    return max(1, min(16, torch.get_num_threads()))
+
+
 def sample_adj_padded(indptr, indices, node_idx, num_neighbors, replace=False, seed=0, seed_dev=None, count=None):
     """sample_adj into buffers of FIXED capacity (GPU graphs only): no size depends on what was sampled and nothing
     synchronises, so the call can sit inside a captured hipGraph (cogdl_amd.graphs.capture / torch.cuda.graph).
@@ -154,10 +166,10 @@ def sample_adj_c(indptr, indices, node_idx, num_neighbors, replace, seed=None):
     out_nodes = torch.empty(cap_n, dtype=torch.long)
     out_edges = torch.empty(cap_e, dtype=torch.long)
     counts = torch.zeros(2, dtype=torch.long)
-    rc = _lib.host().cogdl_host_sample_adj(_lib.ptr(indptr), _lib.ptr(indices), n, _lib.ptr(node_idx), b,
-                                           num_neighbors, int(bool(replace)), seed, _lib.ptr(out_indptr),
-                                           _lib.ptr(out_indices), _lib.ptr(out_nodes), _lib.ptr(out_edges), cap_e,
-                                           cap_n, _lib.ptr(counts))
+    rc = _lib.host().cogdl_host_sample_adj_mt(_lib.ptr(indptr), _lib.ptr(indices), n, _lib.ptr(node_idx), b,
+                                              num_neighbors, int(bool(replace)), seed, _lib.ptr(out_indptr),
+                                              _lib.ptr(out_indices), _lib.ptr(out_nodes), _lib.ptr(out_edges), cap_e,
+                                              cap_n, _lib.ptr(counts), _sampler_threads())
     _lib.check_host(rc, "sample_adj")
     nn, ne = int(counts[0]), int(counts[1])
     return out_indptr, out_indices[:ne].clone(), out_nodes[:nn].clone(), out_edges[:ne].clone()

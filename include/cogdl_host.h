@@ -58,6 +58,17 @@ COGDL_HOST_API int cogdl_host_sample_adj(const int64_t *indptr, const int64_t *i
                                          int64_t *out_nodes, int64_t *out_edges, int64_t cap_edges,
                                          int64_t cap_nodes, int64_t *out_counts);
 
+/* The same with the picks (two of the three dependent random reads per sampled edge) split over `nthreads` host
+ * OpenMP threads (the runtime a torch process already has workers of; nthreads = 1 -- what torch gives DataLoader
+ * workers -- never enters a parallel region, so forked workers stay clear of OpenMP); the relabelling in discovery
+ * order stays sequential.  Bit-identical results for every nthreads >= 1 (the random stream
+ * of a seed row depends on (seed, row) only). */
+COGDL_HOST_API int cogdl_host_sample_adj_mt(const int64_t *indptr, const int64_t *indices, int64_t num_nodes,
+                                            const int64_t *node_idx, int64_t batch, int64_t num_neighbors,
+                                            int replace, uint64_t seed, int64_t *out_indptr, int64_t *out_indices,
+                                            int64_t *out_nodes, int64_t *out_edges, int64_t cap_edges,
+                                            int64_t cap_nodes, int64_t *out_counts, int nthreads);
+
 /* subgraph(indptr, indices, node_idx) -> induced subgraph in CSR, relabelled by position in
  * node_idx.  Replaces sampler.subgraph (sample.cpp:146-188).  out_counts = {E'}. */
 COGDL_HOST_API int cogdl_host_subgraph(const int64_t *indptr, const int64_t *indices, int64_t num_nodes,

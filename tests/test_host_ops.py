@@ -70,6 +70,28 @@ def test_sample_adj_random_modes_structure(replace, k):
     assert all(torch.equal(a, b) for a, b in zip(again, (out_indptr, out_indices, nodes, edges)))
 
 
+@pytest.mark.parametrize("k,replace", [(10, False), (3, True), (-1, False), (40, False)])
+def test_sample_adj_is_the_same_for_every_thread_count(monkeypatch, k, replace):
+    """cogdl_host_sample_adj_mt: the picks are split over OpenMP threads, the result must not depend on how many
+    (a seed row's random stream is a function of (seed, row) only); big enough that the library really splits."""
+    g = synth.scaled(30000, 14, seed=9, topology="rmat", norm=None, self_loops=False)
+    indptr, indices = g.rowptr.long(), g.colind.long()
+    seeds = torch.randperm(30000, generator=torch.Generator().manual_seed(3))[:6000]
+    want = None
+    for threads in ("1", "2", "3", "8"):
+        monkeypatch.setenv("COGDL_AMD_SAMPLER_THREADS", threads)
+        got = ops.sample_adj_c(indptr, indices, seeds, k, replace, seed=77)
+        if want is None:
+            want = got
+            assert got[1].numel() > 2 * 4096  # (one thread per ~4096 sampled edges: more than one is used)
+        assert all(torch.equal(a, b) for a, b in zip(got, want)), threads
+    monkeypatch.setenv("COGDL_AMD_SAMPLER_THREADS", "8")
+    with pytest.raises(BackendError):
+        bad = indices.clone()
+        bad[7] = 30000  # a neighbour id outside the graph: found by whichever thread reads it
+        ops.sample_adj_c(indptr, bad, torch.arange(30000), -1, False)
+
+
 def test_sample_without_replacement_is_uniform():
     # one node with 20 neighbours, sample 5, many seeds: each neighbour picked ~ 25 % of the time
     indptr = torch.tensor([0, 20] + [20] * 20)
