@@ -94,13 +94,13 @@ def _sample_adj_gpu(indptr, indices, node_idx, num_neighbors, replace, seed):
 
 
 def _sampler_threads():
-    """Host threads for the pick phase of the host sampler: COGDL_AMD_SAMPLER_THREADS, else torch's intra-op thread
-    count capped at 16 -- which is 1 inside DataLoader workers (torch sets it so), where the workers are the
-    parallelism; the library itself uses fewer for small batches (one thread per ~4096 sampled edges)."""
+    """OpenMP threads for the pick phase of the host sampler: COGDL_AMD_SAMPLER_THREADS, default 1.  Opt-in because the
+    gain depends on the host: 8 threads made two-hop batches 1.85x (1024 seeds) / 3x (8192) faster on an 8-core box, but
+    on the 256-core NUMA host of the MI355X box they were 3.5x SLOWER at 1024 seeds (1.7 -> 5.9 ms; 8192 seeds:
+    noisy either way) -- one thread there already is 30x the reference's sampler.  DataLoader workers are the
+    parallelism of the reference's own pipeline in any case."""
     env = os.environ.get("COGDL_AMD_SAMPLER_THREADS")
-    if env:
-        return max(1, int(env))
-    return max(1, min(16, torch.get_num_threads()))
+    return max(1, int(env)) if env else 1
 
 
 def sample_adj_padded(indptr, indices, node_idx, num_neighbors, replace=False, seed=0, seed_dev=None, count=None):
