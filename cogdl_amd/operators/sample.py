@@ -12,6 +12,7 @@ Semantics follow cogdl/operators/sample/sample.cpp; differences:
     CPU generator (so `torch.manual_seed` controls sampling) instead of unseeded libc rand().
 """
 import os
+import threading
 
 import torch
 
@@ -146,6 +147,20 @@ def sample_adj_padded(indptr, indices, node_idx, num_neighbors, replace=False, s
     return out_indptr, out_indices, out_nodes, out_edges, counts
 
 
+_SCRATCH = threading.local()
+
+
+def _host_scratch(cap_e, cap_n):
+    """(out_indices[cap_e], out_nodes[cap_n], out_edges[cap_e]) views of this thread's reusable int64 scratch; the
+    caller copies what was actually produced out of it before the next call."""
+    need = 2 * cap_e + cap_n
+    buf = getattr(_SCRATCH, "buf", None)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 1 << 16), dtype=torch.long)
+        _SCRATCH.buf = buf
+    return buf[:cap_e], buf[cap_e:cap_e + cap_n], buf[cap_e + cap_n:cap_e + cap_n + cap_e]
+
+
 def sample_adj_c(indptr, indices, node_idx, num_neighbors, replace, seed=None):
     if torch.is_tensor(indptr) and indptr.is_cuda:
         return _sample_adj_gpu(indptr, indices, node_idx, num_neighbors, replace, seed)
@@ -162,9 +177,9 @@ def sample_adj_c(indptr, indices, node_idx, num_neighbors, replace, seed=None):
     if seed is None:
         seed = 0 if num_neighbors < 0 else int(torch.randint(0, 2 ** 62, (1,)).item())
     out_indptr = torch.empty(b + 1, dtype=torch.long)
-    out_indices = torch.empty(cap_e, dtype=torch.long)
-    out_nodes = torch.empty(cap_n, dtype=torch.long)
-    out_edges = torch.empty(cap_e, dtype=torch.long)
+    # capacity-sized scratch, kept per thread and grown on demand: a second hop asks for tens of MB of upper-bound
+    # capacity of which a fraction is used -- fresh allocations of that size are mmap'ed and page-faulted on every call
+    out_indices, out_nodes, out_edges = _host_scratch(cap_e, cap_n)
     counts = torch.zeros(2, dtype=torch.long)
     rc = _lib.host().cogdl_host_sample_adj_mt(_lib.ptr(indptr), _lib.ptr(indices), n, _lib.ptr(node_idx), b,
                                               num_neighbors, int(bool(replace)), seed, _lib.ptr(out_indptr),
