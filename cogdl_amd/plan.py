@@ -74,6 +74,9 @@ def csr2csc(rowptr, colind, n_cols=None, padded=False):
     m = rowptr.numel() - 1
     nnz = colind.numel()
     n_cols = m if n_cols is None else int(n_cols)
+    if m == 0:  # no rows: no edges whatever colind holds (a block whose target slots are all unused)
+        return CscPlan(torch.zeros(n_cols + 1, dtype=torch.int32, device=dev), torch.zeros(nnz, dtype=torch.int32, device=dev),
+                       torch.arange(nnz, dtype=torch.int32, device=dev), m, n_cols, nnz)
     colptr = torch.empty(n_cols + 1, dtype=torch.int32, device=dev)
     rowind = torch.empty(nnz, dtype=torch.int32, device=dev)
     perm = torch.empty(nnz, dtype=torch.int32, device=dev)
