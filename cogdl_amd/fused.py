@@ -54,3 +54,55 @@ def uninstall():
         if mod is not None:
             mod.spmm = fn
     _orig.clear()
+    uninstall_narrow_side()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Aggregate on the narrower side (second half).  GCNLayer.forward is
+# spmm(graph, linear(x)) (cogdl/layers/gcn_layer.py:51-53): the SpMM always runs at the OUTPUT width.  Where a layer
+# widens (in_features < out_features: the first layer of the OGB example, 128 -> 256, examples/ogb/arxiv/gnn.py:148-150)
+# the same result costs half the SpMM traffic the other way round:
+#       A (X W^T + 1 b^T)  =  (A X) W^T + (A 1) b^T
+# -- the aggregation at the input width, one extra SpMM of width 1 for the row sums of A (the graph's weights may change
+# between calls, so they are not cached).  Same operator, same dispatcher, same parameters; fp32 results differ by
+# reassociation only (checked to 1e-5 against the reference's order, tests/test_install_reference.py).
+_orig_gcn_forward = {}
+
+
+def _gcn_forward_narrow_side(self, graph, x):
+    mod = sys.modules[type(self).__module__]
+    spmm, lin = mod.spmm, self.linear
+    if lin.in_features < lin.out_features and x.dim() == 2:
+        out = torch.nn.functional.linear(spmm(graph, x), lin.weight)
+        if lin.bias is not None:
+            out = out + spmm(graph, torch.ones(x.shape[0], 1, dtype=x.dtype, device=x.device)) * lin.bias
+    else:
+        out = spmm(graph, lin(x))
+    # (the rest of cogdl/layers/gcn_layer.py:55-64, unchanged)
+    if self.norm is not None:
+        out = self.norm(out)
+    if self.act is not None:
+        out = self.act(out)
+    if self.residual is not None:
+        out = out + self.residual(x)
+    if self.dropout is not None:
+        out = self.dropout(out)
+    return out
+
+
+def install_narrow_side():
+    """Rebind cogdl.layers.gcn_layer.GCNLayer.forward to the order-choosing version (opt-in: install(narrow_side=True))."""
+    mod = sys.modules.get("cogdl.layers.gcn_layer")
+    if mod is None:
+        return False
+    cls = mod.GCNLayer
+    if cls.forward is not _gcn_forward_narrow_side:
+        _orig_gcn_forward[cls] = cls.forward
+        cls.forward = _gcn_forward_narrow_side
+    return True
+
+
+def uninstall_narrow_side():
+    for cls, fn in _orig_gcn_forward.items():
+        cls.forward = fn
+    _orig_gcn_forward.clear()

@@ -36,13 +36,15 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
 _finder = None
 
 
-def install(linear=False, fused_gat=True, fused_norm=False):
+def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False):
     """Idempotent.  Returns the list of cogdl module names that are now served by cogdl_amd.
     fused_norm=True rebinds the dispatcher function `cogdl.utils.spmm_utils.spmm` itself (opt-in: that is no longer the
     unchanged dispatcher) to cogdl_amd.fused.spmm, which folds `out_norm * x` / `in_norm * x` into the kernel.
     fused_gat=True (default) also runs the dispatcher's own `initialize_fused_gat()` (utils/spmm_utils.py:241-248)
     once cogdl is imported and a GPU is present: nothing in the reference ever calls it, so GATLayer's fused branch
     (`check_fused_gat()`, layers/gat_layer.py:68) would otherwise stay dead even with a working fused operator.
+    narrow_side=True rebinds GCNLayer.forward (opt-in, like fused_norm: no longer the unchanged layer) to
+    cogdl_amd.fused's version, which aggregates at the input width where a layer widens ((A X) W instead of A (X W)).
     linear=True additionally routes torch.nn.functional.linear -- i.e. the unchanged nn.Linear inside every CogDL
     layer -- through cogdl_amd.linear (hand-written MFMA weight gradient for full-graph shapes)."""
     global _finder
@@ -72,6 +74,10 @@ def install(linear=False, fused_gat=True, fused_norm=False):
         from . import fused as _fused
 
         _fused.install()
+    if narrow_side:
+        from . import fused as _fused
+
+        _fused.install_narrow_side()
     su = sys.modules.get("cogdl.utils.spmm_utils")
     if su is not None:  # force the dispatcher to re-resolve the callables
         for k in ("spmm_flag", "mh_spmm_flag", "fused_gat_flag", "spmm_cpu_flag"):

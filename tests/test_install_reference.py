@@ -123,6 +123,31 @@ w0 = torch.rand(400)
 assert torch.equal(ra, rb) and torch.equal(ca, cb) and torch.equal(wa, wb)
 assert torch.equal(gu.symmetric_normalization(50, ra, ca, wa), orig["symmetric_normalization"](50, rb, cb, wb))
 assert torch.equal(gu.row_normalization(50, ra, ca, wa), orig["row_normalization"](50, rb, cb, wb))
+
+# 9. install(narrow_side=True): GCNLayer aggregates at the input width where it widens -- (A X) W + (A 1) b -- and keeps
+#    the reference's order where it narrows; outputs and every gradient equal the unchanged layer's to fp32 reassociation
+import copy
+from cogdl.layers import GCNLayer
+gN = Graph(edge_index=(r0, c0), edge_weight=w0, num_nodes=50)
+gN.sym_norm()
+for fin, fout in ((8, 32), (32, 8), (16, 16)):
+    torch.manual_seed(fin)
+    layer = GCNLayer(fin, fout, activation="relu", residual=True, dropout=0.0)
+    twin = copy.deepcopy(layer)
+    xN = torch.randn(50, fin, requires_grad=True)
+    xT = xN.detach().clone().requires_grad_()
+    want_o = layer(gN, xN)
+    want_o.square().sum().backward()
+    cogdl_amd.install(narrow_side=True)
+    assert GCNLayer.forward.__module__ == "cogdl_amd.fused"
+    got_o = twin(gN, xT)
+    got_o.square().sum().backward()
+    cogdl_amd.fused.uninstall_narrow_side()
+    assert GCNLayer.forward.__module__ == "cogdl.layers.gcn_layer"
+    assert torch.allclose(got_o, want_o, rtol=1e-5, atol=1e-6), (fin, fout)
+    assert torch.allclose(xT.grad, xN.grad, rtol=1e-4, atol=1e-5), (fin, fout)
+    for pa, pb in zip(twin.parameters(), layer.parameters()):
+        assert torch.allclose(pa.grad, pb.grad, rtol=1e-4, atol=1e-5), (fin, fout)
 shutil.rmtree(scratch, ignore_errors=True)
 print("INSTALL-OK", served)
 '''
