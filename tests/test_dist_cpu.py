@@ -79,6 +79,53 @@ def test_sharded_equals_unsharded(tmp_path, oracle, world, n):
     assert total_halo == total_send  # every requested halo row is sent by exactly one owner
 
 
+def _bench_flow_worker(rank, world, port, shard_nodes, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cogdl_amd.dist import ShardedCSR, _papers_like_shard, sharded_spmm
+
+        # exactly what bench.py --gpus N does on every rank (cogdl_amd/dist.py:bench_sharded_spmm), small and on gloo
+        rowptr, cols, w = _papers_like_shard(rank, world, shard_nodes, 9.0, 0.3, 0, "cpu", 0.25)
+        bounds = torch.arange(world + 1, dtype=torch.long) * shard_nodes
+        sh = ShardedCSR(rowptr, cols, w, bounds, backend=OracleBackend())
+        gen = torch.Generator().manual_seed(100 + rank)
+        x = torch.randn(shard_nodes, 8, generator=gen, requires_grad=True)
+        gout = torch.randn(shard_nodes, 8, generator=gen)
+        y = sharded_spmm(sh, x)
+        y.backward(gout)
+        np.savez(os.path.join(out_dir, "b%d.npz" % rank), rowptr=rowptr.numpy(), cols=cols.numpy(), w=w.numpy(),
+                 x=x.detach().numpy(), gout=gout.numpy(), y=y.detach().numpy(), gx=x.grad.numpy(), n_halo=sh.n_halo,
+                 nnz_remote=sh.nnz_remote)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_flow_generated_shards_equal_the_assembled_global_matrix(tmp_path, oracle, world):
+    """The N > 1 bench's own data flow on gloo: every rank generates ITS shard (the world > 1 branches of the generator:
+    remote sources in per-peer boundary regions), builds the exchange plan, runs forward + backward; the shards are then
+    assembled into the global matrix and the results compared with the unsharded oracle."""
+    s = 400
+    mp.spawn(_bench_flow_worker, args=(world, 29650 + world, s, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(os.path.join(str(tmp_path), "b%d.npz" % r)) for r in range(world)]
+    n = world * s
+    rowptr = np.concatenate([[0]] + [p["rowptr"][1:] + sum(int(q["rowptr"][-1]) for q in parts[:r])
+                                     for r, p in enumerate(parts)]).astype(np.int32)
+    cols = np.concatenate([p["cols"] for p in parts]).astype(np.int32)
+    w = np.concatenate([p["w"] for p in parts]).astype(np.float32)
+    x = np.concatenate([p["x"] for p in parts])
+    gout = np.concatenate([p["gout"] for p in parts])
+    want_y = oracle.csr_spmm_f64(torch.from_numpy(rowptr), torch.from_numpy(cols), torch.from_numpy(w), torch.from_numpy(x))
+    colptr, rowind, w_t, _ = oracle.csr2csc(torch.from_numpy(rowptr), torch.from_numpy(cols), torch.from_numpy(w), n_cols=n)
+    want_gx = oracle.csr_spmm_f64(colptr, rowind, w_t, torch.from_numpy(gout))
+    for r, p in enumerate(parts):
+        np.testing.assert_allclose(p["y"], want_y[r * s:(r + 1) * s], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(p["gx"], want_gx[r * s:(r + 1) * s], rtol=1e-5, atol=1e-6)
+        assert int(p["nnz_remote"]) > 0 and 0 < int(p["n_halo"]) <= int(0.25 * s) + world  # the boundary regions bound the halo
+
+
 def test_papers_like_shard_generator_shape():
     """bench.py's N>1 workload: remote sources come from per-peer boundary slices, so the halo is bounded."""
     from cogdl_amd.dist import _papers_like_shard
