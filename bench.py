@@ -87,6 +87,25 @@ def cpu_baseline(g, x, budget_s=10.0):
     return res
 
 
+def pmc_traffic(topology, feat, live=True):
+    """`roofline.traffic`: HBM-side bytes per csr_spmm launch from the PMC counters.  Measured IN THIS RUN
+    (tools/pmc_live.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over a probe with the same graph and
+    kernel, calibrated on a 1 GiB copy as the guide prescribes for gfx950); only when rocprofv3 is unavailable or fails
+    does the line fall back to the committed summary of tools/gpu_round.sh pmc -- and says so.  -> (bytes | None, info)"""
+    if live:
+        from tools import pmc_live
+
+        r = pmc_live.collect(topology, feat)
+        if "hbm_bytes_per_launch" in r:
+            return r["hbm_bytes_per_launch"], r
+        info = {"live_error": r.get("error")}
+    else:
+        info = {"live_error": "skipped (--no-pmc)"}
+    v, path = load_pmc_traffic("arxiv_%s_F%d" % (topology, feat))
+    info["source"] = "COMMITTED profile %s (not measured in this run)" % path if v is not None else None
+    return v, info
+
+
 def load_pmc_traffic(phase="arxiv_uniform_F128"):
     """HBM-side bytes per launch of the main csr_spmm kernel from the committed rocprofv3 --pmc summary
     (profiles/rNN_pmc_spmm_arxiv.json, the latest round's; made by tools/gpu_round.sh pmc + tools/pmc_summarize.py: separate passes for
@@ -96,9 +115,9 @@ def load_pmc_traffic(phase="arxiv_uniform_F128"):
 
     try:
         path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_spmm_arxiv.json")))[-1]
-        return json.load(open(path))["phases"][phase]["main"]["hbm_bytes_per_launch"]
+        return json.load(open(path))["phases"][phase]["main"]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def gcn_epoch_ms(gd, rowptr64, colind64, x, reps=20, warmup=5, mfma_linear=True, captured=False):
@@ -182,6 +201,39 @@ def trainer_epoch(budget_s=240):
     return out
 
 
+def kernel_alone_ms(gd, xs, reps=50):
+    """The csr_spmm kernel alone (no autograd, no per-call index casts), HIP-event timed on the launch stream."""
+    from cogdl_amd.operators import spmm as spmm_mod
+
+    with torch.no_grad():
+        for _ in range(5):
+            spmm_mod.csr_spmm_raw(gd.rowptr, gd.colind, gd.weight, xs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            spmm_mod.csr_spmm_raw(gd.rowptr, gd.colind, gd.weight, xs)
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def rmat_roofline(dev, feats=(128, 64, 40)):
+    """`roofline.rmat`: the same kernel on the REALISTIC topology -- the arxiv-sized R-MAT graph (power-law degrees,
+    hub rows of 1e4 edges: the real ogbn-arxiv is power-law, the headline's uniform graph never triggers the long-row
+    path) at the headline width and at the two widths CogDL's gcn runs (hidden 64, 40 classes)."""
+    from cogdl_amd import synth
+
+    g = synth.arxiv_like(seed=0, topology="rmat")
+    gd = g.to(dev)
+    out = {"topology": "arxiv-sized R-MAT (a=.57,b=.19,c=.19), nnz=%d, max degree %d" % (g.nnz, int(g.degrees().max()))}
+    for f in feats:
+        ms = kernel_alone_ms(gd, torch.randn(g.num_nodes, f, device=dev))
+        ach = b_alg(g.nnz, g.num_nodes, f) / (ms * 1e-3) / 1e9
+        out["F%d" % f] = {"kernel_ms": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS}
+    out["achieved"], out["frac"] = out["F%d" % feats[0]]["achieved"], out["F%d" % feats[0]]["frac"]
+    return out
+
+
 def bench_single(args):
     from cogdl_amd import synth
     from cogdl_amd.operators import spmm as spmm_mod
@@ -215,18 +267,8 @@ def bench_single(args):
     events, spmm_mod.KERNEL_EVENTS = spmm_mod.KERNEL_EVENTS, None
     kern_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
 
-    # the dominant kernel alone (no autograd, no per-call index casts), HIP-event timed
-    with torch.no_grad():
-        xs = x.detach()
-        for _ in range(5):
-            spmm_mod.csr_spmm_raw(gd.rowptr, gd.colind, gd.weight, xs)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            spmm_mod.csr_spmm_raw(gd.rowptr, gd.colind, gd.weight, xs)
-        e1.record()
-        torch.cuda.synchronize()
-        fwd_ms = e0.elapsed_time(e1) / 50
+    fwd_ms = kernel_alone_ms(gd, x.detach())
+    traffic, traffic_info = pmc_traffic(args.topology, f, live=not args.no_pmc)
 
     bytes_alg = b_alg(g.nnz, g.num_nodes, f)
     achieved = bytes_alg / (kern_ms * 1e-3) / 1e9
@@ -244,12 +286,13 @@ def bench_single(args):
         "roofline": {"bound": "hbm", "kernel": "rowreduce_main_kernel<SpmmOp<float,VEC=2,LPR=64,UNROLL=8,weighted,exact,no-epilogue>> (the HIP events bracket one "
                                "cogdl_hip_csr_spmm call = this kernel + the ~4 us rowreduce_combine_kernel)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": load_pmc_traffic("arxiv_%s_F%d" % (args.topology, f)),
+                     "traffic": traffic, "traffic_info": traffic_info,
                      "algorithmic_bytes_per_launch": bytes_alg,
                      "compulsory_bytes_per_launch": g.nnz * 8 + 4 * (g.num_nodes + 1) + 2 * g.num_nodes * f * 4,
                      "kernel_ms_in_step": kern_ms, "kernel_ms_fwd_alone": fwd_ms,
                      "GEdges_s_fwd_alone": g.nnz / (fwd_ms * 1e-3) / 1e9},
     }
+    result["roofline"]["rmat"] = rmat_roofline(dev)
     result["gnn_epoch"] = gcn_epoch_ms(gd, rowptr64, colind64, x)
     result["gnn_epoch"]["ms_with_torch_linear"] = gcn_epoch_ms(gd, rowptr64, colind64, x, mfma_linear=False)["ms"]
     try:
@@ -271,7 +314,10 @@ def bench_single(args):
     if not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(g, x_cpu)
     if not args.no_shard_base:
-        result["weak_scaling_base"] = shard_base()
+        base = shard_base()
+        result["weak_scaling_base"] = base
+        if "roofline" in base:  # the HBM-RESIDENT number: X of the shard is 7.1 GB, far beyond L2 + Infinity Cache
+            result["roofline"]["hbm_resident"] = base.pop("roofline")
     return result
 
 
@@ -294,7 +340,9 @@ def shard_base(budget_s=200):
         return {"what": "vertex-sharded csr_spmm fwd+bwd at world size 1 on one papers100M-sized shard (the per-GPU work "
                         "of the N > 1 lines)", "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
                 "steps": r["steps"], "nodes_per_gpu": r["config"]["nodes_per_gpu"], "nnz": r["config"]["nnz_global"],
-                "local_block_GEdges_s": r.get("local_block_GEdges_s_rank0")}
+                "local_block_GEdges_s": r.get("local_block_GEdges_s_rank0"),
+                "roofline": dict(r.get("roofline") or {}, what="csr_spmm over one papers100M-sized shard's local block "
+                                 "(13.9 M rows, 4.1e8 edges, X = 7.1 GB): every gathered row comes from HBM")}
     except subprocess.TimeoutExpired:
         return {"error": "timed out after %d s" % budget_s}
 
@@ -303,6 +351,25 @@ def bench_sharded(args):
     from cogdl_amd.dist import bench_sharded_spmm
 
     return bench_sharded_spmm(args)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (one per GPU, torch.distributed.run
+    on 127.0.0.1 -- what cogdl/trainer/trainer.py:253-274 does with mp.spawn) instead of quietly running one rank."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    if not args.selftest_cpu:
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit("bench.py --gpus %d needs %d devices, this host has %d" % (n, n, have))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -315,6 +382,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-trainer", action="store_true", help="skip the reference-Trainer epoch legs (gnn_epoch.trainer_ms)")
     ap.add_argument("--no-shard-base", action="store_true", help="skip the weak_scaling_base leg (the sharded path at world size 1)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc passes for roofline.traffic")
     ap.add_argument("--sharded", action="store_true", help="run the N>1 workload (vertex-sharded SpMM) even at world size 1")
     ap.add_argument("--shard-nodes", type=int, default=0, help="N>1: nodes per GPU (default: papers100M/8)")
     ap.add_argument("--shard-degree", type=float, default=0.0, help="N>1: mean in-degree (default 28.8)")
@@ -323,10 +391,25 @@ def main():
     ap.add_argument("--halo-frac", type=float, default=0.25,
                     help="N>1: halo rows per rank as a fraction of its own rows (remote sources come from boundary "
                          "regions of that total size; <= 0: uniform over the owner shard = worst-case halo)")
+    ap.add_argument("--leg", default="main", choices=["main", "worst"], help="(internal) which leg a child interpreter runs")
+    ap.add_argument("--no-extra-legs", action="store_true", help="N>1: only the main line (no worst-case partition, no configs[3] leg)")
+    ap.add_argument("--no-sage", action="store_true", help="N>1: skip the configs[3] GraphSAGE replica leg")
+    ap.add_argument("--worst-case-scale", type=int, default=4, help="N>1: the worst-case leg's shards are 1/this the size")
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="launcher self-test: gloo ranks on the host with libcogdl_host kernels and tiny shards (tests only; "
+                         "its numbers mean nothing)")
     args = ap.parse_args()
-    if not torch.cuda.is_available():
+    args.bench_script = os.path.abspath(__file__)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if not args.selftest_cpu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not (args.sharded and args.gpus == 1):
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: refusing to report a %d-GPU line from %d rank(s)"
+                         % (args.gpus, world, args.gpus, world))
     if args.gpus > 1 or world > 1 or args.sharded:
         result = bench_sharded(args)
     else:

@@ -55,6 +55,24 @@ class HipBackend:
         return plan.colptr, plan.rowind, (gather_rows(plan.perm, val) if val is not None else None)
 
 
+class HostBackend:
+    """Local kernels on the HOST through libcogdl_host (CogDL's own CPU operator, spmm_cpu: operators/spmm.py:38) for
+    CPU tensors over gloo: the launcher self-test of bench.py (`--selftest-cpu`) and CPU-resident shards.  Never chosen
+    implicitly -- GPU shards without libcogdl_hip fail, they do not land here."""
+
+    def spmm(self, rowptr, colind, val, x, out=None):
+        from .operators.spmm import spmm_cpu
+
+        y = spmm_cpu(rowptr.int(), colind.int(), val, x.detach().float())
+        return y if out is None else out.add_(y)
+
+    def transpose(self, rowptr, colind, val, n_cols):
+        rows = torch.repeat_interleave(torch.arange(rowptr.numel() - 1), (rowptr[1:] - rowptr[:-1]).long())
+        order = torch.sort(colind.long(), stable=True).indices  # stable: CSR order inside a column
+        colptr = _csr_from_sorted_rows(colind.long()[order], n_cols).int()
+        return colptr, rows[order].int(), (val[order] if val is not None else None)
+
+
 # ------------------------------------------------------------------------------------- exchange
 class _Done:
     def wait(self):
@@ -283,17 +301,153 @@ def _rccl_version():
         return None
 
 
+def sharded_leg(rank, world, dev, shard_nodes, degree, feat, remote_frac, halo_frac, steps, warmup, backend=None, seed=0,
+                dump_dir=None):
+    """One measured leg of the N > 1 bench, run by EVERY rank of an initialised process group: generate this rank's
+    papers100M-shaped shard, build the exchange plan, time `steps` forward + backward passes (barrier + synchronise on
+    both sides, max over ranks), then the local block alone.  Returns the same dict on every rank."""
+    cuda = dev.type == "cuda"
+
+    def sync():
+        if cuda:
+            torch.cuda.synchronize(dev)
+
+    rowptr, cols, w = _papers_like_shard(rank, world, shard_nodes, degree, remote_frac, seed, dev, halo_frac)
+    bounds = torch.arange(world + 1, dtype=torch.long) * shard_nodes
+    sync()
+    t_plan = time.perf_counter()
+    sh = ShardedCSR(rowptr, cols, w, bounds, backend=backend)
+    sync()
+    t_plan = time.perf_counter() - t_plan
+    x = torch.randn(shard_nodes, feat, device=dev, requires_grad=True)
+    gout = torch.randn(shard_nodes, feat, device=dev)
+    if dump_dir:  # launcher self-test: this rank's shard, operands and one forward + backward, for the test's oracle
+        import numpy as np
+
+        y = sharded_spmm(sh, x)
+        y.backward(gout)
+        np.savez(os.path.join(dump_dir, "b%d.npz" % rank), rowptr=rowptr.cpu().numpy(), cols=cols.cpu().numpy(),
+                 w=w.cpu().numpy(), x=x.detach().cpu().numpy(), gout=gout.cpu().numpy(), y=y.detach().cpu().numpy(),
+                 gx=x.grad.cpu().numpy(), n_halo=sh.n_halo, nnz_remote=sh.nnz_remote)
+        x.grad = None
+        del y
+    del cols, rowptr, w
+
+    def allsum(v, op=dist.ReduceOp.SUM, dtype=torch.float64):
+        t = torch.tensor([v], device=dev, dtype=dtype)
+        dist.all_reduce(t, op=op)
+        return t.item()
+
+    nnz_global = int(allsum(sh.nnz_local + sh.nnz_remote, dtype=torch.long))
+
+    def step():
+        y = sharded_spmm(sh, x)
+        x.grad = None
+        y.backward(gout)
+
+    for _ in range(warmup):
+        step()
+    sync()
+    dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    dist.barrier()
+    dt = allsum(time.perf_counter() - t0, op=dist.ReduceOp.MAX)
+    # the local block alone (no exchange): what one GPU does on its own columns -- the dominant kernel of a step
+    with torch.no_grad():
+        for _ in range(2):
+            sh.backend.spmm(sh.rowptr_loc, sh.colind_loc, sh.w_loc, x)
+        sync()
+        reps = 10 if cuda else 2
+        if cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            sh.backend.spmm(sh.rowptr_loc, sh.colind_loc, sh.w_loc, x)
+        if cuda:
+            e1.record()
+        sync()
+        loc_ms = (e0.elapsed_time(e1) if cuda else (time.perf_counter() - t1) * 1e3) / reps
+    loc_all = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+    dist.all_gather(loc_all, torch.tensor([loc_ms], dtype=torch.float64, device=dev))
+    loc_all = [float(v) for v in loc_all]
+    halo_rows = allsum(sh.n_halo)
+    remote_edges = allsum(sh.nnz_remote)
+    b_alg = sh.nnz_local * (4 + 4 + feat * 4) + shard_nodes * (4 + feat * 4)
+    return {
+        "value": 2 * nnz_global * steps / dt / 1e9, "unit": "GEdges/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+        "warmup": warmup, "nodes_per_gpu": shard_nodes, "nnz_global": nnz_global, "feat": feat,
+        "remote_frac": remote_frac, "halo_frac": halo_frac, "remote_edge_share": remote_edges / max(nnz_global, 1),
+        "halo_rows_all_ranks": int(halo_rows), "halo_rows_rank0": sh.n_halo,
+        "halo_GB_per_step_all_ranks": halo_rows * feat * 4 * 2 / 1e9,
+        "exchange_plan_build_s_rank0": t_plan,
+        "local_block_ms_by_rank": [round(v, 3) for v in loc_all],
+        "local_block_ms_min": min(loc_all), "local_block_ms_max": max(loc_all),
+        "local_block_spmm_ms_rank0": loc_all[0],
+        "local_block_GEdges_s_rank0": sh.nnz_local / (loc_all[0] * 1e-3) / 1e9,
+        "local_block_algorithmic_bytes": b_alg,
+    }
+
+
+def _child_leg(argv, port_offset, timeout_s):
+    """Run a follow-up leg (`python <argv>`) as a CHILD interpreter of this rank, with the parent's RANK / LOCAL_RANK /
+    WORLD_SIZE and a MASTER_PORT of its own: the children of all ranks form their own process group.  A leg that hangs
+    or dies is killed at `timeout_s` and reported as an error -- it cannot take the main measurement down with it."""
+    import json
+    import subprocess
+    import sys
+
+    # (TORCHELASTIC_USE_AGENT_STORE would make the child's env:// rendezvous look for the launcher's store at the new
+    # port instead of letting its rank 0 create one)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k != "TORCH_NCCL_ASYNC_ERROR_HANDLING"}
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29533")) + port_offset)
+    env["COGDL_AMD_BENCH_CHILD"] = "1"
+    try:
+        proc = subprocess.run([sys.executable] + argv, capture_output=True, text=True, timeout=timeout_s, env=env)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after %d s" % timeout_s}
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if not lines:
+        return {"error": "rc %d: %s" % (proc.returncode, (proc.stderr or proc.stdout)[-400:])}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {"error": "unparsable output: %r" % (e,)}
+
+
 def bench_sharded_spmm(args):
-    """Weak-scaling bench of the vertex-sharded csr_spmm forward + backward (bench.py --gpus N, N > 1)."""
+    """Weak-scaling bench of the vertex-sharded csr_spmm forward + backward (bench.py --gpus N, N > 1; also the
+    `weak_scaling_base` leg of the N = 1 line: world size 1).  Every rank runs this; rank 0 returns the result."""
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", rank))
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    if not dist.is_initialized():
+    cpu = bool(getattr(args, "selftest_cpu", False))
+    leg = getattr(args, "leg", "main")
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: refusing to report a %d-GPU line from %d "
+                         "rank(s)" % (args.gpus, world, args.gpus, world))
+    if cpu:  # launcher self-test (tests/test_dist_cpu.py): gloo ranks on the host, libcogdl_host kernels, tiny shards
+        dev, backend_name, backend = torch.device("cpu"), "gloo", HostBackend()
+    else:
+        n_dev = torch.cuda.device_count()
+        if local >= n_dev:
+            raise SystemExit("bench.py: rank %d needs device %d, this host has %d GPU(s)" % (rank, local, n_dev))
+        dev, backend_name, backend = torch.device("cuda", local), "nccl", None
+        torch.cuda.set_device(dev)
+    own_group = not dist.is_initialized()
+    if own_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if cpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    n_ranks_seen = dist.get_world_size()
     # Weak scaling with the TRUE papers100M shard per GPU: 111,059,956 nodes / 8 = 13.9 M rows, ~4.1e8 edges, X = 7.1 GB
     # per GPU -- at N = 8 this is the whole graph (3.3e9 edges: beyond what int32 CSR indices can address on ONE GPU,
     # which is why the single-GPU leg of the curve cannot be the unsharded graph and the scaling is weak, not strong).
@@ -302,81 +456,81 @@ def bench_sharded_spmm(args):
     f = args.feat
     remote_frac = args.remote_frac if args.remote_frac >= 0 else 0.1
     halo_frac = getattr(args, "halo_frac", 0.25)
-    rowptr, cols, w = _papers_like_shard(rank, world, shard_nodes, degree, remote_frac, 0, dev, halo_frac)
-    bounds = torch.arange(world + 1, dtype=torch.long) * shard_nodes
-    sh = ShardedCSR(rowptr, cols, w, bounds)
-    del cols
-    x = torch.randn(shard_nodes, f, device=dev, requires_grad=True)
-    gout = torch.randn(shard_nodes, f, device=dev)
-    nnz_global = torch.tensor([sh.nnz_local + sh.nnz_remote], device=dev, dtype=torch.long)
-    dist.all_reduce(nnz_global)
-    nnz_global = int(nnz_global)
-
-    def step():
-        y = sharded_spmm(sh, x)
-        x.grad = None
-        y.backward(gout)
-
-    for _ in range(args.warmup):
-        step()
+    m = sharded_leg(rank, world, dev, shard_nodes, degree, f, remote_frac, halo_frac, args.steps, args.warmup, backend,
+                    dump_dir=os.environ.get("COGDL_AMD_SELFTEST_DUMP") if cpu and leg == "main" else None)
+    rccl = None if cpu else _rccl_version()
     dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = float(dt)
-
-    # the local-only part alone (no exchange): what one GPU does on the same shard, for reference
-    from .operators.spmm import csr_spmm_raw
-
-    with torch.no_grad():
-        for _ in range(3):
-            csr_spmm_raw(sh.rowptr_loc, sh.colind_loc, sh.w_loc, x)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            csr_spmm_raw(sh.rowptr_loc, sh.colind_loc, sh.w_loc, x)
-        e1.record()
-        torch.cuda.synchronize()
-        loc_ms = e0.elapsed_time(e1) / 10
-    halo_gb = torch.tensor([sh.halo_bytes(f)], device=dev, dtype=torch.float64)
-    dist.all_reduce(halo_gb)
+    if own_group:
+        dist.destroy_process_group()
+    if not cpu:
+        torch.cuda.empty_cache()
     result = None
     if rank == 0:
         result = {
             "metric": "SpMM GEdges/s (vertex-sharded csr_spmm fwd+bwd, papers100M-shaped shards) @%d GPUs" % world,
-            "value": 2 * nnz_global * args.steps / dt / 1e9,
-            "unit": "GEdges/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "value": m["value"], "unit": "GEdges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "papers100M-like 1-D vertex-sharded csr_spmm fwd+bwd (configs[4]); %.0f%% of every "
-                                   "row's sources in other shards, drawn from boundary regions sized for a halo of "
-                                   "%.2f x the shard's rows (locality-preserving partition; --remote-frac %.3f "
-                                   "--halo-frac 0 = random partition, worst-case halo)"
-                                   % (100 * remote_frac, max(halo_frac, 0.0), (world - 1) / world),
-                       "nodes_per_gpu": shard_nodes, "nnz_global": nnz_global, "feat": f, "remote_frac": remote_frac,
-                       "halo_frac": halo_frac, "halo_rows_rank0": sh.n_halo,
+            "config": {"workload": "papers100M-like 1-D vertex-sharded csr_spmm fwd+bwd (configs[4]); %.1f%% of every "
+                                   "row's sources in other shards, %s" % (100 * remote_frac, (
+                                       "drawn from boundary regions sized for a halo of %.2f x the shard's rows "
+                                       "(locality-preserving partition; the worst_case_partition object is the other "
+                                       "end: a random partition)" % halo_frac) if halo_frac > 0 else
+                                       "uniform over the owners' rows (random partition of a structureless graph: no halo "
+                                       "reuse, the worst case)"),
+                       "nodes_per_gpu": shard_nodes, "nnz_global": m["nnz_global"], "feat": f, "remote_frac": remote_frac,
+                       "halo_frac": halo_frac, "halo_rows_rank0": m["halo_rows_rank0"],
                        "parallelism": "vertex-shard x%d, RCCL all-to-all halo exchange overlapped with local SpMM" % world},
-            "halo_GB_per_step_all_ranks": float(halo_gb) * 2 / 1e9,
-            "n_ranks_seen": dist.get_world_size(), "rccl_version": _rccl_version(),
+            "halo_GB_per_step_all_ranks": m["halo_GB_per_step_all_ranks"],
+            "n_ranks_seen": n_ranks_seen, "rccl_version": rccl,
             "exchange": "all_to_all_single on an explicit comm stream (event-ordered), gather = cogdl_hip_gather_feature_rows, "
                         "backward accumulation = one csr_spmm_acc over the selection matrix",
-            "local_block_spmm_ms_rank0": loc_ms,
-            "local_block_GEdges_s_rank0": sh.nnz_local / (loc_ms * 1e-3) / 1e9,
+            "exchange_plan_build_s_rank0": m["exchange_plan_build_s_rank0"],
+            "local_block_ms_by_rank": m["local_block_ms_by_rank"],
+            "local_block_ms_min": m["local_block_ms_min"], "local_block_ms_max": m["local_block_ms_max"],
+            "local_block_spmm_ms_rank0": m["local_block_spmm_ms_rank0"],
+            "local_block_GEdges_s_rank0": m["local_block_GEdges_s_rank0"],
         }
+        if cpu:
+            result["selftest"] = "gloo ranks on the host, libcogdl_host kernels: exercises the launcher and the data flow only"
+            result["dtype"] = "f32"
         # the dominant kernel of a step: csr_spmm over the rank's local block (SURVEY.md section 8d's formula), timed
         # above with HIP events on its own; X (7.1 GB per shard) is far beyond the caches, so this IS HBM traffic
-        b_alg = sh.nnz_local * (4 + 4 + f * 4) + shard_nodes * (4 + f * 4)
-        result["roofline"] = {"bound": "hbm", "kernel": "rowreduce_main_kernel<SpmmOp<float,...>> on the local block A_pp (rank 0)",
-                              "achieved": b_alg / (loc_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                              "frac": b_alg / (loc_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+        b_alg = m["local_block_algorithmic_bytes"]
+        ach = b_alg / (m["local_block_ms_max"] * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "kernel": "rowreduce_main_kernel<SpmmOp<float,...>> on the local block A_pp "
+                                                        "(the SLOWEST rank's launch time)",
+                              "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
                               "algorithmic_bytes_per_launch": b_alg}
-    dist.barrier()
-    dist.destroy_process_group()
+    if leg != "main" or world == 1 or getattr(args, "no_extra_legs", False):
+        return result
+    # ---- follow-up legs, each in child interpreters with their own process group and a hard timeout -----------------
+    script = os.path.abspath(getattr(args, "bench_script", "bench.py"))
+    common = ["--gpus", str(world), "--feat", str(f)] + (["--selftest-cpu"] if cpu else [])
+    worst_nodes = max(64, shard_nodes // max(1, int(getattr(args, "worst_case_scale", 4))))
+    worst = _child_leg([script, "--sharded", "--leg", "worst"] + common
+                       + ["--shard-nodes", str(worst_nodes), "--shard-degree", str(degree),
+                          "--remote-frac", repr((world - 1) / world), "--halo-frac", "0",
+                          "--steps", str(max(2, args.steps // 2)), "--warmup", "1"], 1, 420)
+    sage = None
+    if not cpu and not getattr(args, "no_sage", False):
+        tool = os.path.join(os.path.dirname(script), "tools", "sage_bench.py")
+        sage = _child_leg([tool, "--captured", "--batch", "1024", "--steps", "50"], 2, 300)
+        if "error" in sage:  # the RCCL all-reduce as a node of the captured graph failed: the eager step with torch DDP
+            first = sage
+            sage = _child_leg([tool, "--batch", "1024", "--steps", "30"], 3, 300)
+            sage["captured_attempt"] = first
+    if rank == 0:
+        if "error" not in worst:
+            worst = {k: worst[k] for k in ("value", "unit", "ms_per_step", "steps", "n_gpus", "n_ranks_seen", "config",
+                                           "halo_GB_per_step_all_ranks", "local_block_ms_min", "local_block_ms_max")
+                     if k in worst}
+            worst["what"] = ("the same sharded fwd+bwd on a RANDOM partition of a structureless graph: (N-1)/N of every row's "
+                             "sources remote and uniform over the owners (no halo reuse) -- the worst case of a 1-D "
+                             "partition, on shards 1/%d the size so that the halo tables fit"
+                             % max(1, int(getattr(args, "worst_case_scale", 4))))
+        result["worst_case_partition"] = worst
+        if sage is not None:
+            result["configs3_sage_replicas"] = sage
     return result

@@ -126,6 +126,64 @@ def test_bench_flow_generated_shards_equal_the_assembled_global_matrix(tmp_path,
         assert int(p["nnz_remote"]) > 0 and 0 < int(p["n_halo"]) <= int(0.25 * s) + world  # the boundary regions bound the halo
 
 
+def _run_bench(argv, env=None, timeout=420):
+    import subprocess
+
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                          timeout=timeout, env=e)
+
+
+def test_bench_gpus_n_self_launches_n_ranks_and_its_data_flow_equals_the_global_matrix(tmp_path, oracle):
+    """`python bench.py --gpus 2` with NO launcher around it spawns its two ranks itself (bench.py:self_launch ->
+    torch.distributed.run; here `--selftest-cpu`: gloo ranks on the host, libcogdl_host kernels, tiny shards) and
+    reports n_gpus == n_ranks_seen == 2; the shards the ranks generated are assembled into the global matrix and the
+    ranks' own forward / backward results compared with the unsharded oracle; the follow-up legs (children with their
+    own process group) report the same rank count."""
+    import json
+
+    s, world = 400, 2
+    proc = _run_bench(["--gpus", str(world), "--selftest-cpu", "--shard-nodes", str(s), "--shard-degree", "9",
+                       "--remote-frac", "0.3", "--steps", "2", "--warmup", "1", "--feat", "8"],
+                      env={"COGDL_AMD_SELFTEST_DUMP": str(tmp_path)})
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert proc.returncode == 0 and len(lines) == 1, proc.stderr[-800:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and line["n_ranks_seen"] == world and line["scaling"] == "weak"
+    assert len(line["local_block_ms_by_rank"]) == world and line["halo_GB_per_step_all_ranks"] > 0
+    worst = line["worst_case_partition"]
+    assert worst.get("n_gpus") == world and worst.get("n_ranks_seen") == world, worst
+    assert worst["config"]["remote_frac"] == 0.5 and worst["config"]["halo_frac"] == 0.0
+    parts = [np.load(os.path.join(str(tmp_path), "b%d.npz" % r)) for r in range(world)]
+    n = world * s
+    rowptr = np.concatenate([[0]] + [p["rowptr"][1:] + sum(int(q["rowptr"][-1]) for q in parts[:r])
+                                     for r, p in enumerate(parts)]).astype(np.int32)
+    cols = np.concatenate([p["cols"] for p in parts]).astype(np.int32)
+    w = np.concatenate([p["w"] for p in parts]).astype(np.float32)
+    x = np.concatenate([p["x"] for p in parts])
+    gout = np.concatenate([p["gout"] for p in parts])
+    want_y = oracle.csr_spmm_f64(torch.from_numpy(rowptr), torch.from_numpy(cols), torch.from_numpy(w), torch.from_numpy(x))
+    colptr, rowind, w_t, _ = oracle.csr2csc(torch.from_numpy(rowptr), torch.from_numpy(cols), torch.from_numpy(w), n_cols=n)
+    want_gx = oracle.csr_spmm_f64(colptr, rowind, w_t, torch.from_numpy(gout))
+    for r, p in enumerate(parts):
+        np.testing.assert_allclose(p["y"], want_y[r * s:(r + 1) * s], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(p["gx"], want_gx[r * s:(r + 1) * s], rtol=1e-5, atol=1e-6)
+        assert int(p["nnz_remote"]) > 0 and int(p["n_halo"]) > 0
+
+
+def test_bench_refuses_a_rank_count_it_cannot_deliver():
+    """--gpus N on a host with fewer devices fails loudly (this container has none), and a launcher that started a
+    different number of ranks than --gpus says is refused: no `n_gpus: 1` line for `--gpus 8`."""
+    if torch.cuda.device_count() < 2:
+        proc = _run_bench(["--gpus", "2"], timeout=120)
+        assert proc.returncode != 0 and "needs 2 devices" in proc.stderr and not proc.stdout.strip()
+    proc = _run_bench(["--gpus", "8", "--selftest-cpu"], env={"WORLD_SIZE": "1", "RANK": "0"}, timeout=120)
+    assert proc.returncode != 0 and "refusing" in proc.stderr and not proc.stdout.strip()
+
+
 def test_papers_like_shard_generator_shape():
     """bench.py's N>1 workload: remote sources come from per-peer boundary slices, so the halo is bounded."""
     from cogdl_amd.dist import _papers_like_shard
