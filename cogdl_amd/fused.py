@@ -23,6 +23,13 @@ def make_spmm(reference_spmm):
         fusable = (torch.is_tensor(x) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and not actnn
                    and (in_norm is not None or out_norm is not None)
                    and getattr(graph, "grb_adj", None) is None)
+        if fusable and torch.is_grad_enabled():
+            # The fused operator treats edge weights and norm vectors as constants of the graph (no gradient).  Learned
+            # or attention edge weights on a normalised block must keep theirs: the reference dispatcher's fast_spmm
+            # (SPMMFunction) produces grad_edge_weight (operators/spmm.py:69-73), and the broadcast multiplies around
+            # it carry the norms' -- so anything that requires grad goes the reference's way.
+            w = getattr(graph, "raw_edge_weight", None)
+            fusable = not any(torch.is_tensor(t) and t.requires_grad for t in (w, in_norm, out_norm))
         if not fusable:
             return reference_spmm(graph, x, actnn=actnn, fast_spmm=fast_spmm, fast_spmm_cpu=fast_spmm_cpu)
         return csrspmm_fused(graph.row_indptr.int(), graph.col_indices.int(), x, graph.raw_edge_weight, out_norm,

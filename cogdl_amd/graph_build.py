@@ -40,9 +40,13 @@ def coo2csr_index(row, col, num_nodes=None):
 # (cogdl/utils/graph_utils.py:40-89): GPU tensors go to the HIP kernels of csrc/graph_norm.hip, everything else (CPU
 # tensors, non-float weights) to the reference's own torch expressions, restated below.
 def _gpu_coo(row, col, val):
+    """Do the HIP kernels take this call?  They sit outside autograd, while the reference's torch expressions are
+    differentiable in the weights: a weight tensor that takes part in autograd (learned edge weights) keeps the
+    reference's path and with it its graph."""
     return (torch.is_tensor(row) and row.is_cuda and row.dtype == torch.long and col.dtype == torch.long and row.dim() == 1
             and (val is None or (val.is_cuda and val.dtype == torch.float32 and val.dim() == 1
-                                 and val.numel() == row.numel())))
+                                 and val.numel() == row.numel()
+                                 and not (val.requires_grad and torch.is_grad_enabled()))))
 
 
 def _check_bad(bad, what, n):

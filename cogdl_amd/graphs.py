@@ -19,8 +19,14 @@ from . import plan as _plan
 
 
 class CapturedStep:
-    def __init__(self, graph, outputs):
+    def __init__(self, graph, outputs, keepalive=()):
         self.graph, self.outputs = graph, outputs
+        # The captured kernels read the step's graph plans (colptr / rowind / perm) and their memoised transposed
+        # weights through RAW pointers.  Those tensors were allocated eagerly during the warm-up runs, i.e. outside
+        # the graph's private pool, and the plan cache (an LRU with a byte budget, PLANS.clear(), or a later
+        # transposed_values() call with another weight tensor, which replaces plan._val_t) would otherwise be their
+        # only owner: this tuple keeps every one of them alive for as long as the graph can be replayed.
+        self._keepalive = tuple(keepalive)
 
     def __call__(self):
         self.graph.replay()
@@ -56,4 +62,7 @@ def capture(step, warmup=3, pool=None):
     if tape.pos != len(tape.plans):
         raise RuntimeError("hipGraph capture: the captured step used %d of the %d recorded plan lookups"
                            % (tape.pos, len(tape.plans)))
-    return CapturedStep(graph, outputs)
+    keep = []
+    for plan in tape.plans:
+        keep.append((plan, plan.colptr, plan.rowind, plan.perm, plan._val_t, plan._val_src))
+    return CapturedStep(graph, outputs, keep)

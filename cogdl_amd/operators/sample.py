@@ -15,6 +15,7 @@ import os
 import threading
 
 import torch
+import torch.utils.data
 
 from .. import _lib
 
@@ -101,7 +102,13 @@ def _sampler_threads():
     noisy either way) -- one thread there already is 30x the reference's sampler.  DataLoader workers are the
     parallelism of the reference's own pipeline in any case."""
     env = os.environ.get("COGDL_AMD_SAMPLER_THREADS")
-    return max(1, int(env)) if env else 1
+    if not env:
+        return 1
+    # A forked DataLoader worker must never enter an OpenMP region: its parent may have used libgomp already, whose
+    # thread pool does not survive fork() (the classic hang) -- workers are the pipeline's parallelism anyway.
+    if torch.utils.data.get_worker_info() is not None:
+        return 1
+    return max(1, min(int(env), torch.get_num_threads()))
 
 
 def sample_adj_padded(indptr, indices, node_idx, num_neighbors, replace=False, seed=0, seed_dev=None, count=None):

@@ -196,7 +196,13 @@ class BatchPipeline:
         x               : node features, on the GPU or in pinned host memory ([N, F])
         y               : labels on the GPU (or None)
         seed_batches    : iterable of 1-D int64 seed tensors on the GPU (distinct ids per batch)
-    The caller must not synchronise the device inside its step (loss.item(), .cpu()) if it wants the overlap."""
+    The caller must not synchronise the device inside its step (loss.item(), .cpu()) if it wants the overlap.
+
+    How the overlap comes about.  Batch i+1 is prepared BEFORE batch i is handed out (so its sampling is enqueued while
+    step i-1 still runs), and the side stream waits only for the event recorded when batch i+1's SEEDS were drawn --
+    which happened one iteration earlier, before step i-1 was enqueued -- not for the whole main stream: waiting for
+    the main stream would put sample(i+1) behind step i-1 and serialise everything.  The sampler's one host read-back
+    (output sizes) waits on the side stream only.  GPU timeline: step i-1 || sample + gather i+1, step i || i+2, ..."""
 
     def __init__(self, indptr, indices, x, y, seed_batches, fanouts):
         self.indptr, self.indices, self.x, self.y = indptr, indices, x, y
@@ -204,10 +210,20 @@ class BatchPipeline:
         self.dev = indptr.device
         self.side = torch.cuda.Stream(device=self.dev)
 
-    def _prepare(self, seeds):
-        main = torch.cuda.current_stream(self.dev)
-        self.side.wait_stream(main)  # the seeds (and anything they depend on) were produced on the caller's stream
+    def _draw(self, it):
+        """The next seed tensor + an event on the caller's stream behind whatever produced it."""
+        try:
+            seeds = next(it)
+        except StopIteration:
+            return None
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.dev))
+        return seeds, ready
+
+    def _prepare(self, drawn):
+        seeds, ready = drawn
         with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)  # the seeds exist; nothing else of the caller's stream is waited for
             n_id, adjs = sample_blocks(self.indptr, self.indices, seeds, self.fanouts)
             xb = gather_rows_by_id(self.x, n_id)
             yb = None if self.y is None else self.y.index_select(0, seeds)
@@ -217,22 +233,21 @@ class BatchPipeline:
 
     def __iter__(self):
         it = iter(self.seed_batches)
-        try:
-            nxt = self._prepare(next(it))
-        except StopIteration:
+        drawn = self._draw(it)
+        if drawn is None:
             return
-        while nxt is not None:
-            seeds, n_id, adjs, xb, yb, done = nxt
+        cur = self._prepare(drawn)
+        drawn = self._draw(it)            # seeds of batch 1, drawn before step 0 is enqueued
+        while cur is not None:
+            nxt_drawn = self._draw(it) if drawn is not None else None  # seeds of batch i+2: before step i is enqueued
+            nxt = self._prepare(drawn) if drawn is not None else None  # batch i+1: overlaps with step i-1 (running)
+            seeds, n_id, adjs, xb, yb, done = cur
             main = torch.cuda.current_stream(self.dev)
             main.wait_event(done)
             for t in [seeds, n_id, xb] + ([yb] if yb is not None else []) + [b for (blk, _) in adjs for b in blk]:
                 t.record_stream(main)  # allocated on the side stream, consumed on the caller's
-            # the consumer's step is enqueued (asynchronously) between this yield and the next _prepare
-            yield seeds, n_id, adjs, xb, yb
-            try:
-                nxt = self._prepare(next(it))
-            except StopIteration:
-                nxt = None
+            yield seeds, n_id, adjs, xb, yb  # the consumer enqueues step i (asynchronously) after this
+            cur, drawn = nxt, nxt_drawn
 
 
 def layerwise_inference(convs, x_all, indptr, indices, batch_size=65536, activation=torch.relu, make_graph=None,

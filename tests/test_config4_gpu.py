@@ -86,3 +86,32 @@ def test_products_scale_two_hops_chain_through_device_counts(products):
                                                             seed=(5 + HOP_SEED_STRIDE) % (1 << 64), count=blk1[4][0:1])
     assert r_cnt.tolist() == [n2, e2, 0] and torch.equal(r_col, col2) and torch.equal(r_nodes, n_id)
     _check_block(indptr, indices, hop1_nodes, r_rp, r_col, r_nodes, r_edges, n2, e2)
+
+
+def test_products_scale_hub_row_picks_are_uniform(products):
+    """Uniformity where the RNG streams are most likely to show bias: the HUB row of the products-shaped graph (R-MAT:
+    ~1e5 neighbours).  400 independent draws of 64 of its edges (different seed words), chi-square of the 25,600 picked
+    positions against the uniform distribution -- over 128 contiguous ranges of the row (a biased range reduction of the
+    32-bit draws would tilt them) and over the position modulo 64 (a per-lane stream defect would)."""
+    indptr, indices, _ = products
+    deg = indptr[1:] - indptr[:-1]
+    hub = int(torch.argmax(deg))
+    d = int(deg[hub])
+    assert d > 30_000, d
+    k, draws = 64, 400
+    seed_node = torch.tensor([hub], device=DEV)
+    picks = []
+    for t in range(draws):
+        _, col, nodes, edges = sample_adj_c(indptr, indices, seed_node, k, False, seed=1000 + t)
+        assert edges.numel() == k and torch.unique(edges).numel() == k
+        picks.append(edges - indptr[hub])
+    pos = torch.cat(picks)
+    assert int(pos.min()) >= 0 and int(pos.max()) < d
+    every = torch.arange(d, device=DEV)
+    for nb, bucket in ((128, lambda p: p * 128 // d), (64, lambda p: p % 64)):
+        size = torch.bincount(bucket(every), minlength=nb).double()
+        expected = size / d * pos.numel()
+        got = torch.bincount(bucket(pos), minlength=nb).double()
+        chi2 = float(((got - expected) ** 2 / expected).sum())
+        dof = nb - 1
+        assert chi2 < dof + 6 * (2 * dof) ** 0.5, (nb, chi2)  # mean dof, sd sqrt(2 dof): six sigma

@@ -10,6 +10,14 @@ size-independent properties of the operator:
     (checked against a torch index_add over all 4.1e8 edges)
   * the transposed structure (cogdl_hip_csr2csc: the hand-written radix sort at 4e8 slots, 24-bit column ids = three
     passes) is a permutation with sorted columns, and transposing twice gives the CSR back.
+
+and -- the parity test proper -- the CPU oracle (oracle.csr_spmm = cogdl/operators/spmm/spmm_cpu.cpp:24-35) on a random
+SUBSET of the output: 50,000 of the 13.9 M rows of A x and 50,000 of the 13.9 M rows of A^T g, every one of them
+computed in full by the oracle from all of its edges (tests/_subset.py) and required to be BIT-IDENTICAL to the GPU's
+rows (all rows here are far below long_row_threshold, so the GPU keeps the reference's summation order).  The halo leg
+at scale: two ranks on this one GPU (gloo staging, as tests/test_dist_gpu.py) with shards 1/8 the true size, 10 % and
+7/8 of the sources remote, the same subset oracle on the ASSEMBLED global matrix (1e-5: a sharded row is the sum of its
+local-block and halo-block partial sums, i.e. re-associated).
 """
 import os
 
@@ -70,6 +78,112 @@ def test_true_shard_rows_sum_to_one_linearity_and_transpose(shard):
     sharded_spmm(sh, x1).backward(torch.ones(SHARD, 4, device=DEV))
     indeg = torch.zeros(SHARD, dtype=torch.float64, device=DEV).index_add_(0, cols, w.double())
     assert float((x1.grad[:, 0].double() - indeg).abs().max()) <= 1e-5 * float(indeg.max())
+
+
+def test_true_shard_subset_oracle_forward_and_grad_bit_exact(shard, oracle):
+    """50 k random rows of Y = A X and 50 k random rows of G_x = A^T G of the true-size shard against the CPU oracle."""
+    from _subset import cols_subset, oracle_cols, oracle_rows, rows_subset
+    from cogdl_amd import _lib
+    from cogdl_amd.dist import sharded_spmm
+
+    sh, rowptr, cols, w = shard
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(SHARD, F, device=DEV, generator=gen, requires_grad=True)
+    g = torch.randn(SHARD, F, device=DEV, generator=gen)
+    y = sharded_spmm(sh, x)
+    y.backward(g)
+    thresh = _lib.hip().cogdl_hip_long_row_threshold(int(sh.nnz_local))
+    cpu_gen = torch.Generator().manual_seed(12)
+    rows_sel = torch.sort(torch.randperm(SHARD, generator=cpu_gen)[:50_000]).values
+    cols_sel = torch.randperm(SHARD, generator=cpu_gen)[:50_000]
+
+    def fetch_from(t):
+        return lambda ids: t.detach()[torch.from_numpy(ids).to(DEV)].cpu().numpy()
+
+    # forward rows
+    sub_rowptr, sub_cols, sub_w = rows_subset(rowptr, cols, w, rows_sel)
+    assert int(np.diff(sub_rowptr).max()) <= thresh and sub_cols.size > 1_000_000
+    want = oracle_rows(oracle, sub_rowptr, sub_cols, sub_w, fetch_from(x))
+    got = y.detach()[rows_sel.to(DEV)].cpu().numpy()
+    assert got.tobytes() == want.tobytes(), "csr_spmm rows of the true-size shard differ from the reference CPU operator"
+    # gradient rows: every edge of the selected columns, grouped by column in CSR order (what the stable transpose gives)
+    e_rows, e_cols, e_w = cols_subset(rowptr, cols, w, cols_sel, SHARD)
+    assert int(np.bincount(np.searchsorted(np.sort(cols_sel.numpy()), e_cols)).max()) <= thresh
+    want_g = oracle_cols(oracle, e_rows, e_cols, e_w, cols_sel.numpy(), fetch_from(g))
+    got_g = x.grad[cols_sel.to(DEV)].cpu().numpy()
+    assert got_g.tobytes() == want_g.tobytes(), "grad_x rows of the true-size shard differ from the reference CPU operator"
+
+
+def _halo_worker(rank, world, port, shard_nodes, remote_frac, halo_frac, feat, n_sel, out_dir):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # two ranks share the one GPU: gloo, not RCCL
+    try:
+        from _subset import cols_subset, rows_subset
+        from cogdl_amd.dist import ShardedCSR, _papers_like_shard, sharded_spmm
+
+        torch.cuda.set_device(0)
+        rowptr, cols, w = _papers_like_shard(rank, world, shard_nodes, 28.8, remote_frac, 0, torch.device(DEV), halo_frac)
+        bounds = torch.arange(world + 1, dtype=torch.long) * shard_nodes
+        sh = ShardedCSR(rowptr, cols, w, bounds)  # HipBackend
+        n = world * shard_nodes
+        lo = rank * shard_nodes
+        x = torch.randn(n, feat, generator=torch.Generator().manual_seed(5))      # the same global operands on every
+        gout = torch.randn(n, feat, generator=torch.Generator().manual_seed(6))   # rank (and in the checking process)
+        xl = x[lo:lo + shard_nodes].to(DEV).requires_grad_()
+        y = sharded_spmm(sh, xl)
+        y.backward(gout[lo:lo + shard_nodes].to(DEV))
+        rows_sel = torch.sort(torch.randperm(shard_nodes, generator=torch.Generator().manual_seed(20 + rank))[:n_sel]).values
+        sub_rowptr, sub_cols, sub_w = rows_subset(rowptr, cols, w, rows_sel)
+        cols_sel = torch.randperm(n, generator=torch.Generator().manual_seed(7))[:n_sel]  # GLOBAL columns, same on all ranks
+        e_rows, e_cols, e_w = cols_subset(rowptr, cols, w, cols_sel, n)
+        mine = cols_sel[(cols_sel >= lo) & (cols_sel < lo + shard_nodes)]
+        np.savez(os.path.join(out_dir, "h%d.npz" % rank), rows_sel=rows_sel.numpy() + lo, sub_rowptr=sub_rowptr,
+                 sub_cols=sub_cols, sub_w=sub_w, y=y.detach()[rows_sel.to(DEV)].cpu().numpy(),
+                 e_rows=e_rows + lo, e_cols=e_cols, e_w=e_w, mine=mine.numpy(),
+                 gx=xl.grad[(mine - lo).to(DEV)].cpu().numpy(), n_halo=sh.n_halo, nnz_remote=sh.nnz_remote,
+                 nnz=sh.nnz_local + sh.nnz_remote)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("remote_frac,halo_frac", [(0.1, 0.25), (0.875, 0.0)])
+def test_two_ranks_eighth_shards_with_halo_subset_oracle(tmp_path, oracle, remote_frac, halo_frac):
+    """The halo leg at scale: 2 ranks x 1.7 M rows (1/8 of the true shard, ~5e7 edges each) on the one GPU through the HIP
+    kernels, rows exchanged through gloo; 10 % remote sources from boundary regions (the bench's default partition) and
+    7/8 remote sources uniform over the owner (the bench's worst case).  20 k rows of Y per rank and 20 k columns of
+    G_x against the oracle on the assembled global matrix."""
+    import torch.multiprocessing as mp
+    from _subset import oracle_cols, oracle_rows
+
+    world, shard_nodes, feat, n_sel = 2, SHARD // 8, 32, 20_000
+    mp.spawn(_halo_worker, args=(world, 29683, shard_nodes, remote_frac, halo_frac, feat, n_sel, str(tmp_path)),
+             nprocs=world, join=True)
+    n = world * shard_nodes
+    x = torch.randn(n, feat, generator=torch.Generator().manual_seed(5)).numpy()
+    gout = torch.randn(n, feat, generator=torch.Generator().manual_seed(6)).numpy()
+    parts = [np.load(os.path.join(str(tmp_path), "h%d.npz" % r)) for r in range(world)]
+    for r, p in enumerate(parts):
+        assert int(p["n_halo"]) > 0 and int(p["nnz_remote"]) > 0.9 * remote_frac * (int(p["nnz"]) - shard_nodes)
+        want = oracle_rows(oracle, p["sub_rowptr"], p["sub_cols"], p["sub_w"], lambda ids: x[ids])
+        scale = np.abs(want).max()
+        np.testing.assert_allclose(p["y"], want, rtol=1e-5, atol=1e-5 * scale)
+    # the gradient: edges of the selected columns from ALL ranks, rank order = ascending global row
+    e_rows = np.concatenate([p["e_rows"] for p in parts])
+    e_cols = np.concatenate([p["e_cols"] for p in parts])
+    e_w = np.concatenate([p["e_w"] for p in parts])
+    cols_sel = torch.randperm(n, generator=torch.Generator().manual_seed(7))[:n_sel].numpy()
+    want_g = oracle_cols(oracle, e_rows, e_cols, e_w, cols_sel, lambda ids: gout[ids])
+    pos = {int(c): i for i, c in enumerate(cols_sel)}
+    checked = 0
+    for p in parts:
+        idx = np.array([pos[int(c)] for c in p["mine"]], dtype=np.int64)
+        np.testing.assert_allclose(p["gx"], want_g[idx], rtol=1e-5, atol=1e-5 * np.abs(want_g).max())
+        checked += len(idx)
+    assert checked == n_sel
 
 
 def test_true_shard_transpose_is_a_sorted_permutation_and_an_involution(shard):

@@ -149,3 +149,32 @@ def test_hip_graph_capture_of_a_gcn_training_step_equals_eager(mfma_linear):
     np.testing.assert_allclose(losses_c, losses_e[3:], rtol=1e-5)
     for a, b in zip(params_c, params_e):
         np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_captured_step_owns_its_plans_cache_eviction_and_new_weights_do_not_corrupt_replays():
+    """Round-2 advisor finding: the captured kernels read the plans' colptr / rowind / perm and the memoised transposed
+    weights by raw pointer; the plan cache used to be their only owner.  After the capture the cache is emptied, the
+    plans' weight memo is replaced (another weight tensor on the same structure) and the freed memory is overwritten --
+    the replays must still equal the eager steps."""
+    import gc
+
+    from cogdl_amd.plan import PLANS
+
+    step_e, params_e = _gcn_step_factory(1)
+    losses_e = [float(step_e()) for _ in range(3 + 3)]
+    step_c, params_c = _gcn_step_factory(1)
+    captured = graphs.capture(step_c, warmup=3)
+    plans = list(PLANS.lru.values())
+    assert plans
+    for plan in plans:
+        plan.transposed_values(torch.rand(plan.nnz, device=DEV))  # replaces plan._val_t / _val_src
+    PLANS.clear()
+    del plans, plan
+    gc.collect()
+    poison = [torch.full((48 << 20,), 0x7F, dtype=torch.uint8, device=DEV) for _ in range(4)]  # lands on whatever was freed
+    torch.cuda.synchronize()
+    del poison
+    losses_c = [float(captured()) for _ in range(3)]
+    np.testing.assert_allclose(losses_c, losses_e[3:], rtol=1e-5)
+    for a, b in zip(params_c, params_e):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-4, atol=1e-6)

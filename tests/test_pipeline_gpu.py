@@ -106,6 +106,37 @@ def test_batch_pipeline_equals_unpipelined_sampling():
     assert got == 5
 
 
+def test_batch_pipeline_prepares_the_next_batch_while_the_previous_step_still_runs():
+    """The overlap itself (round-2 advisor finding: the side stream used to wait for the whole main stream, which put
+    sample(i+1) behind step i-1).  The consumer enqueues a LONG step (tens of ms of matmuls) and records an event behind
+    it; by the time the pipeline hands out batch i it has already sampled and gathered batch i+1 (the sampler's size
+    read-back has returned on the host) -- and step i-1 must still be running on the GPU at that moment."""
+    indptr, indices = (t.to(DEV) for t in _graph(20000, 15, seed=5, topology="rmat"))
+    n = 20000
+    x = torch.randn(n, 32, device=DEV)
+    seeds = [torch.randperm(n, generator=torch.Generator().manual_seed(200 + i))[:256].to(DEV) for i in range(6)]
+    a = torch.randn(4096, 4096, device=DEV)
+
+    def long_step(xb):
+        b = a
+        for _ in range(40):
+            b = (b @ a) * 1e-3
+        return b.sum() + xb.sum()
+
+    long_step(x[:1])
+    torch.cuda.synchronize()
+    ends, still_running = [], []
+    for i, (s, n_id, adjs, xb, yb) in enumerate(BatchPipeline(indptr, indices, x, None, seeds, [5, 5])):
+        if i >= 1 and i < len(seeds) - 1:  # batch i+1 has been prepared: was step i-1 still on the GPU?
+            still_running.append(not ends[i - 1].query())
+        long_step(xb)
+        e = torch.cuda.Event()
+        e.record()
+        ends.append(e)
+    torch.cuda.synchronize()
+    assert len(ends) == 6 and all(still_running), still_running
+
+
 class _MeanConv(torch.nn.Module):
     """SAGELayer(aggr='mean') shape (cogdl/layers/sage_layer.py:8-12,69-87) over a (row_ptr, col) block."""
 

@@ -126,6 +126,72 @@ cogdl_amd.fused.uninstall()
 assert not getattr(spmm_utils.spmm, "_cogdl_amd_fused", False)
 report["fused_norm"] = "ok"
 
+# ---- 2e. fused front with edge weights that take part in autograd: must go the reference's way and KEEP their gradient
+cogdl_amd.install(fused_norm=True)
+blk = block.to(DEV)
+w_learn = torch.ones(blk.col_indices.numel(), device=DEV, requires_grad=True)
+blk.edge_weight = w_learn  # (set_weight clears the norms, data.py:150-154: weights first, then the normalisation)
+blk.row_norm()
+assert blk.in_norm is not None and blk.raw_edge_weight is w_learn
+xs = T(z["x_src"]).to(DEV).requires_grad_()
+Gm = torch.randn(blk.num_nodes, xs.shape[1], device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+(spmm_utils.spmm(blk, xs) * Gm).sum().backward()
+assert w_learn.grad is not None and float(w_learn.grad.abs().sum()) > 0, "fused front dropped the edge-weight gradient"
+gw_fused, gx_fused = w_learn.grad.clone(), xs.grad.clone()
+cogdl_amd.fused.uninstall()
+w_learn.grad = None; xs.grad = None
+(spmm_utils.spmm(blk, xs) * Gm).sum().backward()
+np.testing.assert_allclose(gw_fused.cpu().numpy(), w_learn.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+np.testing.assert_allclose(gx_fused.cpu().numpy(), xs.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+report["fused_norm_keeps_weight_grad"] = "ok"
+
+# ---- 2f. install(narrow_side=True): a WIDENING GCNLayer aggregates at the input width; against the reference's order
+#          (cogdl/layers/gcn_layer.py:51-53: spmm(graph, linear(x))) on the same unchanged class
+z = gold("gcn_layer")
+row, col = coo(z)
+g = Graph(edge_index=(row, col), edge_weight=T(z["edge_weight"]), num_nodes=row.max().item() + 1).to(DEV)
+torch.manual_seed(5)
+wide = GCNLayer(32, 96).to(DEV)
+Gw = torch.randn(g.num_nodes, 96, device=DEV)
+def run_layer():
+    wide.zero_grad()
+    xx = T(z["x"]).to(DEV).requires_grad_()
+    o = wide(g, xx)
+    (o * Gw).sum().backward()
+    return [t.detach().cpu().numpy() for t in (o, xx.grad, wide.linear.weight.grad, wide.linear.bias.grad)]
+ref_order = run_layer()
+before_ns = calls["spmm"]
+cogdl_amd.install(narrow_side=True)
+import cogdl.layers.gcn_layer as gl
+assert gl.GCNLayer.forward is cogdl_amd.fused._gcn_forward_narrow_side
+narrow = run_layer()
+assert calls["spmm"] - before_ns >= 2  # A x at width 32 and A 1 at width 1 (plus their backward launches)
+cogdl_amd.fused.uninstall_narrow_side()
+assert gl.GCNLayer.forward is not cogdl_amd.fused._gcn_forward_narrow_side
+for name, a, b in zip(("out", "grad_x", "grad_W", "grad_b"), narrow, ref_order):
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5 * np.abs(b).max(), err_msg="narrow_side " + name)
+report["narrow_side"] = "ok"
+
+# ---- 2g. Graphsage.inference ITSELF (cogdl/models/nn/graphsage.py:106-119, fed by the reference's NeighborSampler with
+#          sizes=[-1] -> Graph.sample_adj -> the host sampler) against cogdl_amd.pipeline.layerwise_inference (GPU sampler +
+#          gather kernel) with the same unchanged model
+from cogdl.models.nn.graphsage import Graphsage
+from cogdl.data.sampler import NeighborSampler, NeighborSamplerDataset
+from cogdl_amd.pipeline import layerwise_inference
+ds_inf = refpkg.node_dataset(6000, 30000, 24, 5, seed=3)
+data = ds_inf.data
+torch.manual_seed(1)
+sage_model = Graphsage(24, 5, [16], 2, [10, 10], 0.5, "mean").to(DEV).eval()
+loader = NeighborSampler(dataset=NeighborSamplerDataset(ds_inf, sizes=[-1], batch_size=700, mask=None), mask=None,
+                         sizes=[-1], batch_size=700, shuffle=False, num_workers=0)
+with torch.no_grad():
+    want_inf = sage_model.inference(data.x, loader)
+got_inf = layerwise_inference(list(sage_model.convs), data.x.to(DEV), data.row_indptr.to(DEV), data.col_indices.to(DEV),
+                              batch_size=900, make_graph=lambda rp, c: Graph(row_ptr=rp, col=c))
+assert got_inf.shape == want_inf.shape == (6000, 5)
+np.testing.assert_allclose(got_inf.cpu().numpy(), want_inf.numpy(), rtol=1e-4, atol=1e-5)
+report["graphsage_inference"] = "ok"
+
 # ---- 3. experiment() through the reference's Trainer on cuda:0 (configs[0] shape, then configs[1] shape)
 before = calls["spmm"]
 ds = refpkg.cora_like(seed=0)
@@ -149,6 +215,7 @@ def test_unchanged_reference_layers_and_trainer_run_on_the_hip_operators():
     assert proc.returncode == 0 and lines, proc.stdout[-3000:] + proc.stderr[-5000:]
     rep = json.loads(lines[-1][7:])
     assert rep["gcn_layer"] == rep["gat_layer"] == rep["sage_layer"] == "ok"
+    assert rep["fused_norm_keeps_weight_grad"] == rep["narrow_side"] == rep["graphsage_inference"] == "ok"
     lg, lc = rep["cora_losses_gpu"], rep["cora_losses_cpu"]
     assert len(lg) == len(lc) == 6
     # dropout masks come from different generators on cpu / cuda: the trajectories agree in shape, not bitwise --
@@ -158,3 +225,54 @@ def test_unchanged_reference_layers_and_trainer_run_on_the_hip_operators():
     la = rep["arxiv_losses"]
     assert len(la) == 8 and la[-1] < la[0] and all(x == x for x in la)
     print("arxiv-shaped Trainer.train_step ms:", rep["arxiv_train_step_ms"])
+
+
+DDP_SCRIPT = r'''
+# The user-side recipe for the reference's own multi-GPU mechanism (cogdl/trainer/trainer.py:253-303: mp.Process spawn
+# + init_process_group("nccl") + DistributedDataParallel): the install lines sit at MODULE level, so that every spawned
+# rank -- which re-imports this file as __mp_main__ before it unpickles the Trainer -- runs on the HIP operators too.
+import json, os, sys
+ROOT = sys.argv[1] if len(sys.argv) > 1 else os.environ["COGDL_AMD_ROOT"]
+os.environ["COGDL_AMD_ROOT"] = ROOT
+sys.path.insert(0, ROOT)
+from tools import refpkg
+refpkg.setup(install=True)
+import torch
+import cogdl_amd.operators.spmm as our_spmm
+
+if os.environ.get("COGDL_AMD_DDP_MARK"):  # every process that executes a HIP csr_spmm leaves a mark file
+    _raw = our_spmm.csr_spmm_raw
+    def counted(*a, **k):
+        open(os.path.join(os.environ["COGDL_AMD_DDP_MARK"], "spmm.%d" % os.getpid()), "a").write("x")
+        return _raw(*a, **k)
+    our_spmm.csr_spmm_raw = counted
+
+if __name__ == "__main__":
+    ds = refpkg.node_dataset(20000, 120000, 32, 7, seed=0)
+    res, ms = refpkg.run_experiment(ds, model="graphsage", epochs=2, cpu=False, seed=0, distributed=True, devices=[0],
+                                    master_addr="127.0.0.1", master_port=29617, batch_size=512)
+    print("RESULT " + json.dumps({"test_acc": float(res.get("test_acc", float("nan"))), "keys": sorted(res)}))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(refpkg.STAGED, "cogdl")),
+                    reason="staged reference package absent (make -C oracle ref in the build container)")
+def test_reference_trainer_distributed_world1_rccl_on_the_hip_operators(tmp_path):
+    """configs[3] through the reference's OWN DDP path: experiment(model='graphsage', distributed=True, devices=[0]) --
+    Trainer.dist_train spawns the rank, the rank calls init_process_group("nccl") (= RCCL) and wraps the model in
+    DistributedDataParallel (trainer.py:253-303), the NeighborSampler's DataLoader workers sample through libcogdl_host,
+    the SAGELayers aggregate through the HIP csr_spmm -- in the SPAWNED rank (its mark file) as well as in the parent's
+    final evaluation."""
+    script = tmp_path / "ddp_graphsage.py"
+    script.write_text(DDP_SCRIPT)
+    marks = tmp_path / "marks"
+    marks.mkdir()
+    env = dict(os.environ, COGDL_AMD_DDP_MARK=str(marks), COGDL_AMD_ROOT=ROOT)
+    proc = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=900, env=env,
+                          cwd=str(tmp_path))
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert proc.returncode == 0 and lines, proc.stdout[-3000:] + proc.stderr[-5000:]
+    rep = json.loads(lines[-1][7:])
+    assert rep["test_acc"] == rep["test_acc"] and 0.0 <= rep["test_acc"] <= 1.0
+    pids = {int(f.split(".")[1]) for f in os.listdir(str(marks))}
+    assert len(pids) >= 2, "csr_spmm ran in %d process(es): the spawned DDP rank did not use the HIP operators" % len(pids)
