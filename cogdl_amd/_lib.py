@@ -118,6 +118,11 @@ def hip():
     global _hip
     if _hip is None:
         _hip = _load(HIP_LIB_PATH, HIP_SIGNATURES, "libcogdl_hip.so (HIP kernels)")
+        # A/B experiments without code changes: COGDL_AMD_TUNING="key=value,key=value" -> cogdl_hip_set_tuning
+        for item in filter(None, os.environ.get("COGDL_AMD_TUNING", "").split(",")):
+            key, _, value = item.partition("=")
+            if _hip.cogdl_hip_set_tuning(int(key), int(value)) != 0:
+                raise BackendError("COGDL_AMD_TUNING: no tuning key %s" % key)
     return _hip
 
 

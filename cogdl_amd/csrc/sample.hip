@@ -9,10 +9,18 @@
 //        all / with replacement: lanes work independently (counter-based RNG: hash(seed, row, draw))
 //        without replacement:    Floyd's algorithm, the membership test of each draw is one wave-wide ballot over
 //                                the chosen set in LDS; the chosen positions are emitted in ascending order
-//   3. discovery-order relabelling without a hash table: stable radix sort of (node id, position in Q) (rocPRIM);
-//      the head of every run of equal ids is that node's FIRST occurrence; an exclusive scan of the first-occurrence
+//   3. discovery-order relabelling: the local id of a node is the number of FIRST occurrences in Q before its own first
+//      occurrence.  Round 3 (default): the pick kernel records every node's smallest position in Q in a hash table
+//      (open addressing; slot claimed by an integer compare-and-swap, position by an integer atomic minimum -- the
+//      table's CONTENT as a map node -> first position does not depend on the order of the insertions, so the outputs
+//      stay deterministic); kernel `first` looks every position's node up, flags first occurrences and ranks them inside
+//      its 16 k-position block; kernel `relabel` adds the block prefixes.  Four launches per call (three when Q fits one
+//      block) instead of the ~25 of the sort-based form -- a captured mini-batch step is bound by its count of dependent
+//      kernel nodes, not by their work.
+//      Round 1-2 form (tuning key 11 = 1, kept for A/B tests): stable radix sort of (node id, position in Q) (rocPRIM);
+//      the head of every run of equal ids is that node's first occurrence; an exclusive scan of the first-occurrence
 //      flags over Q gives the local ids; a running maximum over the sorted order hands every duplicate its head.
-// Integer work, latency bound at mini-batch sizes (~15 small launches); int64 in and out like the reference.
+// Integer work, latency bound at mini-batch sizes; int64 in and out like the reference.
 #include "common.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -60,6 +68,215 @@ __device__ __forceinline__ int64_t valid_seeds(const int64_t *batch_count, int64
     return v < 0 ? 0 : (v > batch ? batch : v);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Hash-table relabelling (see the file header, step 3).
+constexpr uint32_t kHtEmpty = 0xFFFFFFFFu;     // no node id equals it (ids < 2^31)
+constexpr uint32_t kHtNoPos = 0x7FFFFFFFu;
+constexpr int kRlThreads = 1024, kRlItems = 16, kRlTile = kRlThreads * kRlItems;  // positions of Q per workgroup
+constexpr int64_t kRlMaxBlocks = 8192;         // block prefixes are scanned in LDS by every workgroup
+
+__device__ __forceinline__ uint32_t ht_hash(uint32_t k) {  // murmur3 finaliser
+    k ^= k >> 16;
+    k *= 0x85EBCA6Bu;
+    k ^= k >> 13;
+    k *= 0xC2B2AE35u;
+    k ^= k >> 16;
+    return k;
+}
+struct HashTable {
+    uint32_t *key, *pos;
+    uint32_t mask;  // capacity - 1 (capacity: a power of two >= 2 * |Q|)
+};
+__device__ __forceinline__ void ht_insert(const HashTable &t, uint32_t key, uint32_t pos) {
+    uint32_t h = ht_hash(key) & t.mask;
+    for (;;) {
+        const uint32_t cur = atomicCAS(&t.key[h], kHtEmpty, key);
+        if (cur == kHtEmpty || cur == key) {
+            atomicMin(&t.pos[h], pos);
+            return;
+        }
+        h = (h + 1) & t.mask;
+    }
+}
+__device__ __forceinline__ uint32_t ht_first_pos(const HashTable &t, uint32_t key) {  // the key is in the table
+    uint32_t h = ht_hash(key) & t.mask;
+    for (uint32_t probes = 0; probes <= t.mask; ++probes) {
+        const uint32_t cur = t.key[h];
+        if (cur == key) return t.pos[h];
+        if (cur == kHtEmpty) break;
+        h = (h + 1) & t.mask;
+    }
+    return kHtNoPos;  // (unreachable for inserted keys)
+}
+
+// Exclusive scan of one value per thread over a 1024-thread workgroup; returns the exclusive prefix, *total = the sum.
+// `sh` = 17 words of LDS; two barriers.
+template <typename V>
+__device__ __forceinline__ V wg1024_exclusive_scan(V v, V *sh, V *total) {
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    V incl = v;
+#pragma unroll
+    for (int sft = 1; sft < kWave; sft <<= 1) {
+        const V u = __shfl_up(incl, sft, kWave);
+        if (lane >= sft) incl += u;
+    }
+    __syncthreads();  // (a previous use of sh is over)
+    if (lane == kWave - 1) sh[w] = incl;
+    __syncthreads();
+    V off = 0, tot = 0;
+#pragma unroll
+    for (int ww = 0; ww < kRlThreads / kWave; ++ww) {
+        const V x = sh[ww];
+        if (ww < w) off += x;
+        tot += x;
+    }
+    *total = tot;
+    return off + incl - v;
+}
+
+// prep: block 0 -- flags = 0, per-seed counts and their exclusive scan -> out_indptr (int64; out_indptr[batch] = total);
+// every block -- its share of the hash table set to empty.
+__global__ __launch_bounds__(kRlThreads) void sample_prep_kernel(const int64_t *__restrict__ indptr,
+                                                                 const int64_t *__restrict__ node_idx, int64_t batch,
+                                                                 const int64_t *__restrict__ batch_count, int64_t num_nodes,
+                                                                 int64_t k, int replace, int64_t *__restrict__ out_indptr,
+                                                                 int *__restrict__ flags, HashTable ht) {
+    __shared__ int64_t sh[kRlThreads / kWave + 1];
+    const int64_t cap = (int64_t)ht.mask + 1;
+    for (int64_t i = (int64_t)blockIdx.x * kRlThreads + threadIdx.x; i < cap; i += (int64_t)gridDim.x * kRlThreads) {
+        ht.key[i] = kHtEmpty;
+        ht.pos[i] = kHtNoPos;
+    }
+    if (blockIdx.x != 0) return;
+    int bad = 0;
+    const int64_t valid = valid_seeds(batch_count, batch);
+    int64_t carry = 0;
+    for (int64_t base = 0; base <= batch; base += kRlThreads) {  // entry `batch` (count 0) receives the total
+        const int64_t i = base + threadIdx.x;
+        int64_t c = 0;
+        if (i < valid) {
+            const int64_t s = node_idx[i];
+            if (s < 0 || s >= num_nodes) bad = 1;
+            else c = count_for(indptr[s + 1] - indptr[s], k, replace);
+        }
+        int64_t total;
+        const int64_t ex = wg1024_exclusive_scan<int64_t>(c, sh, &total);
+        if (i <= batch) out_indptr[i] = carry + ex;
+        carry += total;
+    }
+    const int any_bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) *flags = any_bad ? 1 : 0;  // (the kernels that OR further bits in run after this one)
+}
+
+// first: for every position p of Q the first position of its node (head[p]; -1 for padding), the first-occurrence flag
+// and its exclusive rank inside this block of kRlTile positions (lrank[p]); blocksum[b] = first occurrences in block b.
+// Positions behind the picks actually made (p >= batch + total) are padding whatever the key array holds.
+struct RelabelArgs {
+    const uint32_t *keys;
+    int32_t *head, *lrank, *blocksum;
+    int64_t len, batch, cap_edges;
+    uint32_t pad_key;
+    int padded;
+    const int64_t *out_indptr_c;  // (read: total = out_indptr[batch])
+    int64_t *out_indptr, *out_indices, *out_nodes, *out_edges, *out_counts;
+    const int *flags;
+    HashTable ht;
+};
+
+__device__ __forceinline__ void relabel_first_block(const RelabelArgs &a, int64_t blk, int32_t *sh) {
+    const int64_t total = a.out_indptr_c[a.batch];
+    const int64_t p0 = blk * kRlTile + (int64_t)threadIdx.x * kRlItems;  // this thread's kRlItems consecutive positions
+    int32_t hp[kRlItems];
+    int32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < kRlItems; ++i) {
+        const int64_t p = p0 + i;
+        int32_t h = -1;
+        if (p < a.len && (p < a.batch || p - a.batch < total)) {
+            const uint32_t key = a.keys[p];
+            if (key != a.pad_key) h = (int32_t)ht_first_pos(a.ht, key);
+        }
+        hp[i] = h;
+        mine += (h >= 0 && (int64_t)h == p) ? 1 : 0;
+    }
+    int32_t tot;
+    int32_t run = wg1024_exclusive_scan<int32_t>(mine, sh, &tot);
+#pragma unroll
+    for (int i = 0; i < kRlItems; ++i) {
+        const int64_t p = p0 + i;
+        if (p < a.len) {
+            a.head[p] = hp[i];
+            a.lrank[p] = run;
+            run += (hp[i] >= 0 && (int64_t)hp[i] == p) ? 1 : 0;
+        }
+    }
+    if (threadIdx.x == 0) a.blocksum[blk] = tot;
+}
+
+// relabel: local id of position p = (first occurrences in the blocks before head[p]'s) + lrank[head[p]].
+__device__ __forceinline__ void relabel_finish_block(const RelabelArgs &a, int64_t blk, int64_t n_blocks, int32_t *bprefix,
+                                                     int32_t *sh) {
+    // exclusive prefix of the block sums, by every workgroup for itself (n_blocks <= kRlMaxBlocks)
+    int32_t carry = 0;
+    for (int64_t base = 0; base < n_blocks; base += kRlThreads) {
+        const int64_t i = base + threadIdx.x;
+        const int32_t v = i < n_blocks ? a.blocksum[i] : 0;
+        int32_t tot;
+        const int32_t ex = wg1024_exclusive_scan<int32_t>(v, sh, &tot);
+        if (i < n_blocks) bprefix[i] = carry + ex;
+        carry += tot;
+    }
+    __syncthreads();
+    const int64_t n_nodes = carry, total = a.out_indptr_c[a.batch];
+    if (blk == 0 && threadIdx.x == 0) {
+        a.out_counts[0] = n_nodes;
+        a.out_counts[1] = total;
+        a.out_counts[2] = *a.flags;  // 0, or why the result is invalid
+    }
+    const int64_t p0 = blk * kRlTile + (int64_t)threadIdx.x * kRlItems;
+#pragma unroll
+    for (int i = 0; i < kRlItems; ++i) {
+        const int64_t p = p0 + i;
+        if (p >= a.len) break;
+        const int32_t h = a.head[p];
+        if (h >= 0) {
+            const int64_t id = (int64_t)bprefix[h / kRlTile] + a.lrank[h];
+            if (p >= a.batch) a.out_indices[p - a.batch] = id;
+            if ((int64_t)h == p) a.out_nodes[id] = (int64_t)a.keys[p];
+        }
+        if (a.padded) {  // the unused tails get benign values: a well-formed CSR of the full capacity (see sample_pad_kernel)
+            if (p >= n_nodes) a.out_nodes[p] = 0;
+            if (p >= a.batch) {
+                const int64_t j = p - a.batch;
+                if (j >= total) {
+                    a.out_indices[j] = 0;
+                    a.out_edges[j] = 0;
+                }
+                a.out_indptr[a.batch + 1 + j] = total;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kRlThreads) void sample_first_kernel(const RelabelArgs a) {
+    __shared__ int32_t sh[kRlThreads / kWave + 1];
+    relabel_first_block(a, blockIdx.x, sh);
+}
+__global__ __launch_bounds__(kRlThreads) void sample_relabel_hash_kernel(const RelabelArgs a, int64_t n_blocks) {
+    __shared__ int32_t sh[kRlThreads / kWave + 1];
+    __shared__ int32_t bprefix[kRlMaxBlocks];
+    relabel_finish_block(a, blockIdx.x, n_blocks, bprefix, sh);
+}
+// |Q| <= kRlTile: both steps by ONE workgroup in one launch (its own global writes are visible to it behind a barrier).
+__global__ __launch_bounds__(kRlThreads) void sample_relabel_single_kernel(const RelabelArgs a) {
+    __shared__ int32_t sh[kRlThreads / kWave + 1];
+    __shared__ int32_t bprefix[1];
+    relabel_first_block(a, 0, sh);
+    __threadfence_block();
+    __syncthreads();
+    relabel_finish_block(a, 0, 1, bprefix, sh);
+}
+
 __global__ void sample_counts_kernel(const int64_t *__restrict__ indptr, const int64_t *__restrict__ node_idx,
                                      int64_t batch, const int64_t *__restrict__ batch_count, int64_t num_nodes, int64_t k,
                                      int replace, int32_t *__restrict__ cnt, int *__restrict__ flags) {
@@ -82,7 +299,8 @@ __global__ __launch_bounds__(256) void sample_pick_kernel(const int64_t *__restr
                                                           const uint64_t *__restrict__ seed_dev,
                                                           const int64_t *__restrict__ out_indptr,
                                                           int64_t *__restrict__ out_edges, uint32_t *__restrict__ keys,
-                                                          uint32_t pad_key, int64_t cap_edges, int *__restrict__ flags) {
+                                                          uint32_t pad_key, int64_t cap_edges, int *__restrict__ flags,
+                                                          HashTable ht) {
     __shared__ int32_t chosen_all[4][kSampleMaxK];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
@@ -97,7 +315,10 @@ __global__ __launch_bounds__(256) void sample_pick_kernel(const int64_t *__restr
         if (lane == 0) keys[i] = pad_key;
         return;
     }
-    if (lane == 0) keys[i] = (uint32_t)s;
+    if (lane == 0) {
+        keys[i] = (uint32_t)s;
+        if (ht.key) ht_insert(ht, (uint32_t)s, (uint32_t)i);
+    }
     const int64_t start = indptr[s], deg = indptr[s + 1] - start;
     const int64_t off = out_indptr[i], cnt = out_indptr[i + 1] - off;
     auto emit = [&](int64_t j, int64_t pos) {
@@ -106,9 +327,11 @@ __global__ __launch_bounds__(256) void sample_pick_kernel(const int64_t *__restr
             return;
         }
         const int64_t nb = indices[pos];
-        if (nb < 0 || nb >= num_nodes) atomicOr(flags, 2);
+        const bool bad = nb < 0 || nb >= num_nodes;
+        if (bad) atomicOr(flags, 2);
         out_edges[off + j] = pos;
-        keys[batch + off + j] = (uint32_t)nb;
+        keys[batch + off + j] = bad ? pad_key : (uint32_t)nb;  // (an id outside the graph gets no local id; flags say so)
+        if (ht.key && !bad) ht_insert(ht, (uint32_t)nb, (uint32_t)(batch + off + j));
     };
     if (k < 0 || (!replace && deg <= k)) {  // the whole row, in CSR order
         for (int64_t j = lane; j < cnt; j += kWave) emit(j, start + j);
@@ -196,6 +419,7 @@ __global__ void sample_relabel_kernel(const uint32_t *__restrict__ skeys, const 
     if (hj == (int32_t)j) out_nodes[id] = (int64_t)key;
 }
 
+
 struct SampleWs {
     int32_t *cnt;                  // [batch + 1]
     uint32_t *keys, *skeys;        // [len]
@@ -203,6 +427,9 @@ struct SampleWs {
     int *flags;
     char *temp;
     size_t temp_bytes, total;
+    uint32_t *tkey, *tpos;         // hash table of the relabelling, `tcap` slots each
+    int64_t tcap, n_blocks;
+    int32_t *blocksum;             // [n_blocks]
 };
 
 static SampleWs carve(void *base, int64_t batch, int64_t cap_edges, int64_t num_nodes) {
@@ -240,6 +467,12 @@ static SampleWs carve(void *base, int64_t batch, int64_t cap_edges, int64_t num_
     w.head = (int32_t *)take((size_t)len * 4);
     w.head_of = (int32_t *)take((size_t)len * 4);
     w.temp = take(w.temp_bytes);
+    w.tcap = 2048;
+    while (w.tcap < 2 * len) w.tcap <<= 1;
+    w.tkey = (uint32_t *)take((size_t)w.tcap * 4);
+    w.tpos = (uint32_t *)take((size_t)w.tcap * 4);
+    w.n_blocks = std::max<int64_t>(1, (len + kRlTile - 1) / kRlTile);
+    w.blocksum = (int32_t *)take((size_t)w.n_blocks * 4);
     w.total = (size_t)(p - (char *)base);
     return w;
 }
@@ -273,6 +506,47 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
         g_last_hip_error = (int)e;
         return COGDL_HIP_ELAUNCH;
     };
+    const bool hash_relabel = g_tuning[kTuneSampleRelabel] == 0;
+    if (hash_relabel) {
+        if (w.n_blocks > kRlMaxBlocks || w.tcap > (int64_t(1) << 31)) return COGDL_HIP_ERANGE;
+        HashTable ht{w.tkey, w.tpos, (uint32_t)(w.tcap - 1)};
+        const unsigned prep_blocks = (unsigned)std::min<int64_t>(256, std::max<int64_t>(1, w.tcap / (kRlThreads * 8)));
+        hipLaunchKernelGGL(sample_prep_kernel, dim3(prep_blocks), dim3(kRlThreads), 0, s, indptr, node_idx, batch, batch_count,
+                           num_nodes, num_neighbors, replace, out_indptr, w.flags, ht);
+        if (len == 0) {
+            hipError_t e0 = fill_u32_async(out_counts, 0u, 6, s);
+            return e0 == hipSuccess ? launch_status() : fail(e0);
+        }
+        if (batch > 0)
+            hipLaunchKernelGGL(sample_pick_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, s, indptr, indices,
+                               node_idx, batch, batch_count, num_nodes, num_neighbors, replace, seed, seed_dev, out_indptr,
+                               out_edges, w.keys, pad_key, cap_edges, w.flags, ht);
+        RelabelArgs a{};
+        a.keys = w.keys;
+        a.head = w.head_of;
+        a.lrank = w.rank;
+        a.blocksum = w.blocksum;
+        a.len = len;
+        a.batch = batch;
+        a.cap_edges = cap_edges;
+        a.pad_key = pad_key;
+        a.padded = padded;
+        a.out_indptr_c = out_indptr;
+        a.out_indptr = out_indptr;
+        a.out_indices = out_indices;
+        a.out_nodes = out_nodes;
+        a.out_edges = out_edges;
+        a.out_counts = out_counts;
+        a.flags = w.flags;
+        a.ht = ht;
+        if (w.n_blocks == 1) {
+            hipLaunchKernelGGL(sample_relabel_single_kernel, dim3(1), dim3(kRlThreads), 0, s, a);
+        } else {
+            hipLaunchKernelGGL(sample_first_kernel, dim3((unsigned)w.n_blocks), dim3(kRlThreads), 0, s, a);
+            hipLaunchKernelGGL(sample_relabel_hash_kernel, dim3((unsigned)w.n_blocks), dim3(kRlThreads), 0, s, a, w.n_blocks);
+        }
+        return launch_status();
+    }
     hipError_t e = fill_u32_async(w.flags, 0u, 1, s);
     if (e != hipSuccess) return fail(e);
     hipLaunchKernelGGL(sample_counts_kernel, dim3((unsigned)((batch + 256) / 256)), dim3(256), 0, s, indptr, node_idx, batch,
@@ -287,7 +561,7 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
     if (batch > 0)
         hipLaunchKernelGGL(sample_pick_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, s, indptr, indices, node_idx,
                            batch, batch_count, num_nodes, num_neighbors, replace, seed, seed_dev, out_indptr, out_edges, w.keys,
-                           pad_key, cap_edges, w.flags);
+                           pad_key, cap_edges, w.flags, HashTable{nullptr, nullptr, 0u});
     if (cap_edges > 0)
         hipLaunchKernelGGL(sample_pad_kernel, dim3((unsigned)std::min<int64_t>((cap_edges + 255) / 256, 1024)), dim3(256), 0, s,
                            out_indptr, batch, cap_edges, w.keys, pad_key, padded, out_indices, out_edges);

@@ -62,22 +62,24 @@ def test_sample_adj_padded_rejects_what_has_no_fixed_capacity():
     assert int(counts[2]) & 1  # a seed outside the graph is flagged, not fatal on the device
 
 
-@pytest.mark.parametrize("algo", [1, 2, 3], ids=["rocprim-pipeline", "radix-transpose", "radix-transpose-packed-records"])
+@pytest.mark.parametrize("algo", [1, 2, 3, 5], ids=["rocprim-pipeline", "radix-transpose", "radix-transpose-packed-records",
+                                                     "radix-transpose-msd-first"])
 @pytest.mark.parametrize("surplus", [0, 1, 777, 20000])
-def test_csr2csc_padded_ignores_the_slots_behind_the_last_row(surplus, algo):
+@pytest.mark.parametrize("n_cols", [500, 6000], ids=["one-radix-pass", "two-radix-passes"])
+def test_csr2csc_padded_ignores_the_slots_behind_the_last_row(surplus, algo, n_cols):
     _lib.hip().cogdl_hip_set_tuning(10, algo)
     try:
-        _padded_transpose_case(surplus)
+        _padded_transpose_case(surplus, n_cols)
     finally:
         _lib.hip().cogdl_hip_set_tuning(10, 0)
 
 
-def _padded_transpose_case(surplus):
-    g = synth.random_csr(300, 500, 7, seed=surplus)
+def _padded_transpose_case(surplus, n_cols=500):
+    g = synth.random_csr(300, n_cols, 7, seed=surplus)
     rp, ci = g.rowptr.to(DEV), g.colind.to(DEV)
-    junk = torch.randint(0, 500, (surplus,), dtype=torch.int32, device=DEV)
-    want = csr2csc(rp, ci, 500)
-    got = csr2csc(rp, torch.cat([ci, junk]), 500, padded=True)
+    junk = torch.randint(0, n_cols, (surplus,), dtype=torch.int32, device=DEV)
+    want = csr2csc(rp, ci, n_cols)
+    got = csr2csc(rp, torch.cat([ci, junk]), n_cols, padded=True)
     nnz = ci.numel()
     assert torch.equal(got.colptr, want.colptr)
     assert torch.equal(got.rowind[:nnz], want.rowind) and torch.equal(got.perm[:nnz], want.perm)

@@ -23,6 +23,15 @@ DEV = "cuda:0"
 N, B, K = 2_449_029, 8192, 10
 
 
+@pytest.fixture(autouse=True, params=[0, 1], ids=["relabel-hash", "relabel-sort"])
+def relabel_algo(request):
+    from cogdl_amd import _lib
+
+    _lib.hip().cogdl_hip_set_tuning(11, request.param)
+    yield request.param
+    _lib.hip().cogdl_hip_set_tuning(11, 0)
+
+
 @pytest.fixture(scope="module")
 def products():
     src, dst = synth.rmat_pairs(N, int(N * 50.5 / 2), 0, device=DEV)

@@ -21,10 +21,11 @@ def rand(*shape, seed=0, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------ csr2csc
-@pytest.fixture(params=[1, 2, 3], ids=["rocprim-pipeline", "radix-transpose", "radix-transpose-packed-records"])
+@pytest.fixture(params=[1, 2, 3, 5], ids=["rocprim-pipeline", "radix-transpose", "radix-transpose-packed-records", "radix-transpose-msd-first"])
 def csc_algo(request):
-    """csr2csc's two implementations (tuning key 10; the default picks by size): the rocPRIM sort + row look-up and the
-    hand-written two-payload radix sort (csrc/radix_transpose.hip)."""
+    """csr2csc's implementations (tuning key 10; the default picks by size): the rocPRIM sort + row look-up, and the
+    hand-written two-payload radix sort (csrc/radix_transpose.hip) -- LSD, with packed intermediate records from 16 M slots on (3: at
+    any size); 5: MSD-first where two passes suffice (column ids of 10..18 bits)."""
     from cogdl_amd import _lib
 
     _lib.hip().cogdl_hip_set_tuning(10, request.param)

@@ -18,6 +18,41 @@ def T(a):
     return torch.from_numpy(np.asarray(a)).to(DEV)
 
 
+@pytest.fixture(autouse=True, params=[0, 1], ids=["relabel-hash", "relabel-sort"])
+def relabel_algo(request):
+    """Both relabelling forms of csrc/sample.hip (tuning key 11): the hash table of first positions (default, 3-4
+    launches) and the rocPRIM sort-based pipeline of rounds 1-2 (~25 launches)."""
+    from cogdl_amd import _lib
+
+    _lib.hip().cogdl_hip_set_tuning(11, request.param)
+    yield request.param
+    _lib.hip().cogdl_hip_set_tuning(11, 0)
+
+
+@pytest.mark.parametrize("n,deg,batch,k,replace", [(3000, 9, 100, 5, False), (60000, 25, 1500, 10, False),
+                                                   (60000, 25, 1500, 10, True), (200000, 12, 30000, 10, False),
+                                                   (5000, 40, 2000, -1, False), (50, 2, 50, 3, False)])
+def test_hash_relabel_equals_sort_relabel(n, deg, batch, k, replace):
+    """The two relabelling forms give identical outputs (one block of Q, several blocks, the whole-row mode, duplicates
+    galore at the small sizes), for the plain and for the fixed-capacity entry point."""
+    from cogdl_amd import _lib
+
+    g = synth.scaled(n, deg, seed=n + batch, norm=None, topology="rmat")
+    indptr, indices = g.rowptr.long().to(DEV), g.colind.long().to(DEV)
+    seeds = torch.randperm(n, generator=torch.Generator().manual_seed(3))[:batch].to(DEV)
+    outs = []
+    for algo in (0, 1):
+        _lib.hip().cogdl_hip_set_tuning(11, algo)
+        plain = ops.sample_adj_c(indptr, indices, seeds, k, replace, seed=77)
+        padded = ops.sample_adj_padded(indptr, indices, seeds, k, replace, seed=77) if k >= 0 else ()
+        half = (ops.sample_adj_padded(indptr, indices, seeds, k, replace, seed=77,
+                                      count=torch.tensor([batch // 2], device=DEV)) if k >= 0 else ())
+        outs.append([t.cpu() for t in plain + tuple(padded) + tuple(half)])
+    assert len(outs[0]) == len(outs[1])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_full_neighbourhood_equals_reference_golden(golden):
     z = golden("sampler")  # produced by the reference's sample_adj_c(..., -1, False)
     rp, ci, nodes, edges = ops.sample_adj_c(T(z["row_ptr"]), T(z["col_ind"]), T(z["seeds"]), -1, False)
