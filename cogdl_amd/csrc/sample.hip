@@ -72,7 +72,9 @@ __device__ __forceinline__ int64_t valid_seeds(const int64_t *batch_count, int64
 // Hash-table relabelling (see the file header, step 3).
 constexpr uint32_t kHtEmpty = 0xFFFFFFFFu;     // no node id equals it (ids < 2^31)
 constexpr uint32_t kHtNoPos = 0x7FFFFFFFu;
-constexpr int kRlThreads = 1024, kRlItems = 16, kRlTile = kRlThreads * kRlItems;  // positions of Q per workgroup
+constexpr int kRlThreads = 1024;
+constexpr int kRlItems1 = 16, kRlTile1 = kRlThreads * kRlItems1;  // positions of Q of the single-workgroup form
+constexpr int kRlItems = 8, kRlTile = kRlThreads * kRlItems;     // ... per workgroup of the several-block form (register budget: 128)
 constexpr int64_t kRlMaxBlocks = 8192;         // block prefixes are scanned in LDS by every workgroup
 
 __device__ __forceinline__ uint32_t ht_hash(uint32_t k) {  // murmur3 finaliser
@@ -87,26 +89,18 @@ struct HashTable {
     uint32_t *key, *pos;
     uint32_t mask;  // capacity - 1 (capacity: a power of two >= 2 * |Q|)
 };
-__device__ __forceinline__ void ht_insert(const HashTable &t, uint32_t key, uint32_t pos) {
+// -> the slot that holds `key` (the position of Q that inserted it keeps the slot: the look-up later is ONE load of
+// pos[slot] per position, all of a thread's loads in flight at once, instead of a dependent probe sequence each)
+__device__ __forceinline__ uint32_t ht_insert(const HashTable &t, uint32_t key, uint32_t pos) {
     uint32_t h = ht_hash(key) & t.mask;
     for (;;) {
         const uint32_t cur = atomicCAS(&t.key[h], kHtEmpty, key);
         if (cur == kHtEmpty || cur == key) {
             atomicMin(&t.pos[h], pos);
-            return;
+            return h;
         }
         h = (h + 1) & t.mask;
     }
-}
-__device__ __forceinline__ uint32_t ht_first_pos(const HashTable &t, uint32_t key) {  // the key is in the table
-    uint32_t h = ht_hash(key) & t.mask;
-    for (uint32_t probes = 0; probes <= t.mask; ++probes) {
-        const uint32_t cur = t.key[h];
-        if (cur == key) return t.pos[h];
-        if (cur == kHtEmpty) break;
-        h = (h + 1) & t.mask;
-    }
-    return kHtNoPos;  // (unreachable for inserted keys)
 }
 
 // Exclusive scan of one value per thread over a 1024-thread workgroup; returns the exclusive prefix, *total = the sum.
@@ -134,6 +128,57 @@ __device__ __forceinline__ V wg1024_exclusive_scan(V v, V *sh, V *total) {
     return off + incl - v;
 }
 
+// N values per thread in the STRIDED layout (value q of thread t is element q * 1024 + t of a block of N * 1024: a wave's
+// loads and stores are then contiguous 256-byte runs -- with N consecutive elements per thread every memory instruction
+// of a wave touches 64 different lines and the address unit serialises it: 20 us per kernel on one CU, measured):
+// v[q] is replaced by the exclusive prefix of its element in block order; *total = the block's sum.  `sh` = 16 * N + 5
+// words of LDS; four barriers.
+template <int N, typename V>
+__device__ __forceinline__ void wg1024_strided_exclusive_scan(V (&v)[N], V *sh, V *total) {
+    static_assert(16 * N <= 256, "the wave totals are scanned by the first four waves");
+    const int t = threadIdx.x, lane = t & (kWave - 1), w = t >> 6;
+    V incl[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        V x = v[q];
+#pragma unroll
+        for (int sft = 1; sft < kWave; sft <<= 1) {
+            const V u = __shfl_up(x, sft, kWave);
+            if (lane >= sft) x += u;
+        }
+        incl[q] = x;
+    }
+    __syncthreads();  // (a previous use of sh is over)
+    if (lane == kWave - 1) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) sh[q * 16 + w] = incl[q];
+    }
+    __syncthreads();
+    // the 16 * N wave totals, in block order (q major), scanned by the first four waves
+    V mine = 0, x = 0;
+    if (t < 256) {
+        mine = t < 16 * N ? sh[t] : V(0);
+        x = mine;
+#pragma unroll
+        for (int sft = 1; sft < kWave; sft <<= 1) {
+            const V u = __shfl_up(x, sft, kWave);
+            if (lane >= sft) x += u;
+        }
+        if (lane == kWave - 1) sh[16 * N + w] = x;
+    }
+    __syncthreads();
+    if (t < 256) {
+        V off = 0;
+        for (int ww = 0; ww < w; ++ww) off += sh[16 * N + ww];
+        if (t < 16 * N) sh[t] = off + x - mine;  // (read into `mine` before the barrier above)
+        if (t == 16 * N - 1) sh[16 * N + 4] = off + x;
+    }
+    __syncthreads();
+    *total = sh[16 * N + 4];
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = sh[q * 16 + w] + incl[q] - v[q];
+}
+
 // prep: block 0 -- flags = 0, per-seed counts and their exclusive scan -> out_indptr (int64; out_indptr[batch] = total);
 // every block -- its share of the hash table set to empty.
 __global__ __launch_bounds__(kRlThreads) void sample_prep_kernel(const int64_t *__restrict__ indptr,
@@ -141,7 +186,7 @@ __global__ __launch_bounds__(kRlThreads) void sample_prep_kernel(const int64_t *
                                                                  const int64_t *__restrict__ batch_count, int64_t num_nodes,
                                                                  int64_t k, int replace, int64_t *__restrict__ out_indptr,
                                                                  int *__restrict__ flags, HashTable ht) {
-    __shared__ int64_t sh[kRlThreads / kWave + 1];
+    __shared__ int64_t sh[16 * 12 + 5];
     const int64_t cap = (int64_t)ht.mask + 1;
     for (int64_t i = (int64_t)blockIdx.x * kRlThreads + threadIdx.x; i < cap; i += (int64_t)gridDim.x * kRlThreads) {
         ht.key[i] = kHtEmpty;
@@ -151,17 +196,31 @@ __global__ __launch_bounds__(kRlThreads) void sample_prep_kernel(const int64_t *
     int bad = 0;
     const int64_t valid = valid_seeds(batch_count, batch);
     int64_t carry = 0;
-    for (int64_t base = 0; base <= batch; base += kRlThreads) {  // entry `batch` (count 0) receives the total
-        const int64_t i = base + threadIdx.x;
-        int64_t c = 0;
-        if (i < valid) {
-            const int64_t s = node_idx[i];
-            if (s < 0 || s >= num_nodes) bad = 1;
-            else c = count_for(indptr[s + 1] - indptr[s], k, replace);
+    constexpr int PI = 12;  // entries per thread and trip (12 k: a 1024-seed second hop in one trip; strided: entry q * 1024 + t), their gathers in flight together
+    for (int64_t base = 0; base <= batch; base += (int64_t)kRlThreads * PI) {  // entry `batch` (count 0) receives the total
+        int64_t sd[PI], lo[PI], hi[PI], c[PI];
+#pragma unroll
+        for (int q = 0; q < PI; ++q) {
+            const int64_t i = base + (int64_t)q * kRlThreads + threadIdx.x;
+            sd[q] = i < valid ? node_idx[i] : -1;
         }
+#pragma unroll
+        for (int q = 0; q < PI; ++q) {
+            const int64_t i = base + (int64_t)q * kRlThreads + threadIdx.x;
+            const bool ok = sd[q] >= 0 && sd[q] < num_nodes;
+            if (i < valid && !ok) bad = 1;
+            lo[q] = ok ? indptr[sd[q]] : 0;
+            hi[q] = ok ? indptr[sd[q] + 1] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < PI; ++q) c[q] = (sd[q] >= 0 && sd[q] < num_nodes) ? count_for(hi[q] - lo[q], k, replace) : 0;
         int64_t total;
-        const int64_t ex = wg1024_exclusive_scan<int64_t>(c, sh, &total);
-        if (i <= batch) out_indptr[i] = carry + ex;
+        wg1024_strided_exclusive_scan<PI, int64_t>(c, sh, &total);
+#pragma unroll
+        for (int q = 0; q < PI; ++q) {
+            const int64_t i = base + (int64_t)q * kRlThreads + threadIdx.x;
+            if (i <= batch) out_indptr[i] = carry + c[q];
+        }
         carry += total;
     }
     const int any_bad = __syncthreads_or(bad);
@@ -173,6 +232,7 @@ __global__ __launch_bounds__(kRlThreads) void sample_prep_kernel(const int64_t *
 // Positions behind the picks actually made (p >= batch + total) are padding whatever the key array holds.
 struct RelabelArgs {
     const uint32_t *keys;
+    const uint32_t *slots;        // [len] hash-table slot of every position's node (written by the pick kernel)
     int32_t *head, *lrank, *blocksum;
     int64_t len, batch, cap_edges;
     uint32_t pad_key;
@@ -183,39 +243,94 @@ struct RelabelArgs {
     HashTable ht;
 };
 
-__device__ __forceinline__ void relabel_first_block(const RelabelArgs &a, int64_t blk, int32_t *sh) {
-    const int64_t total = a.out_indptr_c[a.batch];
-    const int64_t p0 = blk * kRlTile + (int64_t)threadIdx.x * kRlItems;  // this thread's kRlItems consecutive positions
-    int32_t hp[kRlItems];
-    int32_t mine = 0;
+// Phases A-C of a block of ITEMS * 1024 positions starting at b0, STRIDED: item i of thread t is position
+// b0 + i * 1024 + t.  For each of them the first position of its node (hp[i]; -1 for padding) and the key; hp/ky out,
+// rk[i] = the exclusive rank of the position's own first-occurrence flag inside the block, *tot = first occurrences of
+// the block.  Loads come in unconditional phases -- a load behind a per-lane branch is waited for at the branch's join,
+// i.e. ITEMS serial round trips instead of one; indices are clamped / masked into range and what an unused position
+// reads is ignored.  Two round trips to memory: {keys, slots, total}, then the gathers pos[slot].
+template <int ITEMS>
+__device__ __forceinline__ void relabel_block_ranks(const RelabelArgs &a, int64_t b0, int32_t (&hp)[ITEMS],
+                                                    uint32_t (&ky)[ITEMS], int32_t (&rk)[ITEMS], int64_t &total,
+                                                    int32_t *sh, int32_t *tot) {
+    uint32_t sl[ITEMS];
+    const int64_t last = a.len - 1;
+    total = a.out_indptr_c[a.batch];
 #pragma unroll
-    for (int i = 0; i < kRlItems; ++i) {
-        const int64_t p = p0 + i;
-        int32_t h = -1;
-        if (p < a.len && (p < a.batch || p - a.batch < total)) {
-            const uint32_t key = a.keys[p];
-            if (key != a.pad_key) h = (int32_t)ht_first_pos(a.ht, key);
-        }
-        hp[i] = h;
-        mine += (h >= 0 && (int64_t)h == p) ? 1 : 0;
+    for (int i = 0; i < ITEMS; ++i) {
+        const int64_t pc = min(b0 + (int64_t)i * kRlThreads + threadIdx.x, last);
+        ky[i] = a.keys[pc];
+        sl[i] = a.slots[pc] & a.ht.mask;
     }
-    int32_t tot;
-    int32_t run = wg1024_exclusive_scan<int32_t>(mine, sh, &tot);
 #pragma unroll
-    for (int i = 0; i < kRlItems; ++i) {
-        const int64_t p = p0 + i;
-        if (p < a.len) {
-            a.head[p] = hp[i];
-            a.lrank[p] = run;
-            run += (hp[i] >= 0 && (int64_t)hp[i] == p) ? 1 : 0;
-        }
+    for (int i = 0; i < ITEMS; ++i) hp[i] = (int32_t)a.ht.pos[sl[i]];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int64_t p = b0 + (int64_t)i * kRlThreads + threadIdx.x;
+        const bool used = p < a.len && (p < a.batch || p - a.batch < total) && ky[i] != a.pad_key;
+        if (!used) hp[i] = -1;
+        rk[i] = (used && (int64_t)hp[i] == p) ? 1 : 0;
     }
-    if (threadIdx.x == 0) a.blocksum[blk] = tot;
+    wg1024_strided_exclusive_scan<ITEMS, int32_t>(rk, sh, tot);
 }
 
-// relabel: local id of position p = (first occurrences in the blocks before head[p]'s) + lrank[head[p]].
-__device__ __forceinline__ void relabel_finish_block(const RelabelArgs &a, int64_t blk, int64_t n_blocks, int32_t *bprefix,
-                                                     int32_t *sh) {
+// The outputs of position p whose node has the local id `id` (h = its first position, -1: padding), and -- fixed-capacity
+// form -- benign values in the unused tails: a well-formed CSR of the full capacity (see sample_pad_kernel).
+__device__ __forceinline__ void relabel_emit(const RelabelArgs &a, int64_t p, int32_t h, int64_t id, uint32_t key,
+                                             int64_t n_nodes, int64_t total) {
+    if (h >= 0) {
+        if (p >= a.batch) a.out_indices[p - a.batch] = id;
+        if ((int64_t)h == p) a.out_nodes[id] = (int64_t)key;
+    }
+    if (a.padded) {
+        if (p >= n_nodes) a.out_nodes[p] = 0;
+        if (p >= a.batch) {
+            const int64_t j = p - a.batch;
+            if (j >= total) {
+                a.out_indices[j] = 0;
+                a.out_edges[j] = 0;
+            }
+            a.out_indptr[a.batch + 1 + j] = total;
+        }
+    }
+}
+
+// first (several blocks): head[p], lrank[p] (the rank of p's OWN first-occurrence flag inside its block), blocksum[b].
+__global__ __launch_bounds__(kRlThreads) void sample_first_kernel(const RelabelArgs a) {
+    __shared__ int32_t sh[16 * kRlItems + 5];
+    const int64_t b0 = (int64_t)blockIdx.x * kRlTile;
+    int32_t hp[kRlItems], rk[kRlItems], tot;
+    uint32_t ky[kRlItems];
+    int64_t total;
+    relabel_block_ranks<kRlItems>(a, b0, hp, ky, rk, total, sh, &tot);
+#pragma unroll
+    for (int i = 0; i < kRlItems; ++i) {
+        const int64_t p = b0 + (int64_t)i * kRlThreads + threadIdx.x;
+        if (p < a.len) {
+            a.head[p] = hp[i];
+            a.lrank[p] = rk[i];
+        }
+    }
+    if (threadIdx.x == 0) a.blocksum[blockIdx.x] = tot;
+}
+
+// relabel (several blocks): local id of position p = (first occurrences in the blocks before head[p]'s) + lrank[head[p]].
+__global__ __launch_bounds__(kRlThreads) void sample_relabel_hash_kernel(const RelabelArgs a, int64_t n_blocks) {
+    __shared__ int32_t sh[kRlThreads / kWave + 1];
+    __shared__ int32_t bprefix[kRlMaxBlocks];
+    const int64_t b0 = (int64_t)blockIdx.x * kRlTile;
+    const int64_t last = a.len - 1;
+    // everything this workgroup reads that does not depend on another read is requested first
+    int32_t hd[kRlItems], lr[kRlItems];
+    uint32_t ky[kRlItems];
+    const int64_t total = a.out_indptr_c[a.batch];
+    const int fl = *a.flags;
+#pragma unroll
+    for (int i = 0; i < kRlItems; ++i) {
+        const int64_t pc = min(b0 + (int64_t)i * kRlThreads + threadIdx.x, last);
+        hd[i] = a.head[pc];
+        ky[i] = a.keys[pc];
+    }
     // exclusive prefix of the block sums, by every workgroup for itself (n_blocks <= kRlMaxBlocks)
     int32_t carry = 0;
     for (int64_t base = 0; base < n_blocks; base += kRlThreads) {
@@ -226,55 +341,55 @@ __device__ __forceinline__ void relabel_finish_block(const RelabelArgs &a, int64
         if (i < n_blocks) bprefix[i] = carry + ex;
         carry += tot;
     }
-    __syncthreads();
-    const int64_t n_nodes = carry, total = a.out_indptr_c[a.batch];
-    if (blk == 0 && threadIdx.x == 0) {
-        a.out_counts[0] = n_nodes;
-        a.out_counts[1] = total;
-        a.out_counts[2] = *a.flags;  // 0, or why the result is invalid
-    }
-    const int64_t p0 = blk * kRlTile + (int64_t)threadIdx.x * kRlItems;
 #pragma unroll
     for (int i = 0; i < kRlItems; ++i) {
-        const int64_t p = p0 + i;
-        if (p >= a.len) break;
-        const int32_t h = a.head[p];
-        if (h >= 0) {
-            const int64_t id = (int64_t)bprefix[h / kRlTile] + a.lrank[h];
-            if (p >= a.batch) a.out_indices[p - a.batch] = id;
-            if ((int64_t)h == p) a.out_nodes[id] = (int64_t)a.keys[p];
-        }
-        if (a.padded) {  // the unused tails get benign values: a well-formed CSR of the full capacity (see sample_pad_kernel)
-            if (p >= n_nodes) a.out_nodes[p] = 0;
-            if (p >= a.batch) {
-                const int64_t j = p - a.batch;
-                if (j >= total) {
-                    a.out_indices[j] = 0;
-                    a.out_edges[j] = 0;
-                }
-                a.out_indptr[a.batch + 1 + j] = total;
-            }
+        if (b0 + (int64_t)i * kRlThreads + threadIdx.x > last) hd[i] = -1;
+        lr[i] = a.lrank[max(hd[i], 0)];  // (independent gathers, all in flight)
+    }
+    __syncthreads();
+    const int64_t n_nodes = carry;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.out_counts[0] = n_nodes;
+        a.out_counts[1] = total;
+        a.out_counts[2] = fl;  // 0, or why the result is invalid
+    }
+#pragma unroll
+    for (int i = 0; i < kRlItems; ++i) {
+        const int64_t p = b0 + (int64_t)i * kRlThreads + threadIdx.x;
+        if (p <= last) {
+            const int64_t id = hd[i] >= 0 ? (int64_t)bprefix[hd[i] / kRlTile] + lr[i] : 0;
+            relabel_emit(a, p, hd[i], id, ky[i], n_nodes, total);
         }
     }
 }
 
-__global__ __launch_bounds__(kRlThreads) void sample_first_kernel(const RelabelArgs a) {
-    __shared__ int32_t sh[kRlThreads / kWave + 1];
-    relabel_first_block(a, blockIdx.x, sh);
-}
-__global__ __launch_bounds__(kRlThreads) void sample_relabel_hash_kernel(const RelabelArgs a, int64_t n_blocks) {
-    __shared__ int32_t sh[kRlThreads / kWave + 1];
-    __shared__ int32_t bprefix[kRlMaxBlocks];
-    relabel_finish_block(a, blockIdx.x, n_blocks, bprefix, sh);
-}
-// |Q| <= kRlTile: both steps by ONE workgroup in one launch (its own global writes are visible to it behind a barrier).
+// |Q| <= kRlTile1: ONE workgroup, one launch, two round trips to memory: the ranks of the block travel through LDS
+// (16-bit: ranks < kRlTile1), nothing is re-read from global memory.
 __global__ __launch_bounds__(kRlThreads) void sample_relabel_single_kernel(const RelabelArgs a) {
-    __shared__ int32_t sh[kRlThreads / kWave + 1];
-    __shared__ int32_t bprefix[1];
-    relabel_first_block(a, 0, sh);
-    __threadfence_block();
+    __shared__ int32_t sh[16 * kRlItems1 + 5];
+    __shared__ uint16_t lrank16[kRlTile1];
+    const int fl = *a.flags;
+    int32_t hp[kRlItems1], rk[kRlItems1], tot;
+    uint32_t ky[kRlItems1];
+    int64_t total;
+    relabel_block_ranks<kRlItems1>(a, 0, hp, ky, rk, total, sh, &tot);
+#pragma unroll
+    for (int i = 0; i < kRlItems1; ++i) lrank16[i * kRlThreads + threadIdx.x] = (uint16_t)rk[i];
     __syncthreads();
-    relabel_finish_block(a, 0, 1, bprefix, sh);
+    const int64_t n_nodes = tot;
+    if (threadIdx.x == 0) {
+        a.out_counts[0] = n_nodes;
+        a.out_counts[1] = total;
+        a.out_counts[2] = fl;
+    }
+#pragma unroll
+    for (int i = 0; i < kRlItems1; ++i) {
+        const int64_t p = (int64_t)i * kRlThreads + threadIdx.x;
+        if (p < a.len) {
+            const int64_t id = hp[i] >= 0 ? (int64_t)lrank16[hp[i]] : 0;
+            relabel_emit(a, p, hp[i], id, ky[i], n_nodes, total);
+        }
+    }
 }
 
 __global__ void sample_counts_kernel(const int64_t *__restrict__ indptr, const int64_t *__restrict__ node_idx,
@@ -300,7 +415,7 @@ __global__ __launch_bounds__(256) void sample_pick_kernel(const int64_t *__restr
                                                           const int64_t *__restrict__ out_indptr,
                                                           int64_t *__restrict__ out_edges, uint32_t *__restrict__ keys,
                                                           uint32_t pad_key, int64_t cap_edges, int *__restrict__ flags,
-                                                          HashTable ht) {
+                                                          HashTable ht, uint32_t *__restrict__ slots) {
     __shared__ int32_t chosen_all[4][kSampleMaxK];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
@@ -317,7 +432,7 @@ __global__ __launch_bounds__(256) void sample_pick_kernel(const int64_t *__restr
     }
     if (lane == 0) {
         keys[i] = (uint32_t)s;
-        if (ht.key) ht_insert(ht, (uint32_t)s, (uint32_t)i);
+        if (ht.key) slots[i] = ht_insert(ht, (uint32_t)s, (uint32_t)i);
     }
     const int64_t start = indptr[s], deg = indptr[s + 1] - start;
     const int64_t off = out_indptr[i], cnt = out_indptr[i + 1] - off;
@@ -331,7 +446,7 @@ __global__ __launch_bounds__(256) void sample_pick_kernel(const int64_t *__restr
         if (bad) atomicOr(flags, 2);
         out_edges[off + j] = pos;
         keys[batch + off + j] = bad ? pad_key : (uint32_t)nb;  // (an id outside the graph gets no local id; flags say so)
-        if (ht.key && !bad) ht_insert(ht, (uint32_t)nb, (uint32_t)(batch + off + j));
+        if (ht.key && !bad) slots[batch + off + j] = ht_insert(ht, (uint32_t)nb, (uint32_t)(batch + off + j));
     };
     if (k < 0 || (!replace && deg <= k)) {  // the whole row, in CSR order
         for (int64_t j = lane; j < cnt; j += kWave) emit(j, start + j);
@@ -471,7 +586,7 @@ static SampleWs carve(void *base, int64_t batch, int64_t cap_edges, int64_t num_
     while (w.tcap < 2 * len) w.tcap <<= 1;
     w.tkey = (uint32_t *)take((size_t)w.tcap * 4);
     w.tpos = (uint32_t *)take((size_t)w.tcap * 4);
-    w.n_blocks = std::max<int64_t>(1, (len + kRlTile - 1) / kRlTile);
+    w.n_blocks = len <= kRlTile1 ? 1 : (len + kRlTile - 1) / kRlTile;
     w.blocksum = (int32_t *)take((size_t)w.n_blocks * 4);
     w.total = (size_t)(p - (char *)base);
     return w;
@@ -520,9 +635,10 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
         if (batch > 0)
             hipLaunchKernelGGL(sample_pick_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, s, indptr, indices,
                                node_idx, batch, batch_count, num_nodes, num_neighbors, replace, seed, seed_dev, out_indptr,
-                               out_edges, w.keys, pad_key, cap_edges, w.flags, ht);
+                               out_edges, w.keys, pad_key, cap_edges, w.flags, ht, (uint32_t *)w.first);
         RelabelArgs a{};
         a.keys = w.keys;
+        a.slots = (const uint32_t *)w.first;
         a.head = w.head_of;
         a.lrank = w.rank;
         a.blocksum = w.blocksum;
@@ -561,7 +677,7 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
     if (batch > 0)
         hipLaunchKernelGGL(sample_pick_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, s, indptr, indices, node_idx,
                            batch, batch_count, num_nodes, num_neighbors, replace, seed, seed_dev, out_indptr, out_edges, w.keys,
-                           pad_key, cap_edges, w.flags, HashTable{nullptr, nullptr, 0u});
+                           pad_key, cap_edges, w.flags, HashTable{nullptr, nullptr, 0u}, nullptr);
     if (cap_edges > 0)
         hipLaunchKernelGGL(sample_pad_kernel, dim3((unsigned)std::min<int64_t>((cap_edges + 255) / 256, 1024)), dim3(256), 0, s,
                            out_indptr, batch, cap_edges, w.keys, pad_key, padded, out_indices, out_edges);

@@ -266,11 +266,11 @@ static int csr2csc_impl(const int32_t *rowptr, const int32_t *colind, int64_t m,
         return COGDL_HIP_EWORKSPACE;
     if (!aligned_to(workspace, 256)) return COGDL_HIP_EALIGN;
     if (padded && (m == 0 || n_cols >= 0x7fffffff)) return COGDL_HIP_ERANGE;
-    // The hand-written sort (radix_transpose.hip) at every size (round 3: its table scans are one single-workgroup
-    // launch for small tables, which leaves 7 launches for a two-pass block transpose where the rocPRIM merge-sort
-    // pipeline takes ~12; rounds 1-2 switched at 256 k slots: 51 k slots 67 vs 82 us with three-launch scans).
-    // tuning key 10 = 1 keeps the rocPRIM pipeline for A/B runs.
-    const bool radix = g_tuning[kTuneCsr2csc] != 1;
+    // The hand-written sort (radix_transpose.hip) from 256 k edge slots on: below that a transpose is ~10 launches either
+    // way and rocPRIM's merge sort has the shorter ones (51 k slots: 69 vs 69 us alone, but inside the captured
+    // mini-batch step +0.02 ms per step with the radix sort at every size: its 8192-slot tiles leave a 100 k-slot block
+    // to 14 workgroups with a long serial chain each; 2.5 M slots: 198 vs 112 us the other way).
+    const bool radix = g_tuning[kTuneCsr2csc] >= 2 || (g_tuning[kTuneCsr2csc] == 0 && nnz >= (1 << 18));
     if (radix && m > 0) {
         return radix_transpose(rowptr, colind, m, n_cols, nnz, padded, colptr, rowind, perm, workspace, s);
     }

@@ -119,8 +119,16 @@ def main():
     ap.add_argument("--captured", action="store_true",
                     help="fixed-capacity blocks, the whole step (sampling included) replayed as one hipGraph (single GPU)")
     ap.add_argument("--inference", action="store_true", help="also time layer-wise full-neighbour inference over all nodes")
+    ap.add_argument("--torch-linear", action="store_true",
+                    help="keep torch / hipBLASLt for the SAGE layers' Linear (default: cogdl_amd.linear = install(linear=True): "
+                         "the weight gradient of the first layer is a reduction over all ~1e4..1e5 frontier rows that hipBLASLt "
+                         "runs on 28 workgroups, 72 us of a 0.44 ms captured step)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if not args.torch_linear:
+        from cogdl_amd import linear as cogdl_linear
+
+        cogdl_linear.install()
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(dev)
     if world > 1:
@@ -225,6 +233,7 @@ def main():
             "ms_feature_gather_alone_rank0": ms_gather, "feature_gather_GBs": gather_gbs, "layerwise_inference": infer,
             "batch": args.batch, "frontier_nodes_per_step": nodes // args.steps, "sampled_edges_per_step": edges // args.steps,
             "config": {"nodes": n, "nnz": int(g.nnz), "feat": args.feat, "hidden": args.hidden, "classes": args.classes,
+                       "linear": "torch / hipBLASLt" if args.torch_linear else "cogdl_amd.linear (MFMA weight gradient)",
                        "sampler": "cogdl_hip_sample_adj (GPU-resident graph)", "features": "resident in HBM" if args.features == "hbm" else "pinned host memory, zero-copy gather",
                        "pipeline": ("whole step (2 sampling hops, gather, fwd, bwd, Adam) = one hipGraph replay over fixed-capacity blocks" if args.captured
                                     else "next batch sampled + gathered on a side stream" if args.pipeline else "none"),
