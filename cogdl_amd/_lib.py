@@ -73,6 +73,10 @@ HIP_SIGNATURES = {
     "cogdl_hip_gather_feature_rows_i32": ([_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp], _i32),
     "cogdl_hip_add_rows_at_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp], _i32),
     "cogdl_hip_coo2csr_index": ([_vp, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp], _i32),
+    "cogdl_hip_shard_workspace_bytes": ([_i64, _i64], _sz),
+    "cogdl_hip_shard_count": ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp], _i32),
+    "cogdl_hip_shard_fill": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64] + [_vp] * 8 + [_vp, _sz, _vp], _i32),
+    "cogdl_hip_bfs_step": ([_vp, _vp, _i64, _vp, _i32, _vp, _vp], _i32),
 }
 
 HOST_SIGNATURES = {

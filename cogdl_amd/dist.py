@@ -138,14 +138,95 @@ class ShardedCSR:
     def __init__(self, rowptr, colind_global, weight, bounds, group=None, backend=None):
         """rowptr [n_local+1] (any int dtype), colind_global [nnz] GLOBAL column ids (int64),
         weight [nnz] fp32 or None, bounds [world+1] (partition_bounds)."""
+        from . import _lib
+
         self.group = group
         self.backend = backend or HipBackend()
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         dev = colind_global.device
-        bounds = bounds.to(dev)
-        lo, hi = int(bounds[self.rank]), int(bounds[self.rank + 1])
+        bounds = bounds.to(device=dev, dtype=torch.long).contiguous()
+        if bounds.numel() != self.world + 1:
+            raise _lib.BackendError("ShardedCSR: %d partition bounds for %d ranks" % (bounds.numel(), self.world))
+        blist = bounds.tolist()
+        lo, hi = blist[self.rank], blist[self.rank + 1]
         self.n_local = hi - lo
-        assert rowptr.numel() == self.n_local + 1, "rowptr does not match this rank's row range"
+        if rowptr.numel() != self.n_local + 1:
+            raise _lib.BackendError("ShardedCSR: rowptr has %d entries, this rank owns %d rows" % (rowptr.numel(), self.n_local))
+        if weight is not None and weight.numel() != colind_global.numel():
+            raise _lib.BackendError("ShardedCSR: %d weights for %d edges" % (weight.numel(), colind_global.numel()))
+        if colind_global.is_cuda and isinstance(self.backend, HipBackend):
+            halo_ids, cut = self._split_hip(rowptr, colind_global, weight, bounds, lo, hi, blist[-1])
+        else:  # CPU tensors (gloo tests, HostBackend): the same split with torch expressions
+            halo_ids, cut = self._split_torch(rowptr, colind_global, weight, bounds, lo, hi)
+        self.n_halo = int(halo_ids.numel())
+        self.nnz_local, self.nnz_remote = int(self.colind_loc.numel()), int(self.colind_rem.numel())
+        # how many halo rows come from each owner, and which of MY rows each peer wants
+        self.recv_counts = [int(cut[q + 1] - cut[q]) for q in range(self.world)]
+        counts_t = torch.tensor(self.recv_counts, dtype=torch.long, device=dev)
+        want_t, _ = exchange_rows(counts_t.view(-1, 1), [1] * self.world, [1] * self.world, group)
+        self.send_counts = [int(v) for v in want_t.view(-1).tolist()]
+        send_ids, _ = exchange_rows(halo_ids, self.recv_counts, self.send_counts, group)
+        self.send_idx = (send_ids - lo).long()  # local row ids, grouped by requesting rank
+        # Selection matrix of the backward accumulation: row r lists the positions j of `back` (= of send_idx) that
+        # belong to local row r, in peer order (stable) -> gx += S . back is one deterministic csr_spmm_acc.
+        if self.send_idx.is_cuda and isinstance(self.backend, HipBackend):
+            from .graph_build import coo2csr_index
+
+            try:  # the stable GPU COO -> CSR of the graph-construction path; raises on an id outside [0, n_local)
+                sel_rowptr, order = coo2csr_index(self.send_idx, None, self.n_local)
+            except _lib.BackendError as e:
+                raise _lib.BackendError("ShardedCSR: a peer asked for a row this rank does not own (%s)" % e) from e
+        else:
+            if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.n_local):
+                raise _lib.BackendError("ShardedCSR: a peer asked for a row this rank does not own")
+            order = torch.sort(self.send_idx, stable=True).indices
+            sel_rowptr = _csr_from_sorted_rows(self.send_idx[order], self.n_local)
+        self.sel_rowptr = sel_rowptr.int()
+        self.sel_colind = order.int()
+        self._t_loc = self._t_rem = None
+        self._comm = None  # explicit communication stream (GPU shards), created on first use
+
+    def _split_hip(self, rowptr, colind_global, weight, bounds, lo, hi, n_global):
+        """cogdl_hip_shard_count / cogdl_hip_shard_fill (csrc/shard.hip): two passes over the edges, int32 scratch, one
+        host read of three sizes.  -> (halo_ids, cut)."""
+        from . import _lib
+
+        lib, dev = _lib.hip(), colind_global.device
+        rowptr64, col64 = rowptr.to(torch.long).contiguous(), colind_global.to(torch.long).contiguous()
+        w = None if weight is None else weight.to(torch.float32).contiguous()
+        nnz = col64.numel()
+        ws_bytes = lib.cogdl_hip_shard_workspace_bytes(self.n_local, n_global)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        counts = torch.empty(4, dtype=torch.long, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with _lib.on_device(dev):
+            rc = lib.cogdl_hip_shard_count(_lib.ptr(rowptr64), _lib.ptr(col64), self.n_local, nnz, lo, hi, n_global,
+                                           _lib.ptr(counts), _lib.ptr(ws), ws_bytes, stream)
+        _lib.check(rc, "shard_count")
+        n_loc, n_rem, n_halo, flags = counts.tolist()  # the one synchronisation of building a shard
+        if flags:
+            raise _lib.BackendError("ShardedCSR: a column id lies outside [0, %d)" % n_global)
+
+        def i32(n):
+            return torch.empty(n, dtype=torch.int32, device=dev)
+
+        self.rowptr_loc, self.rowptr_rem = i32(self.n_local + 1), i32(self.n_local + 1)
+        self.colind_loc, self.colind_rem = i32(n_loc), i32(n_rem)
+        self.w_loc = None if w is None else torch.empty(n_loc, dtype=torch.float32, device=dev)
+        self.w_rem = None if w is None else torch.empty(n_rem, dtype=torch.float32, device=dev)
+        halo_ids = torch.empty(n_halo, dtype=torch.long, device=dev)
+        cut = torch.empty(self.world + 1, dtype=torch.long, device=dev)
+        with _lib.on_device(dev):
+            rc = lib.cogdl_hip_shard_fill(_lib.ptr(rowptr64), _lib.ptr(col64), _lib.ptr(w), self.n_local, nnz, lo, hi,
+                                          n_global, _lib.ptr(bounds), self.world + 1, _lib.ptr(self.rowptr_loc),
+                                          _lib.ptr(self.colind_loc), _lib.ptr(self.w_loc), _lib.ptr(self.rowptr_rem),
+                                          _lib.ptr(self.colind_rem), _lib.ptr(self.w_rem), _lib.ptr(halo_ids), _lib.ptr(cut),
+                                          _lib.ptr(ws), ws_bytes, stream)
+        _lib.check(rc, "shard_fill")
+        return halo_ids, cut.tolist()
+
+    def _split_torch(self, rowptr, colind_global, weight, bounds, lo, hi):
+        dev = colind_global.device
         deg = (rowptr[1:] - rowptr[:-1]).long()
         rows = torch.repeat_interleave(torch.arange(self.n_local, device=dev), deg)
         col = colind_global.long()
@@ -161,24 +242,7 @@ class ShardedCSR:
         halo_ids, inv = torch.unique(c_r, return_inverse=True)  # sorted => grouped by owner
         self.rowptr_rem = _csr_from_sorted_rows(r_r, self.n_local).int()
         self.colind_rem = inv.int()
-        self.n_halo = int(halo_ids.numel())
-        self.nnz_local, self.nnz_remote = int(c_l.numel()), int(c_r.numel())
-        # how many halo rows come from each owner, and which of MY rows each peer wants
-        cut = torch.searchsorted(halo_ids, bounds)
-        self.recv_counts = [int(cut[q + 1] - cut[q]) for q in range(self.world)]
-        counts_t = torch.tensor(self.recv_counts, dtype=torch.long, device=dev)
-        want_t, _ = exchange_rows(counts_t.view(-1, 1), [1] * self.world, [1] * self.world, group)
-        self.send_counts = [int(v) for v in want_t.view(-1).tolist()]
-        send_ids, _ = exchange_rows(halo_ids, self.recv_counts, self.send_counts, group)
-        self.send_idx = (send_ids - lo).long()  # local row ids, grouped by requesting rank
-        assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_local)
-        # Selection matrix of the backward accumulation: row r lists the positions j of `back` (= of send_idx) that
-        # belong to local row r, in peer order (stable sort) -> gx += S . back is one deterministic csr_spmm_acc.
-        order = torch.sort(self.send_idx, stable=True).indices
-        self.sel_rowptr = _csr_from_sorted_rows(self.send_idx[order], self.n_local).int()
-        self.sel_colind = order.int()
-        self._t_loc = self._t_rem = None
-        self._comm = None  # explicit communication stream (GPU shards), created on first use
+        return halo_ids, torch.searchsorted(halo_ids, bounds).tolist()
 
     # transposes for the backward pass, built on first use
     def transposed(self):
@@ -244,6 +308,162 @@ class _ShardedSpMM(torch.autograd.Function):
 def sharded_spmm(sh, x_local):
     """Y_local = (A X)[my rows]; differentiable w.r.t. x_local."""
     return _ShardedSpMM.apply(x_local.contiguous(), sh)
+
+
+# ---------------------------------------------------------------------------------- partitioner
+def bfs_order(rowptr, colind, sources=None, max_levels=1 << 20):
+    """Locality reordering for a contiguous 1-D partition: the vertices in breadth-first order (level by level, ties by
+    id) from `sources` (default: vertex 0; every component that the search has not reached is then searched from its
+    smallest vertex).  GPU graphs: cogdl_hip_bfs_step per level (csrc/shard.hip), the order itself as a stable transpose
+    (cogdl_hip_csr2csc) of the vertex -> level map -- no torch sort.  -> perm (int64): perm[i] = the vertex that gets
+    the new id i.  rowptr / colind: int64 CSR of a SYMMETRIC structure (what CogDL's preprocessing produces)."""
+    from . import _lib
+    from .plan import csr2csc
+
+    dev = rowptr.device
+    if not rowptr.is_cuda:
+        raise _lib.BackendError("bfs_order: the graph must live on the GPU")
+    n = rowptr.numel() - 1
+    rp, ci = rowptr.to(torch.long).contiguous(), colind.to(torch.long).contiguous()
+    level = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    changed = torch.zeros(1, dtype=torch.int32, device=dev)
+    src = torch.zeros(1, dtype=torch.long, device=dev) if sources is None else sources.to(dev).long()
+    cur = 0
+    lib = _lib.hip()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    while n:
+        level[src] = cur
+        while True:
+            changed.zero_()
+            with _lib.on_device(dev):
+                _lib.check(lib.cogdl_hip_bfs_step(_lib.ptr(rp), _lib.ptr(ci), n, _lib.ptr(level), cur, _lib.ptr(changed), stream),
+                           "bfs_step")
+            cur += 1
+            if not int(changed.item()) or cur >= max_levels:
+                break
+        rest = torch.nonzero(level < 0)
+        if rest.numel() == 0:
+            break
+        # the remaining components: isolated vertices (the bulk of what an R-MAT generator leaves over) all at once in
+        # one last level, anything with edges from its smallest vertex
+        deg = rp[1:] - rp[:-1]
+        lonely = (level < 0) & (deg == 0)
+        if bool(lonely.any()):
+            level[lonely] = cur
+            cur += 1
+            rest = torch.nonzero(level < 0)
+            if rest.numel() == 0:
+                break
+        src = rest[0]
+    # order = vertices sorted by (level, id): the transpose of the n x n_levels matrix with one entry per vertex
+    iota = torch.arange(n + 1, dtype=torch.int32, device=dev)
+    plan = csr2csc(iota, level, cur + 1)
+    return plan.rowind.long()
+
+
+def edge_balanced_bounds(rowptr, world):
+    """Contiguous row ranges with (nearly) equal EDGE counts -- equal row counts leave a power-law graph's first shard
+    with several times the work of the last."""
+    rp = rowptr.to(torch.long)
+    n, nnz = rp.numel() - 1, int(rp[-1] - rp[0])
+    targets = (torch.arange(1, world, dtype=torch.long, device=rp.device) * nnz) // world + rp[0]
+    inner = torch.searchsorted(rp, targets).clamp(max=n)
+    b = torch.cat([torch.zeros(1, dtype=torch.long, device=rp.device), inner, torch.tensor([n], dtype=torch.long, device=rp.device)])
+    return torch.cummax(b, 0).values.cpu()
+
+
+def permute_graph(rowptr, colind, weight, perm):
+    """P A P^T: vertex perm[i] becomes vertex i (rows and columns).  GPU graphs: cogdl_hip_subgraph over ALL vertices in
+    the new order (the induced-subgraph kernel relabels to positions in the list: exactly the permutation)."""
+    from .operators.sample import subgraph_c
+
+    rp, ci, _, edges = subgraph_c(rowptr.to(torch.long), colind.to(torch.long), perm)
+    return rp, ci, (None if weight is None else weight[edges])
+
+
+def halo_rows(rowptr, colind, bounds):
+    """For every rank of the contiguous partition `bounds`: (edges to other ranks' columns, distinct such columns = rows of
+    its halo table).  GPU graphs: cogdl_hip_shard_count per rank."""
+    from . import _lib
+
+    dev = rowptr.device
+    lib = _lib.hip()
+    rp, ci = rowptr.to(torch.long).contiguous(), colind.to(torch.long).contiguous()
+    blist = [int(v) for v in bounds.tolist()]
+    n_global = blist[-1]
+    out = []
+    counts = torch.empty(4, dtype=torch.long, device=dev)
+    for p in range(len(blist) - 1):
+        lo, hi = blist[p], blist[p + 1]
+        e0, e1 = int(rp[lo]), int(rp[hi])
+        ws_bytes = lib.cogdl_hip_shard_workspace_bytes(hi - lo, n_global)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with _lib.on_device(dev):
+            rc = lib.cogdl_hip_shard_count(_lib.ptr(rp[lo:hi + 1]), _lib.ptr(ci[e0:e1]), hi - lo, e1 - e0, lo, hi, n_global,
+                                           _lib.ptr(counts), _lib.ptr(ws), ws_bytes, torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "shard_count")
+        c = counts.tolist()
+        out.append((c[1], c[2]))
+    return out
+
+
+class Partition:
+    """What partition() returns: the reordered graph, the permutation and what the reordering bought."""
+
+    def __init__(self, rowptr, colind, weight, perm, bounds, halo_before, halo_after):
+        self.rowptr, self.colind, self.weight, self.perm, self.bounds = rowptr, colind, weight, perm, bounds
+        self.inverse = torch.empty_like(perm)
+        self.inverse[perm] = torch.arange(perm.numel(), device=perm.device)
+        self.halo_before, self.halo_after = halo_before, halo_after  # per rank: (remote edges, halo rows)
+
+    def halo_fraction(self, which="after"):
+        """Halo rows of the worst rank as a fraction of its own rows."""
+        h = self.halo_after if which == "after" else self.halo_before
+        rows = [int(self.bounds[p + 1] - self.bounds[p]) for p in range(len(h))]
+        return max(hr / max(r, 1) for (_, hr), r in zip(h, rows))
+
+    def shard(self, rank):
+        """(rowptr, colind_global, weight) of rank's rows of the REORDERED graph: what ShardedCSR takes."""
+        lo, hi = int(self.bounds[rank]), int(self.bounds[rank + 1])
+        e0, e1 = int(self.rowptr[lo]), int(self.rowptr[hi])
+        return (self.rowptr[lo:hi + 1] - self.rowptr[lo], self.colind[e0:e1],
+                None if self.weight is None else self.weight[e0:e1])
+
+
+def partition(rowptr, colind, world, weight=None, order="bfs", balance="edges"):
+    """A 1-D vertex partition of a real (GPU-resident, symmetric) CSR graph for ShardedCSR: relabel for locality
+    (`order`: "bfs" | "degree" (hubs first) | "none"), cut the new id range into `world` contiguous ranges (`balance`:
+    "edges" | "rows"), and measure the halo of every rank before and after.  The analogue in the reference is the
+    METIS partition of ClusteredDataset (cogdl/data/sampler.py:188-243), host-side and for sampling; here every step is
+    a HIP kernel (bfs_step, csr2csc for the order, subgraph for the permutation, shard_count for the halos).
+    x / y of the vertices follow with x[part.perm]; results come back with out[part.inverse]."""
+    n = rowptr.numel() - 1
+    dev = rowptr.device
+    rp, ci = rowptr.to(torch.long), colind.to(torch.long)
+
+    def cut(r):
+        return edge_balanced_bounds(r, world) if balance == "edges" else partition_bounds(n, world)
+
+    before = halo_rows(rp, ci, cut(rp))
+    if order == "bfs":
+        perm = bfs_order(rp, ci)
+    elif order == "degree":
+        from .plan import csr2csc
+
+        deg = (rp[1:] - rp[:-1])
+        key = (int(deg.max()) - deg).int()  # hubs first, ties by id: the stable transpose of vertex -> (max - degree)
+        perm = csr2csc(torch.arange(n + 1, dtype=torch.int32, device=dev), key, int(deg.max()) + 1).rowind.long()
+    elif order == "none":
+        perm = torch.arange(n, device=dev)
+    else:
+        raise ValueError("partition: order must be 'bfs', 'degree' or 'none'")
+    if order == "none":
+        rp2, ci2, w2 = rp, ci, weight
+    else:
+        rp2, ci2, w2 = permute_graph(rp, ci, weight, perm)
+    bounds = cut(rp2)
+    after = halo_rows(rp2, ci2, bounds)
+    return Partition(rp2, ci2, w2, perm, bounds, before, after)
 
 
 # ------------------------------------------------------------------------------- bench (N > 1)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define COGDL_HIP_ABI_VERSION 3
+#define COGDL_HIP_ABI_VERSION 4
 
 /* Exported with default visibility (the library is built -fvisibility=hidden). */
 #if defined(COGDL_HIP_BUILD)
@@ -430,6 +430,38 @@ COGDL_API int cogdl_hip_linear_wgrad_f32(const float *x, const float *grad_out, 
  * the caller then keeps its BLAS call.  x 16-byte aligned. */
 COGDL_API int cogdl_hip_linear_fwd_f32(const float *x, const float *w, const float *bias, float *out, int64_t rows,
                              int64_t k_dim, int64_t n_dim, int w_is_n_by_k, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Vertex-sharded graphs (BASELINE.json configs[4]; no reference counterpart -- CogDL only partitions on the host, with
+ * METIS, for ClusterGCN: cogdl/data/sampler.py:188-243).  csrc/shard.hip.
+ * shard_count / shard_fill: one rank's shard of a 1-D row-partitioned CSR matrix.  The rank owns the rows [lo, hi) =
+ *   n_local rows, `rowptr` [n_local + 1] (int64; it may start at any offset: rowptr[0] is subtracted), `col` [nnz]
+ *   GLOBAL column ids in [0, n_global), `weight` [nnz] fp32 or NULL.
+ *   count: counts[4] (DEVICE int64) = {edges with a column inside [lo, hi), edges outside, distinct outside columns
+ *          (= halo rows), flags (bit 0: a column id outside [0, n_global))}.  The caller reads them (the one
+ *          synchronisation of building a shard) and allocates the outputs of
+ *   fill : rowptr_loc / rowptr_rem [n_local + 1] int32, colind_loc [counts[0]] = col - lo, colind_rem [counts[1]] =
+ *          index into the halo table, w_loc / w_rem (NULL iff weight is NULL), halo_ids [counts[2]] = the distinct
+ *          outside columns ascending (int64), cut [n_bounds] (int64) = halo ids below bounds[q] -- with
+ *          bounds = the partition's row ranges that is where every owner's part of the halo table starts.
+ *   A row's edges keep their CSR order inside both blocks.  The same workspace (cogdl_hip_shard_workspace_bytes) must
+ *   be passed to both calls, untouched in between.  n_global < 2^31 - 1, nnz < 2^31.
+ * bfs_step: one level of a breadth-first search over a CSR graph (int64 rowptr / col, n vertices): every vertex with
+ *   level[v] == cur gives its unvisited (level < 0) neighbours the level cur + 1; *changed (device int, zeroed by the
+ *   caller) is set when it did.  The caller loops over the levels (cogdl_amd/dist.py: bfs_order, the locality
+ *   reordering in front of a contiguous partition).
+ * ------------------------------------------------------------------------------------- */
+COGDL_API size_t cogdl_hip_shard_workspace_bytes(int64_t n_local, int64_t n_global);
+COGDL_API int cogdl_hip_shard_count(const int64_t *rowptr, const int64_t *col, int64_t n_local, int64_t nnz, int64_t lo,
+                          int64_t hi, int64_t n_global, int64_t *counts, void *workspace, size_t workspace_bytes,
+                          void *stream);
+COGDL_API int cogdl_hip_shard_fill(const int64_t *rowptr, const int64_t *col, const float *weight, int64_t n_local,
+                         int64_t nnz, int64_t lo, int64_t hi, int64_t n_global, const int64_t *bounds, int64_t n_bounds,
+                         int32_t *rowptr_loc, int32_t *colind_loc, float *w_loc, int32_t *rowptr_rem,
+                         int32_t *colind_rem, float *w_rem, int64_t *halo_ids, int64_t *cut, void *workspace,
+                         size_t workspace_bytes, void *stream);
+COGDL_API int cogdl_hip_bfs_step(const int64_t *rowptr, const int64_t *col, int64_t n, int32_t *level, int32_t cur,
+                       int *changed, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,169 @@
+"""The GPU partitioner of cogdl_amd/dist.py (round-2 verdict, "missing" item 2): breadth-first locality reordering +
+contiguous cut + measured halos, and the HIP construction of a shard (csrc/shard.hip) against the torch expressions it
+replaces.  The reference's analogue is the host-side METIS partition of ClusteredDataset
+(cogdl/data/sampler.py:188-243); there is nothing to compare numbers with, so the checks are: the shard split equals the
+torch split array for array; a permuted graph is the same operator (P A P^T); a graph WITH locality hidden behind a random
+relabelling gets its small halos back; sharded == unsharded through partition() with two ranks on the one GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from cogdl_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _hidden_band_graph(n, half_width, n_long, seed):
+    """A ring lattice (every vertex linked to its +-1..+-half_width neighbours) plus a few long random links, symmetric,
+    with self loops -- then relabelled by a random permutation, which hides the locality from a contiguous cut."""
+    gen = torch.Generator().manual_seed(seed)
+    base = torch.arange(n)
+    src = torch.cat([base.repeat(half_width), torch.randint(0, n, (n_long,), generator=gen)])
+    dst = torch.cat([torch.cat([(base + d) % n for d in range(1, half_width + 1)]), torch.randint(0, n, (n_long,), generator=gen)])
+    shuffle = torch.randperm(n, generator=gen)
+    g = synth.finalize(shuffle[src], shuffle[dst], n, norm="row")
+    return g
+
+
+def _split(obj_backend, rowptr, cols, w, bounds, rank):
+    from cogdl_amd.dist import HipBackend, ShardedCSR
+
+    sh = object.__new__(ShardedCSR)
+    sh.backend, sh.world, sh.rank = HipBackend(), bounds.numel() - 1, rank
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    sh.n_local = hi - lo
+    fn = sh._split_hip if obj_backend == "hip" else sh._split_torch
+    if obj_backend == "hip":
+        halo, cut = fn(rowptr, cols, w, bounds.to(DEV), lo, hi, int(bounds[-1]))
+    else:
+        halo, cut = fn(rowptr, cols, w, bounds.to(DEV), lo, hi)
+    return sh, halo, cut
+
+
+@pytest.mark.parametrize("world,weighted", [(2, True), (3, False), (8, True)])
+def test_hip_shard_split_equals_torch_split(world, weighted):
+    from cogdl_amd.dist import partition_bounds
+
+    g = synth.scaled(30000, 11, seed=world, topology="rmat")  # hub rows of thousands of edges: many 64-edge chunks per row
+    n = g.num_nodes
+    bounds = partition_bounds(n, world)
+    rp, ci = g.rowptr.long().to(DEV), g.colind.long().to(DEV)
+    w = g.weight.to(DEV) if weighted else None
+    for rank in range(world):
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        e0, e1 = int(rp[lo]), int(rp[hi])
+        args = (rp[lo:hi + 1] - rp[lo], ci[e0:e1], None if w is None else w[e0:e1], bounds, rank)
+        a, halo_a, cut_a = _split("hip", *args)
+        b, halo_b, cut_b = _split("torch", *args)
+        assert torch.equal(halo_a, halo_b) and list(cut_a) == list(cut_b)
+        for name in ("rowptr_loc", "colind_loc", "rowptr_rem", "colind_rem", "w_loc", "w_rem"):
+            x, y = getattr(a, name), getattr(b, name)
+            assert (x is None and y is None) or torch.equal(x, y), name
+        assert a.colind_rem.numel() == 0 or int(a.colind_rem.max()) < halo_a.numel()
+
+
+def test_shard_split_reports_a_column_outside_the_graph():
+    from cogdl_amd._lib import BackendError
+    from cogdl_amd.dist import partition_bounds
+
+    g = synth.scaled(2000, 5, seed=1)
+    rp, ci = g.rowptr.long().to(DEV), g.colind.long().to(DEV).clone()
+    ci[17] = 2000  # one past the last vertex
+    with pytest.raises(BackendError):
+        _split("hip", rp, ci, None, partition_bounds(2000, 1), 0)
+
+
+def test_bfs_partition_recovers_hidden_locality_and_is_the_same_operator(oracle):
+    from cogdl_amd.dist import partition
+    from cogdl_amd.operators.spmm import csr_spmm_raw
+
+    n, world = 60000, 4
+    g = _hidden_band_graph(n, 8, 30, seed=3)
+    rp, ci, w = g.rowptr.long().to(DEV), g.colind.long().to(DEV), g.weight.to(DEV)
+    part = partition(rp, ci, world, weight=w, order="bfs")
+    assert torch.equal(torch.sort(part.perm).values, torch.arange(n, device=DEV))  # a permutation
+    assert int(part.bounds[0]) == 0 and int(part.bounds[-1]) == n and bool((part.bounds[1:] >= part.bounds[:-1]).all())
+    before = max(h for _, h in part.halo_before)
+    after = max(h for _, h in part.halo_after)
+    # behind the random relabelling every rank needs nearly all other vertices; in breadth-first order a rank's halo is
+    # a few bands of the ring plus the long links
+    assert before > 0.5 * n * (world - 1) / world and after < 0.1 * before, (part.halo_before, part.halo_after)
+    # P A P^T x' with x' = x[perm] is (A x)[perm]
+    x = torch.randn(n, 16, device=DEV, generator=torch.Generator(device=DEV).manual_seed(0))
+    y = csr_spmm_raw(g.rowptr.to(DEV), g.colind.to(DEV), w, x)
+    y2 = csr_spmm_raw(part.rowptr.int(), part.colind.int(), part.weight, x[part.perm])
+    np.testing.assert_allclose(y2.cpu().numpy(), y[part.perm].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(part.inverse[part.perm], torch.arange(n, device=DEV))
+
+
+@pytest.mark.parametrize("order", ["degree", "none"])
+def test_partition_orders_on_a_power_law_graph_are_valid_and_edge_balanced(order):
+    from cogdl_amd.dist import partition
+
+    g = synth.scaled(80000, 14, seed=9, topology="rmat", norm=None)
+    rp, ci = g.rowptr.long().to(DEV), g.colind.long().to(DEV)
+    world = 8
+    part = partition(rp, ci, world, order=order)
+    nnz = int(part.rowptr[-1])
+    per_rank = [int(part.rowptr[int(part.bounds[p + 1])] - part.rowptr[int(part.bounds[p])]) for p in range(world)]
+    longest_row = int((part.rowptr[1:] - part.rowptr[:-1]).max())
+    assert sum(per_rank) == nnz and max(per_rank) <= nnz // world + longest_row + 1  # the cut balances EDGES
+    if order == "degree":
+        deg = (part.rowptr[1:] - part.rowptr[:-1])
+        assert bool((deg[1:] <= deg[:-1]).all())  # hubs first
+
+
+def _partition_worker(rank, world, port, n, out_dir):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # two ranks share the one GPU: gloo, not RCCL
+    try:
+        from cogdl_amd.dist import ShardedCSR, partition, sharded_spmm
+        from test_partition_gpu import _hidden_band_graph
+
+        torch.cuda.set_device(0)
+        g = _hidden_band_graph(n, 6, 300, seed=5)  # the same global graph on every rank; every rank partitions it itself
+        part = partition(g.rowptr.long().to(DEV), g.colind.long().to(DEV), world, weight=g.weight.to(DEV), order="bfs")
+        rowptr, cols, w = part.shard(rank)
+        sh = ShardedCSR(rowptr, cols, w, part.bounds)
+        x = torch.randn(n, 24, generator=torch.Generator().manual_seed(5)).to(DEV)
+        gout = torch.randn(n, 24, generator=torch.Generator().manual_seed(6)).to(DEV)
+        lo, hi = int(part.bounds[rank]), int(part.bounds[rank + 1])
+        xl = x[part.perm][lo:hi].clone().requires_grad_()
+        y = sharded_spmm(sh, xl)
+        y.backward(gout[part.perm][lo:hi])
+        np.savez(os.path.join(out_dir, "p%d.npz" % rank), y=y.detach().cpu().numpy(), gx=xl.grad.cpu().numpy(),
+                 ids=part.perm[lo:hi].cpu().numpy(), n_halo=sh.n_halo)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_equals_unsharded_through_the_partitioner(tmp_path, oracle):
+    """Two ranks on the one GPU: each partitions the global graph (deterministic: both get the same answer), takes its
+    shard of the REORDERED graph, runs the sharded SpMM forward + backward on the permuted operands; mapped back through
+    the permutation the results equal the unsharded oracle on the original graph."""
+    import torch.multiprocessing as mp
+
+    n, world = 20000, 2
+    mp.spawn(_partition_worker, args=(world, 29693, n, str(tmp_path)), nprocs=world, join=True)
+    g = _hidden_band_graph(n, 6, 300, seed=5)
+    x = torch.randn(n, 24, generator=torch.Generator().manual_seed(5))
+    gout = torch.randn(n, 24, generator=torch.Generator().manual_seed(6))
+    want_y = oracle.csr_spmm_f64(g.rowptr, g.colind, g.weight, x)
+    colptr, rowind, w_t, _ = oracle.csr2csc(g.rowptr, g.colind, g.weight, n_cols=n)
+    want_gx = oracle.csr_spmm_f64(colptr, rowind, w_t, gout)
+    seen = 0
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "p%d.npz" % r))
+        np.testing.assert_allclose(z["y"], want_y[z["ids"]], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(z["gx"], want_gx[z["ids"]], rtol=1e-5, atol=1e-5)
+        assert int(z["n_halo"]) > 0
+        seen += len(z["ids"])
+    assert seen == n
