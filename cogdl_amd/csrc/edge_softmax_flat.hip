@@ -41,7 +41,13 @@ constexpr int kRowChunk = 512;    // rowptr entries staged in LDS per pass over 
 constexpr int kKMax = 512;        // longest row (in tiles) that uses the in-launch exchange
 constexpr unsigned kSpinLimit = 1u << 12;
 
-template <bool BWD> struct TileSize { static constexpr int value = BWD ? 4096 : 8192; };  // elements (32 KB of LDS)
+// Elements per tile: 32 KB of LDS and 32 KB (forward: read) / 2 x 16 KB (backward) of loads in flight per workgroup
+// whatever the element size.  Round 3: 16-bit values are staged in LDS and held in registers in their OWN type
+// (rounds 1-2: widened to fp32, hence 8192-element tiles for every type: a bf16 tile moved half the bytes of an fp32
+// one at the same fixed per-tile cost -- publish, poll, merge -- and ran no faster, 1.66 vs 1.78 ms on the Reddit-shaped
+// graph); what makes that possible is that nothing is stored back between the statistics and the result any more: the
+// forward output is exp(v - max_row) / sum_row computed from the RAW value at the end, not p * exp(max_piece - max_row).
+template <bool BWD, int ELEM_BYTES = 4> struct TileSize { static constexpr int value = (BWD ? 16384 : 32768) / ELEM_BYTES; };
 
 __device__ __forceinline__ float es_exp(float x) { return __expf(x); }
 
@@ -132,26 +138,26 @@ __device__ __forceinline__ float wg_head_reduce(float v, int h, float *red) {
     return r;
 }
 
+// LDS staging type: fp32 values as float, 16-bit values as themselves.
+template <typename S> __device__ __forceinline__ float lds_ld(const S *p, int i) { return to_f32<S>(p[i]); }
+template <typename S> __device__ __forceinline__ void lds_st(S *p, int i, float v) { p[i] = from_f32<S>(v); }
+
 // Statistics of the LDS span [off, off + cnt) (one row piece; off and cnt multiples of h): thread t walks the
-// elements t, t + 256, ... (head t % h, bank-conflict free).  Forward: the values are replaced by exp(v - max) and
-// (max, sum) is returned; backward: <a, g> is returned in .x.  All threads return the value of head t % h.
-template <bool BWD>
-__device__ __forceinline__ float2 wg_piece_lds(float *tile, const float *tile_g, int off, int cnt, int h, float *red) {
+// elements t, t + 256, ... (head t % h).  Forward: (max, sum of exp(v - max)); backward: <a, g> in .x.  The span is NOT
+// modified.  All threads return the value of head t % h.
+template <bool BWD, typename S>
+__device__ __forceinline__ float2 wg_piece_lds(const S *tile, const S *tile_g, int off, int cnt, int h, float *red) {
     const int t = threadIdx.x;
     if constexpr (BWD) {
         float dot = 0.f;
-        for (int i = t; i < cnt; i += kThreads) dot = fmaf(tile[off + i], tile_g[off + i], dot);
+        for (int i = t; i < cnt; i += kThreads) dot = fmaf(lds_ld(tile, off + i), lds_ld(tile_g, off + i), dot);
         return make_float2(wg_head_reduce<false>(dot, h, red), 0.f);
     } else {
         float mx = -INFINITY;
-        for (int i = t; i < cnt; i += kThreads) mx = fmaxf(mx, tile[off + i]);
+        for (int i = t; i < cnt; i += kThreads) mx = fmaxf(mx, lds_ld(tile, off + i));
         mx = wg_head_reduce<true>(mx, h, red);
         float sum = 0.f;
-        for (int i = t; i < cnt; i += kThreads) {
-            const float p = es_exp(tile[off + i] - mx);
-            tile[off + i] = p;
-            sum += p;
-        }
+        for (int i = t; i < cnt; i += kThreads) sum += es_exp(lds_ld(tile, off + i) - mx);
         return make_float2(mx, wg_head_reduce<false>(sum, h, red));
     }
 }
@@ -286,48 +292,65 @@ __device__ __forceinline__ bool row_totals(const Params &p, int64_t start, int64
 // ---- one complete row in LDS, reduced by an aligned group of `lpr` lanes (a power of two, a multiple of h: lane l sees
 // head l % h).  The group size is a run-time value: one copy of this code serves every row length (seven unrolled
 // instantiations had grown the forward kernel to ~80 KB of instructions, beyond the instruction cache).
-template <bool BWD>
-__device__ __forceinline__ void row_in_lds(float *tile, const float *tile_g, int base, int cnt, int l, int lpr, int h) {
+template <bool BWD, typename S>
+__device__ __forceinline__ void row_in_lds(S *tile, const S *tile_g, int base, int cnt, int l, int lpr, int h) {
     if constexpr (BWD) {
         float dot = 0.f;
-        for (int j = l; j < cnt; j += lpr) dot = fmaf(tile[base + j], tile_g[base + j], dot);
+        for (int j = l; j < cnt; j += lpr) dot = fmaf(lds_ld(tile, base + j), lds_ld(tile_g, base + j), dot);
         for (int s = lpr >> 1; s >= h; s >>= 1) dot += __shfl_xor(dot, s, kWave);
-        for (int j = l; j < cnt; j += lpr) tile[base + j] = tile[base + j] * (tile_g[base + j] - dot);
+        for (int j = l; j < cnt; j += lpr) lds_st(tile, base + j, lds_ld(tile, base + j) * (lds_ld(tile_g, base + j) - dot));
     } else {
         float mx = -INFINITY;
-        for (int j = l; j < cnt; j += lpr) mx = fmaxf(mx, tile[base + j]);
+        for (int j = l; j < cnt; j += lpr) mx = fmaxf(mx, lds_ld(tile, base + j));
         for (int s = lpr >> 1; s >= h; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s, kWave));
         float sum = 0.f;
-        for (int j = l; j < cnt; j += lpr) {
-            const float pe = es_exp(tile[base + j] - mx);
-            tile[base + j] = pe;
-            sum += pe;
-        }
+        for (int j = l; j < cnt; j += lpr) sum += es_exp(lds_ld(tile, base + j) - mx);
         for (int s = lpr >> 1; s >= h; s >>= 1) sum += __shfl_xor(sum, s, kWave);
         const float inv = 1.f / sum;
-        for (int j = l; j < cnt; j += lpr) tile[base + j] *= inv;
+        // the FINAL value replaces the raw one (rounded to the output type here, once): the store step copies it
+        for (int j = l; j < cnt; j += lpr) lds_st(tile, base + j, es_exp(lds_ld(tile, base + j) - mx) * inv);
     }
 }
 
 // Rows of at most `lthr` edges: one lane group per row.  rp = LDS copy of rowptr[r0 .. r0 + nrows].
-template <bool BWD>
-__device__ __forceinline__ void rows_small(float *tile, const float *tile_g, const int32_t *rp, int nrows, int64_t e0,
+template <bool BWD, typename S>
+__device__ __forceinline__ void rows_small(S *tile, const S *tile_g, const int32_t *rp, int nrows, int64_t e0,
                                            int h, int lpr, int lthr) {
     const int ng = kThreads / lpr;
     const int grp = threadIdx.x / lpr, l = threadIdx.x & (lpr - 1);
     for (int i = grp; i < nrows; i += ng) {
         const int len = rp[i + 1] - rp[i];
         if (len == 0 || len > lthr) continue;  // (group-uniform)
-        row_in_lds<BWD>(tile, tile_g, (int)(rp[i] - e0) * h, len * h, l, lpr, h);
+        row_in_lds<BWD, S>(tile, tile_g, (int)(rp[i] - e0) * h, len * h, l, lpr, h);
     }
 }
 
 // ---- 16-byte global vector <-> V floats ------------------------------------------------------------------------
 template <typename T> struct VecOf { static constexpr int V = 16 / sizeof(T); };
 
+// A thread's piece of a tile stays in registers as RAW 16-byte vectors (V elements of T each) and is unpacked where it
+// is used: a 16 k-element bf16 tile costs the 32 VGPRs per array an 8 k-element fp32 tile does.
 template <typename T>
-__device__ __forceinline__ void load16(const T *p, float (&v)[VecOf<T>::V]) {
-    load_vec<T, VecOf<T>::V>(p, v);
+__device__ __forceinline__ void unpack16(const uint4 &q, float (&v)[VecOf<T>::V]) {
+    union { uint4 raw; T e[VecOf<T>::V]; } u;
+    u.raw = q;
+#pragma unroll
+    for (int i = 0; i < VecOf<T>::V; ++i) v[i] = to_f32<T>(u.e[i]);
+}
+template <typename T>
+__device__ __forceinline__ uint4 pack16(const float (&v)[VecOf<T>::V]) {
+    union { uint4 raw; T e[VecOf<T>::V]; } u;
+#pragma unroll
+    for (int i = 0; i < VecOf<T>::V; ++i) u.e[i] = from_f32<T>(v[i]);
+    return u.raw;
+}
+// the last (partial) tile: element-wise guarded, masked elements 0
+template <typename T>
+__device__ __forceinline__ uint4 load16_guarded(const T *p, int i0, int count) {
+    union { uint4 raw; T e[VecOf<T>::V]; } u;
+#pragma unroll
+    for (int k = 0; k < VecOf<T>::V; ++k) u.e[k] = (i0 + k < count) ? p[i0 + k] : from_f32<T>(0.f);
+    return u.raw;
 }
 
 // Reduction of V per-thread slot values over the workgroup, slot k of thread t belonging to head (t*V + k) % h
@@ -369,20 +392,22 @@ __device__ __forceinline__ void wg_slot_reduce(float (&x)[V], int h, float *red)
 // =====================================================================================================================
 // main kernel: one tile per workgroup
 template <typename T, bool BWD>
-__global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
-    constexpr int TILE = TileSize<BWD>::value;
+__global__ __launch_bounds__(kThreads, 4) void es_flat_kernel(const Params p) {  // (4 waves per SIMD = 4 workgroups per CU: <= 128 VGPRs, <= 40 KB LDS)
+    constexpr int TILE = TileSize<BWD, (int)sizeof(T)>::value;
     constexpr int V = VecOf<T>::V;
-    constexpr int NV = TILE / (kThreads * V);  // 16-byte vectors per thread (per array)
-    constexpr int kMaxLong = 256;
-    __shared__ __attribute__((aligned(16))) float tile[TILE];
-    __shared__ __attribute__((aligned(16))) float tile_gs[BWD ? TILE : 4];
+    constexpr int NV = TILE / (kThreads * V);  // 16-byte vectors per thread (per array): 8 forward, 4 + 4 backward
+    constexpr int kMaxLong = 512;
+    using S = T;                               // LDS staging type = the value type (fp32 as float, 16-bit as itself)
+    __shared__ __attribute__((aligned(16))) S tile[TILE];
+    __shared__ __attribute__((aligned(16))) S tile_gs[BWD ? TILE : 16 / sizeof(S)];
     __shared__ int32_t rp[kRowChunk + 1];
     __shared__ float red[4 * kWave];
     __shared__ float2 mrg[kThreads];
     __shared__ float2 pstat[kWave];   // piece statistics per head (register path)
-    __shared__ float fac[2][kWave];   // per partial piece (head, tail) and head id: what the store step applies
-    __shared__ float facm[2][kWave];  // forward, short straddling rows: the row maximum
-    __shared__ int s_nlong, s_long[kMaxLong];
+    __shared__ float fac[2][kWave];   // per partial piece (head, tail) and head id: forward 1 / sum_row, backward dot_row
+    __shared__ float facm[2][kWave];  // forward: the row maximum
+    __shared__ int s_nlong;
+    __shared__ uint16_t s_long[kMaxLong];  // (indices into rp: < kRowChunk)
     const int t = threadIdx.x;
     const T *__restrict__ a = (const T *)p.a;
     const T *__restrict__ g = (const T *)p.g;
@@ -395,24 +420,21 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
     const bool full = count == TILE;
 
     // ---- 1. the tile's values, 16 bytes per lane per load, all loads in flight before anything waits ------------
-    float va[NV][V];
-    float vg[BWD ? NV : 1][V];
+    uint4 ra[NV];
+    uint4 rg[BWD ? NV : 1];
     if (full) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) load16<T>(a + b0 + (int64_t)(j * kThreads + t) * V, va[j]);
+        for (int j = 0; j < NV; ++j) ra[j] = *reinterpret_cast<const uint4 *>(a + b0 + (int64_t)(j * kThreads + t) * V);
         if constexpr (BWD) {
 #pragma unroll
-            for (int j = 0; j < NV; ++j) load16<T>(g + b0 + (int64_t)(j * kThreads + t) * V, vg[j]);
+            for (int j = 0; j < NV; ++j) rg[j] = *reinterpret_cast<const uint4 *>(g + b0 + (int64_t)(j * kThreads + t) * V);
         }
     } else {  // the last tile: element-wise guarded (masked elements: 0)
 #pragma unroll
-        for (int j = 0; j < NV; ++j)
-#pragma unroll
-            for (int k = 0; k < V; ++k) {
-                const int i = (j * kThreads + t) * V + k;
-                va[j][k] = i < count ? to_f32<T>(a[b0 + i]) : 0.f;
-                if constexpr (BWD) vg[j][k] = i < count ? to_f32<T>(g[b0 + i]) : 0.f;
-            }
+        for (int j = 0; j < NV; ++j) {
+            ra[j] = load16_guarded<T>(a + b0, (j * kThreads + t) * V, count);
+            if constexpr (BWD) rg[j] = load16_guarded<T>(g + b0, (j * kThreads + t) * V, count);
+        }
     }
     // ---- 2. the rows of the tile (precomputed by the init kernel) ----------------------------------------------
     const TileInfo ti = p.tinfo[c];
@@ -428,33 +450,46 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
 #pragma unroll
             for (int k = 0; k < V; ++k) x[k] = 0.f;
 #pragma unroll
-            for (int j = 0; j < NV; ++j)
+            for (int j = 0; j < NV; ++j) {
+                float va[V], vg[V];
+                unpack16<T>(ra[j], va);
+                unpack16<T>(rg[j], vg);
 #pragma unroll
-                for (int k = 0; k < V; ++k) x[k] = fmaf(va[j][k], vg[j][k], x[k]);  // masked elements are 0 * 0
+                for (int k = 0; k < V; ++k) x[k] = fmaf(va[k], vg[k], x[k]);  // masked elements are 0 * 0
+            }
             wg_slot_reduce<V, false>(x, h, red);  // x[k] = <a, g> of head (t*V + k) % h over the tile
+            if (t * V < h || (h < V && t == 0)) {
+#pragma unroll
+                for (int k = 0; k < V; ++k)
+                    if (t * V + k < h) pstat[t * V + k] = make_float2(x[k], 0.f);
+            }
         } else {
             float mxs[V];
 #pragma unroll
             for (int k = 0; k < V; ++k) mxs[k] = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < NV; ++j)
+            for (int j = 0; j < NV; ++j) {
+                float va[V];
+                unpack16<T>(ra[j], va);
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
                     const bool valid = full || ((j * kThreads + t) * V + k) < count;
-                    mxs[k] = fmaxf(mxs[k], valid ? va[j][k] : -INFINITY);
+                    mxs[k] = fmaxf(mxs[k], valid ? va[k] : -INFINITY);
                 }
+            }
             wg_slot_reduce<V, true>(mxs, h, red);
 #pragma unroll
             for (int k = 0; k < V; ++k) x[k] = 0.f;
 #pragma unroll
-            for (int j = 0; j < NV; ++j)
+            for (int j = 0; j < NV; ++j) {
+                float va[V];
+                unpack16<T>(ra[j], va);
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
                     const bool valid = full || ((j * kThreads + t) * V + k) < count;
-                    const float pe = valid ? es_exp(va[j][k] - mxs[k]) : 0.f;
-                    va[j][k] = pe;
-                    x[k] += pe;
+                    x[k] += valid ? es_exp(va[k] - mxs[k]) : 0.f;
                 }
+            }
             wg_slot_reduce<V, false>(x, h, red);  // x[k] = sum of exp(v - max) of its head
             // hand (max, sum) per head to the threads that publish / finish: slot k of thread t is head (t*V+k) % h
             if (t * V < h || (h < V && t == 0)) {
@@ -463,33 +498,38 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
                     if (t * V + k < h) pstat[t * V + k] = make_float2(mxs[k], x[k]);
             }
         }
-        if constexpr (BWD) {
-            if (t * V < h || (h < V && t == 0)) {
-#pragma unroll
-                for (int k = 0; k < V; ++k)
-                    if (t * V + k < h) pstat[t * V + k] = make_float2(x[k], 0.f);
-            }
-        }
         __syncthreads();
         if (t < h) piece = pstat[t];
+        float2 tot = piece;
         if (partial) {
             if (he - hs <= p.long_edges) publish<BWD>(p, c, 0, piece);  // super-long rows: published by the init kernel
-            float2 tot;
             if (!row_totals<BWD>(p, hs, he, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
-            if (t < h) fac[0][t] = BWD ? tot.x : es_exp(piece.x - tot.x) / tot.y;
-        } else {
-            if (t < h) fac[0][t] = BWD ? piece.x : 1.f / piece.y;
+        }
+        if (t < h) {
+            fac[0][t] = BWD ? tot.x : 1.f / tot.y;
+            facm[0][t] = tot.x;
         }
         __syncthreads();
-        float f[V];
+        float f[V], fm[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) f[k] = fac[0][(t * V + k) & (h - 1)];
+        for (int k = 0; k < V; ++k) {
+            f[k] = fac[0][(t * V + k) & (h - 1)];
+            fm[k] = facm[0][(t * V + k) & (h - 1)];
+        }
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i0 = (j * kThreads + t) * V;
-            float o[V];
+            float va[V], o[V];
+            unpack16<T>(ra[j], va);
+            if constexpr (BWD) {
+                float vg[V];
+                unpack16<T>(rg[j], vg);
 #pragma unroll
-            for (int k = 0; k < V; ++k) o[k] = BWD ? va[j][k] * (vg[j][k] - f[k]) : va[j][k] * f[k];
+                for (int k = 0; k < V; ++k) o[k] = va[k] * (vg[k] - f[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < V; ++k) o[k] = es_exp(va[k] - fm[k]) * f[k];
+            }
             if (full) {
                 store_vec<T, V>(out + b0 + i0, o);
             } else {
@@ -501,19 +541,14 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
         return;
     }
 
-    // ================= several rows in the tile: LDS resident =====================================================
+    // ================= several rows in the tile: LDS resident (raw values, in their own type) ====================
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int k = 0; k < V; k += 4) {
-            *reinterpret_cast<float4 *>(tile + (j * kThreads + t) * V + k) =
-                make_float4(va[j][k], va[j][k + 1], va[j][k + 2], va[j][k + 3]);
-            if constexpr (BWD)
-                *reinterpret_cast<float4 *>(tile_gs + (j * kThreads + t) * V + k) =
-                    make_float4(vg[j][k], vg[j][k + 1], vg[j][k + 2], vg[j][k + 3]);
-        }
+    for (int j = 0; j < NV; ++j) {
+        reinterpret_cast<uint4 *>(tile)[j * kThreads + t] = ra[j];
+        if constexpr (BWD) reinterpret_cast<uint4 *>(tile_gs)[j * kThreads + t] = rg[j];
+    }
     __syncthreads();
-    const float *tile_g = tile_gs;
+    const S *tile_g = tile_gs;
 
     // ---- partial pieces: the row of the first edge if it began before the tile, of the last edge if it goes on ----
     const bool head_partial = hs < e0;
@@ -528,26 +563,18 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
     const int64_t halo_max = p.tile_e / 4;
     const bool head_halo = head_partial && (he - hs) <= halo_max;
     const bool tail_halo = tail_partial && (te - ts) <= halo_max;
-    float2 head_piece = make_float2(0.f, 0.f), tail_piece = make_float2(0.f, 0.f);
+    float2 head_tot = make_float2(0.f, 1.f), tail_tot = make_float2(0.f, 1.f);
     if (head_halo) {
-        const float2 tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
-        if (t < h) {
-            fac[0][t] = BWD ? tot.x : 1.f / tot.y;
-            facm[0][t] = tot.x;
-        }
+        head_tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
     } else if (head_partial) {
-        head_piece = wg_piece_lds<BWD>(tile, tile_g, 0, head_end, h, red);
-        if (he - hs <= p.long_edges) publish<BWD>(p, c, 0, head_piece);
+        const float2 piece = wg_piece_lds<BWD, S>(tile, tile_g, 0, head_end, h, red);
+        if (he - hs <= p.long_edges) publish<BWD>(p, c, 0, piece);
     }
     if (tail_halo) {
-        const float2 tot = wg_piece_global<T, BWD>(a, g, ts * h, te * h, h, red);
-        if (t < h) {
-            fac[1][t] = BWD ? tot.x : 1.f / tot.y;
-            facm[1][t] = tot.x;
-        }
+        tail_tot = wg_piece_global<T, BWD>(a, g, ts * h, te * h, h, red);
     } else if (tail_partial) {
-        tail_piece = wg_piece_lds<BWD>(tile, tile_g, tail_begin, count - tail_begin, h, red);
-        if (te - ts <= p.long_edges) publish<BWD>(p, c, 1, tail_piece);
+        const float2 piece = wg_piece_lds<BWD, S>(tile, tile_g, tail_begin, count - tail_begin, h, red);
+        if (te - ts <= p.long_edges) publish<BWD>(p, c, 1, piece);
     }
 
     // ---- rows completely inside the tile ---------------------------------------------------------------------------
@@ -567,37 +594,38 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
             if (t == 0) s_nlong = 0;
             for (int i = t; i <= nrows; i += kThreads) rp[i] = p.rowptr[r0 + i];
             __syncthreads();
-            rows_small<BWD>(tile, tile_g, rp, nrows, e0, h, lpr, lthr);
+            rows_small<BWD, S>(tile, tile_g, rp, nrows, e0, h, lpr, lthr);
             // Long complete rows of this chunk: one WAVE per row, four at a time, no workgroup barrier.  A tile holds at
-            // most TILE / h / 33 <= 248 of them (more than lthr >= 32 edges each): the list cannot overflow.
+            // most TILE / h / 33 <= 496 of them (more than lthr >= 32 edges each): the list cannot overflow.
             for (int i = t; i < nrows; i += kThreads) {
                 if (rp[i + 1] - rp[i] > lthr) {
                     const int pos = atomicAdd(&s_nlong, 1);
-                    if (pos < kMaxLong) s_long[pos] = i;
+                    if (pos < kMaxLong) s_long[pos] = (uint16_t)i;
                 }
             }
             __syncthreads();
             const int n_long = min(s_nlong, kMaxLong);
             for (int q = t >> 6; q < n_long; q += 4) {
                 const int i2 = s_long[q];
-                row_in_lds<BWD>(tile, tile_g, (int)(rp[i2] - e0) * h, (rp[i2 + 1] - rp[i2]) * h, t & (kWave - 1), kWave, h);
+                row_in_lds<BWD, S>(tile, tile_g, (int)(rp[i2] - e0) * h, (rp[i2 + 1] - rp[i2]) * h, t & (kWave - 1), kWave, h);
             }
         }
     }
 
-    // ---- row totals of the partial pieces -> the factor the store step applies ----------------------------------
-    //   forward : out = p * exp(m_piece - m_row) / s_row          (fac = that product)
-    //   backward: out = a * (g - dot_row)                          (fac = dot_row)
-    //   (short straddling rows, forward: the span still holds the raw values: out = exp(v - m_row) / s_row)
+    // ---- row totals of the partial pieces -> what the store step applies to their (still raw) values ---------------
+    //   forward : out = exp(v - max_row) / sum_row          (facm = max_row, fac = 1 / sum_row)
+    //   backward: out = a * (g - dot_row)                   (fac = dot_row)
     if (head_partial && !head_halo) {
-        float2 tot;
-        if (!row_totals<BWD>(p, hs, he, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
-        if (t < h) fac[0][t] = BWD ? tot.x : es_exp(head_piece.x - tot.x) / tot.y;
+        if (!row_totals<BWD>(p, hs, he, mrg, head_tot)) head_tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
     }
     if (tail_partial && !tail_halo) {
-        float2 tot;
-        if (!row_totals<BWD>(p, ts, te, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, ts * h, te * h, h, red);
-        if (t < h) fac[1][t] = BWD ? tot.x : es_exp(tail_piece.x - tot.x) / tot.y;
+        if (!row_totals<BWD>(p, ts, te, mrg, tail_tot)) tail_tot = wg_piece_global<T, BWD>(a, g, ts * h, te * h, h, red);
+    }
+    if (t < h) {
+        fac[0][t] = BWD ? head_tot.x : 1.f / head_tot.y;
+        facm[0][t] = head_tot.x;
+        fac[1][t] = BWD ? tail_tot.x : 1.f / tail_tot.y;
+        facm[1][t] = tail_tot.x;
     }
     __syncthreads();
 
@@ -606,17 +634,20 @@ __global__ __launch_bounds__(kThreads) void es_flat_kernel(const Params p) {
     for (int j = 0; j < NV; ++j) {
         const int i0 = (j * kThreads + t) * V;
         float o[V];
+        unpack16<T>(reinterpret_cast<const uint4 *>(tile)[j * kThreads + t], o);
+        if (i0 < head_end || i0 + V > tail_begin) {  // (some element of the vector lies in a partial piece)
+            float vgs[V];
+            if constexpr (BWD) unpack16<T>(reinterpret_cast<const uint4 *>(tile_gs)[j * kThreads + t], vgs);
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const int i = i0 + k;
-            float v = tile[i];
-            if (i < head_end || i >= tail_begin) {
-                const int which = i < head_end ? 0 : 1;
-                const float f = fac[which][i & (h - 1)];
-                if constexpr (BWD) v = v * (tile_g[i] - f);
-                else v = (which == 0 ? head_halo : tail_halo) ? es_exp(v - facm[which][i & (h - 1)]) * f : v * f;
+            for (int k = 0; k < V; ++k) {
+                const int i = i0 + k;
+                if (i < head_end || i >= tail_begin) {
+                    const int which = i < head_end ? 0 : 1;
+                    const float f = fac[which][i & (h - 1)];
+                    if constexpr (BWD) o[k] = o[k] * (vgs[k] - f);
+                    else o[k] = es_exp(o[k] - facm[which][i & (h - 1)]) * f;
+                }
             }
-            o[k] = v;
         }
         if (full) {
             store_vec<T, V>(out + b0 + i0, o);
@@ -726,8 +757,12 @@ bool es_flat_covers(int64_t h, int dtype, const void *a, const void *g, const vo
     return aligned_to(a, 16) && aligned_to(out, 16) && (g == nullptr || aligned_to(g, 16));
 }
 
-static int64_t es_flat_tiles(int64_t nnz, int64_t h, bool bwd) {
-    const int64_t tile_e = (bwd ? esf::TileSize<true>::value : esf::TileSize<false>::value) / h;
+static int64_t es_flat_tile_elems(bool bwd, int elem_bytes) {
+    return elem_bytes == 4 ? (bwd ? esf::TileSize<true, 4>::value : esf::TileSize<false, 4>::value)
+                           : (bwd ? esf::TileSize<true, 2>::value : esf::TileSize<false, 2>::value);
+}
+static int64_t es_flat_tiles(int64_t nnz, int64_t h, bool bwd, int elem_bytes = 4) {
+    const int64_t tile_e = es_flat_tile_elems(bwd, elem_bytes) / h;
     return (nnz + tile_e - 1) / tile_e;
 }
 
@@ -752,8 +787,9 @@ int es_flat_launch(bool bwd, const int32_t *rowptr, const void *a, const void *g
     p.m = m;
     p.nnz = nnz;
     p.h = (int)h;
-    p.tile_e = (int)((bwd ? esf::TileSize<true>::value : esf::TileSize<false>::value) / h);
-    p.n_tiles = es_flat_tiles(nnz, h, bwd);
+    const int elem_bytes = dtype == COGDL_HIP_F32 ? 4 : 2;
+    p.tile_e = (int)(es_flat_tile_elems(bwd, elem_bytes) / h);
+    p.n_tiles = es_flat_tiles(nnz, h, bwd, elem_bytes);
     p.stats = (unsigned *)ws;
     p.tinfo = (esf::TileInfo *)((char *)ws + 256);
     p.rec = (float2 *)((char *)ws + 256 + es_flat_info_bytes(nnz, h));
