@@ -33,6 +33,8 @@
 // read of those rows only.
 #include "rowreduce.h"
 
+#include <type_traits>
+
 namespace cogdl {
 namespace esf {
 
@@ -391,9 +393,11 @@ __device__ __forceinline__ void wg_slot_reduce(float (&x)[V], int h, float *red)
 
 // =====================================================================================================================
 // main kernel: one tile per workgroup
-template <typename T, bool BWD>
-__global__ __launch_bounds__(kThreads, 4) void es_flat_kernel(const Params p) {  // (4 waves per SIMD = 4 workgroups per CU: <= 128 VGPRs, <= 40 KB LDS)
-    constexpr int TILE = TileSize<BWD, (int)sizeof(T)>::value;
+// TILE elements per workgroup, WPE waves per SIMD the register allocation aims at (= workgroups per CU):
+//   default      32 KB of values per tile and array, 4 workgroups per CU (<= 128 VGPRs, <= 40 KB LDS)
+//   16-bit alt   half of that per tile, 6 workgroups per CU (<= 84 VGPRs, <= 26 KB LDS): tuning key 9 bit 2, A/B runs
+template <typename T, bool BWD, int TILE, int WPE>
+__global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) {
     constexpr int V = VecOf<T>::V;
     constexpr int NV = TILE / (kThreads * V);  // 16-byte vectors per thread (per array): 8 forward, 4 + 4 backward
     constexpr int kMaxLong = 512;
@@ -442,6 +446,9 @@ __global__ __launch_bounds__(kThreads, 4) void es_flat_kernel(const Params p) { 
     const int64_t hs = ti.hs, he = ti.he, ts = ti.ts, te = ti.te;
 
     if (r_first == r_last) {
+        // (the guards of the last, partial tile cost two VALU operations per element and pass: compiled out for full tiles)
+        auto one_row_tile = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
         // ================= the whole tile is one piece of one row: everything stays in registers =================
         const bool partial = hs < e0 || he > e1;
         float x[V];
@@ -473,7 +480,7 @@ __global__ __launch_bounds__(kThreads, 4) void es_flat_kernel(const Params p) { 
                 unpack16<T>(ra[j], va);
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
-                    const bool valid = full || ((j * kThreads + t) * V + k) < count;
+                    const bool valid = FULL || ((j * kThreads + t) * V + k) < count;
                     mxs[k] = fmaxf(mxs[k], valid ? va[k] : -INFINITY);
                 }
             }
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(kThreads, 4) void es_flat_kernel(const Params p) { 
                 unpack16<T>(ra[j], va);
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
-                    const bool valid = full || ((j * kThreads + t) * V + k) < count;
+                    const bool valid = FULL || ((j * kThreads + t) * V + k) < count;
                     x[k] += valid ? es_exp(va[k] - mxs[k]) : 0.f;
                 }
             }
@@ -530,7 +537,7 @@ __global__ __launch_bounds__(kThreads, 4) void es_flat_kernel(const Params p) { 
 #pragma unroll
                 for (int k = 0; k < V; ++k) o[k] = es_exp(va[k] - fm[k]) * f[k];
             }
-            if (full) {
+            if (FULL) {
                 store_vec<T, V>(out + b0 + i0, o);
             } else {
 #pragma unroll
@@ -538,6 +545,9 @@ __global__ __launch_bounds__(kThreads, 4) void es_flat_kernel(const Params p) { 
                     if (i0 + k < count) out[b0 + i0 + k] = from_f32<T>(o[k]);
             }
         }
+                };
+        if (full) one_row_tile(std::true_type{});
+        else one_row_tile(std::false_type{});
         return;
     }
 
@@ -736,7 +746,7 @@ __global__ __launch_bounds__(kThreads) void es_flat_init_kernel(const Params p) 
     }
 }
 
-template <typename T, bool BWD>
+template <typename T, bool BWD, int TILE, int WPE>
 static int launch_typed(Params &p, hipStream_t s) {
     const int64_t n_seg = (p.n_tiles + kKMax - 1) / kKMax;
     p.info_per_wave = p.n_tiles < 16384 ? 1 : 0;
@@ -744,7 +754,7 @@ static int launch_typed(Params &p, hipStream_t s) {
     if (n_seg + n_info > 0x7fffffff || p.n_tiles > 0x7fffffff) return COGDL_HIP_ERANGE;
     p.n_seg = (int)n_seg;
     hipLaunchKernelGGL((es_flat_init_kernel<T, BWD>), dim3((unsigned)(n_seg + n_info)), dim3(kThreads), 0, s, p);
-    hipLaunchKernelGGL((es_flat_kernel<T, BWD>), dim3((unsigned)p.n_tiles), dim3(kThreads), 0, s, p);
+    hipLaunchKernelGGL((es_flat_kernel<T, BWD, TILE, WPE>), dim3((unsigned)p.n_tiles), dim3(kThreads), 0, s, p);
     return launch_status();
 }
 
@@ -757,9 +767,10 @@ bool es_flat_covers(int64_t h, int dtype, const void *a, const void *g, const vo
     return aligned_to(a, 16) && aligned_to(out, 16) && (g == nullptr || aligned_to(g, 16));
 }
 
+static bool es_flat_small16() { return (g_tuning[kTuneEsDebug] & 4) != 0; }  // 16-bit values: the half-size tiles
 static int64_t es_flat_tile_elems(bool bwd, int elem_bytes) {
-    return elem_bytes == 4 ? (bwd ? esf::TileSize<true, 4>::value : esf::TileSize<false, 4>::value)
-                           : (bwd ? esf::TileSize<true, 2>::value : esf::TileSize<false, 2>::value);
+    if (elem_bytes == 4 || es_flat_small16()) return bwd ? esf::TileSize<true, 4>::value : esf::TileSize<false, 4>::value;
+    return bwd ? esf::TileSize<true, 2>::value : esf::TileSize<false, 2>::value;
 }
 static int64_t es_flat_tiles(int64_t nnz, int64_t h, bool bwd, int elem_bytes = 4) {
     const int64_t tile_e = es_flat_tile_elems(bwd, elem_bytes) / h;
@@ -796,11 +807,21 @@ int es_flat_launch(bool bwd, const int32_t *rowptr, const void *a, const void *g
     p.long_edges = (int64_t)esf::kKMax * p.tile_e;
     p.debug = (g_tuning[kTuneEsDebug] & 1) | (g_tuning[kTuneEsSpin] < 0 ? 2 : 0);
     p.spin_limit = g_tuning[kTuneEsSpin] > 0 ? (unsigned)g_tuning[kTuneEsSpin] : esf::kSpinLimit;
+    constexpr int F32F = esf::TileSize<false, 4>::value, F32B = esf::TileSize<true, 4>::value;  // 8192 / 4096 elements
+    constexpr int B16F = esf::TileSize<false, 2>::value, B16B = esf::TileSize<true, 2>::value;  // 16384 / 8192
+    const bool small16 = es_flat_small16();
     switch (dtype) {
-        case COGDL_HIP_F32: return bwd ? esf::launch_typed<float, true>(p, s) : esf::launch_typed<float, false>(p, s);
-        case COGDL_HIP_F16: return bwd ? esf::launch_typed<__half, true>(p, s) : esf::launch_typed<__half, false>(p, s);
+        case COGDL_HIP_F32:
+            return bwd ? esf::launch_typed<float, true, F32B, 4>(p, s) : esf::launch_typed<float, false, F32F, 4>(p, s);
+        case COGDL_HIP_F16:
+            if (small16) return bwd ? esf::launch_typed<__half, true, F32B, 6>(p, s) : esf::launch_typed<__half, false, F32F, 6>(p, s);
+            return bwd ? esf::launch_typed<__half, true, B16B, 4>(p, s) : esf::launch_typed<__half, false, B16F, 4>(p, s);
         case COGDL_HIP_BF16:
-            return bwd ? esf::launch_typed<__hip_bfloat16, true>(p, s) : esf::launch_typed<__hip_bfloat16, false>(p, s);
+            if (small16)
+                return bwd ? esf::launch_typed<__hip_bfloat16, true, F32B, 6>(p, s)
+                           : esf::launch_typed<__hip_bfloat16, false, F32F, 6>(p, s);
+            return bwd ? esf::launch_typed<__hip_bfloat16, true, B16B, 4>(p, s)
+                       : esf::launch_typed<__hip_bfloat16, false, B16F, 4>(p, s);
         default: return COGDL_HIP_EDTYPE;
     }
 }
