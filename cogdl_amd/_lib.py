@@ -122,6 +122,13 @@ def hip():
     global _hip
     if _hip is None:
         _hip = _load(HIP_LIB_PATH, HIP_SIGNATURES, "libcogdl_hip.so (HIP kernels)")
+        raw_set = _hip.cogdl_hip_set_tuning
+
+        def set_tuning(key, value):  # (workspace sizes depend on the tuning table: the memo of workspace() goes with it)
+            _WS_BYTES.clear()
+            return raw_set(key, value)
+
+        _hip.cogdl_hip_set_tuning = set_tuning
         # A/B experiments without code changes: COGDL_AMD_TUNING="key=value,key=value" -> cogdl_hip_set_tuning
         for item in filter(None, os.environ.get("COGDL_AMD_TUNING", "").split(",")):
             key, _, value = item.partition("=")
@@ -140,10 +147,18 @@ def host():
 def workspace(query, device, *args):
     """Long-row scratch of a row-wise operator: `query` names its *_workspace_bytes function (torch caching
     allocator: no hipMalloc per call).  Returns (tensor | None, nbytes)."""
-    nbytes = getattr(hip(), query)(*[int(a) for a in args])
+    key = (query,) + args
+    nbytes = _WS_BYTES.get(key)
+    if nbytes is None:  # (a pure function of its arguments: asked once per shape -- an epoch is launch-bound on the host)
+        nbytes = getattr(hip(), query)(*[int(a) for a in args])
+        if len(_WS_BYTES) < 4096:
+            _WS_BYTES[key] = nbytes
     if nbytes == 0:
         return None, 0
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
+_WS_BYTES = {}
 
 
 class _NoCtx:
