@@ -102,8 +102,7 @@ class SPMMFunction(torch.autograd.Function):
         # before backward asks for it (Fingerprint.key() waits on an event recorded right behind the hash
         # kernel, not behind the SpMM).
         rowptr, colind = _lib.csr_structure(rowptr, colind)  # validated + contiguous before anything reads raw pointers
-        _check_csr(rowptr, colind, feat)
-        ctx.transient = _plan.transient()
+        ctx.transient = _plan.transient()  # (the dense operand is checked by csr_spmm_raw)
         ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] and not ctx.transient else None
         out = csr_spmm_raw(rowptr, colind, edge_weight_csr, feat)
         need_w = edge_weight_csr is not None and ctx.needs_input_grad[3]

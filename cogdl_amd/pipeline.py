@@ -55,8 +55,7 @@ def gather_rows_by_id(src, ids, out=None):
     bad = torch.zeros(1, dtype=torch.int32, device=dev)
     fn = _lib.hip().cogdl_hip_gather_feature_rows if ids.dtype == torch.int64 else _lib.hip().cogdl_hip_gather_feature_rows_i32
     with _lib.on_device(dev):
-        rc = fn(_lib.ptr(ids), src.data_ptr(), _lib.ptr(out), n, row_bytes, n_src, _lib.ptr(bad),
-                torch.cuda.current_stream(dev).cuda_stream)
+        rc = fn(_lib.ptr(ids), src.data_ptr(), _lib.ptr(out), n, row_bytes, n_src, _lib.ptr(bad), _lib.stream_of(ids))
     _lib.check(rc, "gather_feature_rows")
     out._cogdl_bad_flag = bad  # checked lazily (BatchPipeline / tests): reading it here would stall the stream
     return out

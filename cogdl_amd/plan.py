@@ -196,7 +196,7 @@ class Fingerprint:
             self.host = torch.empty(FINGERPRINT_PARTS, dtype=torch.int64, pin_memory=True)
             with _lib.on_device(dev):
                 self.event = torch.cuda.Event()
-        stream = torch.cuda.current_stream(dev)
+        stream = _lib.current_stream_obj(dev)
         with _lib.on_device(dev):
             rc = _lib.hip().cogdl_hip_csr_fingerprint(_lib.ptr(rowptr), _lib.ptr(colind), m, nnz,
                                                       self.host.data_ptr(), stream.cuda_stream)
