@@ -199,6 +199,11 @@ extern "C" int cogdl_hip_csr_spmm_variant(const int32_t *rowptr, const int32_t *
         V(8, 1, 64, 8, true)
         V(9, 1, 64, 16, true)
         V(10, 2, 64, 16, true)
+        V(11, 2, 32, 16, true)
+        V(12, 4, 16, 16, true)
+        V(13, 4, 10, 16, true)
+        V(14, 4, 10, 8, true)
+        V(15, 2, 32, 12, true)
         default: return COGDL_HIP_EINVAL;
     }
 #undef V

@@ -50,7 +50,7 @@ def main():
         rounds = 3
         best = {}
         for r in range(rounds):  # interleaved rounds
-            for v in [-1] + list(range(11)):
+            for v in [-1] + list(range(16)):
                 med, mn = timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x, v), reps=20)
                 best.setdefault(v, []).append((med, mn))
         for v, lst in best.items():
