@@ -60,5 +60,8 @@ for k, cs in vals.items():
         e["hbm_write_bytes"] = e["WRITE_SIZE"] * GIB / w
     if "hbm_read_bytes" in e and "hbm_write_bytes" in e:
         e["hbm_bytes_per_launch"] = e["hbm_read_bytes"] + e["hbm_write_bytes"]
+        if e.get("duration_us_profiled"):
+            e["hbm_GBs"] = e["hbm_bytes_per_launch"] / e["duration_us_profiled"] / 1e3
+            e["hbm_frac_of_8TBs"] = e["hbm_GBs"] / 8000.0
     out["kernels"][k] = e
 print(json.dumps(out, indent=1))

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Workload for the rocprofv3 --pmc passes over the operators whose ALGORITHMIC-byte fraction exceeds 100 % of the HBM
+peak (SURVEY.md section 8d prices one gathered row per edge; registers, L2 and the Infinity Cache serve part of it): the
+1 GiB calibration copy, then -- on the Reddit-shaped graph at its true size -- csr_spmm F=64, mhspmm / fused GAT
+forward / mhsddmm / fused GAT backward at H=8 x F=8, csr_sddmm F=64; three launches each.  tools/pmc_by_kernel.py folds
+the counters per kernel: the HBM-side bytes per launch and their rate are the fractions DESIGN.md quotes next to the
+algorithmic ones."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cogdl_amd import synth  # noqa: E402
+from cogdl_amd.operators.edge_softmax import _launch as es_launch  # noqa: E402
+from cogdl_amd.operators.fused_gat import FusedGATFunction, gat_forward  # noqa: E402
+from cogdl_amd.operators.mhspmm import mhsddmm_raw, mhspmm_raw  # noqa: E402
+from cogdl_amd.operators.spmm import csr_sddmm_raw, csr_spmm_raw  # noqa: E402
+
+dev = "cuda:0"
+a = torch.randn(256 * 1024 * 1024, device=dev)
+b = torch.empty_like(a)
+for _ in range(3):
+    b.copy_(a)
+torch.cuda.synchronize()
+del a, b
+g = synth.reddit_like(seed=0, device=dev)
+n, nnz, h, f = g.num_nodes, g.nnz, 8, 8
+x64 = torch.randn(n, 64, device=dev)
+y64 = torch.randn(n, 64, device=dev)
+att = torch.randn(nnz, h, device=dev)
+sm = es_launch("cogdl_hip_edge_softmax_fwd", g.rowptr, att)
+feat = torch.randn(n, h, f, device=dev)
+grad = torch.randn(n, h, f, device=dev)
+ar, ac = torch.randn(n, h, device=dev), torch.randn(n, h, device=dev)
+ar_g, ac_g, ft_g = ar.clone().requires_grad_(), ac.clone().requires_grad_(), feat.clone().requires_grad_()
+for _ in range(3):
+    csr_spmm_raw(g.rowptr, g.colind, g.weight, x64)
+    mhspmm_raw(g.rowptr, g.colind, sm, feat)
+    gat_forward(ar, ac, g.rowptr, g.colind, 0.2, feat)
+    mhsddmm_raw(g.rowptr, g.colind, grad, feat)
+    csr_sddmm_raw(g.rowptr, g.colind, y64, x64)
+    out = FusedGATFunction.apply(ar_g, ac_g, g.rowptr, g.colind, g.rowptr, g.colind, 0.2, ft_g)
+    torch.autograd.grad(out, (ar_g, ac_g, ft_g), grad)
+torch.cuda.synchronize()
+print("reddit nnz", nnz)
