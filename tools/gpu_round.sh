@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc pmc2 pmc3 ops epoch e2e sampler
+# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc pmc2 ops epoch e2e sampler
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -58,11 +58,4 @@ if has pmc2; then
     (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc2_$c" -o pmc -- python "$GRAFT_REPO_ROOT/tools/pmc_probe_es.py") > gpurun_out/pmc2_$c.log 2>&1
   done
   python tools/pmc_by_kernel.py gpurun_out pmc2_ > gpurun_out/pmc2_summary.json 2> gpurun_out/pmc2_summary.err; head -c 3000 gpurun_out/pmc2_summary.json
-fi
-if has pmc3; then
-  for c in FETCH_SIZE WRITE_SIZE; do
-    rm -rf gpurun_out/pmc3_$c
-    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc3_$c" -o pmc -- python "$GRAFT_REPO_ROOT/tools/pmc_probe_ops.py") > gpurun_out/pmc3_$c.log 2>&1
-  done
-  python tools/pmc_by_kernel.py gpurun_out pmc3_ SpmmOp GatFwd GatBwd SddmmOp MhsddmmOp > gpurun_out/pmc3_summary.json 2> gpurun_out/pmc3_summary.err; head -c 6000 gpurun_out/pmc3_summary.json
 fi

@@ -4,7 +4,12 @@ peak (SURVEY.md section 8d prices one gathered row per edge; registers, L2 and t
 1 GiB calibration copy, then -- on the Reddit-shaped graph at its true size -- csr_spmm F=64, mhspmm / fused GAT
 forward / mhsddmm / fused GAT backward at H=8 x F=8, csr_sddmm F=64; three launches each.  tools/pmc_by_kernel.py folds
 the counters per kernel: the HBM-side bytes per launch and their rate are the fractions DESIGN.md quotes next to the
-algorithmic ones."""
+algorithmic ones.
+
+ROUND 3 STATUS: the one attempt to run this under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` ended with "Memory access
+fault by GPU node" inside the profiled process and a hang until the time limit (30 GPU-minutes lost, no counters) -- the
+same operator calls run clean outside the profiler (tools/ops_bench.py, the -m gpu tests).  Not diagnosed; run it under
+a short `timeout` if at all."""
 import os
 import sys
 
