@@ -360,7 +360,7 @@ def self_launch(args):
     import subprocess
 
     n = args.gpus
-    if not args.selftest_cpu:
+    if not args.selftest_cpu and not args.share_gpu:
         have = torch.cuda.device_count()
         if have < n:
             raise SystemExit("bench.py --gpus %d needs %d devices, this host has %d" % (n, n, have))
@@ -398,6 +398,9 @@ def main():
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="launcher self-test: gloo ranks on the host with libcogdl_host kernels and tiny shards (tests only; "
                          "its numbers mean nothing)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="orchestration smoke test on a one-GPU box: all ranks on cuda:0, rows exchanged through gloo (its "
+                         "numbers are not multi-GPU numbers)")
     args = ap.parse_args()
     args.bench_script = os.path.abspath(__file__)
     if args.gpus < 1:

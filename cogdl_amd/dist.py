@@ -553,8 +553,10 @@ def sharded_leg(rank, world, dev, shard_nodes, degree, feat, remote_frac, halo_f
         del y
     del cols, rowptr, w
 
+    cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")  # (gloo: the small collectives on host tensors)
+
     def allsum(v, op=dist.ReduceOp.SUM, dtype=torch.float64):
-        t = torch.tensor([v], device=dev, dtype=dtype)
+        t = torch.tensor([v], device=cdev, dtype=dtype)
         dist.all_reduce(t, op=op)
         return t.item()
 
@@ -592,8 +594,8 @@ def sharded_leg(rank, world, dev, shard_nodes, degree, feat, remote_frac, halo_f
             e1.record()
         sync()
         loc_ms = (e0.elapsed_time(e1) if cuda else (time.perf_counter() - t1) * 1e3) / reps
-    loc_all = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-    dist.all_gather(loc_all, torch.tensor([loc_ms], dtype=torch.float64, device=dev))
+    loc_all = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+    dist.all_gather(loc_all, torch.tensor([loc_ms], dtype=torch.float64, device=cdev))
     loc_all = [float(v) for v in loc_all]
     halo_rows = allsum(sh.n_halo)
     remote_edges = allsum(sh.nnz_remote)
@@ -651,8 +653,12 @@ def bench_sharded_spmm(args):
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: refusing to report a %d-GPU line from %d "
                          "rank(s)" % (args.gpus, world, args.gpus, world))
+    share = bool(getattr(args, "share_gpu", False))
     if cpu:  # launcher self-test (tests/test_dist_cpu.py): gloo ranks on the host, libcogdl_host kernels, tiny shards
         dev, backend_name, backend = torch.device("cpu"), "gloo", HostBackend()
+    elif share:  # orchestration smoke test on a ONE-GPU box: every rank on cuda:0, rows exchanged through gloo (RCCL refuses
+        dev, backend_name, backend = torch.device("cuda", 0), "gloo", None  # two ranks per device); HIP kernels throughout
+        torch.cuda.set_device(dev)
     else:
         n_dev = torch.cuda.device_count()
         if local >= n_dev:
@@ -663,7 +669,7 @@ def bench_sharded_spmm(args):
     if own_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if cpu:
+        if cpu or share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -714,7 +720,9 @@ def bench_sharded_spmm(args):
         }
         if cpu:
             result["selftest"] = "gloo ranks on the host, libcogdl_host kernels: exercises the launcher and the data flow only"
-            result["dtype"] = "f32"
+        if share:
+            result["selftest"] = ("all ranks on cuda:0, halo rows staged through gloo: exercises the orchestration (launcher, "
+                                  "HIP shard construction, child legs) on a one-GPU box; its rate is not a multi-GPU number")
         # the dominant kernel of a step: csr_spmm over the rank's local block (SURVEY.md section 8d's formula), timed
         # above with HIP events on its own; X (7.1 GB per shard) is far beyond the caches, so this IS HBM traffic
         b_alg = m["local_block_algorithmic_bytes"]
@@ -727,14 +735,14 @@ def bench_sharded_spmm(args):
         return result
     # ---- follow-up legs, each in child interpreters with their own process group and a hard timeout -----------------
     script = os.path.abspath(getattr(args, "bench_script", "bench.py"))
-    common = ["--gpus", str(world), "--feat", str(f)] + (["--selftest-cpu"] if cpu else [])
+    common = ["--gpus", str(world), "--feat", str(f)] + (["--selftest-cpu"] if cpu else []) + (["--share-gpu"] if share else [])
     worst_nodes = max(64, shard_nodes // max(1, int(getattr(args, "worst_case_scale", 4))))
     worst = _child_leg([script, "--sharded", "--leg", "worst"] + common
                        + ["--shard-nodes", str(worst_nodes), "--shard-degree", str(degree),
                           "--remote-frac", repr((world - 1) / world), "--halo-frac", "0",
                           "--steps", str(max(2, args.steps // 2)), "--warmup", "1"], 1, 420)
     sage = None
-    if not cpu and not getattr(args, "no_sage", False):
+    if not cpu and not share and not getattr(args, "no_sage", False):
         tool = os.path.join(os.path.dirname(script), "tools", "sage_bench.py")
         sage = _child_leg([tool, "--captured", "--batch", "1024", "--steps", "50"], 2, 300)
         if "error" in sage:  # the RCCL all-reduce as a node of the captured graph failed: the eager step with torch DDP
