@@ -163,3 +163,26 @@ def test_captured_minibatch_step_with_the_gradient_all_reduce_inside_the_graph(r
     np.testing.assert_allclose(losses[1], losses[0], rtol=1e-6)
     for pa, pb in zip(m_a.parameters(), m_b.parameters()):
         np.testing.assert_allclose(pb.detach().cpu().numpy(), pa.detach().cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_bench_gpus_2_orchestration_on_the_one_gpu():
+    """`python bench.py --gpus 2 --share-gpu`: the whole N > 1 bench orchestration on this one-GPU box -- bench.py spawns
+    its two ranks itself, both build their shard with the HIP kernels (real halos), run the sharded step, then the
+    worst-case-partition leg runs in child interpreters with a process group of its own; rows travel through gloo because
+    RCCL refuses two ranks on one device.  The line must report two ranks in both legs."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--shard-nodes",
+                           "200000", "--steps", "2", "--warmup", "1", "--feat", "64"], capture_output=True, text=True,
+                          timeout=600, env=env)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert proc.returncode == 0 and len(lines) == 1, proc.stderr[-1500:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and len(line["local_block_ms_by_rank"]) == 2
+    assert line["config"]["halo_rows_rank0"] > 0 and line["halo_GB_per_step_all_ranks"] > 0
+    worst = line["worst_case_partition"]
+    assert worst.get("n_gpus") == 2 and worst.get("n_ranks_seen") == 2 and worst["config"]["remote_frac"] == 0.5, worst
