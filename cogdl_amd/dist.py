@@ -331,7 +331,13 @@ def bfs_order(rowptr, colind, sources=None, max_levels=1 << 20):
     cur = 0
     lib = _lib.hip()
     stream = torch.cuda.current_stream(dev).cuda_stream
-    while n:
+    lonely = (rp[1:] - rp[:-1]) == 0  # isolated vertices (the bulk of what an R-MAT generator leaves over): one last level
+    if sources is None and n and bool(lonely[0]):
+        first = torch.nonzero(~lonely)
+        src = first[0] if first.numel() else src
+    searches = 0
+    while n and not bool(lonely.all()):
+        searches += 1
         level[src] = cur
         while True:
             changed.zero_()
@@ -341,20 +347,13 @@ def bfs_order(rowptr, colind, sources=None, max_levels=1 << 20):
             cur += 1
             if not int(changed.item()) or cur >= max_levels:
                 break
-        rest = torch.nonzero(level < 0)
+        rest = torch.nonzero((level < 0) & ~lonely)  # the next component, searched from its smallest vertex
         if rest.numel() == 0:
             break
-        # the remaining components: isolated vertices (the bulk of what an R-MAT generator leaves over) all at once in
-        # one last level, anything with edges from its smallest vertex
-        deg = rp[1:] - rp[:-1]
-        lonely = (level < 0) & (deg == 0)
-        if bool(lonely.any()):
-            level[lonely] = cur
-            cur += 1
-            rest = torch.nonzero(level < 0)
-            if rest.numel() == 0:
-                break
-        src = rest[0]
+        # (a graph of a million two-vertex components must not cost a million host round trips: after 32 single-source
+        #  searches everything that is left starts at once)
+        src = rest[0] if searches < 32 else rest.flatten()
+    level[level < 0] = cur
     # order = vertices sorted by (level, id): the transpose of the n x n_levels matrix with one entry per vertex
     iota = torch.arange(n + 1, dtype=torch.int32, device=dev)
     plan = csr2csc(iota, level, cur + 1)

@@ -167,3 +167,57 @@ def test_sharded_equals_unsharded_through_the_partitioner(tmp_path, oracle):
         assert int(z["n_halo"]) > 0
         seen += len(z["ids"])
     assert seen == n
+
+
+def test_shard_split_degenerate_shapes():
+    """A rank without rows, a rank whose rows have no edges, a shard with only remote / only local columns."""
+    from cogdl_amd.dist import partition_bounds
+
+    n = 1000
+    rp = torch.zeros(n + 1, dtype=torch.long, device=DEV)
+    ci = torch.zeros(0, dtype=torch.long, device=DEV)
+    a, halo, cut = _split("hip", rp, ci, None, partition_bounds(n, 1), 0)  # no edges at all
+    assert a.colind_loc.numel() == 0 and a.colind_rem.numel() == 0 and halo.numel() == 0 and list(cut) == [0, 0]
+    bounds = torch.tensor([0, 0, n], dtype=torch.long)  # rank 0 owns nothing
+    a, halo, cut = _split("hip", torch.zeros(1, dtype=torch.long, device=DEV), ci, None, bounds, 0)
+    assert a.rowptr_loc.tolist() == [0] and a.rowptr_rem.tolist() == [0] and halo.numel() == 0
+    # rank 1 of 2 with every column owned by rank 0 (only remote), then by itself (only local)
+    bounds = torch.tensor([0, 500, 1000], dtype=torch.long)
+    deg = 3
+    rp = torch.arange(0, 500 * deg + 1, deg, dtype=torch.long, device=DEV)
+    for lo_col, expect_rem in ((0, True), (500, False)):
+        ci = (torch.arange(500 * deg, device=DEV) % 400) + lo_col
+        w = torch.rand(500 * deg, device=DEV)
+        a, halo, cut = _split("hip", rp, ci, w, bounds, 1)
+        b, halo_b, cut_b = _split("torch", rp, ci, w, bounds, 1)
+        assert (a.colind_rem.numel() > 0) == expect_rem and torch.equal(halo, halo_b) and list(cut) == list(cut_b)
+        for name in ("rowptr_loc", "colind_loc", "rowptr_rem", "colind_rem", "w_loc", "w_rem"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
+def test_bfs_order_covers_components_and_isolated_vertices():
+    from cogdl_amd.dist import bfs_order
+
+    # two rings of 500 vertices that are not connected to each other, plus 24 isolated vertices at the end
+    n = 1024
+    src = torch.cat([torch.arange(500), torch.arange(500, 1000)])
+    dst = torch.cat([(torch.arange(500) + 1) % 500, 500 + (torch.arange(500) + 1) % 500])
+    g = synth.finalize(src, dst, n, norm=None, self_loops=False)
+    perm = bfs_order(g.rowptr.long().to(DEV), g.colind.long().to(DEV))
+    assert torch.equal(torch.sort(perm).values, torch.arange(n, device=DEV))
+    p = perm.cpu()
+    assert int(p[0]) == 0                                    # the search starts at vertex 0
+    assert set(p[:500].tolist()) == set(range(500))          # ring 0 completely before ...
+    assert set(p[500:1000].tolist()) == set(range(500, 1000))  # ... ring 1 (searched from its smallest vertex) ...
+    assert set(p[1000:].tolist()) == set(range(1000, 1024))  # ... and the isolated vertices last
+    assert {int(p[1]), int(p[2])} == {1, 499}                # level 1 of a ring: the two neighbours, by id
+
+
+def test_partition_world_1_is_the_identity_cut():
+    from cogdl_amd.dist import partition
+
+    g = synth.scaled(5000, 6, seed=2, norm=None)
+    part = partition(g.rowptr.long().to(DEV), g.colind.long().to(DEV), 1, order="none")
+    assert part.bounds.tolist() == [0, 5000] and part.halo_after == [(0, 0)] and part.halo_fraction() == 0.0
+    rp, ci, w = part.shard(0)
+    assert torch.equal(rp, g.rowptr.long().to(DEV)) and torch.equal(ci, g.colind.long().to(DEV)) and w is None
