@@ -396,7 +396,10 @@ __device__ __forceinline__ void wg_slot_reduce(float (&x)[V], int h, float *red)
 // TILE elements per workgroup, WPE waves per SIMD the register allocation aims at (= workgroups per CU):
 //   default      32 KB of values per tile and array, 4 workgroups per CU (<= 128 VGPRs, <= 40 KB LDS)
 //   16-bit alt   half of that per tile, 6 workgroups per CU (<= 84 VGPRs, <= 26 KB LDS): tuning key 9 bit 2, A/B runs
-template <typename T, bool BWD, int TILE, int WPE>
+//   KEEP_P       forward, tiles inside ONE row: exp(v - max_piece) of the thread's elements stays in fp32 registers and the
+//                output is p * exp(max_piece - max_row) / sum_row -- one exponential per element instead of two, at the
+//                price of TILE / 256 more live registers (tuning key 9 bit 3, A/B runs)
+template <typename T, bool BWD, int TILE, int WPE, bool KEEP_P = false>
 __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) {
     constexpr int V = VecOf<T>::V;
     constexpr int NV = TILE / (kThreads * V);  // 16-byte vectors per thread (per array): 8 forward, 4 + 4 backward
@@ -452,6 +455,7 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
         // ================= the whole tile is one piece of one row: everything stays in registers =================
         const bool partial = hs < e0 || he > e1;
         float x[V];
+        float pv[(KEEP_P && !BWD) ? NV : 1][V];
         float2 piece = make_float2(0.f, 0.f);  // this thread's view: statistics of head t % h (threads < h publish)
         if constexpr (BWD) {
 #pragma unroll
@@ -494,7 +498,9 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
                     const bool valid = FULL || ((j * kThreads + t) * V + k) < count;
-                    x[k] += valid ? es_exp(va[k] - mxs[k]) : 0.f;
+                    const float pe = valid ? es_exp(va[k] - mxs[k]) : 0.f;
+                    if constexpr (KEEP_P && !BWD) pv[j][k] = pe;
+                    x[k] += pe;
                 }
             }
             wg_slot_reduce<V, false>(x, h, red);  // x[k] = sum of exp(v - max) of its head
@@ -513,7 +519,8 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
             if (!row_totals<BWD>(p, hs, he, mrg, tot)) tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
         }
         if (t < h) {
-            fac[0][t] = BWD ? tot.x : 1.f / tot.y;
+            if constexpr (KEEP_P && !BWD) fac[0][t] = es_exp(piece.x - tot.x) / tot.y;  // what p = exp(v - max_piece) is scaled by
+            else fac[0][t] = BWD ? tot.x : 1.f / tot.y;
             facm[0][t] = tot.x;
         }
         __syncthreads();
@@ -533,6 +540,9 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
                 unpack16<T>(rg[j], vg);
 #pragma unroll
                 for (int k = 0; k < V; ++k) o[k] = va[k] * (vg[k] - f[k]);
+            } else if constexpr (KEEP_P) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) o[k] = pv[j][k] * f[k];
             } else {
 #pragma unroll
                 for (int k = 0; k < V; ++k) o[k] = es_exp(va[k] - fm[k]) * f[k];
@@ -746,7 +756,7 @@ __global__ __launch_bounds__(kThreads) void es_flat_init_kernel(const Params p) 
     }
 }
 
-template <typename T, bool BWD, int TILE, int WPE>
+template <typename T, bool BWD, int TILE, int WPE, bool KEEP_P = false>
 static int launch_typed(Params &p, hipStream_t s) {
     const int64_t n_seg = (p.n_tiles + kKMax - 1) / kKMax;
     p.info_per_wave = p.n_tiles < 16384 ? 1 : 0;
@@ -754,7 +764,7 @@ static int launch_typed(Params &p, hipStream_t s) {
     if (n_seg + n_info > 0x7fffffff || p.n_tiles > 0x7fffffff) return COGDL_HIP_ERANGE;
     p.n_seg = (int)n_seg;
     hipLaunchKernelGGL((es_flat_init_kernel<T, BWD>), dim3((unsigned)(n_seg + n_info)), dim3(kThreads), 0, s, p);
-    hipLaunchKernelGGL((es_flat_kernel<T, BWD, TILE, WPE>), dim3((unsigned)p.n_tiles), dim3(kThreads), 0, s, p);
+    hipLaunchKernelGGL((es_flat_kernel<T, BWD, TILE, WPE, KEEP_P>), dim3((unsigned)p.n_tiles), dim3(kThreads), 0, s, p);
     return launch_status();
 }
 
@@ -810,6 +820,14 @@ int es_flat_launch(bool bwd, const int32_t *rowptr, const void *a, const void *g
     constexpr int F32F = esf::TileSize<false, 4>::value, F32B = esf::TileSize<true, 4>::value;  // 8192 / 4096 elements
     constexpr int B16F = esf::TileSize<false, 2>::value, B16B = esf::TileSize<true, 2>::value;  // 16384 / 8192
     const bool small16 = es_flat_small16();
+    if (!bwd && (g_tuning[kTuneEsDebug] & 8) && !small16) {  // forward with exp(v - max_piece) kept in registers (A/B)
+        switch (dtype) {
+            case COGDL_HIP_F32: return esf::launch_typed<float, false, F32F, 4, true>(p, s);
+            case COGDL_HIP_F16: return esf::launch_typed<__half, false, B16F, 4, true>(p, s);
+            case COGDL_HIP_BF16: return esf::launch_typed<__hip_bfloat16, false, B16F, 4, true>(p, s);
+            default: return COGDL_HIP_EDTYPE;
+        }
+    }
     switch (dtype) {
         case COGDL_HIP_F32:
             return bwd ? esf::launch_typed<float, true, F32B, 4>(p, s) : esf::launch_typed<float, false, F32F, 4>(p, s);
