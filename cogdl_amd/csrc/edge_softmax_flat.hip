@@ -398,7 +398,7 @@ __device__ __forceinline__ void wg_slot_reduce(float (&x)[V], int h, float *red)
 //   16-bit alt   half of that per tile, 6 workgroups per CU (<= 84 VGPRs, <= 26 KB LDS): tuning key 9 bit 2, A/B runs
 //   KEEP_P       forward, tiles inside ONE row: exp(v - max_piece) of the thread's elements stays in fp32 registers and the
 //                output is p * exp(max_piece - max_row) / sum_row -- one exponential per element instead of two, at the
-//                price of TILE / 256 more live registers (tuning key 9 bit 3, A/B runs)
+//                price of TILE / 256 more live registers (the default forward; tuning key 9 bit 3 = off, A/B runs)
 template <typename T, bool BWD, int TILE, int WPE, bool KEEP_P = false>
 __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) {
     constexpr int V = VecOf<T>::V;
@@ -820,7 +820,10 @@ int es_flat_launch(bool bwd, const int32_t *rowptr, const void *a, const void *g
     constexpr int F32F = esf::TileSize<false, 4>::value, F32B = esf::TileSize<true, 4>::value;  // 8192 / 4096 elements
     constexpr int B16F = esf::TileSize<false, 2>::value, B16B = esf::TileSize<true, 2>::value;  // 16384 / 8192
     const bool small16 = es_flat_small16();
-    if (!bwd && (g_tuning[kTuneEsDebug] & 8) && !small16) {  // forward with exp(v - max_piece) kept in registers (A/B)
+    // forward: exp(v - max_piece) of single-row tiles kept in registers (one exponential per element; measured on the
+    // Reddit-shaped graph: fp32 1.68 -> 1.62 ms, bf16 1.41 -> 1.37 ms, the latter despite 65 spilled registers per lane);
+    // tuning key 9 bit 3 switches it off for A/B runs
+    if (!bwd && !(g_tuning[kTuneEsDebug] & 8) && !small16) {
         switch (dtype) {
             case COGDL_HIP_F32: return esf::launch_typed<float, false, F32F, 4, true>(p, s);
             case COGDL_HIP_F16: return esf::launch_typed<__half, false, B16F, 4, true>(p, s);

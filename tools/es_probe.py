@@ -18,7 +18,7 @@ for h in (8, 1):
         a = torch.randn(g.nnz, h, device=DEV).to(dt)
         sm = es_launch("cogdl_hip_edge_softmax_fwd", g.rowptr, a)
         s = a.element_size()
-        variants = ((0, "default"), (1, "no exchange"), (8, "keep p (fwd)"), (9, "keep p no exch"))
+        variants = ((0, "default"), (1, "no exchange"), (8, "2 exp / elem"), (9, "2 exp no exch"))
         if dt != torch.float32:  # 16-bit values: the half-size tiles at 6 workgroups per CU (tuning key 9 bit 2)
             variants += ((4, "8k tiles x6"), (5, "8k x6 no exch"))
         for dbg, label in variants:
