@@ -56,7 +56,7 @@ def _fold(path):
     return [by[k] for k in sorted(by)]
 
 
-def collect(topology="uniform", feat=128, timeout_s=180):
+def collect(topology="uniform", feat=128, timeout_s=100):
     """-> {"hbm_bytes_per_launch": ..., "read": ..., "write": ..., "kernel_us_profiled": ..., "calibration": {...}}
     or {"error": "..."}; never raises."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
