@@ -327,6 +327,146 @@ __device__ __forceinline__ void rows_small(S *tile, const S *tile_g, const int32
     }
 }
 
+// ---- 16-bit values, h >= 2: two elements per LDS access --------------------------------------------------------------
+// A 32-bit LDS word holds two consecutive elements = the heads (2q % h, 2q % h + 1) of ONE edge (rows start at
+// multiples of h, h even).  A lane that walks words keeps two statistics and touches LDS half as often; lanes whose
+// index agrees modulo h / 2 hold the same pair of heads.  (With one element per lane and access the LDS passes of the
+// multi-row tiles were what bounded the bf16 kernels once a tile held 16 k elements.)
+template <typename S>
+__device__ __forceinline__ void lds_ld2(const S *p, int word, float &a, float &b) {
+    union { uint32_t raw; S e[2]; } u;
+    u.raw = reinterpret_cast<const uint32_t *>(p)[word];
+    a = to_f32<S>(u.e[0]);
+    b = to_f32<S>(u.e[1]);
+}
+template <typename S>
+__device__ __forceinline__ void lds_st2(S *p, int word, float a, float b) {
+    union { uint32_t raw; S e[2]; } u;
+    u.e[0] = from_f32<S>(a);
+    u.e[1] = from_f32<S>(b);
+    reinterpret_cast<uint32_t *>(p)[word] = u.raw;
+}
+
+// wg_piece_lds with two elements per access.  Same contract: every thread returns the statistics of head t % h.
+template <bool BWD, typename S>
+__device__ __forceinline__ float2 wg_piece_lds2(const S *tile, const S *tile_g, int off, int cnt, int h, float *red) {
+    const int t = threadIdx.x, hp = h >> 1;
+    const int w0 = off >> 1, nw = cnt >> 1;  // thread t: words t, t + 256, ... = heads (2t % h, 2t % h + 1)
+    float r0, r1, q0 = 0.f, q1 = 0.f;
+    if constexpr (BWD) {
+        float d0 = 0.f, d1 = 0.f;
+        for (int i = t; i < nw; i += kThreads) {
+            float a0, a1, g0, g1;
+            lds_ld2(tile, w0 + i, a0, a1);
+            lds_ld2(tile_g, w0 + i, g0, g1);
+            d0 = fmaf(a0, g0, d0);
+            d1 = fmaf(a1, g1, d1);
+        }
+        r0 = wg_head_reduce<false>(d0, hp, red);
+        r1 = wg_head_reduce<false>(d1, hp, red);
+    } else {
+        float m0 = -INFINITY, m1 = -INFINITY;
+        for (int i = t; i < nw; i += kThreads) {
+            float a0, a1;
+            lds_ld2(tile, w0 + i, a0, a1);
+            m0 = fmaxf(m0, a0);
+            m1 = fmaxf(m1, a1);
+        }
+        m0 = wg_head_reduce<true>(m0, hp, red);
+        m1 = wg_head_reduce<true>(m1, hp, red);
+        float s0 = 0.f, s1 = 0.f;
+        for (int i = t; i < nw; i += kThreads) {
+            float a0, a1;
+            lds_ld2(tile, w0 + i, a0, a1);
+            s0 += es_exp(a0 - m0);
+            s1 += es_exp(a1 - m1);
+        }
+        r0 = m0;
+        r1 = m1;
+        q0 = wg_head_reduce<false>(s0, hp, red);
+        q1 = wg_head_reduce<false>(s1, hp, red);
+    }
+    // thread t holds the heads (2 (t % hp), 2 (t % hp) + 1): hand them over so that every thread returns head t % h
+    __syncthreads();  // (the reads of `red` by the last reduction are over)
+    if (t < hp) {
+        red[2 * t] = r0;
+        red[2 * t + 1] = r1;
+        red[kWave + 2 * t] = q0;
+        red[kWave + 2 * t + 1] = q1;
+    }
+    __syncthreads();
+    const int hd = t & (h - 1);
+    return make_float2(red[hd], red[kWave + hd]);
+}
+
+// row_in_lds with two elements per access: `lpr` lanes (a power of two, a multiple of h / 2) per row, lane l walks the
+// words l, l + lpr, ... of the row = heads (2l % h, 2l % h + 1).
+template <bool BWD, typename S>
+__device__ __forceinline__ void row_in_lds2(S *tile, const S *tile_g, int base, int cnt, int l, int lpr, int h) {
+    const int hp = h >> 1, w0 = base >> 1, nw = cnt >> 1;
+    if constexpr (BWD) {
+        float d0 = 0.f, d1 = 0.f;
+        for (int j = l; j < nw; j += lpr) {
+            float a0, a1, g0, g1;
+            lds_ld2(tile, w0 + j, a0, a1);
+            lds_ld2(tile_g, w0 + j, g0, g1);
+            d0 = fmaf(a0, g0, d0);
+            d1 = fmaf(a1, g1, d1);
+        }
+        for (int s = lpr >> 1; s >= hp && s > 0; s >>= 1) {
+            d0 += __shfl_xor(d0, s, kWave);
+            d1 += __shfl_xor(d1, s, kWave);
+        }
+        for (int j = l; j < nw; j += lpr) {
+            float a0, a1, g0, g1;
+            lds_ld2(tile, w0 + j, a0, a1);
+            lds_ld2(tile_g, w0 + j, g0, g1);
+            lds_st2(tile, w0 + j, a0 * (g0 - d0), a1 * (g1 - d1));
+        }
+    } else {
+        float m0 = -INFINITY, m1 = -INFINITY;
+        for (int j = l; j < nw; j += lpr) {
+            float a0, a1;
+            lds_ld2(tile, w0 + j, a0, a1);
+            m0 = fmaxf(m0, a0);
+            m1 = fmaxf(m1, a1);
+        }
+        for (int s = lpr >> 1; s >= hp && s > 0; s >>= 1) {
+            m0 = fmaxf(m0, __shfl_xor(m0, s, kWave));
+            m1 = fmaxf(m1, __shfl_xor(m1, s, kWave));
+        }
+        float s0 = 0.f, s1 = 0.f;
+        for (int j = l; j < nw; j += lpr) {
+            float a0, a1;
+            lds_ld2(tile, w0 + j, a0, a1);
+            s0 += es_exp(a0 - m0);
+            s1 += es_exp(a1 - m1);
+        }
+        for (int s = lpr >> 1; s >= hp && s > 0; s >>= 1) {
+            s0 += __shfl_xor(s0, s, kWave);
+            s1 += __shfl_xor(s1, s, kWave);
+        }
+        const float i0 = 1.f / s0, i1 = 1.f / s1;
+        for (int j = l; j < nw; j += lpr) {
+            float a0, a1;
+            lds_ld2(tile, w0 + j, a0, a1);
+            lds_st2(tile, w0 + j, es_exp(a0 - m0) * i0, es_exp(a1 - m1) * i1);
+        }
+    }
+}
+
+template <bool BWD, typename S>
+__device__ __forceinline__ void rows_small2(S *tile, const S *tile_g, const int32_t *rp, int nrows, int64_t e0, int h,
+                                            int lpr, int lthr) {
+    const int ng = kThreads / lpr;
+    const int grp = threadIdx.x / lpr, l = threadIdx.x & (lpr - 1);
+    for (int i = grp; i < nrows; i += ng) {
+        const int len = rp[i + 1] - rp[i];
+        if (len == 0 || len > lthr) continue;  // (group-uniform)
+        row_in_lds2<BWD, S>(tile, tile_g, (int)(rp[i] - e0) * h, len * h, l, lpr, h);
+    }
+}
+
 // ---- 16-byte global vector <-> V floats ------------------------------------------------------------------------
 template <typename T> struct VecOf { static constexpr int V = 16 / sizeof(T); };
 
@@ -584,16 +724,23 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
     const bool head_halo = head_partial && (he - hs) <= halo_max;
     const bool tail_halo = tail_partial && (te - ts) <= halo_max;
     float2 head_tot = make_float2(0.f, 1.f), tail_tot = make_float2(0.f, 1.f);
+    const bool two = sizeof(S) == 2 && h >= 2 && !(p.debug & 16);  // 16-bit values: two elements per LDS access
+    auto piece_lds = [&](int off, int cnt) {
+        if constexpr (sizeof(S) == 2) {
+            if (two) return wg_piece_lds2<BWD, S>(tile, tile_g, off, cnt, h, red);
+        }
+        return wg_piece_lds<BWD, S>(tile, tile_g, off, cnt, h, red);
+    };
     if (head_halo) {
         head_tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
     } else if (head_partial) {
-        const float2 piece = wg_piece_lds<BWD, S>(tile, tile_g, 0, head_end, h, red);
+        const float2 piece = piece_lds(0, head_end);
         if (he - hs <= p.long_edges) publish<BWD>(p, c, 0, piece);
     }
     if (tail_halo) {
         tail_tot = wg_piece_global<T, BWD>(a, g, ts * h, te * h, h, red);
     } else if (tail_partial) {
-        const float2 piece = wg_piece_lds<BWD, S>(tile, tile_g, tail_begin, count - tail_begin, h, red);
+        const float2 piece = piece_lds(tail_begin, count - tail_begin);
         if (te - ts <= p.long_edges) publish<BWD>(p, c, 1, piece);
     }
 
@@ -605,16 +752,22 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
         // -- with 8+ lanes per 15-element row the dependent shuffle chains of a few rows were all a wave had to do)
         const int64_t nrows_all = rc1 - rc0 + 1;
         const int mean_elems = (int)min((int64_t)TILE, (int64_t)(tail_begin - head_end) / nrows_all);
-        int lpr = h;
-        while (lpr < kWave && lpr * 8 < mean_elems) lpr <<= 1;
-        const int lthr = 32 * (lpr / h);  // longer rows: one wave each
+        // (two elements per access: half the lanes cover a row, a lane's step is two elements)
+        int lpr = two ? max(h >> 1, 1) : h;
+        while (lpr < kWave && lpr * (two ? 16 : 8) < mean_elems) lpr <<= 1;
+        const int lthr = two ? 64 * lpr / h : 32 * (lpr / h);  // (<= 32 steps per lane) longer rows: one wave each
         for (int64_t r0 = rc0; r0 <= rc1; r0 += kRowChunk) {
             const int nrows = (int)min((int64_t)kRowChunk, rc1 - r0 + 1);
             __syncthreads();
             if (t == 0) s_nlong = 0;
             for (int i = t; i <= nrows; i += kThreads) rp[i] = p.rowptr[r0 + i];
             __syncthreads();
-            rows_small<BWD, S>(tile, tile_g, rp, nrows, e0, h, lpr, lthr);
+            if constexpr (sizeof(S) == 2) {
+                if (two) rows_small2<BWD, S>(tile, tile_g, rp, nrows, e0, h, lpr, lthr);
+                else rows_small<BWD, S>(tile, tile_g, rp, nrows, e0, h, lpr, lthr);
+            } else {
+                rows_small<BWD, S>(tile, tile_g, rp, nrows, e0, h, lpr, lthr);
+            }
             // Long complete rows of this chunk: one WAVE per row, four at a time, no workgroup barrier.  A tile holds at
             // most TILE / h / 33 <= 496 of them (more than lthr >= 32 edges each): the list cannot overflow.
             for (int i = t; i < nrows; i += kThreads) {
@@ -627,7 +780,13 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
             const int n_long = min(s_nlong, kMaxLong);
             for (int q = t >> 6; q < n_long; q += 4) {
                 const int i2 = s_long[q];
-                row_in_lds<BWD, S>(tile, tile_g, (int)(rp[i2] - e0) * h, (rp[i2 + 1] - rp[i2]) * h, t & (kWave - 1), kWave, h);
+                const int rb = (int)(rp[i2] - e0) * h, rc = (rp[i2 + 1] - rp[i2]) * h;
+                if constexpr (sizeof(S) == 2) {
+                    if (two) row_in_lds2<BWD, S>(tile, tile_g, rb, rc, t & (kWave - 1), kWave, h);
+                    else row_in_lds<BWD, S>(tile, tile_g, rb, rc, t & (kWave - 1), kWave, h);
+                } else {
+                    row_in_lds<BWD, S>(tile, tile_g, rb, rc, t & (kWave - 1), kWave, h);
+                }
             }
         }
     }
@@ -815,7 +974,7 @@ int es_flat_launch(bool bwd, const int32_t *rowptr, const void *a, const void *g
     p.tinfo = (esf::TileInfo *)((char *)ws + 256);
     p.rec = (float2 *)((char *)ws + 256 + es_flat_info_bytes(nnz, h));
     p.long_edges = (int64_t)esf::kKMax * p.tile_e;
-    p.debug = (g_tuning[kTuneEsDebug] & 1) | (g_tuning[kTuneEsSpin] < 0 ? 2 : 0);
+    p.debug = (g_tuning[kTuneEsDebug] & (1 | 16)) | (g_tuning[kTuneEsSpin] < 0 ? 2 : 0);
     p.spin_limit = g_tuning[kTuneEsSpin] > 0 ? (unsigned)g_tuning[kTuneEsSpin] : esf::kSpinLimit;
     constexpr int F32F = esf::TileSize<false, 4>::value, F32B = esf::TileSize<true, 4>::value;  // 8192 / 4096 elements
     constexpr int B16F = esf::TileSize<false, 2>::value, B16B = esf::TileSize<true, 2>::value;  // 16384 / 8192

@@ -19,8 +19,8 @@ for h in (8, 1):
         sm = es_launch("cogdl_hip_edge_softmax_fwd", g.rowptr, a)
         s = a.element_size()
         variants = ((0, "default"), (1, "no exchange"), (8, "2 exp / elem"), (9, "2 exp no exch"))
-        if dt != torch.float32:  # 16-bit values: the half-size tiles at 6 workgroups per CU (tuning key 9 bit 2)
-            variants += ((4, "8k tiles x6"), (5, "8k x6 no exch"))
+        if dt != torch.float32:  # 16-bit values: one element per LDS access (bit 4); half-size tiles at 6 workgroups per CU (bit 2)
+            variants += ((16, "1 elem / LDS op"), (4, "8k tiles x6"))
         for dbg, label in variants:
             lib.cogdl_hip_set_tuning(9, dbg)
             f = timeit(lambda: es_launch("cogdl_hip_edge_softmax_fwd", g.rowptr, a), 10)
