@@ -515,6 +515,159 @@ __global__ __launch_bounds__(kScanThreads) void rt_scan_small_kernel(const uint3
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Small structures (sampled blocks of a mini-batch step: at most 16 k edge slots, 16 k columns): the WHOLE stable
+// transpose by ONE workgroup in ONE launch, everything in LDS -- where the rocPRIM pipeline takes 9 launches (key padding,
+// a block sort, four merges, three look-up kernels) and a captured mini-batch step pays ~4.5 us per dependent launch.
+//   1. column histogram (LDS atomics: integer counts, deterministic) -> exclusive scan -> colptr
+//   2. row of every slot: each non-empty row drops its id at its first slot, a running maximum spreads it
+//   3. two stable 7-bit LSD passes over the packed words (column << 14 | slot): per-wave counters + ballot matching for
+//      the ranks (as rt_downsweep_kernel), the wave totals scanned per digit, the tile reordered through LDS
+//   4. perm = the slot, rowind = its row, straight from the sorted words
+// Layout: wave w owns the slots [1024 w, 1024 (w + 1)), item j of lane l is slot 1024 w + 64 j + l.
+constexpr int kSmThreads = 1024, kSmWaves = 16, kSmItems = 16, kSmTile = kSmThreads * kSmItems;  // 16384 slots
+constexpr int kSmSlotBits = 14, kSmDigit = 7, kSmBins = 1 << kSmDigit;
+
+__global__ __launch_bounds__(kSmThreads) void small_transpose_kernel(const int32_t *__restrict__ rowptr,
+                                                                   const int32_t *__restrict__ colind, int m, int n_cols,
+                                                                   int cap, int padded, int32_t *__restrict__ colptr,
+                                                                   int32_t *__restrict__ rowind, int32_t *__restrict__ perm) {
+    __shared__ __attribute__((aligned(16))) uint32_t buf[kSmTile];  // 64 KB: first the histogram, then the reorder buffer
+    __shared__ uint16_t rowof[kSmTile];                             // 32 KB
+    __shared__ uint32_t cnt[kSmWaves][kSmBins];                     // 8 KB
+    __shared__ uint32_t dstart[kSmBins];
+    __shared__ uint32_t wtot[kSmWaves + 1];
+    const int t = threadIdx.x, lane = t & (kWave - 1), w = t >> 6;
+    const int valid = padded ? min(max(rowptr[m], 0), cap) : cap;
+    const uint32_t pad_key = (uint32_t)n_cols, none_key = (uint32_t)n_cols + 1u;  // (n_cols + 2 <= 16384: 14 key bits)
+    // ---- the slots' words; histogram of the columns
+    uint32_t word[kSmItems];
+    for (int i = t; i < kSmTile; i += kSmThreads) {
+        buf[i] = 0;
+        rowof[i] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kSmItems; ++j) {
+        const int e = w * (kSmItems * kWave) + j * kWave + lane;
+        uint32_t key = none_key;
+        if (e < cap) key = e < valid ? (uint32_t)colind[e] : pad_key;
+        if (key > none_key) key = none_key;  // (a column id outside [0, n_cols): sorted behind everything, never written)
+        word[j] = (key << kSmSlotBits) | (uint32_t)e;
+        if (e < cap && key <= pad_key) atomicAdd(&buf[key], 1u);
+    }
+    for (int r = t; r < m; r += kSmThreads) {  // a non-empty row marks its first slot (distinct slots: no conflicts)
+        const int s0 = rowptr[r], s1 = rowptr[r + 1];
+        if (s0 < s1 && s0 >= 0 && s0 < kSmTile) rowof[s0] = (uint16_t)r;
+    }
+    __syncthreads();
+    // ---- colptr = exclusive scan of the histogram over the columns 0 .. n_cols (thread t: 16 consecutive columns)
+    {
+        uint32_t h[kSmItems], sum = 0;
+#pragma unroll
+        for (int i = 0; i < kSmItems; ++i) {
+            h[i] = buf[t * kSmItems + i];
+            sum += h[i];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int sft = 1; sft < kWave; sft <<= 1) {
+            const uint32_t u = __shfl_up(incl, sft, kWave);
+            if (lane >= sft) incl += u;
+        }
+        if (lane == kWave - 1) wtot[w] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int ww = 0; ww < w; ++ww) run += wtot[ww];
+#pragma unroll
+        for (int i = 0; i < kSmItems; ++i) {
+            const int c = t * kSmItems + i;
+            if (c <= n_cols) colptr[c] = (int32_t)run;
+            run += h[i];
+        }
+    }
+    // ---- rows: running maximum of the marks in slot order (thread t: the 16 consecutive slots 16 t ..)
+    {
+        uint32_t v[kSmItems], mx = 0;
+#pragma unroll
+        for (int i = 0; i < kSmItems; ++i) {
+            mx = max(mx, (uint32_t)rowof[t * kSmItems + i]);
+            v[i] = mx;
+        }
+        uint32_t incl = mx;
+#pragma unroll
+        for (int sft = 1; sft < kWave; sft <<= 1) {
+            const uint32_t u = __shfl_up(incl, sft, kWave);
+            if (lane >= sft) incl = max(incl, u);
+        }
+        __syncthreads();  // (wtot is reused; every thread has read its marks)
+        if (lane == kWave - 1) wtot[w] = incl;
+        __syncthreads();
+        uint32_t before = __shfl_up(incl, 1, kWave);
+        if (lane == 0) before = 0;
+        for (int ww = 0; ww < w; ++ww) before = max(before, wtot[ww]);
+#pragma unroll
+        for (int i = 0; i < kSmItems; ++i) rowof[t * kSmItems + i] = (uint16_t)max(v[i], before);
+    }
+    __syncthreads();  // (buf is free again: the histogram has been read)
+    // ---- two stable LSD passes over the 14 key bits
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int shift = kSmSlotBits + pass * kSmDigit;
+        for (int i = t; i < kSmWaves * kSmBins; i += kSmThreads) (&cnt[0][0])[i] = 0;
+        __syncthreads();
+        uint16_t rank[kSmItems];
+#pragma unroll
+        for (int j = 0; j < kSmItems; ++j) {
+            const uint32_t d = (word[j] >> shift) & (kSmBins - 1);
+            const uint64_t peers = match_digit(d, kSmDigit, true);
+            const int lower = __popcll(peers & lt);
+            const uint32_t before = cnt[w][d];  // (LDS operations of a wave complete in order: read, then the leader's write)
+            rank[j] = (uint16_t)(before + lower);
+            if (lower == 0) cnt[w][d] = before + (uint32_t)__popcll(peers);
+        }
+        __syncthreads();
+        uint32_t tot = 0;
+        if (t < kSmBins) {  // thread t owns digit t: every wave's start inside the digit's run
+#pragma unroll
+            for (int ww = 0; ww < kSmWaves; ++ww) {
+                const uint32_t c = cnt[ww][t];
+                cnt[ww][t] = tot;
+                tot += c;
+            }
+        }
+        uint32_t incl = tot;  // exclusive scan of the totals over the 128 digits (waves 0 and 1)
+#pragma unroll
+        for (int sft = 1; sft < kWave; sft <<= 1) {
+            const uint32_t u = __shfl_up(incl, sft, kWave);
+            if (lane >= sft) incl += u;
+        }
+        if (t < kSmBins && lane == kWave - 1) wtot[w] = incl;
+        __syncthreads();
+        if (t < kSmBins) dstart[t] = incl - tot + (w == 1 ? wtot[0] : 0u);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kSmItems; ++j) {
+            const uint32_t d = (word[j] >> shift) & (kSmBins - 1);
+            buf[dstart[d] + cnt[w][d] + rank[j]] = word[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kSmItems; ++j) word[j] = buf[w * (kSmItems * kWave) + j * kWave + lane];
+        __syncthreads();
+    }
+    // ---- outputs: position p = 1024 w + 64 j + l of the sorted order
+#pragma unroll
+    for (int j = 0; j < kSmItems; ++j) {
+        const int pos = w * (kSmItems * kWave) + j * kWave + lane;
+        const uint32_t e = word[j] & ((1u << kSmSlotBits) - 1u);
+        if (pos < cap && (word[j] >> kSmSlotBits) <= pad_key) {
+            perm[pos] = (int32_t)e;
+            rowind[pos] = (int32_t)rowof[e];
+        }
+    }
+}
+
 struct Geometry {
     int bits, n_pass, dbits;
     int64_t n_tiles, table_len;
@@ -708,6 +861,18 @@ int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int
                            n_cols, colptr);
     else
         hipLaunchKernelGGL(rt_colptr_sorted_kernel, dim3(cb), dim3(256), 0, s, keys_final, colptr, nnz, n_cols);
+    return launch_status();
+}
+
+bool small_transpose_covers(int64_t m, int64_t n_cols, int64_t nnz) {
+    return nnz <= rt::kSmTile && n_cols + 2 <= (int64_t(1) << rt::kSmSlotBits) && m >= 1 && m <= 65535;
+}
+
+// One launch, no workspace.  Preconditions: small_transpose_covers(m, n_cols, nnz).
+int small_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols, int64_t nnz, bool padded,
+                    int32_t *colptr, int32_t *rowind, int32_t *perm, hipStream_t s) {
+    hipLaunchKernelGGL(rt::small_transpose_kernel, dim3(1), dim3(rt::kSmThreads), 0, s, rowptr, colind, (int)m, (int)n_cols,
+                       (int)nnz, padded ? 1 : 0, colptr, rowind, perm);
     return launch_status();
 }
 

@@ -197,6 +197,9 @@ namespace cogdl {  // radix_transpose.hip
 size_t radix_transpose_workspace_bytes(int64_t n_cols, int64_t nnz, bool padded);
 int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols, int64_t nnz, bool padded,
                     int32_t *colptr, int32_t *rowind, int32_t *perm, void *workspace, hipStream_t s);
+bool small_transpose_covers(int64_t m, int64_t n_cols, int64_t nnz);
+int small_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols, int64_t nnz, bool padded,
+                    int32_t *colptr, int32_t *rowind, int32_t *perm, hipStream_t s);
 }
 
 static size_t rocprim_csr2csc_bytes(int64_t n_cols, int64_t nnz) {
@@ -274,6 +277,10 @@ static int csr2csc_impl(const int32_t *rowptr, const int32_t *colind, int64_t m,
     if (radix && m > 0) {
         return radix_transpose(rowptr, colind, m, n_cols, nnz, padded, colptr, rowind, perm, workspace, s);
     }
+    // Up to 16 k slots and columns (the sampled blocks of a mini-batch step): one single-workgroup launch, everything in
+    // LDS (radix_transpose.hip: small_transpose_kernel).  tuning key 10 = 1 keeps the rocPRIM pipeline for A/B runs.
+    if (g_tuning[kTuneCsr2csc] != 1 && small_transpose_covers(m, n_cols, nnz))
+        return small_transpose(rowptr, colind, m, n_cols, nnz, padded, colptr, rowind, perm, s);
     const uint32_t *keys_in = (const uint32_t *)colind;
     if (padded) {  // (the key buffer sits in front of the ordinary layout)
         uint32_t *keys = (uint32_t *)workspace;

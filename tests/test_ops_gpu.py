@@ -21,9 +21,10 @@ def rand(*shape, seed=0, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------ csr2csc
-@pytest.fixture(params=[1, 2, 3, 5], ids=["rocprim-pipeline", "radix-transpose", "radix-transpose-packed-records", "radix-transpose-msd-first"])
+@pytest.fixture(params=[0, 1, 2, 3, 5], ids=["default-by-size", "rocprim-pipeline", "radix-transpose", "radix-transpose-packed-records", "radix-transpose-msd-first"])
 def csc_algo(request):
-    """csr2csc's implementations (tuning key 10; the default picks by size): the rocPRIM sort + row look-up, and the
+    """csr2csc's implementations (tuning key 10; the default picks by size: one single-workgroup launch up to 16 k slots
+    and columns, the rocPRIM pipeline up to 256 k slots, the radix transpose above): the rocPRIM sort + row look-up, and the
     hand-written two-payload radix sort (csrc/radix_transpose.hip) -- LSD, with packed intermediate records from 16 M slots on (3: at
     any size); 5: MSD-first where two passes suffice (column ids of 10..18 bits)."""
     from cogdl_amd import _lib
@@ -43,6 +44,46 @@ def test_csr2csc_bit_exact(oracle, csc_algo, m, n_cols, deg):
     assert np.array_equal(plan.colptr.cpu().numpy(), colptr)
     assert np.array_equal(plan.rowind.cpu().numpy(), rowind)
     assert np.array_equal(plan.perm.cpu().numpy(), perm)
+
+
+@pytest.mark.parametrize("m,n_cols,nnz,kind", [(16000, 16382, 16384, "uniform"), (3, 16382, 16384, "hub-rows"),
+                                               (9000, 40, 16384, "hub-columns"), (12000, 12000, 9000, "empty-rows"),
+                                               (1, 1, 16384, "one-cell"), (65535, 200, 5000, "max-rows"),
+                                               (700, 16383, 16000, "one-column-too-many"), (500, 900, 16385, "one-slot-too-many")])
+def test_csr2csc_small_single_workgroup_kernel(oracle, m, n_cols, nnz, kind):
+    """The one-launch LDS transpose of csrc/radix_transpose.hip (default tuning, up to 16384 slots and 16382 columns) at
+    its boundaries -- full tile, a row of thousands of edges, forty columns taking everything, runs of empty rows, the
+    largest row count -- and just beyond them (those go to the rocPRIM pipeline); plain and fixed-capacity form."""
+    from cogdl_amd import _lib
+
+    _lib.hip().cogdl_hip_set_tuning(10, 0)
+    gen = torch.Generator().manual_seed(nnz + m)
+    if kind == "hub-rows":
+        rows = torch.cat([torch.zeros(9000, dtype=torch.long), torch.full((nnz - 9000 - 5,), 1, dtype=torch.long),
+                          torch.full((5,), 2, dtype=torch.long)])
+    elif kind == "empty-rows":
+        rows = torch.sort(torch.randint(0, m // 10, (nnz,), generator=gen) * 10).values  # nine of ten rows are empty
+    else:
+        rows = torch.sort(torch.randint(0, m, (nnz,), generator=gen)).values
+    cols = torch.randint(0, n_cols, (nnz,), generator=gen)
+    if kind == "hub-columns":
+        cols[::2] = 7
+    rowptr = torch.zeros(m + 1, dtype=torch.long)
+    rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=m), 0)
+    rp, ci = rowptr.int(), cols.int()
+    plan = csr2csc(rp.to(DEV), ci.to(DEV), n_cols)
+    colptr, rowind, _, perm = oracle.csr2csc(rp, ci, None, n_cols=n_cols)
+    assert np.array_equal(plan.colptr.cpu().numpy(), colptr)
+    assert np.array_equal(plan.rowind.cpu().numpy(), rowind)
+    assert np.array_equal(plan.perm.cpu().numpy(), perm)
+    # fixed-capacity form: 300 junk slots behind the last row (only where the result still fits the kernel's tile)
+    if nnz + 300 <= 16384 or nnz > 16384:
+        junk = torch.randint(0, n_cols, (300,), dtype=torch.int32, generator=gen)
+        got = csr2csc(rp.to(DEV), torch.cat([ci, junk]).to(DEV), n_cols, padded=True)
+        assert np.array_equal(got.colptr.cpu().numpy(), colptr)
+        assert np.array_equal(got.rowind[:nnz].cpu().numpy(), rowind) and np.array_equal(got.perm[:nnz].cpu().numpy(), perm)
+        assert int(got.rowind.max()) < m and int(got.rowind.min()) >= 0
+        assert torch.equal(torch.sort(got.perm[nnz:]).values.cpu(), torch.arange(nnz, nnz + 300, dtype=torch.int32))
 
 
 def test_csr2csc_hub_rows_hub_columns_and_runs_of_empty_rows(oracle, csc_algo):
