@@ -39,13 +39,19 @@ feat = torch.randn(n, h, f, device=dev)
 grad = torch.randn(n, h, f, device=dev)
 ar, ac = torch.randn(n, h, device=dev), torch.randn(n, h, device=dev)
 ar_g, ac_g, ft_g = ar.clone().requires_grad_(), ac.clone().requires_grad_(), feat.clone().requires_grad_()
-for _ in range(3):
-    csr_spmm_raw(g.rowptr, g.colind, g.weight, x64)
-    mhspmm_raw(g.rowptr, g.colind, sm, feat)
-    gat_forward(ar, ac, g.rowptr, g.colind, 0.2, feat)
-    mhsddmm_raw(g.rowptr, g.colind, grad, feat)
-    csr_sddmm_raw(g.rowptr, g.colind, y64, x64)
-    out = FusedGATFunction.apply(ar_g, ac_g, g.rowptr, g.colind, g.rowptr, g.colind, 0.2, ft_g)
-    torch.autograd.grad(out, (ar_g, ac_g, ft_g), grad)
-torch.cuda.synchronize()
+OPS = {
+    "csr_spmm": lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x64),
+    "mhspmm": lambda: mhspmm_raw(g.rowptr, g.colind, sm, feat),
+    "gat_fwd": lambda: gat_forward(ar, ac, g.rowptr, g.colind, 0.2, feat),
+    "mhsddmm": lambda: mhsddmm_raw(g.rowptr, g.colind, grad, feat),
+    "csr_sddmm": lambda: csr_sddmm_raw(g.rowptr, g.colind, y64, x64),
+    "gat_bwd": lambda: torch.autograd.grad(FusedGATFunction.apply(ar_g, ac_g, g.rowptr, g.colind, g.rowptr, g.colind, 0.2, ft_g),
+                                           (ar_g, ac_g, ft_g), grad),
+}
+which = sys.argv[1:] or list(OPS)  # (one operator per process narrows a fault under the profiler down)
+for name in which:
+    for _ in range(3):
+        OPS[name]()
+    torch.cuda.synchronize()
+    print("done", name, flush=True)
 print("reddit nnz", nnz)
