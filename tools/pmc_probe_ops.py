@@ -6,10 +6,11 @@ forward / mhsddmm / fused GAT backward at H=8 x F=8, csr_sddmm F=64; three launc
 the counters per kernel: the HBM-side bytes per launch and their rate are the fractions DESIGN.md quotes next to the
 algorithmic ones.
 
-ROUND 3 STATUS: the one attempt to run this under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` ended with "Memory access
-fault by GPU node" inside the profiled process and a hang until the time limit (30 GPU-minutes lost, no counters) -- the
-same operator calls run clean outside the profiler (tools/ops_bench.py, the -m gpu tests).  Not diagnosed; run it under
-a short `timeout` if at all."""
+ROUND 3 STATUS: run with ALL operators in one process under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` this probe ended
+with "Memory access fault by GPU node" and hung until the time limit (30 GPU-minutes lost); run ONE operator per process
+(`python tools/pmc_probe_ops.py <name>`, under a 75 s `timeout`) every operator profiles cleanly -- that is how
+profiles/r03_pmc_ops.json was collected.  The fault of the combined run is not diagnosed.
+"""
 import os
 import sys
 
