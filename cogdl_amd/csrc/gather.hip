@@ -100,12 +100,6 @@ static int launch_rows(const I *ids, const void *src, void *out, int64_t n, int6
     return launch_status();
 }
 
-// out[i, :] = src[perm[i], :] for int32 positions (cogdl_hip_gather_rows: edge values / attention rows through a CSC
-// plan's permutation): the same kernel, rows of row_bytes bytes (a multiple of 4).
-int gather_rows_by_perm(const int32_t *perm, const void *src, void *out, int64_t n, int64_t row_bytes, hipStream_t s) {
-    return launch_rows<int32_t, false>(perm, src, out, n, row_bytes, n, nullptr, s);
-}
-
 }  // namespace cogdl
 
 using namespace cogdl;

@@ -197,7 +197,6 @@ namespace cogdl {  // radix_transpose.hip
 size_t radix_transpose_workspace_bytes(int64_t n_cols, int64_t nnz, bool padded);
 int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols, int64_t nnz, bool padded,
                     int32_t *colptr, int32_t *rowind, int32_t *perm, void *workspace, hipStream_t s);
-int gather_rows_by_perm(const int32_t *perm, const void *src, void *out, int64_t n, int64_t row_bytes, hipStream_t s);  // gather.hip
 bool small_transpose_covers(int64_t m, int64_t n_cols, int64_t nnz);
 int small_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols, int64_t nnz, bool padded,
                     int32_t *colptr, int32_t *rowind, int32_t *perm, hipStream_t s);
@@ -319,11 +318,10 @@ extern "C" int cogdl_hip_gather_rows(const int32_t *perm, const void *src, void 
     const int64_t total = n * h;
     const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
     hipStream_t s = (hipStream_t)stream;
-    // Rows of a multiple of 4 bytes: the vectorised row gather of gather.hip (16-byte vectors where the row allows, four
-    // independent id -> row chains in flight per lane).  The element-wise kernel below ran ONE dependent chain per lane and
-    // trip: 2.0 ms to move the 1.4 GB of a Reddit-sized [E, 8] attention tensor (8.5 % of the roofline).
-    if ((elem_bytes == 4 || elem_bytes == 2) && (h * elem_bytes) % 4 == 0)
-        return gather_rows_by_perm(perm, src, out, n, h * elem_bytes, s);
+    // (Tried in round 3: the vectorised row gather of gather.hip -- 16-byte vectors, four independent id -> row chains in
+    //  flight per lane -- instead of the element-wise kernel below: no faster (Reddit-sized [E, 8] fp32: 3.00 vs 3.00 ms,
+    //  [E] fp32: 2.18 vs 2.03 ms).  A random gather of 4..32-byte rows is bound by the 64 / 128-byte line every row drags
+    //  in, not by latency: 1.15e8 lines x 64 B = 7.3 GB of real traffic for 1.4 GB of useful bytes.)
     if (elem_bytes == 4)
         hipLaunchKernelGGL(gather_rows_kernel<uint32_t>, dim3(blocks), dim3(256), 0, s, perm, (const uint32_t *)src,
                            (uint32_t *)out, total, h);
