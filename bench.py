@@ -10,11 +10,15 @@ N > 1 : configs[4] -- vertex-sharded csr_spmm (1-D row partition, halo rows exch
         overlapped with the local-column SpMM), weak scaling: a fixed papers100M-like shard per GPU (10 % of a row's
         sources in other shards, taken from boundary regions that give a halo of 0.25 x the shard's rows = a
         locality-preserving partition; --remote-frac / --halo-frac set them, the halo volume is reported).
-        value = global nnz * 2 * steps / time (max over ranks).
+        value = global nnz * 2 * steps / time (max over ranks).  Started without a launcher, `bench.py --gpus N` spawns
+        its N ranks itself (torch.distributed.run on 127.0.0.1); a rank count that differs from --gpus is refused.  Two
+        follow-up legs run in child process groups with hard timeouts and land in the same line: worst_case_partition
+        (random partition: (N-1)/N of the sources remote) and configs3_sage_replicas (tools/sage_bench.py --captured).
 
-One JSON line on stdout (rank 0).  Extra objects: roofline (dominant kernel, HIP-event timed inside the timed
-region) and cpu_baseline (the reference's own csr_spmm_cpu, built from /root/reference by oracle/Makefile, timed on
-this host's cores; N=1 only).
+One JSON line on stdout (rank 0).  Extra objects: roofline (dominant kernel, HIP-event timed inside the timed region;
+`traffic` = PMC bytes measured by rocprofv3 passes inside this run; `rmat` and `hbm_resident` = the same kernel on the
+power-law topology and on a shard far beyond the caches) and cpu_baseline (the reference's own csr_spmm_cpu, built from
+/root/reference by oracle/Makefile, timed on this host's cores; N=1 only).
 """
 import argparse
 import json

@@ -621,9 +621,10 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
         g_last_hip_error = (int)e;
         return COGDL_HIP_ELAUNCH;
     };
-    const bool hash_relabel = g_tuning[kTuneSampleRelabel] == 0;
+    // (beyond 6.7e7 positions -- the block prefixes no longer fit one workgroup's LDS scan -- the sort-based form below
+    //  takes over: it has no such limit)
+    const bool hash_relabel = g_tuning[kTuneSampleRelabel] == 0 && w.n_blocks <= kRlMaxBlocks && w.tcap <= (int64_t(1) << 31);
     if (hash_relabel) {
-        if (w.n_blocks > kRlMaxBlocks || w.tcap > (int64_t(1) << 31)) return COGDL_HIP_ERANGE;
         HashTable ht{w.tkey, w.tpos, (uint32_t)(w.tcap - 1)};
         const unsigned prep_blocks = (unsigned)std::min<int64_t>(256, std::max<int64_t>(1, w.tcap / (kRlThreads * 8)));
         hipLaunchKernelGGL(sample_prep_kernel, dim3(prep_blocks), dim3(kRlThreads), 0, s, indptr, node_idx, batch, batch_count,
