@@ -18,7 +18,8 @@ N > 1 : configs[4] -- vertex-sharded csr_spmm (1-D row partition, halo rows exch
 One JSON line on stdout (rank 0).  Extra objects: roofline (dominant kernel, HIP-event timed inside the timed region;
 `traffic` = PMC bytes measured by rocprofv3 passes inside this run; `rmat` and `hbm_resident` = the same kernel on the
 power-law topology and on a shard far beyond the caches) and cpu_baseline (the reference's own csr_spmm_cpu, built from
-/root/reference by oracle/Makefile, timed on this host's cores; N=1 only).
+/root/reference by oracle/Makefile, timed on this host's cores; N=1 only).  The N = 1 line also carries configs3_sage: the
+captured GraphSAGE mini-batch step of configs[3] on this GPU (child interpreter), the base of the replica legs.
 """
 import argparse
 import json
@@ -317,12 +318,29 @@ def bench_single(args):
                 result["gnn_epoch"]["reference_cpu_trainer_ms"] = tr["cpu_reference"]["train_step_ms_median"]
     if not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(g, x_cpu)
+    if not args.no_sage:
+        result["configs3_sage"] = sage_leg()
     if not args.no_shard_base:
         base = shard_base()
         result["weak_scaling_base"] = base
         if "roofline" in base:  # the HBM-RESIDENT number: X of the shard is 7.1 GB, far beyond L2 + Infinity Cache
             result["roofline"]["hbm_resident"] = base.pop("roofline")
     return result
+
+
+def sage_leg(budget_s=240):
+    """`configs3_sage`: BASELINE.json configs[3] on this GPU -- GraphSAGE mini-batch training on the products-shaped graph,
+    the whole sampled step (two sampling hops, feature gather, forward, backward, Adam) replayed as one hipGraph
+    (tools/sage_bench.py --captured, 1024 seeds, child interpreter): the one-GPU base of the replica legs the N > 1 lines
+    carry.  An error or a timeout is reported, it cannot take the line down."""
+    from cogdl_amd.dist import _child_leg
+
+    r = _child_leg([os.path.join(ROOT, "tools", "sage_bench.py"), "--captured", "--batch", "1024", "--steps", "50"], 7, budget_s)
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "batch", "frontier_nodes_per_step",
+            "sampled_edges_per_step", "ms_sampling_alone_rank0", "ms_feature_gather_alone_rank0", "config", "error")
+    if "error" in r:
+        r["error"] = r["error"][-300:]
+    return {k: r[k] for k in keep if k in r}
 
 
 def shard_base(budget_s=200):
@@ -397,7 +415,7 @@ def main():
                          "regions of that total size; <= 0: uniform over the owner shard = worst-case halo)")
     ap.add_argument("--leg", default="main", choices=["main", "worst"], help="(internal) which leg a child interpreter runs")
     ap.add_argument("--no-extra-legs", action="store_true", help="N>1: only the main line (no worst-case partition, no configs[3] leg)")
-    ap.add_argument("--no-sage", action="store_true", help="N>1: skip the configs[3] GraphSAGE replica leg")
+    ap.add_argument("--no-sage", action="store_true", help="skip the configs[3] GraphSAGE leg (N=1: configs3_sage, N>1: the replica leg)")
     ap.add_argument("--worst-case-scale", type=int, default=4, help="N>1: the worst-case leg's shards are 1/this the size")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="launcher self-test: gloo ranks on the host with libcogdl_host kernels and tiny shards (tests only; "
