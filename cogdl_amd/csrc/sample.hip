@@ -582,12 +582,13 @@ static SampleWs carve(void *base, int64_t batch, int64_t cap_edges, int64_t num_
     w.head = (int32_t *)take((size_t)len * 4);
     w.head_of = (int32_t *)take((size_t)len * 4);
     w.temp = take(w.temp_bytes);
+    w.n_blocks = len <= kRlTile1 ? 1 : (len + kRlTile - 1) / kRlTile;
     w.tcap = 2048;
     while (w.tcap < 2 * len) w.tcap <<= 1;
+    if (w.n_blocks > kRlMaxBlocks) w.tcap = 0;  // the sort-based relabelling takes these sizes: no table (it would be GBs)
     w.tkey = (uint32_t *)take((size_t)w.tcap * 4);
     w.tpos = (uint32_t *)take((size_t)w.tcap * 4);
-    w.n_blocks = len <= kRlTile1 ? 1 : (len + kRlTile - 1) / kRlTile;
-    w.blocksum = (int32_t *)take((size_t)w.n_blocks * 4);
+    w.blocksum = (int32_t *)take((size_t)std::min<int64_t>(w.n_blocks, kRlMaxBlocks) * 4);
     w.total = (size_t)(p - (char *)base);
     return w;
 }
@@ -623,7 +624,7 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
     };
     // (beyond 6.7e7 positions -- the block prefixes no longer fit one workgroup's LDS scan -- the sort-based form below
     //  takes over: it has no such limit)
-    const bool hash_relabel = g_tuning[kTuneSampleRelabel] == 0 && w.n_blocks <= kRlMaxBlocks && w.tcap <= (int64_t(1) << 31);
+    const bool hash_relabel = g_tuning[kTuneSampleRelabel] == 0 && w.n_blocks <= kRlMaxBlocks && w.tcap > 0;
     if (hash_relabel) {
         HashTable ht{w.tkey, w.tpos, (uint32_t)(w.tcap - 1)};
         const unsigned prep_blocks = (unsigned)std::min<int64_t>(256, std::max<int64_t>(1, w.tcap / (kRlThreads * 8)));

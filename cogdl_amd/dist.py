@@ -634,11 +634,41 @@ def _child_leg(argv, port_offset, timeout_s):
         return {"error": "timed out after %d s" % timeout_s}
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
     if not lines:
+        if proc.returncode == 0 and int(env.get("RANK", "0")) != 0:
+            return {}  # only rank 0 of a leg prints its line: a clean exit without one is what the other ranks look like
         return {"error": "rc %d: %s" % (proc.returncode, (proc.stderr or proc.stdout)[-400:])}
     try:
         return json.loads(lines[-1])
     except ValueError as e:
         return {"error": "unparsable output: %r" % (e,)}
+
+
+def _any_rank(flag, port_offset, timeout_s=120):
+    """True on EVERY rank iff `flag` is true on at least one of them -- the ranks' vote on whether a follow-up leg has to be
+    repeated in another form, through a TCPStore of its own (the main process group is gone by then; a rank deciding on its
+    own would wait alone in the next leg's rendezvous until the timeout).  None when the vote itself fails."""
+    from datetime import timedelta
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if world == 1:
+        return bool(flag)
+    port = int(os.environ.get("MASTER_PORT", "29533")) + port_offset
+    try:
+        store = dist.TCPStore("127.0.0.1", port, world, rank == 0, timeout=timedelta(seconds=timeout_s))
+        store.add("yes", 1 if flag else 0)
+        store.add("in", 1)
+        deadline = time.time() + timeout_s
+        while store.add("in", 0) < world:
+            if time.time() > deadline:
+                return None
+            time.sleep(0.01)
+        verdict = store.add("yes", 0) > 0
+        store.add("out", 1)
+        while rank == 0 and store.add("out", 0) < world and time.time() < deadline:  # the store lives in rank 0
+            time.sleep(0.01)
+        return verdict
+    except Exception:
+        return None
 
 
 def bench_sharded_spmm(args):
@@ -741,13 +771,23 @@ def bench_sharded_spmm(args):
                           "--remote-frac", repr((world - 1) / world), "--halo-frac", "0",
                           "--steps", str(max(2, args.steps // 2)), "--warmup", "1"], 1, 420)
     sage = None
-    if not cpu and not share and not getattr(args, "no_sage", False):
+    if not getattr(args, "no_sage", False) and not share:
         tool = os.path.join(os.path.dirname(script), "tools", "sage_bench.py")
-        sage = _child_leg([tool, "--captured", "--batch", "1024", "--steps", "50"], 2, 300)
-        if "error" in sage:  # the RCCL all-reduce as a node of the captured graph failed: the eager step with torch DDP
+        captured, eager = [tool, "--captured", "--batch", "1024", "--steps", "50"], [tool, "--batch", "1024", "--steps", "30"]
+        if cpu:  # launcher self-test: stand-ins that exercise the legs' control flow -- the first form fails on rank 1 ONLY
+            captured = ["-c", "import os, sys; r = int(os.environ['RANK']); print('{\"selftest_leg\": \"captured\"}' if r == 0 "
+                              "else ''); sys.exit(1 if r == 1 else 0)"]
+            eager = ["-c", "import os; print('{\"selftest_leg\": \"eager\"}' if os.environ['RANK'] == '0' else '')"]
+        sage = _child_leg(captured, 2, 300)
+        # the RCCL all-reduce as a node of the captured graph failed somewhere: the eager step with torch DDP -- on ALL
+        # ranks or on none (the ranks vote; only rank 0 of a leg prints a line, so a rank cannot tell from its own child)
+        again = _any_rank("error" in sage, 4)
+        if again:
             first = sage
-            sage = _child_leg([tool, "--batch", "1024", "--steps", "30"], 3, 300)
+            sage = _child_leg(eager, 3, 300)
             sage["captured_attempt"] = first
+        elif again is None:
+            sage.setdefault("note", "the ranks' vote on repeating this leg failed; not repeated")
     if rank == 0:
         if "error" not in worst:
             worst = {k: worst[k] for k in ("value", "unit", "ms_per_step", "steps", "n_gpus", "n_ranks_seen", "config",

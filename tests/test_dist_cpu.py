@@ -157,6 +157,10 @@ def test_bench_gpus_n_self_launches_n_ranks_and_its_data_flow_equals_the_global_
     worst = line["worst_case_partition"]
     assert worst.get("n_gpus") == world and worst.get("n_ranks_seen") == world, worst
     assert worst["config"]["remote_frac"] == 0.5 and worst["config"]["halo_frac"] == 0.0
+    # the configs[3] leg's control flow (stand-ins in this mode): its first form fails on rank 1 ONLY while rank 0's child
+    # succeeds -- the ranks vote (dist._any_rank) and ALL repeat the leg in its second form; nobody waits alone
+    sage = line["configs3_sage_replicas"]
+    assert sage["selftest_leg"] == "eager" and sage["captured_attempt"] == {"selftest_leg": "captured"}, sage
     parts = [np.load(os.path.join(str(tmp_path), "b%d.npz" % r)) for r in range(world)]
     n = world * s
     rowptr = np.concatenate([[0]] + [p["rowptr"][1:] + sum(int(q["rowptr"][-1]) for q in parts[:r])
@@ -299,3 +303,21 @@ def test_sage_replicas_ddp_world2(tmp_path):
         opt.step()
     for a, b in zip(p0, model.parameters()):
         np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_any_rank_vote_is_the_same_on_every_rank():
+    """dist._any_rank: every rank gets True iff at least one voted True (TCPStore of its own, no process group)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = ("import os, sys; sys.path.insert(0, %r); from cogdl_amd.dist import _any_rank; "
+            "print('VOTE', _any_rank(os.environ['RANK'] in os.environ['YES'].split(','), 0, 60))" % ROOT)
+    for yes, want in (("", "False"), ("2", "True"), ("0,1,2", "True")):
+        procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True,
+                                  env=dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_PORT=str(port), YES=yes))
+                 for r in range(3)]
+        outs = [p.communicate(timeout=120)[0] for p in procs]
+        assert all("VOTE " + want in o for o in outs), (yes, outs)
