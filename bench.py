@@ -27,7 +27,9 @@ import os
 import sys
 import time
 
-import torch
+T0 = time.time()  # before `import torch` (minutes on a fresh box): the N>1 legs are budgeted against the whole command
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -415,6 +417,8 @@ def main():
                          "regions of that total size; <= 0: uniform over the owner shard = worst-case halo)")
     ap.add_argument("--leg", default="main", choices=["main", "worst"], help="(internal) which leg a child interpreter runs")
     ap.add_argument("--no-extra-legs", action="store_true", help="N>1: only the main line (no worst-case partition, no configs[3] leg)")
+    ap.add_argument("--legs-budget-s", type=float, default=420.0,
+                    help="N>1: no follow-up leg is started once this many seconds have passed (all ranks decide together)")
     ap.add_argument("--no-sage", action="store_true", help="skip the configs[3] GraphSAGE leg (N=1: configs3_sage, N>1: the replica leg)")
     ap.add_argument("--worst-case-scale", type=int, default=4, help="N>1: the worst-case leg's shards are 1/this the size")
     ap.add_argument("--selftest-cpu", action="store_true",
@@ -424,6 +428,7 @@ def main():
                     help="orchestration smoke test on a one-GPU box: all ranks on cuda:0, rows exchanged through gloo (its "
                          "numbers are not multi-GPU numbers)")
     args = ap.parse_args()
+    args.t0 = T0
     args.bench_script = os.path.abspath(__file__)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

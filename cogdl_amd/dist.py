@@ -33,6 +33,8 @@ import time
 import torch
 import torch.distributed as dist
 
+_T_IMPORT = time.time()  # bench legs are budgeted against the time since this process started working
+
 
 # ------------------------------------------------------------------------------------- backends
 class HipBackend:
@@ -715,6 +717,10 @@ def bench_sharded_spmm(args):
                     dump_dir=os.environ.get("COGDL_AMD_SELFTEST_DUMP") if cpu and leg == "main" else None)
     rccl = None if cpu else _rccl_version()
     dist.barrier()
+    t_start = float(getattr(args, "t0", _T_IMPORT))
+    elapsed = torch.tensor([time.time() - t_start], dtype=torch.float64, device=dev if backend_name == "nccl" else "cpu")
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)  # the same figure on every rank: the legs below are skipped by ALL or none
+    elapsed = float(elapsed)
     if own_group:
         dist.destroy_process_group()
     if not cpu:
@@ -763,28 +769,41 @@ def bench_sharded_spmm(args):
     if leg != "main" or world == 1 or getattr(args, "no_extra_legs", False):
         return result
     # ---- follow-up legs, each in child interpreters with their own process group and a hard timeout -----------------
+    # The whole command has to "finish within minutes" (the bench contract): every leg has a hard timeout, and a leg is
+    # not started at all once the budget is gone -- decided on figures every rank shares (the all-reduced time above,
+    # then a vote), never by a rank on its own.
+    budget_s = float(getattr(args, "legs_budget_s", 420.0))
+    if elapsed > budget_s:
+        if rank == 0:
+            result["legs_skipped"] = "main leg took %.0f s of a %.0f s budget" % (elapsed, budget_s)
+        return result
     script = os.path.abspath(getattr(args, "bench_script", "bench.py"))
     common = ["--gpus", str(world), "--feat", str(f)] + (["--selftest-cpu"] if cpu else []) + (["--share-gpu"] if share else [])
     worst_nodes = max(64, shard_nodes // max(1, int(getattr(args, "worst_case_scale", 4))))
     worst = _child_leg([script, "--sharded", "--leg", "worst"] + common
                        + ["--shard-nodes", str(worst_nodes), "--shard-degree", str(degree),
                           "--remote-frac", repr((world - 1) / world), "--halo-frac", "0",
-                          "--steps", str(max(2, args.steps // 2)), "--warmup", "1"], 1, 420)
+                          "--steps", str(max(2, args.steps // 2)), "--warmup", "1"], 1, 240)
     sage = None
-    if not getattr(args, "no_sage", False) and not share:
+    run_sage = not getattr(args, "no_sage", False) and not share
+    if run_sage and _any_rank(time.time() - t_start > budget_s, 5, 60) is not False:
+        run_sage = False
+        if rank == 0:
+            result["legs_skipped"] = "configs3_sage_replicas: the %.0f s budget was spent (or the ranks' vote failed)" % budget_s
+    if run_sage:
         tool = os.path.join(os.path.dirname(script), "tools", "sage_bench.py")
         captured, eager = [tool, "--captured", "--batch", "1024", "--steps", "50"], [tool, "--batch", "1024", "--steps", "30"]
         if cpu:  # launcher self-test: stand-ins that exercise the legs' control flow -- the first form fails on rank 1 ONLY
             captured = ["-c", "import os, sys; r = int(os.environ['RANK']); print('{\"selftest_leg\": \"captured\"}' if r == 0 "
                               "else ''); sys.exit(1 if r == 1 else 0)"]
             eager = ["-c", "import os; print('{\"selftest_leg\": \"eager\"}' if os.environ['RANK'] == '0' else '')"]
-        sage = _child_leg(captured, 2, 300)
+        sage = _child_leg(captured, 2, 180)
         # the RCCL all-reduce as a node of the captured graph failed somewhere: the eager step with torch DDP -- on ALL
         # ranks or on none (the ranks vote; only rank 0 of a leg prints a line, so a rank cannot tell from its own child)
-        again = _any_rank("error" in sage, 4)
+        again = _any_rank("error" in sage, 4, 60)
         if again:
             first = sage
-            sage = _child_leg(eager, 3, 300)
+            sage = _child_leg(eager, 3, 180)
             sage["captured_attempt"] = first
         elif again is None:
             sage.setdefault("note", "the ranks' vote on repeating this leg failed; not repeated")

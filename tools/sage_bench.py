@@ -147,7 +147,9 @@ def main():
     y_all = torch.randint(0, args.classes, (n,), device=dev, generator=gen)
     torch.manual_seed(0)
     model = Sage(args.feat, args.hidden, args.classes).to(dev)
-    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index]) if world > 1 else model
+    # (--captured averages the gradients itself, inside the captured graph: no DDP hooks on the parameters then; the
+    #  replicas start from the same weights because every rank seeds the initialisation alike)
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index]) if world > 1 and not args.captured else model
     opt = torch.optim.Adam(net.parameters(), lr=0.01)
 
     def draw_seeds():
