@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc pmc2 ops epoch e2e sampler
+# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc pmc2 pmcops ops epoch e2e sampler
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -58,4 +58,15 @@ if has pmc2; then
     (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc2_$c" -o pmc -- python "$GRAFT_REPO_ROOT/tools/pmc_probe_es.py") > gpurun_out/pmc2_$c.log 2>&1
   done
   python tools/pmc_by_kernel.py gpurun_out pmc2_ > gpurun_out/pmc2_summary.json 2> gpurun_out/pmc2_summary.err; head -c 3000 gpurun_out/pmc2_summary.json
+fi
+if has pmcops; then
+  # ONE operator per process, each under its own short timeout (a combined run faulted and hung under the profiler in
+  # round 3: tools/pmc_probe_ops.py's header); a pass that times out loses 75 s, not the call
+  for op in csr_spmm mhspmm gat_fwd mhsddmm csr_sddmm gat_bwd; do
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rm -rf gpurun_out/pmcops_${op}_$c
+      (cd /tmp && timeout 75 rocprofv3 --kernel-trace --pmc $c -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmcops_${op}_$c" -o pmc -- python "$GRAFT_REPO_ROOT/tools/pmc_probe_ops.py" $op) > gpurun_out/pmcops_${op}_$c.log 2>&1
+      echo "pmcops $op $c rc=$?"
+    done
+  done
 fi
