@@ -58,3 +58,49 @@ def test_experiment_gcn_cora_shaped_cpu_matches_untouched_reference():
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (lo, lr)
     for k in ("test_acc", "val_acc"):
         assert abs(ours["res"][k] - ref["res"][k]) < 1e-9, (ours["res"], ref["res"])
+
+
+SAGE_SCRIPT = r'''
+import json, os, sys, tempfile
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT)
+from tools import refpkg
+refpkg.setup(install=True)
+import torch
+torch.set_num_threads(4)
+import cogdl.data.data as cdata
+served = cdata.sample_adj_c.__module__
+log = tempfile.NamedTemporaryFile(prefix="cogdl_sampler_pids_", delete=False).name
+inner = cdata.sample_adj_c
+def traced(*a, **k):                      # which PROCESS samples: the reference's loaders fork 4 workers
+    with open(log, "a") as f:
+        f.write("%d\n" % os.getpid())
+    return inner(*a, **k)
+cdata.sample_adj_c = traced
+ds = refpkg.node_dataset(6000, 30000, 32, 5, seed=0)
+res, ms = refpkg.run_experiment(ds, model="graphsage", epochs=3, cpu=True, seed=0, batch_size=256)
+pids = [int(x) for x in open(log).read().split()]
+os.unlink(log)
+print("RESULT " + json.dumps({"losses": res["train_losses"], "test_acc": float(res["test_acc"]), "sampler": served,
+                              "calls": len(pids), "worker_calls": sum(p != os.getpid() for p in pids),
+                              "worker_pids": len({p for p in pids if p != os.getpid()})}))
+'''
+
+
+@pytest.mark.skipif(not refpkg.available(), reason="reference package not present (run `make -C oracle ref`)")
+def test_experiment_graphsage_cpu_samples_in_the_references_forked_loader_workers():
+    """BASELINE.json configs[3]'s model on the reference's CPU path: experiment(model='graphsage') with the reference's
+    own GraphSAGEDataWrapper (cogdl/wrappers/data_wrapper/node_classification/graphsage_dw.py:30-39: NeighborSampler
+    loaders with num_workers=4) on top of cogdl_amd.install().  Graph.sample_adj (cogdl/data/data.py:792-832) then calls
+    this library's host sampler INSIDE the forked worker processes -- HIP-free, fork-safe (SURVEY.md section 8b) -- for the random
+    training hops and the full-neighbourhood test pass (sizes=[-1], Graphsage.inference); training makes progress."""
+    env = dict(os.environ, TORCH_EXTENSIONS_DIR=os.path.join("/tmp", "cogdl_ref_torch_ext"))
+    proc = subprocess.run([sys.executable, "-c", SAGE_SCRIPT, ROOT], capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert proc.returncode == 0 and lines, proc.stdout[-1500:] + proc.stderr[-3000:]
+    r = json.loads(lines[-1][7:])
+    assert r["sampler"] == "cogdl_amd.operators.sample", r
+    assert r["worker_calls"] > 0 and r["worker_pids"] >= 2, r      # sampled in several forked workers, not in the parent
+    losses = r["losses"]
+    assert len(losses) == 3 and all(l == l and abs(l) < 1e3 for l in losses) and losses[-1] < losses[0], r
+    assert 0.0 <= r["test_acc"] <= 1.0
