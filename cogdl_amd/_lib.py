@@ -51,8 +51,14 @@ HIP_SIGNATURES = {
     "cogdl_hip_gspmm": ([_vp] * 5 + [_i32, _vp, _i32, _i32, _vp, _i64, _i64, _i64, _vp, _sz, _vp], _i32),
     "cogdl_hip_gat_fwd_workspace_bytes": ([_i64, _i64, _i64, _i32], _sz),
     "cogdl_hip_gat_fwd": ([_vp] * 5 + [_f32] + [_vp] * 3 + [_i64, _i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
-    "cogdl_hip_gat_bwd_workspace_bytes": ([_i64, _i64, _i64, _i64, _i32], _sz),
+    "cogdl_hip_gat_bwd_workspace_bytes": ([_i64, _i64, _i64, _i64, _i64, _i32], _sz),
     "cogdl_hip_gat_bwd": ([_vp] * 7 + [_f32] + [_vp] * 8 + [_sz, _i64, _i64, _i64, _i64, _i64, _i32, _vp], _i32),
+    "cogdl_hip_gat_dropout_fwd": ([_vp] * 5 + [_f32, _f32, _u64] + [_vp] * 3 + [_i64, _i64, _i64, _i64, _i32, _vp, _sz, _vp],
+                                  _i32),
+    "cogdl_hip_gat_dropout_bwd": ([_vp] * 8 + [_f32, _f32, _u64] + [_vp] * 8
+                                  + [_sz, _i64, _i64, _i64, _i64, _i64, _i32, _vp], _i32),
+    "cogdl_hip_edge_dropout_mask": ([_i64, _i64, _f32, _u64, _vp, _vp], _i32),
+    "cogdl_hip_edge_dropout_mask_host": ([_i64, _i64, _f32, _u64, _vp], _i32),
     "cogdl_hip_csr_fingerprint": ([_vp, _vp, _i64, _i64, _vp, _vp], _i32),
     "cogdl_hip_linear_fwd_f32": ([_vp] * 4 + [_i64, _i64, _i64, _i32, _vp], _i32),
     "cogdl_hip_linear_wgrad_workspace_bytes": ([_i64, _i64, _i64], _sz),
@@ -183,8 +189,19 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-_raw_stream = torch._C._cuda_getCurrentRawStream  # (device index) -> hipStream_t as an int: ~0.3 us; building a
-_STREAM_OBJ = {}                                   # torch.cuda.Stream object (torch.cuda.current_stream) costs ~5 us
+# (device index) -> hipStream_t as an int: ~0.3 us; building a torch.cuda.Stream object (torch.cuda.current_stream) costs
+# ~5 us.  Resolved lazily: a torch build without CUDA/ROCm does not define the symbol, and the host-only paths
+# (libcogdl_host, the CPU reference tests) must still import this module.
+_raw_stream_fn = None
+_STREAM_OBJ = {}
+
+
+def _raw_stream(index):
+    global _raw_stream_fn
+    if _raw_stream_fn is None:
+        _raw_stream_fn = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (
+            lambda i: torch.cuda.current_stream(i).cuda_stream)
+    return _raw_stream_fn(index)
 
 
 def stream_of(t):

@@ -97,7 +97,7 @@ struct GspmmOp {
             s.acc[i] = s.acc[i] + (valid ? msg : 0.f);
         }
     }
-    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *, const LaneVals &) const {}
     __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {

@@ -71,7 +71,7 @@ struct MhsddmmOp {
             if (c.l % kSpan == 0 && j + idx < cnt) out[base + j + idx] = r;
         }
     }
-    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *, const LaneVals &) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &, const State &, int64_t, bool) const {}
     __device__ __forceinline__ void pack(const State &, float (&)[kRec]) const {}

@@ -36,7 +36,7 @@
 //   void fetch(Ctx, Batch&, u, col, e, LaneVals, sub, jj)   issue the loads of edge e (column col) into slot u
 //   void apply(Ctx, State&, Batch, u, valid, e, jpos)       fold slot u (edge e, position jpos in its LPR-chunk)
 //   constant   kLds: floats of LDS scratch per lane (0: none); the group's LPR*kLds floats are passed to chunk_begin
-//   void chunk_begin(Ctx&, State&, base, cnt, my_c, sub, l, lds)   before the gathers of each LPR-chunk of edges
+//   void chunk_begin(Ctx&, State&, base, cnt, my_c, sub, l, lds, lv)   before the gathers of each LPR-chunk of edges
 //                                                 (fused GAT: the chunk's softmax weights, once per (edge, head))
 //   void batch_end(Ctx, State&, base, j, cnt)    after the UNROLL applies of one batch (per-edge outputs: one joint
 //                                                 cross-lane reduction of the batch's partial dot products)
@@ -203,7 +203,7 @@ __device__ __forceinline__ void reduce_edges(const Op &op, typename Op::Ctx &ctx
             my_c = colind[base + l];
             op.lane_load(ctx, lv, base + l);
         }
-        op.chunk_begin(ctx, st, base, cnt, my_c, sub, l, lds);
+        op.chunk_begin(ctx, st, base, cnt, my_c, sub, l, lds, lv);
         for (int j = 0; j < cnt; j += UNROLL) {
             typename Op::Batch b;
             // Issue all UNROLL gathers back to back (no branches: a masked tail slot re-reads the row's last valid

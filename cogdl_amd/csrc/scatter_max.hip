@@ -72,7 +72,7 @@ struct ScatterMaxOp {
             }
         }
     }
-    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *, const LaneVals &) const {}
     __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
@@ -176,7 +176,7 @@ struct ScatterMaxBwdOp {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) s.acc[i] = s.acc[i] + ((take && b.id[u][i] == c.row) ? b.g[u][i] : 0.f);
     }
-    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *, const LaneVals &) const {}
     __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {

@@ -74,7 +74,7 @@ struct SddmmOp {
         const float r = group_sum<LPR>(p);
         if (c.l == jpos) s.my_out = r;
     }
-    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *, const LaneVals &) const {}
     __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &c, State &s, int base, int cnt) const {
         if (c.l < cnt) out[base + c.l] = s.my_out;

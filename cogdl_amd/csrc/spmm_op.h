@@ -105,7 +105,7 @@ struct SpmmOp {
             else s.acc[i] = s.acc[i] + vv;
         }
     }
-    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *) const {}
+    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *, const LaneVals &) const {}
     __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {

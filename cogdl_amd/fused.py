@@ -62,6 +62,7 @@ def uninstall():
             mod.spmm = fn
     _orig.clear()
     uninstall_narrow_side()
+    uninstall_gat_dropout()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -113,3 +114,58 @@ def uninstall_narrow_side():
     for cls, fn in _orig_gcn_forward.items():
         cls.forward = fn
     _orig_gcn_forward.clear()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The branch of GATLayer.forward CogDL's gat model takes BY DEFAULT (attn_drop = 0.5: cogdl/models/nn/gat.py:30):
+#       edge_attention = leakyrelu(h_l[row] + h_r[col]);  edge_softmax;  nn.Dropout;  mhspmm      (gat_layer.py:72-77)
+# The score construction, its autograd (torch's sort-based indexing backward over an [E, H] tensor, twice per layer) and
+# the dropout are the layer's own torch code: on the Reddit-shaped graph they make a training step 370 ms where the
+# operators themselves take ~25.  `install(fused_gat_dropout=True)` rebinds GATLayer.forward (opt-in, like narrow_side:
+# no longer the unchanged layer) so that this branch, too, is ONE fused operator: `fused_gat_dropout_func` -- the dropout
+# mask a pure function of (seed, edge, head), regenerated in the backward; nothing of size [E, H] exists.  Same
+# parameters, same statistics of the mask (each attention element kept with probability 1 - p and scaled by 1/(1 - p),
+# independently), a different random stream than torch's; with attn_drop = 0 or in eval mode it is the reference's own
+# fused branch without the `graph.is_symmetric()` restriction (the operator uses the true transpose).
+_orig_gat_forward = {}
+
+
+def _gat_forward_fused_dropout(self, graph, x):
+    if not (torch.is_tensor(x) and x.is_cuda):
+        return _orig_gat_forward[type(self)](self, graph, x)
+    from .operators.fused_gat import fused_gat_dropout_func
+
+    h = torch.matmul(x, self.W).view(-1, self.nhead, self.out_features)
+    h[torch.isnan(h)] = 0.0
+    h_l = (self.a_l * h).sum(dim=-1)
+    h_r = (self.a_r * h).sum(dim=-1)
+    p = float(self.dropout.p) if self.training else 0.0
+    out = fused_gat_dropout_func(h_l, h_r, graph.row_indptr.int(), graph.col_indices.int(), self.alpha, h, p)
+    out = out.view(out.shape[0], -1)
+    # (the rest of cogdl/layers/gat_layer.py:79-86, unchanged)
+    if self.residual:
+        res = self.residual(x)
+        out += res
+    if self.norm is not None:
+        out = self.norm(out)
+    if self.act is not None:
+        out = self.act(out)
+    return out
+
+
+def install_gat_dropout():
+    """Rebind cogdl.layers.gat_layer.GATLayer.forward to the fused attention-dropout version (install(fused_gat_dropout=True))."""
+    mod = sys.modules.get("cogdl.layers.gat_layer")
+    if mod is None:
+        return False
+    cls = mod.GATLayer
+    if cls.forward is not _gat_forward_fused_dropout:
+        _orig_gat_forward[cls] = cls.forward
+        cls.forward = _gat_forward_fused_dropout
+    return True
+
+
+def uninstall_gat_dropout():
+    for cls, fn in _orig_gat_forward.items():
+        cls.forward = fn
+    _orig_gat_forward.clear()

@@ -36,7 +36,7 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
 _finder = None
 
 
-def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False):
+def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False, fused_gat_dropout=False):
     """Idempotent.  Returns the list of cogdl module names that are now served by cogdl_amd.
     fused_norm=True rebinds the dispatcher function `cogdl.utils.spmm_utils.spmm` itself (opt-in: that is no longer the
     unchanged dispatcher) to cogdl_amd.fused.spmm, which folds `out_norm * x` / `in_norm * x` into the kernel.
@@ -45,6 +45,10 @@ def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False):
     (`check_fused_gat()`, layers/gat_layer.py:68) would otherwise stay dead even with a working fused operator.
     narrow_side=True rebinds GCNLayer.forward (opt-in, like fused_norm: no longer the unchanged layer) to
     cogdl_amd.fused's version, which aggregates at the input width where a layer widens ((A X) W instead of A (X W)).
+    fused_gat_dropout=True rebinds GATLayer.forward (opt-in, same caveat) so that the branch the gat model takes by
+    default -- attn_drop 0.5: leaky_relu(h_l[row] + h_r[col]) -> edge_softmax -> nn.Dropout -> mhspmm,
+    layers/gat_layer.py:72-77 -- is one fused operator with the dropout mask regenerated from a seed (cogdl_amd/fused.py).
+    `import cogdl` (or cogdl.layers) must have happened before; call install() again afterwards otherwise.
     linear=True additionally routes torch.nn.functional.linear -- i.e. the unchanged nn.Linear inside every CogDL
     layer -- through cogdl_amd.linear (hand-written MFMA weight gradient for full-graph shapes)."""
     global _finder
@@ -78,6 +82,10 @@ def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False):
         from . import fused as _fused
 
         _fused.install_narrow_side()
+    if fused_gat_dropout:
+        from . import fused as _fused
+
+        _fused.install_gat_dropout()
     su = sys.modules.get("cogdl.utils.spmm_utils")
     if su is not None:  # force the dispatcher to re-resolve the callables
         for k in ("spmm_flag", "mh_spmm_flag", "fused_gat_flag", "spmm_cpu_flag"):

@@ -6,7 +6,11 @@ when `attn_drop == 0 and graph.is_symmetric()` (layers/gat_layer.py:68) and then
 (row_ptr, col_ind) and again as the "CSC" (utils/spmm_utils.py:258-261).  Here col_ptr/row_ind are accepted
 for signature compatibility but NOT trusted: the backward uses the true, cached transpose of (row_ptr,
 col_ind), so the op is also correct for non-symmetric graphs and sampled blocks.
-Semantics = the unfused path: edge_softmax(LeakyReLU(attn_row[row] + attn_col[col])) then mh_spmm.
+Semantics = the unfused path: edge_softmax(LeakyReLU(attn_row[row] + attn_col[col])) then mh_spmm.  Any H x F (the
+reference's backward has no shape limit, operators/fused_gat.py:28-40).
+
+`fused_gat_dropout_func` adds the attention dropout of the branch CogDL's gat model takes by default (attn_drop 0.5,
+models/nn/gat.py:30; layers/gat_layer.py:72-77) inside the same kernels.
 """
 import torch
 
@@ -16,7 +20,9 @@ from ..plan import PLANS, Fingerprint
 _lib.hip()
 
 
-def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat):
+def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, p=0.0, seed=0):
+    """out [N_dst, H, F], edge_max, edge_sum [N_dst, H].  p > 0: attention dropout inside the kernel, the mask a pure
+    function of (seed, edge position, head) -- see include/cogdl_hip.h."""
     dev = _lib.require_cuda(attn_row, attn_col, row_ptr, col_ind, in_feat)
     if in_feat.dim() != 3 or in_feat.dtype not in _lib.DTYPE_CODE:
         raise _lib.BackendError("in_feat must be [N, H, F] float32/float16/bfloat16")
@@ -30,38 +36,42 @@ def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat):
     edge_sum = torch.empty((v, h), dtype=torch.float32, device=dev)
     nnz, code = col_ind.numel(), _lib.DTYPE_CODE[feat.dtype]
     ws, ws_bytes = _lib.workspace("cogdl_hip_gat_fwd_workspace_bytes", dev, nnz, h, f, code)
+    lib = _lib.hip()
     with _lib.on_device(dev):
-        rc = _lib.hip().cogdl_hip_gat_fwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(attn_row),
-                                          _lib.ptr(attn_col), _lib.ptr(feat), float(negative_slope), _lib.ptr(out),
-                                          _lib.ptr(edge_max), _lib.ptr(edge_sum), v, h, f, nnz, code,
-                                          _lib.ptr(ws), ws_bytes, _lib.stream_of(feat))
+        if p > 0.0:
+            rc = lib.cogdl_hip_gat_dropout_fwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(attn_row),
+                                               _lib.ptr(attn_col), _lib.ptr(feat), float(negative_slope), float(p),
+                                               int(seed), _lib.ptr(out), _lib.ptr(edge_max), _lib.ptr(edge_sum), v, h,
+                                               f, nnz, code, _lib.ptr(ws), ws_bytes, _lib.stream_of(feat))
+        else:
+            rc = lib.cogdl_hip_gat_fwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(attn_row), _lib.ptr(attn_col),
+                                       _lib.ptr(feat), float(negative_slope), _lib.ptr(out), _lib.ptr(edge_max),
+                                       _lib.ptr(edge_sum), v, h, f, nnz, code, _lib.ptr(ws), ws_bytes,
+                                       _lib.stream_of(feat))
     _lib.check(rc, "gat_fwd")
     return out, edge_max, edge_sum
 
 
-def _unfused_backward(negative_slope, row_ptr, col_ind, in_feat, attn_row, attn_col, grad_out):
-    """Shapes the fused backward does not cover: differentiate the composition of the unfused HIP operators."""
-    from .edge_softmax import csr_edge_softmax
-    from .mhspmm import csrmhspmm
-
-    with torch.enable_grad():
-        ar, ac, ft = (t.detach().float().requires_grad_() for t in (attn_row, attn_col, in_feat))
-        deg = (row_ptr[1:] - row_ptr[:-1]).long()
-        row = torch.repeat_interleave(torch.arange(deg.numel(), device=deg.device), deg)
-        score = torch.nn.functional.leaky_relu(ar[row] + ac[col_ind.long()], negative_slope)
-        out = csrmhspmm(row_ptr, col_ind, ft, csr_edge_softmax(row_ptr, score))
-        g_ar, g_ac, g_ft = torch.autograd.grad(out, (ar, ac, ft), grad_out.float())
-    return g_ft, g_ar, g_ac
+def edge_dropout_mask(nnz, heads, p, seed, device):
+    """d[e,h] of the fused dropout as a dense [nnz, heads] fp32 tensor (0 or the keep scale): what
+    `FusedGATFunction` with (p, seed) applies to the attention, for tests and for callers that want the same mask on the
+    unfused operators."""
+    mask = torch.empty((nnz, heads), dtype=torch.float32, device=device)
+    with _lib.on_device(mask.device):
+        rc = _lib.hip().cogdl_hip_edge_dropout_mask(nnz, heads, float(p), int(seed), _lib.ptr(mask),
+                                                    _lib.stream_of(mask))
+    _lib.check(rc, "edge_dropout_mask")
+    return mask
 
 
 class FusedGATFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, negative_slope, in_feat):
+    def forward(ctx, attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, negative_slope, in_feat, p=0.0, seed=0):
         row_ptr, col_ind = _lib.csr_structure(row_ptr, col_ind)
         ctx.fp = Fingerprint(row_ptr, col_ind, in_feat.shape[0])  # before the kernel: lands early for backward
-        out, edge_max, edge_sum = gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat)
+        out, edge_max, edge_sum = gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, p, seed)
         ctx.save_for_backward(row_ptr, col_ind, edge_max, edge_sum, in_feat, attn_row, attn_col, out)
-        ctx.negative_slope = float(negative_slope)
+        ctx.negative_slope, ctx.p, ctx.seed = float(negative_slope), float(p), int(seed)
         return out
 
     @staticmethod
@@ -80,22 +90,43 @@ class FusedGATFunction(torch.autograd.Function):
         grad_ac = torch.empty((n_src, h), dtype=torch.float32, device=dev)
         lib = _lib.hip()
         nnz, code = col_ind.numel(), _lib.DTYPE_CODE[dt]
-        ws_bytes = lib.cogdl_hip_gat_bwd_workspace_bytes(v, h, f, nnz, code)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ws, ws_bytes = _lib.workspace("cogdl_hip_gat_bwd_workspace_bytes", dev, v, n_src, h, f, nnz, code)
         with _lib.on_device(dev):
-            rc = lib.cogdl_hip_gat_bwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(plan.colptr),
-                                       _lib.ptr(plan.rowind), _lib.ptr(ar), _lib.ptr(ac), _lib.ptr(feat),
-                                       ctx.negative_slope, _lib.ptr(edge_max), _lib.ptr(edge_sum), _lib.ptr(o),
-                                       _lib.ptr(g), _lib.ptr(grad_feat), _lib.ptr(grad_ar), _lib.ptr(grad_ac),
-                                       _lib.ptr(ws), ws_bytes, v, n_src, h, f, nnz, code, _lib.stream_of(g))
-        if rc == _lib.EUNSUPPORTED:  # a valid call whose shape the fused backward declines (any other status raises)
-            grad_feat, grad_ar, grad_ac = _unfused_backward(ctx.negative_slope, row_ptr, col_ind, in_feat, attn_row,
-                                                            attn_col, grad_out)
-        else:
-            _lib.check(rc, "gat_bwd")
+            if ctx.p > 0.0:
+                rc = lib.cogdl_hip_gat_dropout_bwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(plan.colptr),
+                                                   _lib.ptr(plan.rowind), _lib.ptr(plan.perm), _lib.ptr(ar),
+                                                   _lib.ptr(ac), _lib.ptr(feat), ctx.negative_slope, ctx.p, ctx.seed,
+                                                   _lib.ptr(edge_max), _lib.ptr(edge_sum), _lib.ptr(o), _lib.ptr(g),
+                                                   _lib.ptr(grad_feat), _lib.ptr(grad_ar), _lib.ptr(grad_ac),
+                                                   _lib.ptr(ws), ws_bytes, v, n_src, h, f, nnz, code,
+                                                   _lib.stream_of(g))
+            else:
+                rc = lib.cogdl_hip_gat_bwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(plan.colptr),
+                                           _lib.ptr(plan.rowind), _lib.ptr(ar), _lib.ptr(ac), _lib.ptr(feat),
+                                           ctx.negative_slope, _lib.ptr(edge_max), _lib.ptr(edge_sum), _lib.ptr(o),
+                                           _lib.ptr(g), _lib.ptr(grad_feat), _lib.ptr(grad_ar), _lib.ptr(grad_ac),
+                                           _lib.ptr(ws), ws_bytes, v, n_src, h, f, nnz, code, _lib.stream_of(g))
+        _lib.check(rc, "gat_bwd")
         return (grad_ar.to(attn_row.dtype), grad_ac.to(attn_col.dtype), None, None, None, None, None,
-                grad_feat.to(in_feat.dtype))
+                grad_feat.to(in_feat.dtype), None, None)
 
 
 def fused_gat_func(attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, negative_slope, in_feat):
     return FusedGATFunction.apply(attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, negative_slope, in_feat)
+
+
+def new_dropout_seed():
+    """A 63-bit seed for one application of the fused attention dropout, drawn from torch's CPU generator: runs are
+    reproducible under torch.manual_seed, and no device synchronisation is involved."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def fused_gat_dropout_func(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, p, seed=None):
+    """`fused_gat_func` with nn.Dropout(p) on the attention (cogdl/layers/gat_layer.py:72-77 as one operator): the mask is
+    a pure function of (seed, edge position, head); seed=None draws one from torch's generator."""
+    if not 0.0 <= p <= 1.0:
+        raise ValueError("dropout probability has to be between 0 and 1, but got %s" % p)
+    if seed is None:
+        seed = new_dropout_seed() if p > 0.0 else 0
+    return FusedGATFunction.apply(attn_row, attn_col, row_ptr, col_ind, None, None, negative_slope, in_feat, float(p),
+                                  int(seed))

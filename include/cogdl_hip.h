@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define COGDL_HIP_ABI_VERSION 4
+#define COGDL_HIP_ABI_VERSION 5
 
 /* Exported with default visibility (the library is built -fvisibility=hidden). */
 #if defined(COGDL_HIP_BUILD)
@@ -263,19 +263,34 @@ COGDL_API int cogdl_hip_gspmm(const int32_t *rowptr, const int32_t *colind, cons
  * Forward workspace (optional): cogdl_hip_gat_fwd_workspace_bytes -- hub rows are then split over whole
  * workgroups and their (max, sum, acc) states merged like flash-attention blocks.
  * Backward needs the CSC view (colptr,rowind from cogdl_hip_csr2csc), the forward
- * output and a workspace of cogdl_hip_gat_bwd_workspace_bytes(v, h, f, nnz, dtype) bytes (D[v,h] plus the
- * long-row scratch of its two passes; a workspace of only v*h floats disables the long-row path).
+ * output and a workspace of cogdl_hip_gat_bwd_workspace_bytes(v, n_src, h, f, nnz, dtype) bytes (D[v,h], the per-tile
+ * partials of the tiled shapes, plus the long-row scratch of its two passes; a workspace without the latter disables
+ * the long-row path).
  * feat / out / grad_out / grad_feat have element type `dtype` (f32, f16 or bf16: read natively, fp32
  * arithmetic, grad_feat rounded once on store); attention vectors, statistics and their gradients are fp32.
- * It returns COGDL_HIP_EUNSUPPORTED for shapes it does not cover (H*F must fit 64 lanes x one 16-byte vector
- * and F/vec must be a power of two unless H == 1); callers then compose the unfused operators.
+ * Any H and F: rows of up to 64 lanes x one 16-byte vector whose heads are a power-of-two number of lanes take one lane
+ * group per row; everything else (8 heads x 64 features, 6 x 12, ...) runs in column tiles with the per-(row, head)
+ * scalars finished by a second small kernel (csrc/gat_tiled.hip) -- the reference's backward has no shape limit
+ * (operators/fused_gat.py:28-40).
+ *
+ * Attention dropout (ABI v5).  CogDL's gat model runs with attn_drop = 0.5 by default (models/nn/gat.py:30), which
+ * sends GATLayer.forward through leaky_relu(h_l[row] + h_r[col]) -> edge_softmax -> nn.Dropout -> mhspmm
+ * (layers/gat_layer.py:72-77).  cogdl_hip_gat_dropout_fwd / _bwd are that composition as ONE forward kernel and two
+ * backward passes:  out[v,h,:] = sum_e d[e,h] * a[e,h] * feat[colind[e],h,:],  d[e,h] = keep(e,h) ? scale : 0.
+ * The mask is a pure function of (seed, e, h) -- Philox4x32-10, csrc/philox.h: counter (e, 0, h / 8, 0), key = seed, the
+ * (h % 8)-th 16-bit piece compared with thresh = round(p * 65536); scale = 65536 / (65536 - thresh) (p = 0.5: 2, as
+ * torch) -- with e the edge's position in (rowptr, colind), so nothing of size [E,H] is stored between forward and
+ * backward: the backward regenerates it (its column pass reads e from `perm`, the CSC-slot -> CSR-position array of
+ * cogdl_hip_csr2csc).  cogdl_hip_edge_dropout_mask writes d[e,h] as a dense [nnz,h] fp32 tensor (tests; callers that
+ * want the same mask on the unfused operators).  h <= 64.  p = 0 is the plain operator.
  * ------------------------------------------------------------------------------------- */
 COGDL_API size_t cogdl_hip_gat_fwd_workspace_bytes(int64_t nnz, int64_t h, int64_t f, int dtype);
 COGDL_API int cogdl_hip_gat_fwd(const int32_t *rowptr, const int32_t *colind, const float *attn_row,
                       const float *attn_col, const void *feat, float negative_slope, void *out,
                       float *edge_max, float *edge_sum, int64_t v, int64_t h, int64_t f, int64_t nnz,
                       int dtype, void *workspace, size_t workspace_bytes, void *stream);
-COGDL_API size_t cogdl_hip_gat_bwd_workspace_bytes(int64_t v, int64_t h, int64_t f, int64_t nnz, int dtype);
+COGDL_API size_t cogdl_hip_gat_bwd_workspace_bytes(int64_t v, int64_t n_src, int64_t h, int64_t f, int64_t nnz,
+                      int dtype);
 COGDL_API int cogdl_hip_gat_bwd(const int32_t *rowptr, const int32_t *colind, const int32_t *colptr,
                       const int32_t *rowind, const float *attn_row, const float *attn_col,
                       const void *feat, float negative_slope, const float *edge_max,
@@ -283,6 +298,20 @@ COGDL_API int cogdl_hip_gat_bwd(const int32_t *rowptr, const int32_t *colind, co
                       void *grad_feat, float *grad_attn_row, float *grad_attn_col,
                       void *workspace, size_t workspace_bytes, int64_t v, int64_t n_src, int64_t h,
                       int64_t f, int64_t nnz, int dtype, void *stream);
+COGDL_API int cogdl_hip_gat_dropout_fwd(const int32_t *rowptr, const int32_t *colind, const float *attn_row,
+                      const float *attn_col, const void *feat, float negative_slope, float p, uint64_t seed,
+                      void *out, float *edge_max, float *edge_sum, int64_t v, int64_t h, int64_t f, int64_t nnz,
+                      int dtype, void *workspace, size_t workspace_bytes, void *stream);
+COGDL_API int cogdl_hip_gat_dropout_bwd(const int32_t *rowptr, const int32_t *colind, const int32_t *colptr,
+                      const int32_t *rowind, const int32_t *perm, const float *attn_row, const float *attn_col,
+                      const void *feat, float negative_slope, float p, uint64_t seed, const float *edge_max,
+                      const float *edge_sum, const void *out, const void *grad_out,
+                      void *grad_feat, float *grad_attn_row, float *grad_attn_col,
+                      void *workspace, size_t workspace_bytes, int64_t v, int64_t n_src, int64_t h,
+                      int64_t f, int64_t nnz, int dtype, void *stream);
+COGDL_API int cogdl_hip_edge_dropout_mask(int64_t nnz, int64_t h, float p, uint64_t seed, float *mask, void *stream);
+/* the same mask into HOST memory, computed on the host by the same code (no GPU needed: CPU tests pin the generator) */
+COGDL_API int cogdl_hip_edge_dropout_mask_host(int64_t nnz, int64_t h, float p, uint64_t seed, float *mask);
 
 /* ---------------------------------------------------------------------------------------
  * Helpers used by the graph-plan cache and the vertex-sharded (multi-GPU) SpMM.

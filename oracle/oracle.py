@@ -70,8 +70,8 @@ class _Sigs:
     oracle_coo2csr_index = ([_vp, _i64, _i64, _vp, _vp], None)
     oracle_sample_adj = ([_vp, _vp, _i64, _vp, _i64, _i64, _i32] + [_vp] * 4 + [_i64, _i64, _vp], _i32)
     oracle_subgraph = ([_vp, _vp, _i64, _vp, _i64] + [_vp] * 3 + [_i64, _vp], _i32)
-    oracle_gat_fwd = ([_vp] * 5 + [_f32] + [_vp] * 2 + [_i64] * 3, None)
-    oracle_gat_bwd = ([_vp] * 7 + [_f32] + [_vp] * 7 + [_i64] * 4, None)
+    oracle_gat_fwd = ([_vp] * 5 + [_f32] + [_vp] * 3 + [_i64] * 3, None)
+    oracle_gat_bwd = ([_vp] * 7 + [_f32] + [_vp] * 9 + [_i64] * 4, None)
     oracle_num_threads = ([], _i32)
 
 
@@ -171,33 +171,75 @@ def mhtranspose(perm, att):
     return out
 
 
-def gat_fwd(rowptr, colind, h_l, h_r, feat, slope, return_att=False):
+def gat_fwd(rowptr, colind, h_l, h_r, feat, slope, return_att=False, drop=None):
+    """drop: nullable [E,H] values of nn.Dropout on the attention (0 / 1/(1-p)), cogdl/layers/gat_layer.py:75."""
     rowptr, colind = _np(rowptr, np.int32), _np(colind, np.int32)
     h_l, h_r, feat = _np(h_l, np.float32), _np(h_r, np.float32), _np(feat, np.float32)
+    drop = None if drop is None else _np(drop, np.float32)
     v, (_, h, f) = rowptr.shape[0] - 1, feat.shape
     out = np.empty((v, h, f), np.float32)
     att = np.empty((int(rowptr[v]), h), np.float32) if return_att else None
-    lib().oracle_gat_fwd(_p(rowptr), _p(colind), _p(h_l), _p(h_r), _p(feat), float(slope), _p(out), _p(att), v, h, f)
+    lib().oracle_gat_fwd(_p(rowptr), _p(colind), _p(h_l), _p(h_r), _p(feat), float(slope), _p(out), _p(att), _p(drop),
+                         v, h, f)
     return (out, att) if return_att else out
 
 
-def gat_bwd(rowptr, colind, h_l, h_r, feat, slope, gout, n_src=None, scales=False):
+def gat_bwd(rowptr, colind, h_l, h_r, feat, slope, gout, n_src=None, scales=False, drop=None):
     """fp64 gradients of the unfused GAT composition -> (grad_feat [n_src,H,F], grad_h_l [V,H], grad_h_r [n_src,H]);
-    scales=True appends the three sums of absolute terms (the base of a floating-point tolerance)."""
+    scales=True appends the three sums of absolute terms (the base of a floating-point tolerance).
+    drop: nullable [E,H] dropout values on the attention, in CSR edge order."""
     rowptr, colind = _np(rowptr, np.int32), _np(colind, np.int32)
     h_l, h_r, feat, gout = (_np(a, np.float32) for a in (h_l, h_r, feat, gout))
+    drop = None if drop is None else _np(drop, np.float32)
     v, (ns, h, f) = rowptr.shape[0] - 1, feat.shape
     n_src = ns if n_src is None else n_src
-    colptr, rowind, _, _ = csr2csc(rowptr, colind, None, n_cols=n_src)
+    colptr, rowind, _, perm = csr2csc(rowptr, colind, None, n_cols=n_src)
+    perm = _np(perm, np.int32)
     grad_feat = np.empty((n_src, h, f), np.float32)
     grad_l, grad_r = np.empty((v, h), np.float32), np.empty((n_src, h), np.float32)
     abs_f = np.empty_like(grad_feat) if scales else None
     abs_l = np.empty_like(grad_l) if scales else None
     abs_r = np.empty_like(grad_r) if scales else None
     lib().oracle_gat_bwd(_p(rowptr), _p(colind), _p(colptr), _p(rowind), _p(h_l), _p(h_r), _p(feat), float(slope),
-                         _p(gout), _p(grad_feat), _p(grad_l), _p(grad_r), _p(abs_f), _p(abs_l), _p(abs_r), v, n_src,
-                         h, f)
+                         _p(gout), _p(grad_feat), _p(grad_l), _p(grad_r), _p(abs_f), _p(abs_l), _p(abs_r), _p(drop),
+                         _p(perm), v, n_src, h, f)
     return (grad_feat, grad_l, grad_r, abs_f, abs_l, abs_r) if scales else (grad_feat, grad_l, grad_r)
+
+
+# ---------------------------------------------------------------------------- attention dropout mask
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123
+    philox.h): ctr [..., 4] uint32, key [..., 2] uint32 -> [..., 4] uint32.  The published algorithm restated in numpy;
+    pinned against Random123's known-answer vectors in tests/test_gat_dropout.py."""
+    m0, m1, w0, w1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+    c = [np.asarray(ctr, np.uint32)[..., i].copy() for i in range(4)]
+    k = [np.asarray(key, np.uint32)[..., i].copy() for i in range(2)]
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            p0 = m0 * c[0].astype(np.uint64)
+            p1 = m1 * c[2].astype(np.uint64)
+            c = [(p1 >> np.uint64(32)).astype(np.uint32) ^ c[1] ^ k[0], p1.astype(np.uint32),
+                 (p0 >> np.uint64(32)).astype(np.uint32) ^ c[3] ^ k[1], p0.astype(np.uint32)]
+            k = [k[0] + w0, k[1] + w1]
+    return np.stack(c, axis=-1)
+
+
+def edge_dropout_mask(nnz, heads, p, seed):
+    """d[e,h] of the fused GAT attention dropout (include/cogdl_hip.h, "Attention dropout"): counter (e, 0, h // 8, 0),
+    key = (seed low, seed high) -> the (h % 8)-th 16-bit piece u; keep iff u >= thresh = round(p * 65536);
+    d = 65536 / (65536 - thresh) where kept, else 0.  -> float32 [nnz, heads]."""
+    thresh = int(np.float32(min(max(np.float32(p) * np.float32(65536.0), 0.0), 65536.0)) + np.float32(0.5))
+    scale = np.float32(0.0) if thresh >= 65536 else np.float32(65536.0) / np.float32(65536 - thresh)
+    out = np.zeros((nnz, heads), np.float32)
+    e = np.arange(nnz, dtype=np.uint32)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], np.uint32)
+    for b in range((heads + 7) // 8):
+        ctr = np.stack([e, np.zeros_like(e), np.full_like(e, b), np.zeros_like(e)], axis=-1)
+        w = philox4x32_10(ctr, np.broadcast_to(key, (nnz, 2)))
+        for j in range(min(8, heads - 8 * b)):
+            u = (w[:, j >> 1] >> np.uint32(16 * (j & 1))) & np.uint32(0xFFFF)
+            out[:, 8 * b + j] = np.where(u >= thresh, scale, np.float32(0.0))
+    return out
 
 
 # ---------------------------------------------------------------------------- scatter max

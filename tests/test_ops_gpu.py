@@ -371,11 +371,14 @@ def _gat_inputs(g, n_src, h, f, seed):
             rand(g.num_nodes, h, f, seed=seed + 3))
 
 
-@pytest.mark.parametrize("h,f", [(8, 8), (4, 8), (1, 41), (2, 16), (1, 64), (4, 16), (3, 5), (8, 32)])
+@pytest.mark.parametrize("h,f", [(8, 8), (4, 8), (1, 41), (2, 16), (1, 64), (4, 16), (3, 5), (8, 32), (6, 12), (8, 64),
+                                 (4, 128), (16, 64), (1, 300)])
 def test_fused_gat_forward_backward(oracle, gat_kernel, h, f):
     """fused_gat_func == edge_softmax(LeakyReLU(attn_row[row] + attn_col[col])) -> mh_spmm  (the oracle's fp64
     composition, cogdl/layers/gat_layer.py:73-77); gradients against float64 autograd of the same maths.
-    (3,5) and (8,32) fall outside the fused backward's shape coverage and exercise the unfused-composition path."""
+    (3,5), (8,32), (6,12), (8,64), (4,128) and (16,64) take the column-tiled backward (csrc/gat_tiled.hip): heads that are
+    not a power-of-two number of lanes, rows wider than one lane group -- the reference's backward has no shape limit
+    (operators/fused_gat.py:28-40)."""
     from cogdl_amd.operators.fused_gat import fused_gat_func
 
     g = synth.random_csr(150, 120, 7, seed=h * 100 + f, weighted=False)
@@ -554,9 +557,9 @@ def test_coo2csr_index_gpu_doc_example_and_errors():
         coo2csr_index(torch.tensor([0, 7], device=DEV), torch.tensor([0, 1], device=DEV), 5)
 
 
-def test_gat_bwd_status_codes_distinguish_unsupported_from_invalid():
-    """COGDL_HIP_EUNSUPPORTED (7) = a valid call whose shape the fused backward declines -> the operator composes the
-    unfused kernels; COGDL_HIP_EINVAL (1) = a bad call -> BackendError, never masked by the fallback."""
+def test_gat_bwd_status_codes():
+    """Every H x F is covered (one lane group per row, or column tiles); COGDL_HIP_EINVAL (1) = a bad call ->
+    BackendError; a workspace without the tiled scratch -> COGDL_HIP_EWORKSPACE."""
     from cogdl_amd import _lib
 
     lib = _lib.hip()
@@ -564,20 +567,21 @@ def test_gat_bwd_status_codes_distinguish_unsupported_from_invalid():
     rp, ci = g.rowptr.to(DEV), g.colind.to(DEV)
     v, nnz = 20, g.nnz
 
-    def call(h, f, null_feat=False):
+    def call(h, f, null_feat=False, short_ws=False):
         t = lambda *s: torch.zeros(*s, device=DEV)  # noqa: E731
         ar, ac, feat, out, go = t(v, h), t(v, h), t(v, h, f), t(v, h, f), t(v, h, f)
         emax, esum, gf, gar, gac = t(v, h), t(v, h) + 1, t(v, h, f), t(v, h), t(v, h)
-        wsb = lib.cogdl_hip_gat_bwd_workspace_bytes(v, h, f, nnz, 0)
+        wsb = lib.cogdl_hip_gat_bwd_workspace_bytes(v, v, h, f, nnz, 0)
         ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
         return lib.cogdl_hip_gat_bwd(_lib.ptr(rp), _lib.ptr(ci), _lib.ptr(rp), _lib.ptr(ci), _lib.ptr(ar), _lib.ptr(ac),
                                      None if null_feat else _lib.ptr(feat), 0.2, _lib.ptr(emax), _lib.ptr(esum),
                                      _lib.ptr(out), _lib.ptr(go), _lib.ptr(gf), _lib.ptr(gar), _lib.ptr(gac),
-                                     _lib.ptr(ws), wsb, v, v, h, f, nnz, 0, _lib.stream_of(rp))
+                                     _lib.ptr(ws), 256 if short_ws else wsb, v, v, h, f, nnz, 0, _lib.stream_of(rp))
 
     assert call(8, 8) == 0
-    assert call(3, 5) == _lib.EUNSUPPORTED == 7
+    assert call(3, 5) == 0 and call(8, 64) == 0
     assert call(8, 8, null_feat=True) == 1
+    assert call(8, 64, short_ws=True) == 5  # COGDL_HIP_EWORKSPACE
     assert lib.cogdl_hip_strerror(7) == b"shape not covered by this entry point"
     torch.cuda.synchronize()
 

@@ -93,6 +93,55 @@ for a, b in zip(grads["fused"], grads["unfused"]):
     np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4)
 report["gat_layer"] = "ok"
 
+# ---- 2b'. install(fused_gat_dropout=True): the branch the gat model takes BY DEFAULT (attn_drop 0.5, models/nn/gat.py:30;
+#           gat_layer.py:72-77) as one fused operator on the same unchanged GATLayer class.
+#           (i) eval mode / p = 0: the reference's CPU output and all four gradients (golden), whatever is_symmetric() says;
+#           (ii) training, p = 0.5: equal to the reference's own unfused branch run with the SAME mask -- the layer's
+#           nn.Dropout replaced by a multiplication with the exported mask of the seed the fused layer drew.
+import cogdl_amd, cogdl_amd.fused
+from cogdl_amd.operators.fused_gat import edge_dropout_mask, new_dropout_seed
+reference_forward = GATLayer.forward
+cogdl_amd.install(fused_gat_dropout=True)
+assert GATLayer.forward is cogdl_amd.fused._gat_forward_fused_dropout
+gat5 = GATLayer(16, 8, nhead=4, attn_drop=0.5, alpha=0.2).to(DEV)
+with torch.no_grad():
+    gat5.W.copy_(T(z["W"])); gat5.a_l.copy_(T(z["a_l"])); gat5.a_r.copy_(T(z["a_r"]))
+g._adj.set_symmetric(False)
+gat5.eval()
+x = T(z["x"]).to(DEV).requires_grad_()
+out = gat5(g, x)
+np.testing.assert_allclose(out.detach().cpu().numpy(), z["out"], rtol=2e-4, atol=2e-5)
+(out * T(z["G"]).to(DEV)).sum().backward()
+for got, key in ((x.grad, "grad_x"), (gat5.W.grad, "grad_W"), (gat5.a_l.grad, "grad_a_l"), (gat5.a_r.grad, "grad_a_r")):
+    np.testing.assert_allclose(got.cpu().numpy(), z[key], rtol=1e-3, atol=1e-4, err_msg=key)
+gat5.train()
+gat5.zero_grad()
+torch.manual_seed(77)
+x = T(z["x"]).to(DEV).requires_grad_()
+out_drop = gat5(g, x)
+(out_drop * T(z["G"]).to(DEV)).sum().backward()
+got = [t.detach().cpu().numpy() for t in (out_drop, x.grad, gat5.W.grad, gat5.a_l.grad, gat5.a_r.grad)]
+assert np.abs(got[0] - z["out"]).max() > 1e-2, "attention dropout had no effect in training mode"
+torch.manual_seed(77)
+mask = edge_dropout_mask(col.numel(), 4, 0.5, new_dropout_seed(), DEV)
+kept = float((mask > 0).float().mean())
+assert 0.45 < kept < 0.55 and float(mask.max()) == 2.0
+class MaskAsDropout(torch.nn.Module):  # stands in for nn.Dropout(0.5) in the reference's own forward
+    p = 0.5
+    def forward(self, att):
+        return att * mask
+gat5.dropout = MaskAsDropout()
+gat5.zero_grad()
+x = T(z["x"]).to(DEV).requires_grad_()
+out_ref = reference_forward(gat5, g, x)
+(out_ref * T(z["G"]).to(DEV)).sum().backward()
+want = [t.detach().cpu().numpy() for t in (out_ref, x.grad, gat5.W.grad, gat5.a_l.grad, gat5.a_r.grad)]
+for a, b, name in zip(got, want, ("out", "grad_x", "grad_W", "grad_a_l", "grad_a_r")):
+    np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4, err_msg="fused dropout vs the reference branch with the same mask: " + name)
+cogdl_amd.fused.uninstall()
+assert GATLayer.forward is reference_forward
+report["gat_layer_fused_dropout"] = "ok"
+
 # ---- 2c. Graph.sample_adj(-1) + SAGELayer(mean) and MaxAggregator on cuda
 z = gold("sage_layer")
 rp = T(z["g_row_indptr"]); deg = rp[1:] - rp[:-1]
@@ -214,7 +263,7 @@ def test_unchanged_reference_layers_and_trainer_run_on_the_hip_operators():
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT ")]
     assert proc.returncode == 0 and lines, proc.stdout[-3000:] + proc.stderr[-5000:]
     rep = json.loads(lines[-1][7:])
-    assert rep["gcn_layer"] == rep["gat_layer"] == rep["sage_layer"] == "ok"
+    assert rep["gcn_layer"] == rep["gat_layer"] == rep["sage_layer"] == rep["gat_layer_fused_dropout"] == "ok"
     assert rep["fused_norm_keeps_weight_grad"] == rep["narrow_side"] == rep["graphsage_inference"] == "ok"
     lg, lc = rep["cora_losses_gpu"], rep["cora_losses_cpu"]
     assert len(lg) == len(lc) == 6

@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs[2] end to end (a profile, not bench.py's contract line): one full-graph training step of
-CogDL's GAT (cogdl/models/nn/gat.py: GATLayer(602 -> 8 x 8 heads, ELU) + GATLayer(64 -> 41 x 1 head); GATLayer.forward,
-cogdl/layers/gat_layer.py:59-86) on the Reddit-shaped graph at its TRUE size (232,965 nodes, 114,848,857 nnz), in fp32
-and in bf16 (configs[2]'s dtype: torch.autocast(bfloat16) around the forward, fp32 master weights -- the layer's matmul
-yields bf16 features, which fused_gat_func / csrmhspmm read and write natively), through the operators a CogDL layer
-would call:
-  fused    attn_drop = 0:   fused_gat_func                      (gat_layer.py:68-70)
-  unfused  attn_drop = 0.5 (the model's default): leaky_relu(h_l[row] + h_r[col]) -> csr_edge_softmax -> dropout ->
-           csrmhspmm        (gat_layer.py:72-77; the gathers / leaky_relu / dropout are torch's)
-plus the bf16 forward (inference) of the fused path.  Usage: python tools/gat_bench.py [--steps 5]"""
+"""BASELINE.json configs[2] end to end: one full-graph training step of CogDL's GAT (cogdl/models/nn/gat.py:
+GATLayer(602 -> 8 x 8 heads, ELU) + GATLayer(64 -> 41 x 1 head); GATLayer.forward, cogdl/layers/gat_layer.py:59-86) on
+the Reddit-shaped graph at its TRUE size (232,965 nodes, 114,848,857 nnz), in fp32 and in bf16 (configs[2]'s dtype:
+torch.autocast(bfloat16) around the forward, fp32 master weights -- the layer's matmul yields bf16 features, which the
+fused operator / csrmhspmm read and write natively), through the operators a CogDL layer would call:
+  fused-dropout  attn_drop = 0.5 (the gat model's DEFAULT, models/nn/gat.py:30) with install(fused_gat_dropout=True):
+                 fused_gat_dropout_func -- score, softmax, dropout (mask regenerated from a seed) and aggregation in one
+                 forward kernel and two backward passes (csrc/gat_op.h)
+  fused          attn_drop = 0:   fused_gat_func                      (gat_layer.py:68-70)
+  unfused        attn_drop = 0.5 on the UNCHANGED layer: leaky_relu(h_l[row] + h_r[col]) -> csr_edge_softmax -> dropout ->
+                 csrmhspmm        (gat_layer.py:72-77; the gathers / leaky_relu / dropout and their autograd are torch's)
+plus the per-kernel roofline figures of configs[2]'s operators in bf16 (SURVEY.md 8d's algorithmic bytes / HIP-event
+time / 8 TB/s): csr_edge_softmax forward / backward on the [E, 8] attention tensor, the fused GAT forward / backward of
+both layers' shapes with and without dropout.
+Usage: python tools/gat_bench.py [--steps 5] [--leg]      (--leg: bench.py's configs2_gat object -- bf16 only, one JSON line)"""
 import argparse
 import json
 import os
@@ -21,16 +26,19 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cogdl_amd import synth  # noqa: E402
 from cogdl_amd.operators.edge_softmax import csr_edge_softmax  # noqa: E402
-from cogdl_amd.operators.fused_gat import fused_gat_func, gat_forward  # noqa: E402
+from cogdl_amd.operators.fused_gat import fused_gat_dropout_func, fused_gat_func  # noqa: E402
 from cogdl_amd.operators.mhspmm import csrmhspmm  # noqa: E402
 
 DEV = "cuda:0"
+HBM_PEAK_GBS = 8000.0
 
 
 class GatLayer(torch.nn.Module):
-    def __init__(self, in_feats, out_feats, nhead, attn_drop, alpha=0.2):
+    """GATLayer.forward's arithmetic (gat_layer.py:59-77) on raw CSR tensors; `mode` picks the branch."""
+
+    def __init__(self, in_feats, out_feats, nhead, attn_drop, mode, alpha=0.2):
         super().__init__()
-        self.nhead, self.out_feats, self.alpha, self.p = nhead, out_feats, alpha, attn_drop
+        self.nhead, self.out_feats, self.alpha, self.p, self.mode = nhead, out_feats, alpha, attn_drop, mode
         self.W = torch.nn.Parameter(torch.randn(in_feats, out_feats * nhead) * (1.0 / in_feats ** 0.5))
         self.a_l = torch.nn.Parameter(torch.randn(1, nhead, out_feats) * 0.1)
         self.a_r = torch.nn.Parameter(torch.randn(1, nhead, out_feats) * 0.1)
@@ -39,7 +47,9 @@ class GatLayer(torch.nn.Module):
         rowptr, colind, row = g
         h = torch.matmul(x, self.W).view(-1, self.nhead, self.out_feats)
         h_l, h_r = (self.a_l * h).sum(dim=-1), (self.a_r * h).sum(dim=-1)
-        if self.p == 0.0:
+        if self.mode == "fused-dropout":
+            out = fused_gat_dropout_func(h_l, h_r, rowptr, colind, self.alpha, h, self.p if self.training else 0.0)
+        elif self.mode == "fused":
             out = fused_gat_func(h_l, h_r, rowptr, colind, rowptr, colind, self.alpha, h)
         else:
             att = F.leaky_relu(h_l[row] + h_r[colind.long()], self.alpha)
@@ -48,9 +58,62 @@ class GatLayer(torch.nn.Module):
         return out.reshape(out.shape[0], -1)
 
 
+def timed(fn, reps, warmup=2):
+    """HIP-event time per call on torch's current stream (the stream the operators launch on)."""
+    for _ in range(warmup):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def kernel_rooflines(gr, n, reps=10):
+    """configs[2]'s operators alone, bf16: algorithmic bytes / time / 8 TB/s."""
+    nnz, out = int(gr.nnz), {}
+
+    def entry(ms, nbytes):
+        ach = nbytes / (ms * 1e-3) / 1e9
+        return {"ms": round(ms, 4), "algorithmic_GB": round(nbytes / 1e9, 3), "achieved_GBs": round(ach, 1),
+                "frac": round(ach / HBM_PEAK_GBS, 4)}
+
+    # csr_edge_softmax on the [E, 8] attention tensor (the unfused branch's softmax), bf16
+    s, h = 2, 8
+    val = torch.randn(nnz, h, device=DEV).bfloat16().requires_grad_()
+    with torch.no_grad():
+        out["edge_softmax_fwd_bf16_H8"] = entry(timed(lambda: csr_edge_softmax(gr.rowptr, val), reps),
+                                                nnz * h * 2 * s + 4 * (n + 1))
+    sm = csr_edge_softmax(gr.rowptr, val)
+    gsm = torch.randn_like(sm)
+    out["edge_softmax_bwd_bf16_H8"] = entry(
+        timed(lambda: torch.autograd.grad(sm, val, gsm, retain_graph=True), reps), nnz * h * 3 * s)
+    del val, sm, gsm
+    # fused GAT forward / backward, both layers' shapes, without and with the attention dropout
+    for h, f in ((8, 8), (1, 41)):
+        ar, ac = torch.randn(n, h, device=DEV).requires_grad_(), torch.randn(n, h, device=DEV).requires_grad_()
+        feat = torch.randn(n, h, f, device=DEV).bfloat16().requires_grad_()
+        gout = torch.randn(n, h, f, device=DEV).bfloat16()
+        b_fwd = nnz * (4 + 4 * h + h * f * s) + n * (4 + 2 * h * 4 + h * f * s)
+        b_bwd = 2 * nnz * (4 + 4 * h + 2 * h * f * s)
+        for p, tag in ((0.0, ""), (0.5, "_dropout")):
+            def fwd():
+                return fused_gat_dropout_func(ar, ac, gr.rowptr, gr.colind, 0.2, feat, p, seed=1)
+            with torch.no_grad():
+                out["gat_fwd%s_bf16_H%dF%d" % (tag, h, f)] = entry(timed(fwd, reps), b_fwd)
+            o = fwd()
+            out["gat_bwd%s_bf16_H%dF%d" % (tag, h, f)] = entry(
+                timed(lambda: torch.autograd.grad(o, (ar, ac, feat), gout, retain_graph=True), reps), b_bwd)
+            del o
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--leg", action="store_true", help="bench.py's configs2_gat object: bf16 only, one JSON line")
     args = ap.parse_args()
     n, feats, classes = 232_965, 602, 41
     gr = synth.reddit_like(seed=0, device=DEV)
@@ -60,11 +123,17 @@ def main():
     y = torch.randint(0, classes, (n,), device=DEV)
     mask = torch.rand(n, device=DEV) < 0.66  # Reddit: 153,431 of 232,965 nodes train
     res = {"graph": {"nodes": n, "nnz": int(gr.nnz), "max_degree": int(deg.max())}}
-    for name, p, amp in (("fused (attn_drop 0) f32", 0.0, None), ("fused (attn_drop 0) bf16", 0.0, torch.bfloat16),
-                         ("unfused (attn_drop 0.5, model default) f32", 0.5, None),
-                         ("unfused (attn_drop 0.5, model default) bf16", 0.5, torch.bfloat16)):
+    variants = [("fused-dropout (attn_drop 0.5 = model default; install(fused_gat_dropout=True)) bf16", "fused-dropout", 0.5, torch.bfloat16),
+                ("fused (attn_drop 0) bf16", "fused", 0.0, torch.bfloat16),
+                ("unfused (attn_drop 0.5 on the unchanged layer) bf16", "unfused", 0.5, torch.bfloat16)]
+    if not args.leg:
+        variants += [("fused-dropout (attn_drop 0.5 = model default; install(fused_gat_dropout=True)) f32", "fused-dropout", 0.5, None),
+                     ("fused (attn_drop 0) f32", "fused", 0.0, None),
+                     ("unfused (attn_drop 0.5 on the unchanged layer) f32", "unfused", 0.5, None)]
+    steps = {}
+    for name, mode, p, amp in variants:
         torch.manual_seed(0)
-        l1, l2 = GatLayer(feats, 8, 8, p).to(DEV), GatLayer(64, classes, 1, p).to(DEV)
+        l1, l2 = GatLayer(feats, 8, 8, p, mode).to(DEV), GatLayer(64, classes, 1, p, mode).to(DEV)
         opt = torch.optim.Adam(list(l1.parameters()) + list(l2.parameters()), lr=0.005)
 
         def step():
@@ -75,35 +144,37 @@ def main():
                 loss = F.cross_entropy(out[mask].float(), y[mask])
             loss.backward()
             opt.step()
+            return loss
 
         for _ in range(2):
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            loss = step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / args.steps * 1e3
-        res[name] = {"ms_per_epoch": ms, "GEdges_per_s_both_layers_fwd_bwd": 4 * gr.nnz / ms / 1e6,
-                     "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}
-        print("%-46s %8.1f ms per full-graph training step" % (name, ms), flush=True)
+        steps[name] = {"ms_per_step": round(ms, 2), "GEdges_per_s_both_layers_fwd_bwd": round(4 * gr.nnz / ms / 1e6, 2),
+                       "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "loss": float(loss)}
+        print("%-90s %8.1f ms per full-graph training step" % (name, ms), file=sys.stderr if args.leg else sys.stdout, flush=True)
         del l1, l2, opt
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
-    # bf16 inference forward of the aggregation (fused path), both layers' shapes
-    for h, f in ((8, 8), (1, 41)):
-        ar, ac = torch.randn(n, h, device=DEV), torch.randn(n, h, device=DEV)
-        feat = torch.randn(n, h, f, device=DEV).bfloat16()
-        for _ in range(2):
-            gat_forward(ar, ac, gr.rowptr, gr.colind, 0.2, feat)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            gat_forward(ar, ac, gr.rowptr, gr.colind, 0.2, feat)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 10 * 1e3
-        res["fused forward bf16 H=%d F=%d" % (h, f)] = {"ms": ms, "GEdges_per_s": gr.nnz / ms / 1e6}
-        print("fused forward bf16 H=%d F=%-3d                 %8.2f ms" % (h, f, ms), flush=True)
+    res["training_step"] = steps
+    res["kernels"] = kernel_rooflines(gr, n)
+    if not args.leg:
+        for k, v in res["kernels"].items():
+            print("%-34s %8.3f ms  %6.1f %% of 8 TB/s (%.2f GB algorithmic)" % (k, v["ms"], 100 * v["frac"], v["algorithmic_GB"]))
+    if args.leg:
+        d = steps[variants[0][0]]
+        res = {"what": "BASELINE configs[2]: 2-layer GAT (602 -> 8 heads x 8 -> 41), Reddit-shaped graph at its true size "
+                       "(232,965 nodes, %d nnz), bf16 autocast, one full-graph training step (forward, loss, backward, Adam)" % gr.nnz,
+               "ms_per_step": d["ms_per_step"], "dtype": "bf16", "steps": args.steps,
+               "ms_per_step_default_args_fused_dropout": d["ms_per_step"],
+               "ms_per_step_attn_drop_0_fused": steps[variants[1][0]]["ms_per_step"],
+               "ms_per_step_default_args_unchanged_layer": steps[variants[2][0]]["ms_per_step"],
+               "peak_mem_GB": {k.split(" ")[0]: v["peak_mem_GB"] for k, v in steps.items()},
+               "roofline": res["kernels"], "graph": res["graph"]}
     print(json.dumps(res))
 
 
