@@ -19,7 +19,9 @@ One JSON line on stdout (rank 0).  Extra objects: roofline (dominant kernel, HIP
 `traffic` = PMC bytes measured by rocprofv3 passes inside this run; `rmat` and `hbm_resident` = the same kernel on the
 power-law topology and on a shard far beyond the caches) and cpu_baseline (the reference's own csr_spmm_cpu, built from
 /root/reference by oracle/Makefile, timed on this host's cores; N=1 only).  The N = 1 line also carries configs3_sage: the
-captured GraphSAGE mini-batch step of configs[3] on this GPU (child interpreter), the base of the replica legs.
+captured GraphSAGE mini-batch step of configs[3] on this GPU (child interpreter), the base of the replica legs, and
+configs2_gat: the GAT training step of configs[2] (Reddit-shaped graph, bf16) with the model's default arguments through
+the fused attention-dropout operator, beside the unchanged layer's time and the per-kernel roofline fractions.
 """
 import argparse
 import json
@@ -320,6 +322,8 @@ def bench_single(args):
                 result["gnn_epoch"]["reference_cpu_trainer_ms"] = tr["cpu_reference"]["train_step_ms_median"]
     if not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(g, x_cpu)
+    if not args.no_gat:
+        result["configs2_gat"] = gat_leg()
     if not args.no_sage:
         result["configs3_sage"] = sage_leg()
     if not args.no_shard_base:
@@ -328,6 +332,22 @@ def bench_single(args):
         if "roofline" in base:  # the HBM-RESIDENT number: X of the shard is 7.1 GB, far beyond L2 + Infinity Cache
             result["roofline"]["hbm_resident"] = base.pop("roofline")
     return result
+
+
+def gat_leg(budget_s=300):
+    """`configs2_gat`: BASELINE.json configs[2] on this GPU -- one full-graph training step of CogDL's 2-layer GAT on the
+    Reddit-shaped graph at its true size, bf16 (tools/gat_bench.py --leg, child interpreter): with the model's DEFAULT
+    arguments (attn_drop 0.5, models/nn/gat.py:30) through the fused attention-dropout operator
+    (install(fused_gat_dropout=True)), with attn_drop 0 through fused_gat_func, and with the default arguments on the
+    unchanged layer (torch's gathers / dropout around csr_edge_softmax + csrmhspmm); `roofline` = the fractions of
+    configs[2]'s kernels alone (edge_softmax forward / backward, fused GAT forward / backward with and without dropout).
+    An error or a timeout is reported, it cannot take the line down."""
+    from cogdl_amd.dist import _child_leg
+
+    r = _child_leg([os.path.join(ROOT, "tools", "gat_bench.py"), "--leg", "--steps", "5"], 8, budget_s)
+    if "error" in r:
+        r["error"] = r["error"][-300:]
+    return r
 
 
 def sage_leg(budget_s=240):
@@ -404,6 +424,7 @@ def main():
     ap.add_argument("--feat", type=int, default=128)
     ap.add_argument("--topology", default="uniform", choices=["uniform", "rmat"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-gat", action="store_true", help="skip the configs2_gat leg (GAT on the Reddit-shaped graph, bf16)")
     ap.add_argument("--no-trainer", action="store_true", help="skip the reference-Trainer epoch legs (gnn_epoch.trainer_ms)")
     ap.add_argument("--no-shard-base", action="store_true", help="skip the weak_scaling_base leg (the sharded path at world size 1)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc passes for roofline.traffic")

@@ -64,33 +64,54 @@ def edge_dropout_mask(nnz, heads, p, seed, device):
     return mask
 
 
+PAD_FEATURES = True  # tests switch it off to drive the kernels at the caller's own (odd, unaligned) widths
+
+
+def _padded_width(f, elem_bytes):
+    """Feature width the kernels run at.  A row of F elements whose byte length is not a multiple of 16 forces narrow,
+    unaligned loads on EVERY gathered row (F = 41 in bf16: 82-byte rows, one 2-byte load per lane: the second layer of
+    the gat model ran at 32 % of the roofline); padding feat once per call to the next multiple of 16 bytes costs a pass
+    over [N, H, F] -- nothing next to the per-edge gathers -- and the padded columns are exact zeros throughout."""
+    if not PAD_FEATURES:
+        return f
+    q = 16 // elem_bytes
+    return (f + q - 1) // q * q
+
+
 class FusedGATFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, negative_slope, in_feat, p=0.0, seed=0):
         row_ptr, col_ind = _lib.csr_structure(row_ptr, col_ind)
         ctx.fp = Fingerprint(row_ptr, col_ind, in_feat.shape[0])  # before the kernel: lands early for backward
-        out, edge_max, edge_sum = gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, p, seed)
-        ctx.save_for_backward(row_ptr, col_ind, edge_max, edge_sum, in_feat, attn_row, attn_col, out)
-        ctx.negative_slope, ctx.p, ctx.seed = float(negative_slope), float(p), int(seed)
-        return out
+        f = in_feat.shape[-1]
+        fp = _padded_width(f, in_feat.element_size()) if in_feat.dim() == 3 and in_feat.dtype in _lib.DTYPE_CODE else f
+        feat = in_feat.detach()
+        if fp != f:
+            feat = torch.nn.functional.pad(feat, (0, fp - f))
+        out, edge_max, edge_sum = gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, feat, p, seed)
+        ctx.save_for_backward(row_ptr, col_ind, edge_max, edge_sum, feat, attn_row, attn_col, out)
+        ctx.negative_slope, ctx.p, ctx.seed, ctx.f = float(negative_slope), float(p), int(seed), f
+        ctx.feat_dtype = in_feat.dtype
+        return out[..., :f].contiguous() if fp != f else out
 
     @staticmethod
     def backward(ctx, grad_out):
-        row_ptr, col_ind, edge_max, edge_sum, in_feat, attn_row, attn_col, out = ctx.saved_tensors
+        row_ptr, col_ind, edge_max, edge_sum, feat, attn_row, attn_col, out = ctx.saved_tensors
         dev = grad_out.device
-        v, (n_src, h, f) = row_ptr.numel() - 1, in_feat.shape
+        v, (n_src, h, fp) = row_ptr.numel() - 1, feat.shape
         # feat / out / grad_out are read in the layer's dtype (bf16 for configs[2]): no fp32 copies
-        dt = in_feat.dtype
-        g = grad_out.contiguous() if grad_out.dtype == dt else grad_out.to(dt).contiguous()
-        feat, o = in_feat.detach().contiguous(), out.detach().contiguous()
+        dt = feat.dtype
+        g = grad_out if grad_out.dtype == dt else grad_out.to(dt)
+        g = torch.nn.functional.pad(g, (0, fp - ctx.f)) if fp != ctx.f else g.contiguous()
+        feat, o = feat.contiguous(), out.contiguous()
         ar, ac = attn_row.detach().contiguous().float(), attn_col.detach().contiguous().float()
         plan = PLANS.get(ctx.fp, row_ptr, col_ind, n_src)
-        grad_feat = torch.empty((n_src, h, f), dtype=dt, device=dev)
+        grad_feat = torch.empty((n_src, h, fp), dtype=dt, device=dev)
         grad_ar = torch.empty((v, h), dtype=torch.float32, device=dev)
         grad_ac = torch.empty((n_src, h), dtype=torch.float32, device=dev)
         lib = _lib.hip()
         nnz, code = col_ind.numel(), _lib.DTYPE_CODE[dt]
-        ws, ws_bytes = _lib.workspace("cogdl_hip_gat_bwd_workspace_bytes", dev, v, n_src, h, f, nnz, code)
+        ws, ws_bytes = _lib.workspace("cogdl_hip_gat_bwd_workspace_bytes", dev, v, n_src, h, fp, nnz, code)
         with _lib.on_device(dev):
             if ctx.p > 0.0:
                 rc = lib.cogdl_hip_gat_dropout_bwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(plan.colptr),
@@ -98,17 +119,19 @@ class FusedGATFunction(torch.autograd.Function):
                                                    _lib.ptr(ac), _lib.ptr(feat), ctx.negative_slope, ctx.p, ctx.seed,
                                                    _lib.ptr(edge_max), _lib.ptr(edge_sum), _lib.ptr(o), _lib.ptr(g),
                                                    _lib.ptr(grad_feat), _lib.ptr(grad_ar), _lib.ptr(grad_ac),
-                                                   _lib.ptr(ws), ws_bytes, v, n_src, h, f, nnz, code,
+                                                   _lib.ptr(ws), ws_bytes, v, n_src, h, fp, nnz, code,
                                                    _lib.stream_of(g))
             else:
                 rc = lib.cogdl_hip_gat_bwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(plan.colptr),
                                            _lib.ptr(plan.rowind), _lib.ptr(ar), _lib.ptr(ac), _lib.ptr(feat),
                                            ctx.negative_slope, _lib.ptr(edge_max), _lib.ptr(edge_sum), _lib.ptr(o),
                                            _lib.ptr(g), _lib.ptr(grad_feat), _lib.ptr(grad_ar), _lib.ptr(grad_ac),
-                                           _lib.ptr(ws), ws_bytes, v, n_src, h, f, nnz, code, _lib.stream_of(g))
+                                           _lib.ptr(ws), ws_bytes, v, n_src, h, fp, nnz, code, _lib.stream_of(g))
         _lib.check(rc, "gat_bwd")
+        if fp != ctx.f:
+            grad_feat = grad_feat[..., :ctx.f].contiguous()
         return (grad_ar.to(attn_row.dtype), grad_ac.to(attn_col.dtype), None, None, None, None, None,
-                grad_feat.to(in_feat.dtype), None, None)
+                grad_feat.to(ctx.feat_dtype), None, None)
 
 
 def fused_gat_func(attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, negative_slope, in_feat):

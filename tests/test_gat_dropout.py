@@ -113,9 +113,13 @@ def _check(oracle, g, n_src, h, f, p, seed, dtype=torch.float32, rtol=2e-5, rtol
 @pytest.mark.gpu
 @pytest.mark.parametrize("h,f", [(8, 8), (4, 8), (1, 41), (2, 16), (1, 64), (4, 16), (3, 5), (8, 32), (6, 12), (8, 64),
                                  (4, 128), (16, 64), (33, 4), (64, 2)])
-def test_fused_gat_dropout_forward_backward_vs_oracle_with_the_same_mask(oracle, gat_kernel, h, f):
+@pytest.mark.parametrize("pad", [True, False], ids=["padded-rows", "raw-width"])
+def test_fused_gat_dropout_forward_backward_vs_oracle_with_the_same_mask(oracle, gat_kernel, h, f, pad, monkeypatch):
     """Tolerance: 2e-5 x the sum of the absolute values of the terms of each output (fp32 accumulation of fp32 inputs;
     the oracle supplies the sums)."""
+    from cogdl_amd.operators import fused_gat
+
+    monkeypatch.setattr(fused_gat, "PAD_FEATURES", pad)
     g = synth.random_csr(150, 120, 7, seed=h * 100 + f, weighted=False)
     _check(oracle, g, 120, h, f, 0.5, seed=1000 + h * f)
 
@@ -142,12 +146,13 @@ def test_fused_gat_dropout_hub_rows(oracle, gat_kernel, hubs, h, f):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_fused_gat_dropout_16bit(oracle, dtype):
+@pytest.mark.parametrize("h,f", [(8, 8), (1, 41), (3, 5)])
+def test_fused_gat_dropout_16bit(oracle, dtype, h, f):
     """configs[2]'s dtype: features / outputs / their gradients in bf16 (read natively, fp32 arithmetic, one rounding on
     store): 2^-7 (bf16) / 2^-10 (f16) x the sum of absolute terms."""
     g = synth.random_csr(200, 200, 9, seed=3, weighted=False)
     tol = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
-    _check(oracle, g, 200, 8, 8, 0.5, seed=21, dtype=dtype, rtol=tol, rtol_g=tol)
+    _check(oracle, g, 200, h, f, 0.5, seed=21, dtype=dtype, rtol=tol, rtol_g=tol)
 
 
 @pytest.mark.gpu

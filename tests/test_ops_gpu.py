@@ -373,14 +373,19 @@ def _gat_inputs(g, n_src, h, f, seed):
 
 @pytest.mark.parametrize("h,f", [(8, 8), (4, 8), (1, 41), (2, 16), (1, 64), (4, 16), (3, 5), (8, 32), (6, 12), (8, 64),
                                  (4, 128), (16, 64), (1, 300)])
-def test_fused_gat_forward_backward(oracle, gat_kernel, h, f):
+@pytest.mark.parametrize("pad", [True, False], ids=["padded-rows", "raw-width"])
+def test_fused_gat_forward_backward(oracle, gat_kernel, h, f, pad, monkeypatch):
     """fused_gat_func == edge_softmax(LeakyReLU(attn_row[row] + attn_col[col])) -> mh_spmm  (the oracle's fp64
     composition, cogdl/layers/gat_layer.py:73-77); gradients against float64 autograd of the same maths.
     (3,5), (8,32), (6,12), (8,64), (4,128) and (16,64) take the column-tiled backward (csrc/gat_tiled.hip): heads that are
     not a power-of-two number of lanes, rows wider than one lane group -- the reference's backward has no shape limit
     (operators/fused_gat.py:28-40)."""
+    from cogdl_amd.operators import fused_gat
     from cogdl_amd.operators.fused_gat import fused_gat_func
 
+    # the autograd operator pads rows to a multiple of 16 bytes (fused_gat._padded_width); "raw-width" drives the kernels
+    # at the caller's own width (odd F, heads of 3 or 5 lanes: the column-tiled backward)
+    monkeypatch.setattr(fused_gat, "PAD_FEATURES", pad)
     g = synth.random_csr(150, 120, 7, seed=h * 100 + f, weighted=False)
     a_row, a_col, feat, gout = _gat_inputs(g, 120, h, f, seed=h + f)
     want = oracle.gat_fwd(g.rowptr, g.colind, a_row, a_col, feat, 0.2)

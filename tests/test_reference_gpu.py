@@ -95,7 +95,8 @@ report["gat_layer"] = "ok"
 
 # ---- 2b'. install(fused_gat_dropout=True): the branch the gat model takes BY DEFAULT (attn_drop 0.5, models/nn/gat.py:30;
 #           gat_layer.py:72-77) as one fused operator on the same unchanged GATLayer class.
-#           (i) eval mode / p = 0: the reference's CPU output and all four gradients (golden), whatever is_symmetric() says;
+#           (i) eval mode / p = 0: the reference's CPU output (golden) and the four gradients of the reference's own
+#           unfused branch on this GPU, whatever is_symmetric() says;
 #           (ii) training, p = 0.5: equal to the reference's own unfused branch run with the SAME mask -- the layer's
 #           nn.Dropout replaced by a multiplication with the exported mask of the seed the fused layer drew.
 import cogdl_amd, cogdl_amd.fused
@@ -112,8 +113,10 @@ x = T(z["x"]).to(DEV).requires_grad_()
 out = gat5(g, x)
 np.testing.assert_allclose(out.detach().cpu().numpy(), z["out"], rtol=2e-4, atol=2e-5)
 (out * T(z["G"]).to(DEV)).sum().backward()
-for got, key in ((x.grad, "grad_x"), (gat5.W.grad, "grad_W"), (gat5.a_l.grad, "grad_a_l"), (gat5.a_r.grad, "grad_a_r")):
-    np.testing.assert_allclose(got.cpu().numpy(), z[key], rtol=1e-3, atol=1e-4, err_msg=key)
+# (gradients: against the reference's fused / unfused GPU branches above -- the golden grad_* come from the reference's
+#  CPU fallback, whose softmax denominator is not differentiated: tests/test_layers_gpu.py documents the discrepancy)
+for got, want_g, key in zip((x.grad, gat5.W.grad, gat5.a_l.grad, gat5.a_r.grad), grads["unfused"], ("x", "W", "a_l", "a_r")):
+    np.testing.assert_allclose(got.cpu().numpy(), want_g, rtol=1e-3, atol=1e-4, err_msg=key)
 gat5.train()
 gat5.zero_grad()
 torch.manual_seed(77)

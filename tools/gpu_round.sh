@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc pmc2 pmcops ops epoch e2e sampler
+# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc pmc2 pmcops ops epoch e2e sampler hunt gat
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -68,5 +68,25 @@ if has pmcops; then
       (cd /tmp && timeout 75 rocprofv3 --kernel-trace --pmc $c -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmcops_${op}_$c" -o pmc -- python "$GRAFT_REPO_ROOT/tools/pmc_probe_ops.py" $op) > gpurun_out/pmcops_${op}_$c.log 2>&1
       echo "pmcops $op $c rc=$?"
     done
+  done
+fi
+if has gat; then
+  timeout 600 python tools/gat_bench.py > gpurun_out/gat_bench.txt 2>&1; tail -25 gpurun_out/gat_bench.txt | cut -c1-400
+fi
+if has hunt; then
+  # The memory fault of round 3's combined PMC probe: the SAME operator sequence in one process, without
+  # the profiler, under allocation layouts / dispatch modes that expose out-of-bounds accesses the caching allocator hides:
+  #   plain      as is
+  #   nocache    every tensor its own hipMalloc (no neighbours from the caching allocator's big blocks)
+  #   serialize  AMD_SERIALIZE_KERNEL=3: one kernel at a time, as the counter collection runs them
+  # each under a hard 200 s limit (-s KILL); the logs say which operator was running when a fault hit.
+  for mode in plain nocache serialize; do
+    case $mode in
+      plain) envs="" ;;
+      nocache) envs="PYTORCH_NO_CUDA_MEMORY_CACHING=1" ;;
+      serialize) envs="AMD_SERIALIZE_KERNEL=3" ;;
+    esac
+    env $envs timeout -s KILL 200 python tools/pmc_probe_ops.py > gpurun_out/hunt_$mode.log 2>&1
+    echo "hunt $mode rc=$? $(grep -c -i 'memory access fault' gpurun_out/hunt_$mode.log) fault line(s); last: $(grep done gpurun_out/hunt_$mode.log | tail -1)"
   done
 fi
