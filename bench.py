@@ -408,9 +408,32 @@ def self_launch(args):
         have = torch.cuda.device_count()
         if have < n:
             raise SystemExit("bench.py --gpus %d needs %d devices, this host has %d" % (n, n, have))
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
+    # The follow-up legs and votes use MASTER_PORT + 1 .. + 8 (cogdl_amd/dist.py: _child_leg / _any_rank offsets): reserve a
+    # base whose whole range is free NOW (all nine bound at once), instead of finding a collision as a leg timeout later.
+    port = None
+    for _ in range(64):
+        with socket.socket() as probe:
+            probe.bind(("127.0.0.1", 0))
+            base = probe.getsockname()[1]
+        if base + 8 > 65535:
+            continue
+        held = []
+        try:
+            for off in range(9):
+                sk = socket.socket()
+                sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                sk.bind(("127.0.0.1", base + off))
+                held.append(sk)
+            port = base
+        except OSError:
+            pass
+        finally:
+            for sk in held:
+                sk.close()
+        if port is not None:
+            break
+    if port is None:
+        raise SystemExit("bench.py: no run of 9 free TCP ports on 127.0.0.1 for the ranks' rendezvous and the follow-up legs")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd)

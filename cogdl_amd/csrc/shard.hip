@@ -62,11 +62,18 @@ __global__ __launch_bounds__(256) void shard_rows_kernel(const int64_t *__restri
                                                          int32_t *__restrict__ cnt_rem, int32_t *__restrict__ mark,
                                                          int32_t *__restrict__ colind_loc, W *__restrict__ w_loc,
                                                          int32_t *__restrict__ colind_rem, W *__restrict__ w_rem,
-                                                         int *__restrict__ flags) {
+                                                         int *__restrict__ flags, int64_t nnz) {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_local) return;
-    const int64_t start = rowptr[r] - rowptr[0], end = rowptr[r + 1] - rowptr[0];  // (rowptr may be a slice of a global one)
+    int64_t start = rowptr[r] - rowptr[0], end = rowptr[r + 1] - rowptr[0];  // (rowptr may be a slice of a global one)
+    // The caller's row pointer is validated HERE, before anything is read through it: a row that runs backwards or out
+    // of col[0, nnz), or a last row that does not end at nnz, raises flag bit 2 and is treated as empty (both passes
+    // agree, so the counts and the fill stay consistent); the host raises on the flag word.
+    if (start < 0 || end < start || end > nnz || (r == n_local - 1 && end != nnz)) {
+        if (lane == 0) atomicOr(flags, 2);
+        start = end = 0;
+    }
     int64_t at_loc = FILL ? cnt_loc[r] : 0, at_rem = FILL ? cnt_rem[r] : 0;        // (FILL: the scanned counts)
     int32_t n_loc = 0, n_rem = 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -205,7 +212,7 @@ extern "C" int cogdl_hip_shard_count(const int64_t *rowptr, const int64_t *col, 
     if (n_local > 0)
         hipLaunchKernelGGL((shard_rows_kernel<false, float>), dim3((unsigned)((n_local + 3) / 4)), dim3(256), 0, s, rowptr, col,
                            (const float *)nullptr, n_local, lo, hi, n_global, w.cnt_loc, w.cnt_rem, w.mark, (int32_t *)nullptr,
-                           (float *)nullptr, (int32_t *)nullptr, (float *)nullptr, flags);
+                           (float *)nullptr, (int32_t *)nullptr, (float *)nullptr, flags, nnz);
     size_t tb = w.temp_bytes;
     e = rocprim::exclusive_scan(w.temp, tb, w.cnt_loc, w.cnt_loc, int32_t(0), (size_t)(n_local + 1), rocprim::plus<int32_t>(), s);
     if (e != hipSuccess) return fail(e);
@@ -235,7 +242,7 @@ extern "C" int cogdl_hip_shard_fill(const int64_t *rowptr, const int64_t *col, c
     if (n_local > 0)
         hipLaunchKernelGGL((shard_rows_kernel<true, float>), dim3((unsigned)((n_local + 3) / 4)), dim3(256), 0, s, rowptr, col,
                            weight, n_local, lo, hi, n_global, w.cnt_loc, w.cnt_rem, w.mark, colind_loc, w_loc, colind_rem, w_rem,
-                           flags);
+                           flags, nnz);
     const unsigned blocks = (unsigned)std::min<int64_t>((std::max(n_global, n_bounds) + 255) / 256, 1 << 16);
     hipLaunchKernelGGL(shard_halo_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, s, w.mark, n_global, halo_ids, bounds,
                        n_bounds, cut);

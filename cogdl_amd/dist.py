@@ -133,6 +133,27 @@ def _csr_from_sorted_rows(rows, n_rows):
     return rowptr
 
 
+def _raise_on_shard_flags(flags, n_global, what):
+    """The flag word of cogdl_hip_shard_count (csrc/shard.hip): bit 0 = a column id outside [0, n_global), bit 1 = a
+    row pointer that runs backwards, out of col[0, nnz), or does not end at nnz.  The kernel validates BEFORE it reads
+    through the pointers (offending rows / columns are skipped), the host raises here."""
+    from . import _lib
+
+    if flags & 2:
+        raise _lib.BackendError("%s: rowptr is not a non-decreasing CSR row pointer ending at nnz = colind.numel()" % what)
+    if flags & 1:
+        raise _lib.BackendError("%s: a column id lies outside [0, %d)" % (what, n_global))
+
+
+def _check_csr_pointer(rp, nnz, what):
+    """Host-side validation for the one-off preprocessing entry points whose kernels take no nnz (bfs_order): one
+    reduction and one synchronisation per GRAPH, before any raw pointer is handed out."""
+    from . import _lib
+
+    if rp.numel() < 1 or int(rp[0]) != 0 or int(rp[-1]) != nnz or not bool((rp[1:] >= rp[:-1]).all()):
+        raise _lib.BackendError("%s: rowptr must start at 0, be non-decreasing and end at colind.numel() = %d" % (what, nnz))
+
+
 # ------------------------------------------------------------------------------------ the shard
 class ShardedCSR:
     """One rank's shard of a row-partitioned CSR matrix plus its halo exchange plan."""
@@ -156,10 +177,24 @@ class ShardedCSR:
             raise _lib.BackendError("ShardedCSR: rowptr has %d entries, this rank owns %d rows" % (rowptr.numel(), self.n_local))
         if weight is not None and weight.numel() != colind_global.numel():
             raise _lib.BackendError("ShardedCSR: %d weights for %d edges" % (weight.numel(), colind_global.numel()))
-        if colind_global.is_cuda and isinstance(self.backend, HipBackend):
-            halo_ids, cut = self._split_hip(rowptr, colind_global, weight, bounds, lo, hi, blist[-1])
-        else:  # CPU tensors (gloo tests, HostBackend): the same split with torch expressions
-            halo_ids, cut = self._split_torch(rowptr, colind_global, weight, bounds, lo, hi)
+        # A rank that raised here on its own would leave its peers blocked in the exchanges below: every rank validates
+        # and splits locally, the ranks agree on the outcome with one all-reduce, and then ALL of them raise or none.
+        err = None
+        try:
+            if colind_global.is_cuda and isinstance(self.backend, HipBackend):
+                halo_ids, cut = self._split_hip(rowptr, colind_global, weight, bounds, lo, hi, blist[-1])
+            else:  # CPU tensors (gloo tests, HostBackend): the same split with torch expressions
+                _check_csr_pointer(rowptr.to(torch.long) - rowptr[0].to(torch.long), colind_global.numel(), "ShardedCSR")
+                halo_ids, cut = self._split_torch(rowptr, colind_global, weight, bounds, lo, hi)
+        except (_lib.BackendError, RuntimeError) as e:
+            err = e
+        bad = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
+        if self.world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+        if err is not None:
+            raise err
+        if int(bad.item()):
+            raise _lib.BackendError("ShardedCSR: another rank rejected its shard (invalid row pointer / column ids); all ranks stop")
         self.n_halo = int(halo_ids.numel())
         self.nnz_local, self.nnz_remote = int(self.colind_loc.numel()), int(self.colind_rem.numel())
         # how many halo rows come from each owner, and which of MY rows each peer wants
@@ -206,8 +241,7 @@ class ShardedCSR:
                                            _lib.ptr(counts), _lib.ptr(ws), ws_bytes, stream)
         _lib.check(rc, "shard_count")
         n_loc, n_rem, n_halo, flags = counts.tolist()  # the one synchronisation of building a shard
-        if flags:
-            raise _lib.BackendError("ShardedCSR: a column id lies outside [0, %d)" % n_global)
+        _raise_on_shard_flags(flags, n_global, "ShardedCSR")
 
         def i32(n):
             return torch.empty(n, dtype=torch.int32, device=dev)
@@ -327,6 +361,7 @@ def bfs_order(rowptr, colind, sources=None, max_levels=1 << 20):
         raise _lib.BackendError("bfs_order: the graph must live on the GPU")
     n = rowptr.numel() - 1
     rp, ci = rowptr.to(torch.long).contiguous(), colind.to(torch.long).contiguous()
+    _check_csr_pointer(rp, ci.numel(), "bfs_order")  # (cogdl_hip_bfs_step reads col[rowptr[u] .. rowptr[u+1]) unguarded)
     level = torch.full((n,), -1, dtype=torch.int32, device=dev)
     changed = torch.zeros(1, dtype=torch.int32, device=dev)
     src = torch.zeros(1, dtype=torch.long, device=dev) if sources is None else sources.to(dev).long()
@@ -390,6 +425,7 @@ def halo_rows(rowptr, colind, bounds):
     dev = rowptr.device
     lib = _lib.hip()
     rp, ci = rowptr.to(torch.long).contiguous(), colind.to(torch.long).contiguous()
+    _check_csr_pointer(rp, ci.numel(), "halo_rows")  # (the per-rank slices below are cut with rp's own entries)
     blist = [int(v) for v in bounds.tolist()]
     n_global = blist[-1]
     out = []
@@ -404,6 +440,7 @@ def halo_rows(rowptr, colind, bounds):
                                            _lib.ptr(counts), _lib.ptr(ws), ws_bytes, torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(rc, "shard_count")
         c = counts.tolist()
+        _raise_on_shard_flags(c[3], n_global, "halo_rows")
         out.append((c[1], c[2]))
     return out
 

@@ -9,7 +9,10 @@ no atomics, per output element the edges are added in the caller's edge order.  
 sort done once per edge list (cogdl_hip_coo2csr_index) and memoised on the identity of the index tensors; the caller's
 tensors and the Graph are never reordered.  Everything else -- CPU tensors, other dtypes, and the purely elementwise
 `s_*_e` / `s_*_t` operators (a gather and one arithmetic op: torch already runs those at memory speed) -- executes the
-reference's own torch expressions.
+reference's own torch expressions.  A GPU call of an AGGREGATING operator that lands there (half precision, a width the
+kernel does not broadcast, a 2-D index) says so once per (operator, reason) with a `TorchRouteWarning`: these operators
+ARE torch compositions in the reference, so the route is the reference's semantics, not a fallback from a failed kernel
+-- but it is never silent.
 """
 import collections
 
@@ -94,6 +97,26 @@ def _hip_ok(*tensors):
     return all(t is None or (t.is_cuda and t.dtype == torch.float32) for t in tensors)
 
 
+class TorchRouteWarning(UserWarning):
+    """A GPU call of an aggregating operator ran the reference's torch expressions (gather, multiply, scatter_add_ with
+    atomics) instead of the fused HIP kernel, because its arguments are outside what the kernel covers."""
+
+
+_ROUTE_NOTED = set()
+
+
+def _note_torch_route(op, *tensors, why):
+    """Never silent: the first GPU call per (operator, reason) that takes the torch route says so.  CPU tensors are the
+    reference's own path and stay quiet."""
+    if not any(torch.is_tensor(t) and t.is_cuda for t in tensors) or (op, why) in _ROUTE_NOTED:
+        return
+    _ROUTE_NOTED.add((op, why))
+    import warnings
+
+    warnings.warn("cogdl_amd.operators.ops.%s: GPU tensors on the reference's torch route (%s); the fused HIP kernel covers "
+                  "2-D float32 features with 1-D int64 edge indices" % (op, why), TorchRouteWarning, stacklevel=3)
+
+
 # --------------------------------------------------------------------------------------------- scatter_add / op_aggr
 class _ScatterRows(torch.autograd.Function):
     """out[v] = scale_v * sum_{e: dst[e] == v} data[e]  (op_aggr, ops.py:28-40)."""
@@ -143,6 +166,9 @@ def scatter_add(data, dst, num_nodes, dim=0):
     """ops.py:4-11: zeros([num_nodes, F]).scatter_add_(dim, dst expanded over the columns, data)."""
     idx = _rows_index(dst, data) if (dim == 0 and data.dim() == 2 and _hip_ok(data)) else None
     if idx is None or data.shape[0] == 0 or data.shape[1] == 0:
+        if data.numel() > 0:
+            _note_torch_route("scatter_add", data, dst, why="dim %d, dtype %s, data %s, dst %s %s"
+                              % (dim, data.dtype, tuple(data.shape), dst.dtype, tuple(dst.shape)))
         return _scatter_add_torch(data, dst, num_nodes, dim)
     return _ScatterRows.apply(data, idx, int(num_nodes), False)
 
@@ -161,6 +187,8 @@ def op_aggr(op, msg, dst, num_nodes):
     idx = _rows_index(dst, msg) if (msg.dim() == 2 and _hip_ok(msg)) else None
     if idx is not None and msg.shape[0] > 0 and msg.shape[1] > 0:
         return _ScatterRows.apply(msg, idx, int(num_nodes), op == "mean")
+    if msg.numel() > 0:
+        _note_torch_route("op_aggr", msg, dst, why="dtype %s, msg %s, dst %s %s" % (msg.dtype, tuple(msg.shape), dst.dtype, tuple(dst.shape)))
     out = _scatter_add_torch(msg, dst, num_nodes)
     if op == "mean":  # counts are exact in fp32 either way: same deg^-1 as the reference's scatter_add_ of ones
         inv = torch.bincount(dst.reshape(-1), minlength=num_nodes).float().pow(-1)
@@ -224,6 +252,11 @@ def src_op_e_aggr_coo(op1, op2, n_feat, e_feat, row, col, data=None):
              and (data is None or (data.dim() == 1 and data.numel() == row.numel())))
     if fused:
         return _SrcOpEdgeAggr.apply(n_feat, e_feat, data, row, col, op1, op2 == "mean")
+    if row.numel() > 0:
+        _note_torch_route("s_%s_e_%s" % (op1, op2), n_feat, e_feat, row,
+                          why="n_feat %s %s, e_feat %s %s, row %s, col %s, data %s"
+                          % (n_feat.dtype, tuple(n_feat.shape), e_feat.dtype, tuple(e_feat.shape), row.dtype, col.dtype,
+                             None if data is None else tuple(data.shape)))
     src = n_feat[col]
     msg = op_src_edge(op1, src, e_feat)
     if data is not None:

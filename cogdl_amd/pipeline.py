@@ -201,13 +201,23 @@ class BatchPipeline:
     step i-1 still runs), and the side stream waits only for the event recorded when batch i+1's SEEDS were drawn --
     which happened one iteration earlier, before step i-1 was enqueued -- not for the whole main stream: waiting for
     the main stream would put sample(i+1) behind step i-1 and serialise everything.  The sampler's one host read-back
-    (output sizes) waits on the side stream only.  GPU timeline: step i-1 || sample + gather i+1, step i || i+2, ..."""
+    (output sizes) waits on the side stream only.  GPU timeline: step i-1 || sample + gather i+1, step i || i+2, ...
 
-    def __init__(self, indptr, indices, x, y, seed_batches, fanouts):
+    CONTRACT (what the overlap costs).  The side stream is NOT ordered behind the consumer's steps, so while iterating
+      * `indptr`, `indices`, `x` and `y` must stay IMMUTABLE: a step that updates features, labels or the graph in place
+        (feature caching, label propagation) races with the prefetch of the next batches;
+      * the seed iterator is consumed TWO items ahead of the step being run (a stateful iterator -- curriculum, hard
+        negatives chosen from the last step's loss -- sees the step's effect two batches late).
+    `strict=True` gives both up for safety: the side stream waits for the main stream before every prefetch (sampling of
+    batch i+1 then starts only after step i-1 has finished: the pre-round-3 behaviour, no overlap with the step) and
+    seeds are drawn one batch ahead only."""
+
+    def __init__(self, indptr, indices, x, y, seed_batches, fanouts, strict=False):
         self.indptr, self.indices, self.x, self.y = indptr, indices, x, y
         self.seed_batches, self.fanouts = seed_batches, list(fanouts)
         self.dev = indptr.device
         self.side = torch.cuda.Stream(device=self.dev)
+        self.strict = bool(strict)
 
     def _draw(self, it):
         """The next seed tensor + an event on the caller's stream behind whatever produced it."""
@@ -221,8 +231,12 @@ class BatchPipeline:
 
     def _prepare(self, drawn):
         seeds, ready = drawn
+        if self.strict:
+            self.side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)  # the seeds exist; nothing else of the caller's stream is waited for
+            if seeds.is_cuda:
+                seeds.record_stream(self.side)  # allocated on the caller's stream, read on this one
             n_id, adjs = sample_blocks(self.indptr, self.indices, seeds, self.fanouts)
             xb = gather_rows_by_id(self.x, n_id)
             yb = None if self.y is None else self.y.index_select(0, seeds)

@@ -321,3 +321,39 @@ def test_any_rank_vote_is_the_same_on_every_rank():
                  for r in range(3)]
         outs = [p.communicate(timeout=120)[0] for p in procs]
         assert all("VOTE " + want in o for o in outs), (yes, outs)
+
+
+def _bad_shard_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cogdl_amd import _lib, synth
+        from cogdl_amd.dist import ShardedCSR, partition_bounds
+
+        n = 200
+        g = synth.scaled(n, 6, seed=1)
+        bounds = partition_bounds(n, world)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        e0, e1 = int(g.rowptr[lo]), int(g.rowptr[hi])
+        rowptr = (g.rowptr[lo:hi + 1] - g.rowptr[lo]).long()
+        if rank == 1:  # ONE rank holds a row pointer that runs backwards
+            rowptr[3] = rowptr[5] + 2
+        try:
+            ShardedCSR(rowptr, g.colind[e0:e1].long(), g.weight[e0:e1], bounds, backend=OracleBackend())
+            msg = "no error"
+        except _lib.BackendError as e:
+            msg = str(e)
+        open(os.path.join(out_dir, "bad%d.txt" % rank), "w").write(msg)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_an_invalid_shard_on_one_rank_stops_every_rank_instead_of_hanging_the_exchange(tmp_path):
+    """Round-3 advisor: the shard build validated nothing about rowptr (the HIP split reads col[] through it), and a rank
+    that raised alone left its peers blocked in the next collective.  Now every rank validates, the ranks agree with one
+    all-reduce, and ALL of them raise."""
+    mp.spawn(_bad_shard_worker, args=(2, 29688, str(tmp_path)), nprocs=2, join=True)
+    m0, m1 = (open(os.path.join(str(tmp_path), "bad%d.txt" % r)).read() for r in (0, 1))
+    assert "rowptr must start at 0, be non-decreasing" in m1
+    assert "another rank rejected its shard" in m0

@@ -174,3 +174,32 @@ def test_fresh_source_ids_on_a_fixed_destination_list(oracle):
     for k in range(4):
         step(k)
     assert len(ops._PLANS) == 1  # one destination plan served all four steps
+
+
+def test_gpu_calls_outside_the_fused_kernel_take_the_torch_route_loudly():
+    """The aggregating operators are torch compositions in the reference (cogdl/operators/ops.py:4-52); a GPU call whose
+    arguments the fused kernel does not cover (half precision here) runs those expressions -- with ONE TorchRouteWarning
+    per (operator, reason), never silently -- and CPU calls (the reference's own path) stay quiet."""
+    import warnings
+
+    from cogdl_amd.operators import ops
+
+    ops._ROUTE_NOTED.clear()
+    n, e = 50, 400
+    gen = torch.Generator().manual_seed(0)
+    row, col = torch.randint(0, n, (e,), generator=gen), torch.randint(0, n, (e,), generator=gen)
+    x, ef = torch.randn(n, 8, generator=gen), torch.randn(e, 8, generator=gen)
+    want = ops.src_op_e_aggr_coo("mul", "sum", x, ef, row, col)  # CPU: quiet
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", ops.TorchRouteWarning)
+        ops.src_op_e_aggr_coo("mul", "sum", x, ef, row, col)
+        got32 = ops.src_op_e_aggr_coo("mul", "sum", x.to(DEV), ef.to(DEV), row.to(DEV), col.to(DEV))  # fused: quiet
+    assert torch.allclose(got32.cpu(), want, rtol=1e-5, atol=1e-5)
+    with pytest.warns(ops.TorchRouteWarning, match="s_mul_e_sum"):
+        got16 = ops.src_op_e_aggr_coo("mul", "sum", x.to(DEV).half(), ef.to(DEV).half(), row.to(DEV), col.to(DEV))
+    assert got16.dtype == torch.float16 and torch.allclose(got16.float().cpu(), want, rtol=5e-2, atol=5e-2)
+    with warnings.catch_warnings():  # the same (operator, reason) again: already noted
+        warnings.simplefilter("error", ops.TorchRouteWarning)
+        ops.src_op_e_aggr_coo("mul", "sum", x.to(DEV).half(), ef.to(DEV).half(), row.to(DEV), col.to(DEV))
+    with pytest.warns(ops.TorchRouteWarning, match="scatter_add"):
+        ops.scatter_add(ef.to(DEV).double(), row.to(DEV), n)

@@ -179,3 +179,41 @@ def test_gat_bwd_oracle_equals_float64_autograd_of_the_unfused_composition(oracl
         np.testing.assert_allclose(gr, r64.grad.numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(oracle.gat_fwd(g.rowptr, g.colind, h_l, h_r, feat, 0.2), out.detach().numpy(),
                                    rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("seeds,fanout,width", [(1024, 10, 128), (128, 10, 100), (8192, 10, 47)])
+def test_scatter_max_oracle_against_an_independent_float64_torch_evaluation(oracle, seeds, fanout, width):
+    """`oracle_scatter_max_*` restates scatter_max.cu:5-75, which is CUDA-only: NO reference-produced vector exists for it
+    and none can be produced here (the row stays "parity unpinned", oracle/README.md).  As far as it CAN be pinned: at
+    the block sizes of configs[3] (seeds x fan-out edges into a frontier of sources; MaxAggregator, sage_layer.py:21-29)
+    the oracle's maximum equals torch's float64 `scatter_reduce(amax)` over the same edges, its argmax is the FIRST edge
+    (CSR order) attaining that maximum -- scatter_max.cu:18-24 updates on `>` only --, and its backward equals
+    `index_put_(accumulate=True)` of the routed gradients (scatter_max.cu:44-60) in float64."""
+    gen = torch.Generator().manual_seed(seeds + width)
+    n_src = seeds * (1 + fanout // 2)
+    deg = torch.randint(0, fanout + 1, (seeds,), generator=gen)
+    rowptr = torch.zeros(seeds + 1, dtype=torch.int32)
+    rowptr[1:] = torch.cumsum(deg, 0).int()
+    nnz = int(rowptr[-1])
+    colind = torch.randint(0, n_src, (nnz,), generator=gen).int()
+    x = torch.randn(n_src, width, generator=gen)
+    x[::7] = x[1::7][: x[::7].shape[0]]  # ties between different sources
+    out, arg = oracle.scatter_max_fwd(rowptr, colind, x, quirk=False)
+    row = torch.repeat_interleave(torch.arange(seeds), deg.long())
+    gathered = x.double()[colind.long()]
+    want = torch.full((seeds, width), -float("inf"), dtype=torch.float64)
+    want = want.scatter_reduce(0, row.view(-1, 1).expand(-1, width), gathered, "amax", include_self=True)
+    has = deg > 0
+    assert np.array_equal(out[has.numpy()], want[has].float().numpy())
+    # first edge in CSR order that attains the maximum
+    hit = gathered == want[row]
+    pos = torch.where(hit, torch.arange(nnz).view(-1, 1).expand(-1, width), torch.full((1, 1), nnz))
+    first = torch.full((seeds, width), nnz, dtype=torch.long).scatter_reduce(0, row.view(-1, 1).expand(-1, width), pos, "amin")
+    want_arg = torch.where(first < nnz, colind.long()[first.clamp(max=nnz - 1)], torch.full((1, 1), -1))
+    assert np.array_equal(arg[has.numpy()], want_arg[has].int().numpy())
+    g = torch.randn(seeds, width, generator=gen)
+    got_g = oracle.scatter_max_bwd(g, arg, n_src)
+    ok = torch.from_numpy(arg) >= 0
+    r, c = torch.nonzero(ok, as_tuple=True)
+    want_g = torch.zeros(n_src, width, dtype=torch.float64).index_put_((torch.from_numpy(arg)[ok].long(), c), g.double()[ok], accumulate=True)
+    np.testing.assert_allclose(got_g, want_g.numpy(), rtol=1e-6, atol=1e-6)

@@ -58,7 +58,15 @@ def _fold(path):
 
 def collect(topology="uniform", feat=128, timeout_s=100):
     """-> {"hbm_bytes_per_launch": ..., "read": ..., "write": ..., "kernel_us_profiled": ..., "calibration": {...}}
-    or {"error": "..."}; never raises."""
+    or {"error": "..."}; never raises (a rocprofv3 with another CSV schema, a truncated file, ... must not take the bench
+    line down: it then falls back to the committed profile and says so)."""
+    try:
+        return _collect(topology, feat, timeout_s)
+    except Exception as e:
+        return {"error": "pmc_live.collect: %r" % (e,)}
+
+
+def _collect(topology, feat, timeout_s):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return {"error": "rocprofv3 not found"}
