@@ -25,6 +25,7 @@ HIP_SIGNATURES = {
     "cogdl_hip_set_tuning": ([_i32, _i32], _i32),
     "cogdl_hip_csr_spmm_workspace_bytes": ([_i64, _i64, _i32], _sz),
     "cogdl_hip_long_row_threshold": ([_i64], _i32),
+    "cogdl_hip_exact_row_edges": ([_i64], _i32),
     "cogdl_hip_csr_spmm": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_csr_spmm_acc": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_csr_spmm_variant": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _i32, _vp, _sz, _vp], _i32),

@@ -180,8 +180,9 @@ __global__ __launch_bounds__(kThreads) void rt_upsweep_kernel(const Params p) {
 //                           writes two arrays (rowind, perm) and no sorted keys (colptr comes from rt_colptr_perm).
 template <bool FIRST, int PACK = 0, bool MSD2 = false>
 __global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params p) {
-    static_assert(PACK == 0 || (FIRST ? PACK == 1 : PACK == 2), "packed out in the first pass, packed in in the second");
+    static_assert(PACK == 0 || (FIRST ? PACK == 1 : (PACK == 2 || PACK == 3)), "packed out in the first pass, packed in afterwards");
     static_assert(!MSD2 || PACK == 2, "the MSD second pass reads packed records");
+    constexpr bool PACK_IN = PACK == 2 || PACK == 3;  // PACK 3: a MIDDLE pass of a sort with more than two passes -- reads and writes (e, word)
     __shared__ __attribute__((aligned(16))) uint32_t buf[kTile];
     __shared__ uint32_t cnt[kWaves][kMaxBins];  // per wave: running count, then the wave's start inside the digit's run
     __shared__ uint32_t dstart[kMaxBins];       // where the digit's run starts in the reordered tile
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params 
             const int l = l0 + j * kWave;
             key[j] = l < valid ? (uint32_t)src[l] : p.pad_key;
         }
-    } else if constexpr (PACK == 2) {
+    } else if constexpr (PACK_IN) {
         const int32_t *__restrict__ esrc = p.e_in + tile0, *__restrict__ wsrc = p.row_in + tile0;
         const uint32_t row_mask = (1u << p.row_bits) - 1u;
 #pragma unroll
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params 
             const int l = l0 + j * kWave;
             const bool ok = l < n_here;
             const uint32_t wd = ok ? (uint32_t)wsrc[l] : 0u;
-            key[j] = wd >> p.row_bits;  // (the digit of this pass; p.shift = 0)
+            key[j] = wd >> p.row_bits;  // (the digits still to be sorted by, this pass's at the bottom; p.shift = 0)
             pr[j] = (int32_t)(wd & row_mask);
             pe[j] = ok ? esrc[l] : 0;
         }
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params 
 #pragma unroll
     for (int j = 0; j < kRows; ++j) {
         if (l0 + j * kWave < n_here) {
-            if constexpr (PACK == 2) buf[spos[j]] = (key[j] << p.row_bits) | (uint32_t)pr[j];  // digit and row in one round
+            if constexpr (PACK_IN) buf[spos[j]] = (key[j] << p.row_bits) | (uint32_t)pr[j];  // digit(s) and row in one round
             else buf[spos[j]] = key[j];
         }
     }
@@ -347,6 +348,10 @@ __global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params 
             if constexpr (PACK == 2) {
                 gpos[q] = delta[(k >> p.row_bits) & mask] + (uint32_t)sidx;
                 p.row_out[gpos[q]] = (int32_t)(k & ((1u << p.row_bits) - 1u));
+            } else if constexpr (PACK == 3) {  // the word goes on without this pass's digit
+                gpos[q] = delta[(k >> p.row_bits) & mask] + (uint32_t)sidx;
+                const uint32_t row_mask = (1u << p.row_bits) - 1u;
+                p.row_out[gpos[q]] = (int32_t)((((k >> p.row_bits) >> p.bits) << p.row_bits) | (k & row_mask));
             } else {
                 gpos[q] = delta[(k >> p.shift) & mask] + (uint32_t)sidx;
                 if constexpr (PACK == 0) p.keys_out[gpos[q]] = k;
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params 
 #pragma unroll
     for (int q = 0; q < kRows; ++q)
         if (q * kThreads + t < n_here) p.e_out[gpos[q]] = (int32_t)buf[q * kThreads + t];
-    if constexpr (PACK == 2) return;  // (the row went out with the digit)
+    if constexpr (PACK_IN) return;  // (the row went out with the digit)
     __syncthreads();
     // ---- payload 2: the row (packed: with the key's remaining digit above it)
 #pragma unroll
@@ -681,10 +686,17 @@ static unsigned bits_for(int64_t n_keys) {  // enough bits for key values 0 .. n
     return b;
 }
 
+// Digit width.  Default: up to 9 bits (two passes for ids of up to 18 bits).  Tuning key 10 = 6: digits of at most 6 bits
+// -- THREE passes for 18-bit ids, but 64 bins over an 8192-slot tile are runs of 512 bytes: whole 128-byte lines and a
+// handful of DRAM pages per tile instead of 512 half-line pieces (the two 9-bit passes move ~10 GB for 1.84 GB
+// algorithmic on the Reddit-shaped graph: partial-line read-modify-write fills, profiles/r02_pmc_csr2csc.json).
+static int max_digit_bits() { return g_tuning[kTuneCsr2csc] == 6 ? 6 : kMaxBits; }
+
 static Geometry geometry(int64_t n_cols, int64_t nnz, bool padded) {
     Geometry g{};
     g.bits = (int)bits_for(padded ? n_cols + 1 : n_cols);
-    g.n_pass = (g.bits + kMaxBits - 1) / kMaxBits;
+    const int maxb = max_digit_bits();
+    g.n_pass = (g.bits + maxb - 1) / maxb;
     g.dbits = (g.bits + g.n_pass - 1) / g.n_pass;
     g.n_tiles = (nnz + kTile - 1) / kTile;
     // (the MSD second pass cuts every bucket of the first into tiles of its own: at most one partly filled tile more per
@@ -744,7 +756,10 @@ int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int
     const bool msd = g.n_pass == 2 && row_bits + g.dbits <= 32 && tune == 5;
     // (LSD: packed records from 16 M slots on: below that the per-column searches of rt_colptr_perm cost more than the
     //  one staged array they save -- arxiv-shaped, 2.5 M slots: 125 vs 117 us; Reddit-shaped, 115 M: 2.00 vs 2.06 ms)
-    const bool packed = msd || (g.n_pass == 2 && row_bits + g.dbits <= 32 && (nnz >= (int64_t(1) << 24) || tune == 3));
+    // (three or more passes -- tuning key 10 = 6 -- are always packed when the first intermediate word fits: the key's
+    //  remaining digits above the row)
+    const bool packed = msd || (g.n_pass == 2 && row_bits + g.dbits <= 32 && (nnz >= (int64_t(1) << 24) || tune == 3)) ||
+                        (g.n_pass >= 3 && row_bits + (g.bits - g.dbits) <= 32 && tune == 6);
     if (g.n_tiles > 0x7fffffff || g.table_len > 0x7fffffff || m > 0x7fff0000) return COGDL_HIP_ERANGE;  // (int row loops)
     char *ws = (char *)workspace;
     uint32_t *table = (uint32_t *)(ws + g.off_table), *scanned = (uint32_t *)(ws + g.off_scanned);
@@ -849,7 +864,8 @@ int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int
         p.table = scanned;
         if (packed) {
             if (first) hipLaunchKernelGGL((rt_downsweep_kernel<true, 1>), dim3(dgrid), dim3(kThreads), 0, s, p);
-            else hipLaunchKernelGGL((rt_downsweep_kernel<false, 2>), dim3(dgrid), dim3(kThreads), 0, s, p);
+            else if (last) hipLaunchKernelGGL((rt_downsweep_kernel<false, 2>), dim3(dgrid), dim3(kThreads), 0, s, p);
+            else hipLaunchKernelGGL((rt_downsweep_kernel<false, 3>), dim3(dgrid), dim3(kThreads), 0, s, p);
         } else {
             if (first) hipLaunchKernelGGL((rt_downsweep_kernel<true, 0>), dim3(dgrid), dim3(kThreads), 0, s, p);
             else hipLaunchKernelGGL((rt_downsweep_kernel<false, 0>), dim3(dgrid), dim3(kThreads), 0, s, p);

@@ -79,7 +79,17 @@ struct RowSched {
     XcdMap rowblocks;
     LongRows lr;
     int sort_rows;  // deal a workgroup's rows to its lane groups by decreasing length (see rowreduce_main_kernel)
+    int wave_split; // > 0: in a skewed workgroup, rows of more than this many edges are reduced by ALL lane groups of their wave
 };
+
+// Rows of at most this many edges are always reduced sequentially by one lane group, in CSR order (the reference's
+// summation order: bit-identical fp32 results); longer rows MAY be cut into contiguous pieces whose partial states are
+// merged in order (wave-scope split in skewed workgroups, workgroup-scope chunks beyond the long-row threshold).
+constexpr int kWaveSplitMin = 64;
+inline int wave_split_edges() {
+    const int t = g_tuning[kTuneWaveSplit];  // tuning key 12: < 0 = off, 0 = default, > 0 = override
+    return t < 0 ? 0 : (t > 0 ? t : kWaveSplitMin);
+}
 
 // Threshold above which a row is split.  The sequential time of a row of T edges (~T/UNROLL gather round trips of
 // ~1 us) must stay a small fraction of the launch; small graphs need a low threshold, large ones amortise more.
@@ -291,8 +301,13 @@ __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSche
 // row well above the mean; the test is workgroup-uniform, uniform graphs pay one barrier and one pass over GPB LDS
 // words).  `slot` = this group's natural position, `leader` = one lane per group.  On return (true) `mine` is the
 // natural position of the row this group now owns and (ok, start, end) describe that row.  Called by ALL threads.
+// Which rank a group takes: its own slot (wave 0 gets the longest rows: best when a wave takes as long as its longest
+// row) -- or, when the workgroup holds a MEDIUM row (more than split_min edges, at most `thresh`) that its wave will
+// reduce with all its groups together (wave time = sum / groups), rank `rr_rank` = sub * 4 + wave: round-robin over
+// the waves, equal sums.
 template <int GPB>
-__device__ __forceinline__ bool deal_rows_by_length(int slot, bool leader, bool &ok, int &start, int &end, int &mine) {
+__device__ __forceinline__ bool deal_rows_by_length(int slot, bool leader, bool &ok, int &start, int &end, int &mine,
+                                                    int rr_rank, int split_min, int thresh) {
     __shared__ int sort_deg[GPB], sort_start[GPB], sort_slot[GPB];
     const int deg = ok ? end - start : -1;
     if (leader) {
@@ -300,11 +315,12 @@ __device__ __forceinline__ bool deal_rows_by_length(int slot, bool leader, bool 
         sort_start[slot] = start;
     }
     __syncthreads();
-    int dmax = 0, dsum = 0;
+    int dmax = 0, dsum = 0, dmed = 0;
     for (int q = 0; q < GPB; ++q) {
         const int dq = max(sort_deg[q], 0);
         dmax = max(dmax, dq);
         dsum += dq;
+        if (dq <= thresh) dmed = max(dmed, dq);
     }
     if (dmax * GPB < 2 * dsum + 8 * GPB) return false;
     int rank = 0;  // by (length descending, natural position ascending)
@@ -314,7 +330,7 @@ __device__ __forceinline__ bool deal_rows_by_length(int slot, bool leader, bool 
     }
     if (leader) sort_slot[rank] = slot;
     __syncthreads();
-    mine = sort_slot[slot];
+    mine = sort_slot[(split_min > 0 && dmed > split_min) ? rr_rank : slot];
     ok = sort_deg[mine] >= 0;
     start = sort_start[mine];
     end = start + max(sort_deg[mine], 0);
@@ -351,6 +367,7 @@ __global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const 
         start = s.rowptr[row];
         end = s.rowptr[row + 1];
     }
+    bool skewed = false;
     if constexpr (RPW > 1) {
         // Several rows share a wave, and a wave takes as long as its LONGEST row: on a skewed graph a wave with one
         // 100-edge row and three 5-edge rows idles 70 % of its lanes.  The workgroup's GPB rows are therefore dealt to
@@ -358,9 +375,13 @@ __global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const 
         // RPW longest rows, wave 3 the shortest, the sum over waves of their longest row -- the lane time spent --
         // drops by 2-3x on R-MAT graphs.  Only the row -> lane-group assignment changes: every row is still reduced
         // sequentially by one group in CSR order (bit-identical results).
+        // With the wave-scope split (below) a wave's time is the SUM of its rows' lengths / RPW instead of their maximum,
+        // so the ranks are dealt ROUND-ROBIN over the four waves (wave w takes ranks w, w + 4, ...: equal sums).
         if (g_sort_rows(s)) {
             int mine;
-            if (deal_rows_by_length<GPB>(wave * RPW + sub, lane_on && l == 0, ok, start, end, mine)) row = rb * GPB + mine;
+            skewed = deal_rows_by_length<GPB>(wave * RPW + sub, lane_on && l == 0, ok, start, end, mine, sub * 4 + wave,
+                                              kWave % LPR == 0 ? s.wave_split : 0, s.lr.thresh);
+            if (skewed) row = rb * GPB + mine;
             if (!lane_on) {
                 ok = false;
                 start = end = 0;
@@ -371,12 +392,62 @@ __global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const 
         start = __builtin_amdgcn_readfirstlane(start);
         end = __builtin_amdgcn_readfirstlane(end);
     }
-    if (end - start > s.lr.thresh) return;  // long row: the long-row workgroups compute it
+    const bool is_long = end - start > s.lr.thresh;  // long row: the long-row workgroups compute it
+    float *const my_lds = op_lds + (threadIdx.x / LPR) * LPR * Op::kLds;
+    if constexpr (RPW > 1 && kWave % LPR == 0) {
+        // Wave-scope split of MEDIUM rows (skewed workgroups only).  A row of a few hundred edges, below the long-row
+        // threshold, is one lane group walking ~len / UNROLL dependent gather batches while the other groups of its wave
+        // finished their 5-edge rows long ago.  In a wave that holds such a row (> wave_split edges) the groups first
+        // reduce their own SHORT rows as always, then every medium row of the wave is reduced by all RPW groups together:
+        // contiguous slices, the partial states merged in slice order through shuffles (no LDS, no barrier) and finished
+        // by group 0.  Rows of at most wave_split edges keep the reference's sequential order (bit-identical); a split
+        // row is re-associated at its slice borders only (deterministic).
+        const bool medium = ok && !is_long && s.wave_split > 0 && end - start > s.wave_split;
+        if (skewed && __ballot(medium) != 0ull) {
+            typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
+            if (ok && !is_long && !medium) {  // (group-uniform)
+                op.row_load(ctx, row, true);
+                typename Op::State st;
+                op.init(ctx, st, row, true);
+                reduce_edges<Op>(op, ctx, st, s.colind, start, end, sub, l, my_lds);
+                op.row_end(ctx, st, row, true);
+            }
+            unsigned long long todo = __ballot(medium && l == 0);
+            while (todo) {  // (wave-uniform)
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int64_t r2 = rb * GPB + (int64_t)__shfl((int)(row - rb * GPB), src, kWave);
+                const int s2 = __shfl(start, src, kWave), e2 = __shfl(end, src, kWave);
+                const int per = ((e2 - s2 + RPW - 1) / RPW + Op::UNROLL - 1) / Op::UNROLL * Op::UNROLL;
+                const int sb = min(s2 + sub * per, e2), se = min(sb + per, e2);
+                op.row_load(ctx, r2, true);
+                typename Op::State st;
+                if (sub == 0) op.init(ctx, st, r2, true);  // (an accumulating operator reads the existing output once)
+                else op.init_zero(st);
+                reduce_edges<Op>(op, ctx, st, s.colind, sb, se, sub, l, my_lds);
+                if constexpr (Op::kReduce) {
+                    float rec[Op::kRec];
+                    op.pack(st, rec);
+                    for (int q = 1; q < RPW; ++q) {  // slice order: group 0, 1, 2, ...
+                        float other_rec[Op::kRec];
+#pragma unroll
+                        for (int i = 0; i < Op::kRec; ++i) other_rec[i] = __shfl(rec[i], q * LPR + l, kWave);
+                        typename Op::State other;
+                        op.unpack(other, other_rec);
+                        op.merge(ctx, st, other);  // (all groups execute it: merge may shuffle inside a group)
+                    }
+                }
+                op.row_end(ctx, st, r2, sub == 0);
+            }
+            return;
+        }
+    }
+    if (is_long) return;
     typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
     op.row_load(ctx, row, ok);
     typename Op::State st;
     op.init(ctx, st, row, ok);
-    reduce_edges<Op>(op, ctx, st, s.colind, start, end, sub, l, op_lds + (threadIdx.x / LPR) * LPR * Op::kLds);
+    reduce_edges<Op>(op, ctx, st, s.colind, start, end, sub, l, my_lds);
     op.row_end(ctx, st, row, ok);
 }
 
@@ -456,6 +527,7 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
     s.m = m;
     s.rowblocks = make_xcd_map(n_rowblocks);
     s.sort_rows = g_tuning[kTuneRowSort] == 0 ? 1 : 0;
+    s.wave_split = wave_split_edges();
     s.lr.thresh = INT_MAX;
     if (nnz > 0 && (!Op::kReduce || workspace)) {
         plan_long_rows(s.lr, nnz);

@@ -129,6 +129,11 @@ extern "C" size_t cogdl_hip_mhspmm_workspace_bytes(int64_t nnz, int64_t h, int64
 
 extern "C" int cogdl_hip_long_row_threshold(int64_t nnz) { return pick_long_thresh(nnz); }
 
+extern "C" int cogdl_hip_exact_row_edges(int64_t nnz) {
+    const int split = wave_split_edges();
+    return split > 0 ? std::min(split, pick_long_thresh(nnz)) : pick_long_thresh(nnz);
+}
+
 extern "C" int cogdl_hip_csr_spmm(const int32_t *rowptr, const int32_t *colind, const void *val, const void *x,
                                   void *out, int64_t m, int64_t k, int64_t nnz, int dtype, void *workspace,
                                   size_t workspace_bytes, void *stream) {

@@ -51,7 +51,7 @@ def test_epilogue_hub_rows_and_full_size_graph(oracle):
     ref = oracle.csr_spmm(g.rowptr, g.colind, g.weight, s_out.view(-1, 1) * x)
     want = np.maximum(s_in.view(-1, 1).numpy() * ref, 0)
     scale = s_in.view(-1, 1).numpy() * oracle.csr_spmm_abs(g.rowptr, g.colind, g.weight, s_out.view(-1, 1) * x)
-    short = np.diff(g.rowptr.numpy()) <= _lib.hip().cogdl_hip_long_row_threshold(g.nnz)
+    short = np.diff(g.rowptr.numpy()) <= _lib.hip().cogdl_hip_exact_row_edges(g.nnz)
     assert got[short].tobytes() == want[short].astype(np.float32).tobytes()
     assert np.all(np.abs(got - want) <= 1e-5 * scale + 1e-6)
 

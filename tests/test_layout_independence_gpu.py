@@ -98,7 +98,7 @@ def test_every_operator_gives_the_same_bits_under_three_allocation_and_dispatch_
         assert proc.returncode == 0 and lines, "%s: rc %d, last %s\n%s" % (mode, proc.returncode, last, proc.stderr[-3000:])
         results[mode] = json.loads(lines[-1][7:])
     ref = results["plain"]
-    assert len(ref) >= 40
+    assert len(ref) >= 30
     for mode in ("nocache", "serialize"):
         diff = [k for k in ref if results[mode].get(k) != ref[k]]
         assert not diff, "%s differs from plain in: %s" % (mode, diff)

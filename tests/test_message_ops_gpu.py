@@ -96,7 +96,7 @@ def test_hub_destinations(oracle, k):
     gen = torch.Generator().manual_seed(k)
     x, ef, w = torch.randn(n, k, generator=gen), torch.randn(e, k, generator=gen), torch.rand(e, generator=gen)
     g = _graph(row.to(DEV), col.to(DEV), w.to(DEV))
-    thresh = _lib.hip().cogdl_hip_long_row_threshold(e)
+    thresh = _lib.hip().cogdl_hip_exact_row_edges(e)
     deg = torch.bincount(row, minlength=n)
     short = (deg <= thresh).numpy()
     assert (~short).sum() >= 3

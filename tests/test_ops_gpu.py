@@ -21,7 +21,7 @@ def rand(*shape, seed=0, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------ csr2csc
-@pytest.fixture(params=[0, 1, 2, 3, 5], ids=["default-by-size", "rocprim-pipeline", "radix-transpose", "radix-transpose-packed-records", "radix-transpose-msd-first"])
+@pytest.fixture(params=[0, 1, 2, 3, 5, 6], ids=["default-by-size", "rocprim-pipeline", "radix-transpose", "radix-transpose-packed-records", "radix-transpose-msd-first", "radix-transpose-6-bit-digits"])
 def csc_algo(request):
     """csr2csc's implementations (tuning key 10; the default picks by size: one single-workgroup launch up to 16 k slots
     and columns, the rocPRIM pipeline up to 256 k slots, the radix transpose above): the rocPRIM sort + row look-up, and the
@@ -473,7 +473,7 @@ def test_scatter_max_bwd_gather_hub_sources(oracle, hubs, k):
     got = scatter_max_bp_csc(plan.colptr, plan.rowind, gr.to(DEV), idx, 60)
     assert torch.equal(got, scatter_max_bp_csc(plan.colptr, plan.rowind, gr.to(DEV), idx, 60))
     got = got.cpu().numpy()
-    short = np.diff(gt.rowptr.numpy()) <= _lib.hip().cogdl_hip_long_row_threshold(gt.nnz)
+    short = np.diff(gt.rowptr.numpy()) <= _lib.hip().cogdl_hip_exact_row_edges(gt.nnz)
     assert got[short].tobytes() == want[short].tobytes()
     scale = oracle.scatter_max_bwd(gr.abs(), idx.cpu().numpy(), 60)
     assert np.all(np.abs(got - want) <= 1e-5 * scale + 1e-12)

@@ -77,6 +77,34 @@ def test_shard_split_reports_a_column_outside_the_graph():
         _split("hip", rp, ci, None, partition_bounds(2000, 1), 0)
 
 
+@pytest.mark.parametrize("damage", ["backwards", "past_nnz", "short_end", "negative"])
+def test_shard_split_rejects_an_invalid_row_pointer_before_reading_through_it(damage):
+    """Round-3 advisor: the HIP split read col[rowptr[r] .. rowptr[r+1]) unguarded.  The kernel now validates every row
+    (flag bit 1; offending rows are skipped, nothing is read out of bounds) and the host raises -- also from bfs_order
+    and halo_rows, which hand the same arrays to raw-pointer kernels."""
+    from cogdl_amd._lib import BackendError
+    from cogdl_amd.dist import bfs_order, halo_rows, partition_bounds
+
+    g = synth.scaled(2000, 5, seed=2)
+    rp, ci = g.rowptr.long().to(DEV).clone(), g.colind.long().to(DEV)
+    nnz = ci.numel()
+    if damage == "backwards":
+        rp[100] = rp[102] + 5
+    elif damage == "past_nnz":
+        rp[1500:] += 10 ** 6  # would read a megabyte past col
+    elif damage == "short_end":
+        rp[-1] = nnz - 3
+    else:
+        rp[7] = -4
+    with pytest.raises(BackendError, match="rowptr"):
+        _split("hip", rp, ci, None, partition_bounds(2000, 1), 0)
+    with pytest.raises(BackendError, match="rowptr"):
+        bfs_order(rp, ci)
+    with pytest.raises(BackendError, match="rowptr"):
+        halo_rows(rp, ci, partition_bounds(2000, 2))
+    torch.cuda.synchronize()
+
+
 def test_bfs_partition_recovers_hidden_locality_and_is_the_same_operator(oracle):
     from cogdl_amd.dist import partition
     from cogdl_amd.operators.spmm import csr_spmm_raw

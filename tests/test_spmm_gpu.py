@@ -19,7 +19,7 @@ def T(a, dev=DEV):
 def long_thresh(nnz):
     from cogdl_amd import _lib
 
-    return _lib.hip().cogdl_hip_long_row_threshold(int(nnz))
+    return _lib.hip().cogdl_hip_exact_row_edges(int(nnz))
 
 
 def assert_rows_match(got, want, rowptr, nnz, scale=None):
