@@ -85,10 +85,15 @@ struct RowSched {
 // Rows of at most this many edges are always reduced sequentially by one lane group, in CSR order (the reference's
 // summation order: bit-identical fp32 results); longer rows MAY be cut into contiguous pieces whose partial states are
 // merged in order (wave-scope split in skewed workgroups, workgroup-scope chunks beyond the long-row threshold).
-constexpr int kWaveSplitMin = 64;
+// OFF by default (tuning key 12: <= 0 = off, n > 0 = split rows of more than n edges): measured on the MI355X it buys
+// nothing -- arxiv-sized R-MAT graph, csr_spmm F=64: 133.3 us off / 136.3 (n = 64) / 132.1 (n = 32), F=40: 118.9 / 116.2 /
+// 114.8, fused GAT forward 239 / 238 / 233 us (profiles/r04_wavesplit_ab.txt) -- because only 2.8 % of that graph's edges
+// sit in rows of 65..128 edges: half of its edges are in rows ABOVE the long-row threshold (the workgroup-scope path),
+// and the rest of the imbalance is between waves, not inside them.  Kept as an option (and tested) because graphs with
+// a heavier middle of the degree distribution are where it would pay.
 inline int wave_split_edges() {
-    const int t = g_tuning[kTuneWaveSplit];  // tuning key 12: < 0 = off, 0 = default, > 0 = override
-    return t < 0 ? 0 : (t > 0 ? t : kWaveSplitMin);
+    const int t = g_tuning[kTuneWaveSplit];
+    return t > 0 ? t : 0;
 }
 
 // Threshold above which a row is split.  The sequential time of a row of T edges (~T/UNROLL gather round trips of
@@ -527,7 +532,7 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
     s.m = m;
     s.rowblocks = make_xcd_map(n_rowblocks);
     s.sort_rows = g_tuning[kTuneRowSort] == 0 ? 1 : 0;
-    s.wave_split = wave_split_edges();
+    s.wave_split = wave_split_edges();  // (set to 0 below when the caller asked for sequential rows: no workspace)
     s.lr.thresh = INT_MAX;
     if (nnz > 0 && (!Op::kReduce || workspace)) {
         plan_long_rows(s.lr, nnz);
@@ -539,6 +544,7 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
             s.lr.partial = (float *)((char *)workspace + kFoundBytes);
         }
     }
+    if (s.lr.thresh == INT_MAX) s.wave_split = 0;  // no workspace = every row sequentially, in the reference's order
     if (!grid_fits(s.rowblocks, s.lr.n_long_blocks)) return COGDL_HIP_ERANGE;
     dim3 grid(s.lr.n_long_blocks + xcd_grid(s.rowblocks), (unsigned)tiles);
     hipLaunchKernelGGL((rowreduce_main_kernel<Op>), grid, dim3(256), 0, stream, op, s);

@@ -75,7 +75,7 @@ COGDL_API int cogdl_hip_last_hip_error(void);
  * intermediate records wherever two passes suffice -- by default only from 16 M slots on, 5 = MSD-first where two passes
  * suffice, 6 = digits of at most 6 bits: three passes of whole-line runs for 18-bit ids; both measured slower),
  * key 11 = sampler relabelling (1 = the sort-based form), key 12 = wave-scope split of medium rows in skewed workgroups
- * (0 = rows of more than 64 edges, < 0 = off, > 0 = that many edges).
+ * (<= 0 = off, the default; n > 0 = rows of more than n edges).
  * Defaults are the measured optima. */
 COGDL_API int cogdl_hip_set_tuning(int key, int value);
 
@@ -99,10 +99,11 @@ COGDL_API int cogdl_hip_set_tuning(int key, int value);
 COGDL_API size_t cogdl_hip_csr_spmm_workspace_bytes(int64_t nnz, int64_t k, int dtype);
 COGDL_API int cogdl_hip_long_row_threshold(int64_t nnz);
 /* Rows of at most this many edges are ALWAYS reduced sequentially in CSR order (fp32: bit-identical to the reference's
- * csr_spmm_cpu loop, spmm_cpu.cpp:24-35): min(64, cogdl_hip_long_row_threshold(nnz)) by default.  Longer rows may be cut into
- * contiguous pieces whose partial sums are merged in order -- by the lane groups of one wave in workgroups whose rows
- * are skewed (wave-scope split, tuning key 12: < 0 off, > 0 the split length), by whole workgroups beyond the long-row
- * threshold: deterministic, re-associated at the piece borders (<= 1e-6 relative). */
+ * csr_spmm_cpu loop, spmm_cpu.cpp:24-35): cogdl_hip_long_row_threshold(nnz) by default.  Longer rows are cut into
+ * contiguous pieces whose partial sums are merged in order by whole workgroups -- and, if the wave-scope split of medium
+ * rows is switched on (tuning key 12 = n > 0: rows of more than n edges in workgroups whose rows are skewed; off by
+ * default, it measured no gain), by the lane groups of one wave; then this function returns min(n, threshold).
+ * Deterministic, re-associated at the piece borders only (<= 1e-6 relative). */
 COGDL_API int cogdl_hip_exact_row_edges(int64_t nnz);
 COGDL_API int cogdl_hip_csr_spmm(const int32_t *rowptr, const int32_t *colind, const void *val,
                        const void *x, void *out, int64_t m, int64_t k, int64_t nnz, int dtype,

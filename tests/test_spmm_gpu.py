@@ -360,3 +360,40 @@ def test_strided_index_views_are_made_contiguous_before_hashing(oracle):
     assert out.detach().cpu().numpy().tobytes() == oracle.csr_spmm(g.rowptr, g.colind, g.weight, x).tobytes()
     colptr, rowind, w_t, _ = oracle.csr2csc(g.rowptr, g.colind, g.weight)
     assert xd.grad.cpu().numpy().tobytes() == oracle.csr_spmm(colptr, rowind, w_t, gout).tobytes()
+
+
+@pytest.fixture
+def wave_split_32():
+    from cogdl_amd import _lib
+
+    _lib.hip().cogdl_hip_set_tuning(12, 32)
+    yield 32
+    _lib.hip().cogdl_hip_set_tuning(12, 0)
+
+
+@pytest.mark.parametrize("k", [64, 40, 16, 128])
+def test_wave_scope_split_of_medium_rows(oracle, wave_split_32, k):
+    """Tuning key 12 (off by default): in a skewed workgroup the rows of more than n edges are reduced by all lane groups
+    of their wave, partial states merged in slice order through shuffles.  Rows of at most n edges keep the reference's
+    order (bit-exact), split rows are within 1e-5 of the magnitude of their terms, results are run-to-run identical, and
+    a call without a workspace (= "every row sequentially") is still bit-exact at any length."""
+    from cogdl_amd import _lib
+
+    g = synth.arxiv_like(seed=0, topology="rmat")
+    assert _lib.hip().cogdl_hip_exact_row_edges(g.nnz) == 32
+    x = torch.randn(g.num_nodes, k, generator=torch.Generator().manual_seed(2))
+    want = oracle.csr_spmm(g.rowptr, g.colind, g.weight, x, nthreads=oracle.num_threads())
+    got = hip_spmm(g.rowptr, g.colind, g.weight, x)
+    assert_rows_match(got, want, g.rowptr, g.nnz, oracle.csr_spmm_abs(g.rowptr, g.colind, g.weight, x))
+    assert got.tobytes() == hip_spmm(g.rowptr, g.colind, g.weight, x).tobytes()
+    _lib.hip().cogdl_hip_set_tuning(12, 0)
+    off = hip_spmm(g.rowptr, g.colind, g.weight, x)
+    _lib.hip().cogdl_hip_set_tuning(12, 32)
+    deg = np.diff(g.rowptr.numpy())
+    assert got[deg <= 32].tobytes() == off[deg <= 32].tobytes()
+    if k != 128:  # (k = 128 in fp32 is one wave per row: nothing to split)
+        assert np.any(got != off), "the split did not engage on the R-MAT graph"
+    hubs = synth.hub_csr(600, 600, hubs=((3, 129), (4, 1000), (17, 90), (18, 257), (40, 70), (41, 100)), seed=k)
+    xs = torch.randn(600, k, generator=torch.Generator().manual_seed(3))
+    seq = csr_spmm_raw(hubs.rowptr.to(DEV), hubs.colind.to(DEV), hubs.weight.to(DEV), xs.to(DEV), split_long_rows=False)
+    assert seq.cpu().numpy().tobytes() == oracle.csr_spmm(hubs.rowptr, hubs.colind, hubs.weight, xs).tobytes()
