@@ -391,7 +391,7 @@ def test_wave_scope_split_of_medium_rows(oracle, wave_split_32, k):
     _lib.hip().cogdl_hip_set_tuning(12, 32)
     deg = np.diff(g.rowptr.numpy())
     assert got[deg <= 32].tobytes() == off[deg <= 32].tobytes()
-    if k != 128:  # (k = 128 in fp32 is one wave per row: nothing to split)
+    if k not in (128, 40):  # (k = 128 in fp32 is one wave per row, k = 40 runs in lane groups of 10 that do not tile a wave: no split)
         assert np.any(got != off), "the split did not engage on the R-MAT graph"
     hubs = synth.hub_csr(600, 600, hubs=((3, 129), (4, 1000), (17, 90), (18, 257), (40, 70), (41, 100)), seed=k)
     xs = torch.randn(600, k, generator=torch.Generator().manual_seed(3))
