@@ -199,7 +199,8 @@ def trainer_epoch(budget_s=240):
     if not refpkg.available():
         return None
     out = {}
-    for key, argv in (("gpu", ["gpu", "30"]), ("gpu_mfma_linear", ["gpu", "30", "linear"]), ("cpu_reference", ["cpu", "3"])):
+    for key, argv in (("gpu", ["gpu", "30"]), ("gpu_mfma_linear", ["gpu", "30", "linear"]),
+                      ("gpu_mfma_linear_structure_memo", ["gpu", "30", "linear", "memo"]), ("cpu_reference", ["cpu", "3"])):
         try:
             proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trainer_epoch.py")] + argv,
                                   capture_output=True, text=True, timeout=budget_s)
@@ -385,6 +386,7 @@ def shard_base(budget_s=200):
                         "of the N > 1 lines)", "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
                 "steps": r["steps"], "nodes_per_gpu": r["config"]["nodes_per_gpu"], "nnz": r["config"]["nnz_global"],
                 "local_block_GEdges_s": r.get("local_block_GEdges_s_rank0"),
+                "predicted": r.get("predicted"),
                 "roofline": dict(r.get("roofline") or {}, what="csr_spmm over one papers100M-sized shard's local block "
                                  "(13.9 M rows, 4.1e8 edges, X = 7.1 GB): every gathered row comes from HBM")}
     except subprocess.TimeoutExpired:

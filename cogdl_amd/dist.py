@@ -638,7 +638,14 @@ def sharded_leg(rank, world, dev, shard_nodes, degree, feat, remote_frac, halo_f
     halo_rows = allsum(sh.n_halo)
     remote_edges = allsum(sh.nnz_remote)
     b_alg = sh.nnz_local * (4 + 4 + feat * 4) + shard_nodes * (4 + feat * 4)
+    nnz_gpu = nnz_global / world
+    # (the per-rank halo of the bench's generator: halo_frac x the shard's rows wherever ranks have peers; measured when they do)
+    halo_pred = sh.n_halo if world > 1 else (halo_frac * shard_nodes if halo_frac > 0 else min(remote_frac * nnz_gpu, 7.0 * shard_nodes))
+    rf_pred = remote_frac if remote_frac >= 0 else 0.1
+    predicted = predict_scaling(shard_nodes, nnz_gpu, feat, rf_pred if world == 1 else remote_edges / max(nnz_global, 1),
+                                halo_pred, max(loc_all) / max(sh.nnz_local / 1e9, 1e-12))
     return {
+        "predicted": predicted,
         "value": 2 * nnz_global * steps / dt / 1e9, "unit": "GEdges/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
         "warmup": warmup, "nodes_per_gpu": shard_nodes, "nnz_global": nnz_global, "feat": feat,
         "remote_frac": remote_frac, "halo_frac": halo_frac, "remote_edge_share": remote_edges / max(nnz_global, 1),
@@ -651,6 +658,51 @@ def sharded_leg(rank, world, dev, shard_nodes, degree, feat, remote_frac, halo_f
         "local_block_GEdges_s_rank0": sh.nnz_local / (loc_all[0] * 1e-3) / 1e9,
         "local_block_algorithmic_bytes": b_alg,
     }
+
+
+XGMI_LINK_GBS = 153.0   # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, point to point)
+XGMI_LINK_EFF = 0.8     # what a large RCCL send/recv is ASSUMED to reach of it -- a stated prior, not a measurement
+
+
+def predict_scaling(shard_nodes, nnz_per_gpu, feat, remote_frac, halo_rows_per_rank, local_ms_per_gedge, worlds=(2, 4, 8),
+                    link_gbs=XGMI_LINK_GBS, link_eff=XGMI_LINK_EFF, elem=4):
+    """A falsifiable PRIOR for the weak-scaling curve of the sharded SpMM (forward + backward), made from what ONE GPU can
+    measure -- so that the first hardware 1 -> 2 -> 4 -> 8 run has something to be compared with.
+
+    Model of one step on every rank (all ranks alike), the structure of `_ShardedSpMM`:
+        forward :  gather  ->  [ all-to-all of the halo rows  ||  local-block SpMM ]  ->  halo-block SpMM
+        backward:  halo-block transpose SpMM  ->  [ reverse all-to-all  ||  local-block transpose SpMM ]  ->  accumulate
+      t_local  = (1 - remote_frac) * nnz_per_gpu edges at the measured rate of the local block (ms per 10^9 edges)
+      t_remote = remote_frac * nnz_per_gpu edges at the same rate (the halo table is smaller than X: an upper bound)
+      t_a2a    = halo_rows * feat * elem bytes per direction, spread evenly over the N - 1 peers = N - 1 xGMI links used
+                 at once (point to point: no switch), each at link_gbs * link_eff
+      t_fix    = gather of the requested rows + accumulation of the returned ones: 3 passes over halo_rows * feat * elem at
+                 ~2 TB/s (row gathers at mini-batch granularity)
+      step     = 2 * max(t_local, t_a2a) + 2 * t_remote + t_fix;     efficiency(N) = step(1) / step(N),
+      step(1)  = 2 * nnz_per_gpu edges at the measured rate (world size 1: every edge is local, no exchange).
+    What it deliberately leaves out -- and the hardware run will show -- is RCCL's launch / protocol latency per
+    all-to-all (tens of microseconds against ~10-40 ms here), contention between the exchange and the local block for
+    HBM, and load imbalance between ranks (max over ranks, not the mean)."""
+    out = {"model": "step = 2*max(t_local, t_a2a) + 2*t_remote + t_fix; a2a over the N-1 point-to-point xGMI links at "
+                    "%.0f GB/s x %.2f each; local/remote blocks at the measured single-GPU rate" % (link_gbs, link_eff),
+           "inputs": {"shard_nodes": shard_nodes, "nnz_per_gpu": nnz_per_gpu, "feat": feat, "remote_frac": remote_frac,
+                      "halo_rows_per_rank": halo_rows_per_rank, "local_ms_per_gedge": local_ms_per_gedge}}
+    gedges = nnz_per_gpu / 1e9
+    step1 = 2 * gedges * local_ms_per_gedge
+    halo_bytes = halo_rows_per_rank * feat * elem
+    for n in worlds:
+        t_local = (1 - remote_frac) * gedges * local_ms_per_gedge
+        t_remote = remote_frac * gedges * local_ms_per_gedge
+        t_a2a = halo_bytes / max(n - 1, 1) / (link_gbs * 1e9 * link_eff) * 1e3
+        t_fix = 3 * halo_bytes / 2e12 * 1e3
+        step = 2 * max(t_local, t_a2a) + 2 * t_remote + t_fix
+        out[str(n)] = {"halo_GB_per_rank_per_direction": round(halo_bytes / 1e9, 4), "a2a_ms": round(t_a2a, 3),
+                       "local_block_ms": round(t_local, 3), "remote_block_ms": round(t_remote, 3), "fixed_ms": round(t_fix, 3),
+                       "step_ms": round(step, 3), "exchange_hidden": bool(t_a2a <= t_local),
+                       "efficiency": round(step1 / step, 4),
+                       "GEdges_s_all_gpus": round(2 * n * gedges / (step * 1e-3), 2)}
+    out["step_ms_world1"] = round(step1, 3)
+    return out
 
 
 def _child_leg(argv, port_offset, timeout_s):
@@ -789,7 +841,14 @@ def bench_sharded_spmm(args):
             "local_block_ms_min": m["local_block_ms_min"], "local_block_ms_max": m["local_block_ms_max"],
             "local_block_spmm_ms_rank0": m["local_block_spmm_ms_rank0"],
             "local_block_GEdges_s_rank0": m["local_block_GEdges_s_rank0"],
+            # a PRIOR for the curve, from this run's own single-GPU rates and a stated xGMI rate (predict_scaling): what a
+            # hardware 2 / 4 / 8-GPU run is to be compared with -- at world size N, predicted[str(N)] is this line's own forecast
+            "predicted": m["predicted"],
         }
+        if world > 1 and str(world) in m["predicted"]:
+            pr = m["predicted"][str(world)]
+            result["predicted_vs_measured"] = {"predicted_step_ms": pr["step_ms"], "measured_step_ms": m["ms_per_step"],
+                                               "measured_over_predicted": m["ms_per_step"] / max(pr["step_ms"], 1e-9)}
         if cpu:
             result["selftest"] = "gloo ranks on the host, libcogdl_host kernels: exercises the launcher and the data flow only"
         if share:

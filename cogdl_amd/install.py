@@ -36,7 +36,7 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
 _finder = None
 
 
-def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False, fused_gat_dropout=False):
+def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False, fused_gat_dropout=False, structure_memo=False):
     """Idempotent.  Returns the list of cogdl module names that are now served by cogdl_amd.
     fused_norm=True rebinds the dispatcher function `cogdl.utils.spmm_utils.spmm` itself (opt-in: that is no longer the
     unchanged dispatcher) to cogdl_amd.fused.spmm, which folds `out_norm * x` / `in_norm * x` into the kernel.
@@ -49,6 +49,9 @@ def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False, f
     default -- attn_drop 0.5: leaky_relu(h_l[row] + h_r[col]) -> edge_softmax -> nn.Dropout -> mhspmm,
     layers/gat_layer.py:72-77 -- is one fused operator with the dropout mask regenerated from a seed (cogdl_amd/fused.py).
     `import cogdl` (or cogdl.layers) must have happened before; call install() again afterwards otherwise.
+    structure_memo=True rebinds the two properties Graph.row_indptr / Graph.col_indices (opt-in, same caveat) so that the
+    `.int()` copies the dispatcher makes on every call, and the content hash this library takes of them, happen once per
+    structure (cogdl_amd/structure_memo.py).
     linear=True additionally routes torch.nn.functional.linear -- i.e. the unchanged nn.Linear inside every CogDL
     layer -- through cogdl_amd.linear (hand-written MFMA weight gradient for full-graph shapes)."""
     global _finder
@@ -86,6 +89,10 @@ def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False, f
         from . import fused as _fused
 
         _fused.install_gat_dropout()
+    if structure_memo:
+        from . import structure_memo as _memo
+
+        _memo.install()
     su = sys.modules.get("cogdl.utils.spmm_utils")
     if su is not None:  # force the dispatcher to re-resolve the callables
         for k in ("spmm_flag", "mh_spmm_flag", "fused_gat_flag", "spmm_cpu_flag"):
@@ -127,6 +134,8 @@ def _rebind_graph_build():
 
 
 def uninstall():
+    if "cogdl_amd.structure_memo" in sys.modules:
+        sys.modules["cogdl_amd.structure_memo"].uninstall()
     if "cogdl_amd.linear" in sys.modules:
         sys.modules["cogdl_amd.linear"].uninstall()
     if "cogdl_amd.fused" in sys.modules:

@@ -15,7 +15,7 @@ models/nn/gat.py:30; layers/gat_layer.py:72-77) inside the same kernels.
 import torch
 
 from .. import _lib
-from ..plan import PLANS, Fingerprint
+from ..plan import PLANS, Fingerprint, fingerprint_of
 
 _lib.hip()
 
@@ -82,7 +82,7 @@ class FusedGATFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, negative_slope, in_feat, p=0.0, seed=0):
         row_ptr, col_ind = _lib.csr_structure(row_ptr, col_ind)
-        ctx.fp = Fingerprint(row_ptr, col_ind, in_feat.shape[0])  # before the kernel: lands early for backward
+        ctx.fp = fingerprint_of(row_ptr, col_ind, in_feat.shape[0])  # before the kernel: lands early for backward
         f = in_feat.shape[-1]
         fp = _padded_width(f, in_feat.element_size()) if in_feat.dim() == 3 and in_feat.dtype in _lib.DTYPE_CODE else f
         feat = in_feat.detach()

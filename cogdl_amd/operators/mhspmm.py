@@ -11,7 +11,7 @@ Backward (same maths as MHSPMMFunction.backward, operators/mhspmm.py:52-64):
 import torch
 
 from .. import _lib
-from ..plan import PLANS, Fingerprint
+from ..plan import PLANS, Fingerprint, fingerprint_of
 
 _lib.hip()
 
@@ -56,7 +56,7 @@ class MHSPMMFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rowptr, colind, feat, attention):
         rowptr, colind = _lib.csr_structure(rowptr, colind)
-        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None  # before the kernel
+        ctx.fp = fingerprint_of(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None  # before the kernel
         out = mhspmm_raw(rowptr, colind, attention, feat)
         ctx.save_for_backward(rowptr, colind, feat, attention)
         return out

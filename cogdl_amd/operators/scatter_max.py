@@ -14,7 +14,7 @@ import os
 import torch
 
 from .. import _lib
-from ..plan import PLANS, Fingerprint
+from ..plan import PLANS, Fingerprint, fingerprint_of
 
 _lib.hip()
 
@@ -76,7 +76,7 @@ class ScatterMaxFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rowptr, colind, feat, reference_exact=False):
         rowptr, colind = _lib.csr_structure(rowptr, colind)
-        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None  # before the kernel
+        ctx.fp = fingerprint_of(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] else None  # before the kernel
         out, max_id = scatter_max_fp(rowptr, colind, feat)
         if reference_exact:  # acc = FLT_MIN; if (acc < B) {acc = B; max_id = cid}  (scatter_max.cu:16-23)
             below = ((rowptr[1:] > rowptr[:-1]).view(-1, 1)) & ~(out > FLT_MIN)

@@ -18,7 +18,7 @@ import torch
 
 from .. import _lib
 from .. import plan as _plan
-from ..plan import PLANS, Fingerprint, csr2csc, gather_rows
+from ..plan import PLANS, Fingerprint, fingerprint_of, csr2csc, gather_rows
 
 _lib.hip()  # fail at import if the HIP library is missing (no silent `csrspmm = None`)
 
@@ -103,7 +103,7 @@ class SPMMFunction(torch.autograd.Function):
         # kernel, not behind the SpMM).
         rowptr, colind = _lib.csr_structure(rowptr, colind)  # validated + contiguous before anything reads raw pointers
         ctx.transient = _plan.transient()  # (the dense operand is checked by csr_spmm_raw)
-        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] and not ctx.transient else None
+        ctx.fp = fingerprint_of(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] and not ctx.transient else None
         out = csr_spmm_raw(rowptr, colind, edge_weight_csr, feat)
         need_w = edge_weight_csr is not None and ctx.needs_input_grad[3]
         ctx.n_src = feat.shape[0]
@@ -173,7 +173,7 @@ class FusedSPMMFunction(torch.autograd.Function):
         rowptr, colind = _lib.csr_structure(rowptr, colind)
         _check_csr(rowptr, colind, feat)
         ctx.transient = bool(transient) or _plan.transient()
-        ctx.fp = Fingerprint(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] and not ctx.transient else None
+        ctx.fp = fingerprint_of(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] and not ctx.transient else None
         out = csr_spmm_epilogue_raw(rowptr, colind, edge_weight_csr, feat, out_norm, in_norm, bias, relu)
         ctx.n_src, ctx.relu, ctx.has_bias = feat.shape[0], bool(relu), bias is not None
         ctx.save_for_backward(rowptr, colind, edge_weight_csr, out_norm, in_norm, out if relu else None)

@@ -226,6 +226,18 @@ class Fingerprint:
             pass
 
 
+def fingerprint_of(rowptr, colind, n_cols):
+    """The structure's Fingerprint for an operator call: the memoised one when the tensors come from a Graph under
+    `install(structure_memo=True)` (cogdl_amd/structure_memo.py: no hash kernel, no event, no pinned buffer per call),
+    otherwise a fresh hash enqueued now."""
+    memo = getattr(rowptr, "_cogdl_amd_struct", None)
+    if memo is not None:
+        fp = memo.fingerprint(rowptr, colind, int(n_cols))
+        if fp is not None:
+            return fp
+    return Fingerprint(rowptr, colind, n_cols)
+
+
 class PlanCache:
     def __init__(self, budget_bytes=None):
         if budget_bytes is None:

@@ -1,0 +1,112 @@
+"""Opt-in (`install(structure_memo=True)`): the int32 view of a Graph's CSR structure and its content fingerprint are
+computed ONCE per structure instead of on every operator call.
+
+CogDL's dispatcher hands the native operators fresh `.int()` copies of `graph.row_indptr` / `graph.col_indices` on every
+call (cogdl/utils/spmm_utils.py:98-109, 172-188, 201-226): two cast kernels per call, and -- because the copies' addresses
+never repeat -- this library has to hash their CONTENTS (one more kernel, an event, a pinned buffer) to find the cached
+transpose for the backward pass.  In a full-graph epoch that is ~25 us of host time per SpMM call on a step that is
+launch-bound on the host.
+
+What is rebound: the two PROPERTIES `cogdl.data.Graph.row_indptr` / `.col_indices`.  They return the Graph's own int64
+tensor wrapped in a thin torch.Tensor subclass (same storage, same version counter, torch functions disabled so every
+operation on it yields plain tensors) whose only override is `.int()`: it returns a memoised int32 copy, keyed on the
+identity of the int64 source (address, version counter, shape, device) and kept on the Adjacency object -- an in-place
+change of the structure, a new tensor, `graph.to(device)` all miss the memo and rebuild it.  The int32 copy carries the
+memo record, where the operators (cogdl_amd/operators/spmm.py, fused_gat.py, mhspmm.py) find the pair of tensors the
+record vouches for and a Fingerprint computed once.  Nothing else about the Graph changes; `uninstall()` restores the
+reference's properties."""
+import sys
+
+import torch
+
+from .plan import Fingerprint, tensor_key
+
+_ATTR = "__cogdl_amd_structure_memo__"  # (double underscores on both sides: outside Adjacency.keys, data.py:352-356)
+_orig = {}
+
+
+class StructureMemo:
+    """rowptr32 / colind32 of ONE structure + its fingerprint (hashed on first use, then reused)."""
+    __slots__ = ("src_keys", "rowptr32", "colind32", "_fp", "n_cols_fp")
+
+    def __init__(self):
+        self.src_keys = [None, None]
+        self.rowptr32 = self.colind32 = None
+        self._fp = {}
+
+    def __reduce__(self):  # pickled with its Graph (Trainer.dist_train spawns ranks): events / pinned buffers stay behind
+        return (StructureMemo, ())
+
+    def fingerprint(self, rowptr, colind, n_cols):
+        """The Fingerprint of (rowptr, colind) if those are the memoised tensors, else None."""
+        if rowptr is not self.rowptr32 or colind is not self.colind32:
+            return None
+        fp = self._fp.get(n_cols)
+        if fp is None:
+            fp = Fingerprint(rowptr, colind, n_cols)
+            self._fp = {n_cols: fp}
+        return fp
+
+
+class _StructIndex(torch.Tensor):
+    """A Graph's int64 row_indptr / col_indices whose .int() is memoised (see the module docstring)."""
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @staticmethod
+    def __new__(cls, base, memo, which):
+        t = torch.Tensor._make_subclass(cls, base)
+        t._memo, t._which, t._src = memo, which, base
+        return t
+
+    def int(self, *args, **kwargs):
+        if args or kwargs:
+            return self._src.int(*args, **kwargs)
+        memo, which, base = self._memo, self._which, self._src
+        key = tensor_key(base)
+        cached = memo.rowptr32 if which == 0 else memo.colind32
+        if cached is None or memo.src_keys[which] != key:
+            cached = base.int()
+            cached._cogdl_amd_struct = memo
+            memo.src_keys[which] = key
+            memo._fp = {}
+            if which == 0:
+                memo.rowptr32 = cached
+            else:
+                memo.colind32 = cached
+        return cached
+
+
+def lookup(rowptr, colind, n_cols):
+    """The memoised Fingerprint for an operator call's (rowptr, colind), or None (then the caller hashes as before)."""
+    memo = getattr(rowptr, "_cogdl_amd_struct", None)
+    return memo.fingerprint(rowptr, colind, n_cols) if memo is not None else None
+
+
+def _wrap(adj, base, which):
+    if not torch.is_tensor(base) or base.dtype != torch.int64 or not base.is_cuda:
+        return base  # CPU graphs: the reference's own path, untouched
+    memo = adj.__dict__.get(_ATTR)
+    if memo is None:
+        memo = StructureMemo()
+        adj.__dict__[_ATTR] = memo
+    return _StructIndex(base, memo, which)
+
+
+def install():
+    mod = sys.modules.get("cogdl.data.data")
+    if mod is None:
+        return False
+    cls = mod.Graph
+    if cls in _orig:
+        return True
+    p_row, p_col = cls.__dict__["row_indptr"], cls.__dict__["col_indices"]
+    _orig[cls] = (p_row, p_col)
+    cls.row_indptr = property(lambda self: _wrap(self._adj, p_row.fget(self), 0), p_row.fset, p_row.fdel, p_row.__doc__)
+    cls.col_indices = property(lambda self: _wrap(self._adj, p_col.fget(self), 1), p_col.fset, p_col.fdel, p_col.__doc__)
+    return True
+
+
+def uninstall():
+    for cls, (p_row, p_col) in _orig.items():
+        cls.row_indptr, cls.col_indices = p_row, p_col
+    _orig.clear()

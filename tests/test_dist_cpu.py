@@ -153,6 +153,11 @@ def test_bench_gpus_n_self_launches_n_ranks_and_its_data_flow_equals_the_global_
     assert proc.returncode == 0 and len(lines) == 1, proc.stderr[-800:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == world and line["n_ranks_seen"] == world and line["scaling"] == "weak"
+    # the line's own forecast of the curve (cogdl_amd.dist.predict_scaling) and its comparison with what was measured
+    pred = line["predicted"]
+    assert {"2", "4", "8", "model", "inputs", "step_ms_world1"} <= set(pred)
+    assert all(0 < pred[n]["efficiency"] <= 1.0 and pred[n]["a2a_ms"] >= 0 for n in ("2", "4", "8"))
+    assert line["predicted_vs_measured"]["predicted_step_ms"] == pred[str(world)]["step_ms"]
     assert len(line["local_block_ms_by_rank"]) == world and line["halo_GB_per_step_all_ranks"] > 0
     worst = line["worst_case_partition"]
     assert worst.get("n_gpus") == world and worst.get("n_ranks_seen") == world, worst
@@ -357,3 +362,24 @@ def test_an_invalid_shard_on_one_rank_stops_every_rank_instead_of_hanging_the_ex
     m0, m1 = (open(os.path.join(str(tmp_path), "bad%d.txt" % r)).read() for r in (0, 1))
     assert "rowptr must start at 0, be non-decreasing" in m1
     assert "another rank rejected its shard" in m0
+
+
+def test_predict_scaling_model():
+    """The prior attached to every sharded bench line: exchange hidden behind the local block -> the efficiency is what
+    the halo-block work and the fixed passes cost; a halo so large that the links are the bottleneck -> the step is
+    bound by the all-to-all, more peers (more links used at once) shorten it."""
+    from cogdl_amd.dist import predict_scaling
+
+    # the bench's default shard: 13.9 M rows, 4.1e8 edges, F = 128, 10 % remote sources, halo = 0.25 x rows, 6.0 TB/s-ish local block
+    p = predict_scaling(13_882_494, 4.14e8, 128, 0.1, 0.25 * 13_882_494, 37.0 / 0.414)
+    assert p["step_ms_world1"] == pytest.approx(2 * 37.0, rel=1e-3)
+    for n in ("2", "4", "8"):
+        assert p[n]["halo_GB_per_rank_per_direction"] == pytest.approx(0.25 * 13_882_494 * 128 * 4 / 1e9, rel=1e-3)
+    assert p["2"]["a2a_ms"] == pytest.approx(1.777e9 / (153e9 * 0.8) * 1e3, rel=1e-2)  # one peer: one link
+    assert p["8"]["a2a_ms"] == pytest.approx(p["2"]["a2a_ms"] / 7, rel=1e-3)           # seven peers: seven links at once
+    assert p["8"]["exchange_hidden"] and p["8"]["efficiency"] > p["2"]["efficiency"] - 1e-9
+    assert 0.9 < p["8"]["efficiency"] <= 1.0
+    # worst case: 7/8 of the sources remote and uniform -> halo ~ 7 x the shard's rows: link-bound at every N
+    w = predict_scaling(3_470_000, 1.03e8, 128, 0.875, 7 * 3_470_000, 90.0)
+    assert not w["2"]["exchange_hidden"] and w["2"]["step_ms"] > 2 * w["2"]["a2a_ms"]
+    assert w["8"]["a2a_ms"] < w["2"]["a2a_ms"]

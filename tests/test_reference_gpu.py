@@ -145,6 +145,47 @@ cogdl_amd.fused.uninstall()
 assert GATLayer.forward is reference_forward
 report["gat_layer_fused_dropout"] = "ok"
 
+# ---- 2b''. install(structure_memo=True): Graph.row_indptr / col_indices hand out a memoised .int() -- the unchanged
+#            dispatcher then runs many GCNLayer steps on ONE structure hash and ONE pair of int32 copies, same results.
+import cogdl_amd.plan as plan_mod
+import cogdl_amd.structure_memo as memo_mod
+zg = gold("gcn_layer")
+row_g, col_g = coo(zg)
+gg = Graph(edge_index=(row_g, col_g), edge_weight=T(zg["edge_weight"]), num_nodes=row_g.max().item() + 1).to(DEV)
+lay = GCNLayer(32, 16).to(DEV)
+with torch.no_grad():
+    lay.linear.weight.copy_(T(zg["W"])); lay.linear.bias.copy_(T(zg["b"]))
+def gcn_steps(n):
+    outs = []
+    for _ in range(n):
+        xx = T(zg["x"]).to(DEV).requires_grad_()
+        oo = lay(gg, xx)
+        (oo * T(zg["G"]).to(DEV)).sum().backward()
+        outs.append((oo.detach().clone(), xx.grad.clone()))
+    return outs
+hashes = {"n": 0}
+real_init = plan_mod.Fingerprint.__init__
+def counting_init(self, *a, **k):
+    hashes["n"] += 1
+    real_init(self, *a, **k)
+plan_mod.Fingerprint.__init__ = counting_init
+plain = gcn_steps(3)
+assert hashes["n"] == 3, hashes
+cogdl_amd.install(structure_memo=True)
+assert type(gg.row_indptr) is memo_mod._StructIndex and gg.row_indptr.int() is gg.row_indptr.int()
+hashes["n"] = 0
+memoised = gcn_steps(5)
+assert hashes["n"] == 1, "the structure was hashed %d times for 5 steps" % hashes["n"]
+for (o1, g1), (o2, g2) in zip(plain, memoised):
+    assert torch.equal(o1, o2) and torch.equal(g1, g2)
+np.testing.assert_allclose(memoised[-1][0].cpu().numpy(), zg["out_train"], rtol=1e-4, atol=1e-5)
+gg2 = gg.to("cpu").to(DEV)  # a moved graph: new tensors, the memo is not reused across them
+assert gg2.row_indptr.int() is not gg.row_indptr.int()
+memo_mod.uninstall()
+plan_mod.Fingerprint.__init__ = real_init
+assert type(gg.row_indptr) is torch.Tensor
+report["structure_memo"] = "ok"
+
 # ---- 2c. Graph.sample_adj(-1) + SAGELayer(mean) and MaxAggregator on cuda
 z = gold("sage_layer")
 rp = T(z["g_row_indptr"]); deg = rp[1:] - rp[:-1]
@@ -266,7 +307,7 @@ def test_unchanged_reference_layers_and_trainer_run_on_the_hip_operators():
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT ")]
     assert proc.returncode == 0 and lines, proc.stdout[-3000:] + proc.stderr[-5000:]
     rep = json.loads(lines[-1][7:])
-    assert rep["gcn_layer"] == rep["gat_layer"] == rep["sage_layer"] == rep["gat_layer_fused_dropout"] == "ok"
+    assert rep["gcn_layer"] == rep["gat_layer"] == rep["sage_layer"] == rep["gat_layer_fused_dropout"] == rep["structure_memo"] == "ok"
     assert rep["fused_norm_keeps_weight_grad"] == rep["narrow_side"] == rep["graphsage_inference"] == "ok"
     lg, lc = rep["cora_losses_gpu"], rep["cora_losses_cpu"]
     assert len(lg) == len(lc) == 6

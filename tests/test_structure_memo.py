@@ -1,0 +1,45 @@
+"""cogdl_amd/structure_memo.py (install(structure_memo=True)): the memoised `.int()` of a Graph's CSR index tensors.
+CPU part: the tensor subclass itself (identity, invalidation, plain results, pickling).  GPU part: the unchanged
+dispatcher on a Graph takes ONE structure hash for many calls and gives the same results as without the memo."""
+import pickle
+
+import pytest
+import torch
+
+from cogdl_amd.structure_memo import StructureMemo, _StructIndex
+
+
+def test_int_is_memoised_and_invalidated_by_in_place_changes():
+    memo = StructureMemo()
+    base = torch.tensor([0, 2, 3, 5], dtype=torch.int64)
+    t = _StructIndex(base, memo, 0)
+    a = t.int()
+    assert a.dtype == torch.int32 and a.tolist() == [0, 2, 3, 5] and a is memo.rowptr32 and a._cogdl_amd_struct is memo
+    assert _StructIndex(base, memo, 0).int() is a  # a second property access: the same copy, no cast
+    base[3] = 6  # in-place change of the Graph's structure: version counter moves, the memo misses
+    b = _StructIndex(base, memo, 0).int()
+    assert b is not a and b.tolist() == [0, 2, 3, 6] and memo.rowptr32 is b
+    other = torch.tensor([0, 1, 1, 2], dtype=torch.int64)  # a new tensor behind the property (graph.row_indptr = ...)
+    c = _StructIndex(other, memo, 0).int()
+    assert c.tolist() == [0, 1, 1, 2]
+    # with arguments .int() is torch's own
+    assert _StructIndex(base, memo, 0).int(memory_format=torch.contiguous_format).dtype == torch.int32
+
+
+def test_the_wrapper_is_an_ordinary_tensor_everywhere_else():
+    memo = StructureMemo()
+    base = torch.arange(5, dtype=torch.int64)
+    t = _StructIndex(base, memo, 1)
+    assert isinstance(t, torch.Tensor) and t.dtype == torch.int64 and t.data_ptr() == base.data_ptr()
+    for r in (t + 1, t[1:], t.float(), t.to(torch.int16), torch.cat([t, t]), t[1:] - t[:-1], t.clone()):
+        assert type(r) is torch.Tensor
+    assert t.long() is t and t.to(torch.int64) is t  # (no-op conversions hand the same object back, as for any tensor)
+    assert int(t[-1]) == 4 and t.tolist() == [0, 1, 2, 3, 4] and t.numel() == 5
+    assert torch.equal(torch.repeat_interleave(torch.arange(4), t[1:] - t[:-1]), torch.arange(4))
+
+
+def test_memo_pickles_empty():
+    memo = StructureMemo()
+    _StructIndex(torch.arange(3, dtype=torch.int64), memo, 0).int()
+    back = pickle.loads(pickle.dumps(memo))
+    assert isinstance(back, StructureMemo) and back.rowptr32 is None and back.colind32 is None
