@@ -17,7 +17,7 @@ int check_fwd(const int32_t *rowptr, const float *attn_row, const float *attn_co
 }
 
 // Layout of the backward workspace:
-//   [D: v*h floats][TILED: pdot tiles*max(v,n_src)*h | pd tiles*v*h | hsum max(v,n_src)*h]
+//   [row-pass records {attn_row, max, 1/sum, D}: v*h float4][TILED: pdot tiles*max(v,n_src)*h | pd tiles*v*h | hsum max(v,n_src)*h]
 //   [long-row scratch of the row pass][... of the column pass]
 struct BwdLayout {
     size_t d, pdot, pd, hsum, row, col, total_min, total;
@@ -25,7 +25,7 @@ struct BwdLayout {
 size_t pad256(size_t b) { return (b + 255) / 256 * 256; }
 BwdLayout bwd_layout(const GatBwdGeometry &g, int64_t v, int64_t n_src, int64_t h, int64_t nnz) {
     BwdLayout L{};
-    L.d = gat_dvec_bytes(v, h);
+    L.d = gat_stats_bytes(v, h);
     if (g.tiled) {
         const size_t rows = (size_t)std::max<int64_t>(std::max(v, n_src), 0);
         L.pdot = pad256((size_t)g.tiles * rows * (size_t)h * sizeof(float));
@@ -70,7 +70,7 @@ int gat_bwd_entry(const int32_t *rowptr, const int32_t *colind, const int32_t *c
     b.gfeat = grad_feat, b.gar = grad_attn_row, b.gac = grad_attn_col;
     b.v = v, b.n_src = n_src, b.h = h, b.f = f, b.nnz = nnz;
     char *w = (char *)workspace;
-    b.dvec = (float *)w;
+    b.stats = (float4 *)w;
     b.t_pdot = (float *)(w + L.d);
     b.t_pd = (float *)(w + L.d + L.pdot);
     b.t_hsum = (float *)(w + L.d + L.pdot + L.pd);

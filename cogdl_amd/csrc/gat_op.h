@@ -406,7 +406,10 @@ struct GatBwdRowOp {
     const T *feat;  // feat / out / grad_out in the layer's dtype (f32, f16, bf16): read natively, fp32 arithmetic
     const float *edge_max, *edge_sum;
     const T *out, *grad_out;
-    float *dvec, *grad_attn_row;
+    float4 *stats;  // [V, H] {attn_row, edge_max, 1 / edge_sum, D}: everything the column pass needs per (row, head), as
+                    // ONE 16-byte gather per edge and lane instead of four 4-byte gathers from four arrays (each of
+                    // which drags its own 64-byte sector in: the four scalars cost as much traffic as the feature row)
+    float *grad_attn_row;
     float slope;
     int heads, fdim, lph;
     GatDrop drop;
@@ -503,7 +506,7 @@ struct GatBwdRowOp {
         } else {
             dot = head_sum<LPR>(dot, lph);
             if (ok && c.m.head_lane) {
-                dvec[row * heads + c.m.hd] = c.d;
+                stats[row * heads + c.m.hd] = make_float4(c.ar, c.mx, c.inv, c.d);
                 grad_attn_row[row * heads + c.m.hd] = dot - c.d * s.csum;
             }
         }
@@ -533,7 +536,7 @@ struct GatBwdColOp {
     static constexpr int kLds = 0;
     const float *attn_row, *attn_col;
     const T *feat;
-    const float *edge_max, *edge_sum, *dvec;
+    const float4 *stats;  // [V, H] {attn_row, edge_max, 1 / edge_sum, D} (written by the row pass)
     const T *grad_out;
     T *grad_feat;  // rounded once on store (fp32 accumulation)
     float *grad_attn_col;
@@ -559,7 +562,7 @@ struct GatBwdColOp {
     using LaneVals = DropLane<DROP>;
     struct Batch {
         float g[UNROLL][VEC];
-        float ar[UNROLL], mx[UNROLL], ls[UNROLL], dd[UNROLL];
+        float4 st[UNROLL];
         float d[DROP ? UNROLL : 1];
     };
 
@@ -589,19 +592,15 @@ struct GatBwdColOp {
     }
     __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int r, int64_t, const LaneVals &lv, int sub,
                                           int jj) const {
-        const int64_t rh = (int64_t)r * heads + c.m.hd;
-        b.ar[u] = attn_row[rh];
-        b.mx[u] = edge_max[rh];
-        b.ls[u] = edge_sum[rh];
-        b.dd[u] = dvec[rh];
+        b.st[u] = stats[(int64_t)r * heads + c.m.hd];
         load_vec<T, VEC>(grad_out + (int64_t)r * (heads * fdim) + c.m.cc, b.g[u]);
         if constexpr (DROP) b.d[u] = drop_factor<LPR>(drop, lv, sub, jj, c.m.hd, heads);
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
                                           int) const {
         if (valid) {
-            const float pre = b.ar[u] + c.ac;
-            const float a = gat_exp(leaky(pre, slope) - b.mx[u]) / b.ls[u];
+            const float pre = b.st[u].x + c.ac;
+            const float a = gat_exp(leaky(pre, slope) - b.st[u].y) * b.st[u].z;
             const float ce = a * (pre > 0.f ? 1.f : slope);
             const float aw = DROP ? a * b.d[DROP ? u : 0] : a;
             const float cw = DROP ? ce * b.d[DROP ? u : 0] : ce;
@@ -610,7 +609,7 @@ struct GatBwdColOp {
                 s.acc[i] = fmaf(aw, b.g[u][i], s.acc[i]);
                 s.t[i] = fmaf(cw, b.g[u][i], s.t[i]);
             }
-            s.cd = fmaf(ce, b.dd[u], s.cd);
+            s.cd = fmaf(ce, b.st[u].w, s.cd);
         }
     }
     __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *,
@@ -762,7 +761,8 @@ struct GatBwdArgs {
     const void *out, *gout;
     float slope;
     void *gfeat;
-    float *gar, *gac, *dvec;
+    float *gar, *gac;
+    float4 *stats;
     int64_t v, n_src, h, f, nnz;
     void *ws_row, *ws_col;  // long-row scratch of the two passes (either both or none)
     size_t wsb_row, wsb_col;
@@ -809,8 +809,8 @@ inline GatBwdGeometry gat_bwd_geometry(int64_t h, int64_t f, int align, int elem
     g.tiles = (need + g.lpr - 1) / g.lpr;
     return g;
 }
-inline size_t gat_dvec_bytes(int64_t v, int64_t h) {
-    return ((size_t)(v > 0 ? v : 0) * (size_t)(h > 0 ? h : 0) * sizeof(float) + 255) / 256 * 256;
+inline size_t gat_stats_bytes(int64_t v, int64_t h) {  // [V, H] float4 records of the row pass
+    return ((size_t)(v > 0 ? v : 0) * (size_t)(h > 0 ? h : 0) * sizeof(float4) + 255) / 256 * 256;
 }
 
 template <typename T, int VEC, int LPR, bool DROP>
@@ -819,11 +819,11 @@ static int gat_launch_bwd(const GatBwdArgs &b, hipStream_t s) {
     GatDrop row_drop = b.drop;
     row_drop.eid = nullptr;  // the row pass walks the CSR itself
     GatBwdRowOp<T, VEC, LPR, 4, DROP, false> row_op{b.ar, b.ac, (const T *)b.feat, b.emax, b.esum, (const T *)b.out,
-                                                    (const T *)b.gout, b.dvec, b.gar, b.slope, (int)b.h, (int)b.f,
+                                                    (const T *)b.gout, b.stats, b.gar, b.slope, (int)b.h, (int)b.f,
                                                     lph, row_drop, GatTiles{}};
     int rc = launch_rowreduce(row_op, b.rowptr, b.colind, b.v, b.nnz, 1, b.ws_row, b.wsb_row, s);
     if (rc != COGDL_HIP_OK) return rc;
-    GatBwdColOp<T, VEC, LPR, 4, DROP, false> col_op{b.ar, b.ac, (const T *)b.feat, b.emax, b.esum, b.dvec,
+    GatBwdColOp<T, VEC, LPR, 4, DROP, false> col_op{b.ar, b.ac, (const T *)b.feat, b.stats,
                                                     (const T *)b.gout, (T *)b.gfeat, b.gac, b.slope, (int)b.h,
                                                     (int)b.f, lph, b.drop, GatTiles{}};
     return launch_rowreduce(col_op, b.colptr, b.rowind, b.n_src, b.nnz, 1, b.ws_col, b.wsb_col, s);

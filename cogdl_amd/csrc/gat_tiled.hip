@@ -17,9 +17,10 @@ namespace cogdl {
 // out[r,h] = sum_{t in tiles of head h} pdot[t,r,h]  -  (ROW ? D[r,h] * hsum[r,h] : hsum[r,h]);   ROW also writes D.
 template <bool ROW>
 __global__ __launch_bounds__(256) void gat_finish_kernel(const float *__restrict__ pdot, const float *__restrict__ pd,
-                                                         const float *__restrict__ hsum, float *__restrict__ dvec,
-                                                         float *__restrict__ out, int64_t rows, int heads, int fdim,
-                                                         int tile_cols) {
+                                                         const float *__restrict__ hsum, float4 *__restrict__ stats,
+                                                         const float *__restrict__ attn_row, const float *__restrict__ edge_max,
+                                                         const float *__restrict__ edge_sum, float *__restrict__ out,
+                                                         int64_t rows, int heads, int fdim, int tile_cols) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * heads) return;
     const int h = (int)(i % heads);
@@ -30,7 +31,8 @@ __global__ __launch_bounds__(256) void gat_finish_kernel(const float *__restrict
         if constexpr (ROW) d += pd[(int64_t)t * rows * heads + i];
     }
     if constexpr (ROW) {
-        dvec[i] = d;
+        const float ls = edge_sum[i];
+        stats[i] = make_float4(attn_row[i], edge_max[i], ls > 0.f ? 1.f / ls : 0.f, d);  // (the column pass's per-edge record)
         out[i] = dot - d * hsum[i];
     } else {
         out[i] = dot - hsum[i];
@@ -43,23 +45,24 @@ static int launch_tiled(const GatBwdArgs &b, int64_t tiles, hipStream_t s) {
     row_drop.eid = nullptr;
     const int tile_cols = LPR * VEC;
     GatBwdRowOp<T, VEC, LPR, 4, DROP, true> row_op{b.ar, b.ac, (const T *)b.feat, b.emax, b.esum, (const T *)b.out,
-                                                   (const T *)b.gout, b.dvec, b.gar, b.slope, (int)b.h, (int)b.f, 0,
+                                                   (const T *)b.gout, b.stats, b.gar, b.slope, (int)b.h, (int)b.f, 0,
                                                    row_drop, GatTiles{b.t_pdot, b.t_pd, b.t_hsum, b.v}};
     int rc = launch_rowreduce(row_op, b.rowptr, b.colind, b.v, b.nnz, tiles, b.ws_row, b.wsb_row, s);
     if (rc != COGDL_HIP_OK) return rc;
     if (b.v > 0) {
         hipLaunchKernelGGL(gat_finish_kernel<true>, dim3((unsigned)((b.v * b.h + 255) / 256)), dim3(256), 0, s, b.t_pdot,
-                           b.t_pd, b.t_hsum, b.dvec, b.gar, b.v, (int)b.h, (int)b.f, tile_cols);
+                           b.t_pd, b.t_hsum, b.stats, b.ar, b.emax, b.esum, b.gar, b.v, (int)b.h, (int)b.f, tile_cols);
         if ((rc = launch_status()) != COGDL_HIP_OK) return rc;
     }
-    GatBwdColOp<T, VEC, LPR, 4, DROP, true> col_op{b.ar, b.ac, (const T *)b.feat, b.emax, b.esum, b.dvec,
+    GatBwdColOp<T, VEC, LPR, 4, DROP, true> col_op{b.ar, b.ac, (const T *)b.feat, b.stats,
                                                    (const T *)b.gout, (T *)b.gfeat, b.gac, b.slope, (int)b.h, (int)b.f,
                                                    0, b.drop, GatTiles{b.t_pdot, nullptr, b.t_hsum, b.n_src}};
     rc = launch_rowreduce(col_op, b.colptr, b.rowind, b.n_src, b.nnz, tiles, b.ws_col, b.wsb_col, s);
     if (rc != COGDL_HIP_OK) return rc;
     if (b.n_src > 0) {
         hipLaunchKernelGGL(gat_finish_kernel<false>, dim3((unsigned)((b.n_src * b.h + 255) / 256)), dim3(256), 0, s,
-                           b.t_pdot, nullptr, b.t_hsum, nullptr, b.gac, b.n_src, (int)b.h, (int)b.f, tile_cols);
+                           b.t_pdot, nullptr, b.t_hsum, nullptr, nullptr, nullptr, nullptr, b.gac, b.n_src, (int)b.h, (int)b.f,
+                           tile_cols);
         rc = launch_status();
     }
     return rc;

@@ -179,8 +179,10 @@ assert hashes["n"] == 1, "the structure was hashed %d times for 5 steps" % hashe
 for (o1, g1), (o2, g2) in zip(plain, memoised):
     assert torch.equal(o1, o2) and torch.equal(g1, g2)
 np.testing.assert_allclose(memoised[-1][0].cpu().numpy(), zg["out_train"], rtol=1e-4, atol=1e-5)
-gg2 = gg.to("cpu").to(DEV)  # a moved graph: new tensors, the memo is not reused across them
-assert gg2.row_indptr.int() is not gg.row_indptr.int()
+before = gg.row_indptr.int()
+gg.to("cpu"); gg.to(DEV)  # (Graph.to moves in place) new tensors behind the properties: the memo misses and is rebuilt
+after = gg.row_indptr.int()
+assert after is not before and torch.equal(after, before) and gg.row_indptr.int() is after
 memo_mod.uninstall()
 plan_mod.Fingerprint.__init__ = real_init
 assert type(gg.row_indptr) is torch.Tensor

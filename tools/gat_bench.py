@@ -114,6 +114,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--leg", action="store_true", help="bench.py's configs2_gat object: bf16 only, one JSON line")
+    ap.add_argument("--only", default=None, help="run only the training-step variant whose name starts with this (profiling)")
     args = ap.parse_args()
     n, feats, classes = 232_965, 602, 41
     gr = synth.reddit_like(seed=0, device=DEV)
@@ -130,6 +131,8 @@ def main():
         variants += [("fused-dropout (attn_drop 0.5 = model default; install(fused_gat_dropout=True)) f32", "fused-dropout", 0.5, None),
                      ("fused (attn_drop 0) f32", "fused", 0.0, None),
                      ("unfused (attn_drop 0.5 on the unchanged layer) f32", "unfused", 0.5, None)]
+    if args.only:
+        variants = [v for v in variants if v[0].startswith(args.only)]
     steps = {}
     for name, mode, p, amp in variants:
         torch.manual_seed(0)
@@ -161,6 +164,9 @@ def main():
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
     res["training_step"] = steps
+    if args.only:
+        print(json.dumps(res))
+        return
     res["kernels"] = kernel_rooflines(gr, n)
     if not args.leg:
         for k, v in res["kernels"].items():

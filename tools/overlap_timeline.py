@@ -132,7 +132,7 @@ def main():
         wire = Wire(wire_ms * wire_scale, khz)
         cdist.exchange_rows = wire
         sh.transposed()
-        for it in range(2):  # (first pass warms the allocator; the second one is reported)
+        for it in range(4):  # (the first passes warm the allocator and the clocks; the last one is reported)
             spans.clear()
             wire.log.clear()
             torch.cuda.synchronize()
