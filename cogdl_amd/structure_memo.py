@@ -10,7 +10,8 @@ launch-bound on the host.
 What is rebound: the two PROPERTIES `cogdl.data.Graph.row_indptr` / `.col_indices`.  They return the Graph's own int64
 tensor wrapped in a thin torch.Tensor subclass (same storage, same version counter, torch functions disabled so every
 operation on it yields plain tensors) whose only override is `.int()`: it returns a memoised int32 copy, keyed on the
-identity of the int64 source (address, version counter, shape, device) and kept on the Adjacency object -- an in-place
+identity of the int64 source (the tensor OBJECT, which the memo keeps alive, and its version counter) and kept on the
+Adjacency object -- an in-place
 change of the structure, a new tensor, `graph.to(device)` all miss the memo and rebuild it.  The int32 copy carries the
 memo record, where the operators (cogdl_amd/operators/spmm.py, fused_gat.py, mhspmm.py) find the pair of tensors the
 record vouches for and a Fingerprint computed once.  Nothing else about the Graph changes; `uninstall()` restores the
@@ -19,7 +20,7 @@ import sys
 
 import torch
 
-from .plan import Fingerprint, tensor_key
+from .plan import Fingerprint
 
 _ATTR = "__cogdl_amd_structure_memo__"  # (double underscores on both sides: outside Adjacency.keys, data.py:352-356)
 _orig = {}
@@ -27,10 +28,14 @@ _orig = {}
 
 class StructureMemo:
     """rowptr32 / colind32 of ONE structure + its fingerprint (hashed on first use, then reused)."""
-    __slots__ = ("src_keys", "rowptr32", "colind32", "_fp", "n_cols_fp")
+    __slots__ = ("src", "src_version", "rowptr32", "colind32", "_fp")
 
     def __init__(self):
-        self.src_keys = [None, None]
+        # The int64 SOURCE tensors are held, not just their addresses: a freed source's address can be handed to a new
+        # tensor with the same shape and version 0 (graph.to("cpu"); graph.to("cuda")), which an address key would take
+        # for the old one.  Identity of the object + its version counter cannot be recycled while the memo holds it.
+        self.src = [None, None]
+        self.src_version = [None, None]
         self.rowptr32 = self.colind32 = None
         self._fp = {}
 
@@ -62,12 +67,11 @@ class _StructIndex(torch.Tensor):
         if args or kwargs:
             return self._src.int(*args, **kwargs)
         memo, which, base = self._memo, self._which, self._src
-        key = tensor_key(base)
         cached = memo.rowptr32 if which == 0 else memo.colind32
-        if cached is None or memo.src_keys[which] != key:
+        if cached is None or memo.src[which] is not base or memo.src_version[which] != base._version:
             cached = base.int()
             cached._cogdl_amd_struct = memo
-            memo.src_keys[which] = key
+            memo.src[which], memo.src_version[which] = base, base._version
             memo._fp = {}
             if which == 0:
                 memo.rowptr32 = cached

@@ -26,6 +26,21 @@ def test_int_is_memoised_and_invalidated_by_in_place_changes():
     assert _StructIndex(base, memo, 0).int(memory_format=torch.contiguous_format).dtype == torch.int32
 
 
+def test_a_recycled_address_is_not_mistaken_for_the_old_source():
+    """graph.to("cpu"); graph.to("cuda") frees the int64 source and may get the SAME address back for different contents
+    (same shape, version 0): the memo keys on the tensor object it holds, not on its address."""
+    memo = StructureMemo()
+    base = torch.tensor([0, 2, 3, 5], dtype=torch.int64)
+    a = _StructIndex(base, memo, 0).int()
+    addr = base.data_ptr()
+    del base
+    for _ in range(64):  # (the memo keeps the old source alive, so its address cannot come back; whatever does come is a new object)
+        other = torch.tensor([0, 1, 1, 9], dtype=torch.int64)
+        got = _StructIndex(other, memo, 0).int()
+        assert got.tolist() == [0, 1, 1, 9] and other.data_ptr() != addr or got is not a
+        addr = other.data_ptr()
+
+
 def test_the_wrapper_is_an_ordinary_tensor_everywhere_else():
     memo = StructureMemo()
     base = torch.arange(5, dtype=torch.int64)
