@@ -5,7 +5,7 @@ edge_softmax, multi-head SpMM, scatter_max, fused GAT attention, sample_adj / CO
 vertex-sharded SpMM over RCCL.  Everything else in CogDL is used as-is; `install()` slots these
 operators underneath CogDL's unchanged dispatcher (cogdl/utils/spmm_utils.py) and Graph class.
 """
-__version__ = "0.3.0"
+__version__ = "0.4.0"
 
 from .install import install, uninstall  # noqa: F401
 from .plan import transient_structures  # noqa: F401
