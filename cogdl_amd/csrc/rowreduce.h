@@ -80,6 +80,7 @@ struct RowSched {
     LongRows lr;
     int sort_rows;  // deal a workgroup's rows to its lane groups by decreasing length (see rowreduce_main_kernel)
     int wave_split; // > 0: in a skewed workgroup, rows of more than this many edges are reduced by ALL lane groups of their wave
+    int debug;      // timing experiments (tuning key 13; WRONG results): 1 = row blocks exit, 2 = long-row workgroups exit
 };
 
 // Rows of at most this many edges are always reduced sequentially by one lane group, in CSR order (the reference's
@@ -204,12 +205,34 @@ __device__ __forceinline__ float transpose_reduce(const float (&p)[U], int l) {
     return v[0];
 }
 
+// Fold ONE chunk of cnt <= LPR edges (base .. base + cnt) whose column ids / per-edge scalars the lanes already hold.
+template <class Op>
+__device__ __forceinline__ void reduce_chunk(const Op &op, typename Op::Ctx &ctx, typename Op::State &st, int base, int cnt,
+                                             int my_c, const typename Op::LaneVals &lv, int sub, int l, float *lds) {
+    constexpr int LPR = Op::LPR, UNROLL = Op::UNROLL;
+    op.chunk_begin(ctx, st, base, cnt, my_c, sub, l, lds, lv);
+    for (int j = 0; j < cnt; j += UNROLL) {
+        typename Op::Batch b;
+        // Issue all UNROLL gathers back to back (no branches: a masked tail slot re-reads the row's last valid
+        // neighbour, an L1 hit, and is ignored by apply()).
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int jj = min(j + u, cnt - 1);
+            op.fetch(ctx, b, u, group_bcast<LPR>(my_c, sub, jj), base + jj, lv, sub, jj);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) op.apply(ctx, st, b, u, (j + u) < cnt, base + j + u, j + u);
+        op.batch_end(ctx, st, base, j, cnt);
+    }
+    op.chunk_end(ctx, st, base, cnt);
+}
+
 // Fold edges [start, end) of one row into st, in order.  All lanes of the group execute it.
 template <class Op>
 __device__ __forceinline__ void reduce_edges(const Op &op, typename Op::Ctx &ctx, typename Op::State &st,
                                              const int32_t *__restrict__ colind, int start, int end, int sub, int l,
                                              float *lds) {
-    constexpr int LPR = Op::LPR, UNROLL = Op::UNROLL;
+    constexpr int LPR = Op::LPR;
     for (int base = start; base < end; base += LPR) {
         const int cnt = min(LPR, end - base);
         int my_c = 0;
@@ -218,25 +241,21 @@ __device__ __forceinline__ void reduce_edges(const Op &op, typename Op::Ctx &ctx
             my_c = colind[base + l];
             op.lane_load(ctx, lv, base + l);
         }
-        op.chunk_begin(ctx, st, base, cnt, my_c, sub, l, lds, lv);
-        for (int j = 0; j < cnt; j += UNROLL) {
-            typename Op::Batch b;
-            // Issue all UNROLL gathers back to back (no branches: a masked tail slot re-reads the row's last valid
-            // neighbour, an L1 hit, and is ignored by apply()).
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int jj = min(j + u, cnt - 1);
-                op.fetch(ctx, b, u, group_bcast<LPR>(my_c, sub, jj), base + jj, lv, sub, jj);
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) op.apply(ctx, st, b, u, (j + u) < cnt, base + j + u, j + u);
-            op.batch_end(ctx, st, base, j, cnt);
-        }
-        op.chunk_end(ctx, st, base, cnt);
+        reduce_chunk<Op>(op, ctx, st, base, cnt, my_c, lv, sub, l, lds);
     }
 }
 
 // One workgroup per run of `chunks_per_block` chunks: the leading blocks of the main grid.
+//
+// Round 4: the run is walked as ONE stream per lane group.  A hub row of 10^4 edges spans ~80 chunks and a workgroup's run
+// of ~19 chunks mostly belongs to one row, so a group keeps ONE state across all pieces of the same row (group g takes
+// slice g of every piece) and the 16 group states are merged -- LDS, two barriers, a sequential merge by group 0 -- once
+// per (row, run) instead of once per 128-edge piece; the pieces of the run that carry no state of their own get the
+// operator's identity record, so the combine kernel is unchanged.  And the column ids / per-edge scalars of the NEXT
+// piece's slice are loaded before the gathers of the current one are issued: a piece costs one memory round trip, not
+// two plus two barriers (measured: the long-row workgroups alone took 99 us for the 1.2 M hub edges of the arxiv-sized
+// R-MAT graph -- 19 pieces x ~5 us per workgroup, a serial chain -- against 51 us at the gather rate of the row blocks).
+// Deterministic as before: a long row's summation order is fixed by (chunk size, group count), not by timing.
 template <class Op>
 __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSched &s, float *op_lds) {
     constexpr int LPR = Op::LPR;
@@ -257,13 +276,20 @@ __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSche
     const int l = lane % LPR;
     const bool lane_on = (kWave % LPR == 0) || sub < RPW;
     const int g = (threadIdx.x >> 6) * RPW + sub;
+    float *const my_lds = op_lds + (threadIdx.x / LPR) * LPR * Op::kLds;
     typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
-    for (int t = 0; t < n; ++t) {
-        const int64_t c = c_begin + t;
-        for (int slot = 0; slot < 2; ++slot) {
-            int32_t row;  // workgroup-uniform
+
+    // piece index p = 2 * t + slot (t-th chunk of the run); this group's slice of it
+    struct Piece {
+        int p, sb, se;
+        int32_t row;
+    };
+    auto find_piece = [&](int from) {  // the first valid piece at or after index `from` (workgroup-uniform)
+        Piece q{2 * n, 0, 0, -1};
+        for (int p = from; p < 2 * n; ++p) {
+            int32_t row;
             int lo, hi;
-            if (!decode_piece(lr, s.rowptr, tbl, c, t, slot, row, lo, hi)) continue;
+            if (!decode_piece(lr, s.rowptr, tbl, c_begin + (p >> 1), p >> 1, p & 1, row, lo, hi)) continue;
             const int per = (hi - lo + G - 1) / G;  // contiguous slices
             int sb = min(lo + g * per, hi), se = min(sb + per, hi);
             if (!lane_on) sb = se = hi;
@@ -271,35 +297,87 @@ __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSche
                 sb = __builtin_amdgcn_readfirstlane(sb);
                 se = __builtin_amdgcn_readfirstlane(se);
             }
-            op.row_load(ctx, row, true);
-            typename Op::State st;
-            op.init_zero(st);
-            reduce_edges<Op>(op, ctx, st, s.colind, sb, se, sub, l, op_lds + (threadIdx.x / LPR) * LPR * Op::kLds);
-            if constexpr (Op::kReduce) {
-                float rec[NREC];
+            q = Piece{p, sb, se, row};
+            break;
+        }
+        return q;
+    };
+    auto load_first_chunk = [&](const Piece &q, int &c, typename Op::LaneVals &lv) {
+        c = 0;
+        lv = typename Op::LaneVals{};
+        if (l < min(LPR, q.se - q.sb)) {
+            c = s.colind[q.sb + l];
+            op.lane_load(ctx, lv, q.sb + l);
+        }
+    };
+    auto record_of = [&](int p) {
+        return lr.partial + (2 * (c_begin + (p >> 1)) + (p & 1)) * lr.rec_stride + (int64_t)blockIdx.y * NREC * LPR;
+    };
+
+    typename Op::State st;
+    op.init_zero(st);
+    int32_t cur_row = -1;
+    int cur_p = -1;
+    auto flush = [&]() {  // merge the G group states of the row in hand (group order) into the record of its first piece here
+        if constexpr (Op::kReduce) {
+            if (cur_row < 0) return;
+            float rec[NREC];
+            op.pack(st, rec);
+            if (lane_on) {
+#pragma unroll
+                for (int i = 0; i < NREC; ++i) red[g][i][l] = rec[i];
+            }
+            __syncthreads();
+            if (g == 0) {
+                for (int q = 1; q < G; ++q) {  // fixed order: group 0, 1, 2, ...
+#pragma unroll
+                    for (int i = 0; i < NREC; ++i) rec[i] = red[q][i][l];
+                    typename Op::State other;
+                    op.unpack(other, rec);
+                    op.merge(ctx, st, other);
+                }
                 op.pack(st, rec);
-                if (lane_on) {
+                float *dst = record_of(cur_p);
 #pragma unroll
-                    for (int i = 0; i < NREC; ++i) red[g][i][l] = rec[i];
-                }
-                __syncthreads();
-                if (g == 0) {
-                    for (int q = 1; q < G; ++q) {  // fixed order: group 0, 1, 2, ...
+                for (int i = 0; i < NREC; ++i) dst[i * LPR + l] = rec[i];
+            }
+            __syncthreads();
+        }
+    };
+
+    Piece cur = find_piece(0);
+    int pc;
+    typename Op::LaneVals plv;
+    if (cur.row >= 0) load_first_chunk(cur, pc, plv);
+    while (cur.row >= 0) {
+        const Piece nxt = find_piece(cur.p + 1);
+        const int my_c = pc;
+        const typename Op::LaneVals lv = plv;
+        if (nxt.row >= 0) load_first_chunk(nxt, pc, plv);  // in flight while this piece gathers
+        if (cur.row != cur_row) {
+            flush();
+            cur_row = cur.row;
+            cur_p = cur.p;
+            op.row_load(ctx, cur.row, true);
+            op.init_zero(st);
+        } else if constexpr (Op::kReduce) {
+            if (g == 0) {  // this piece's record: the operator's identity (its edges are in the state carried on)
+                typename Op::State zero;
+                op.init_zero(zero);
+                float rec[NREC];
+                op.pack(zero, rec);
+                float *dst = record_of(cur.p);
 #pragma unroll
-                        for (int i = 0; i < NREC; ++i) rec[i] = red[q][i][l];
-                        typename Op::State other;
-                        op.unpack(other, rec);
-                        op.merge(ctx, st, other);
-                    }
-                    op.pack(st, rec);
-                    float *dst = lr.partial + (2 * c + slot) * lr.rec_stride + (int64_t)blockIdx.y * NREC * LPR;
-#pragma unroll
-                    for (int i = 0; i < NREC; ++i) dst[i * LPR + l] = rec[i];
-                }
-                __syncthreads();
+                for (int i = 0; i < NREC; ++i) dst[i * LPR + l] = rec[i];
             }
         }
+        if (cur.sb < cur.se) {
+            reduce_chunk<Op>(op, ctx, st, cur.sb, min(LPR, cur.se - cur.sb), my_c, lv, sub, l, my_lds);
+            if (cur.sb + LPR < cur.se) reduce_edges<Op>(op, ctx, st, s.colind, cur.sb + LPR, cur.se, sub, l, my_lds);
+        }
+        cur = nxt;
     }
+    flush();
 }
 
 // Deal the GPB rows of a workgroup to its GPB lane groups by decreasing length -- if the workgroup is skewed (longest
@@ -352,9 +430,10 @@ template <class Op>
 __global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const RowSched s) {
     __shared__ float op_lds[Op::kLds > 0 ? 256 * Op::kLds : 1];  // one buffer for both kinds of workgroup
     if (blockIdx.x < s.lr.n_long_blocks) {
-        rowreduce_long_block<Op>(op, s, op_lds);
+        if (s.debug != 2) rowreduce_long_block<Op>(op, s, op_lds);
         return;
     }
+    if (s.debug == 1) return;
     constexpr int LPR = Op::LPR;
     constexpr int RPW = kWave / LPR;  // row groups per wave
     constexpr int GPB = RPW * 4;      // row groups per 256-thread workgroup
@@ -532,6 +611,7 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
     s.m = m;
     s.rowblocks = make_xcd_map(n_rowblocks);
     s.sort_rows = g_tuning[kTuneRowSort] == 0 ? 1 : 0;
+    s.debug = g_tuning[kTuneRowDebug];
     s.wave_split = wave_split_edges();  // (set to 0 below when the caller asked for sequential rows: no workspace)
     s.lr.thresh = INT_MAX;
     if (nnz > 0 && (!Op::kReduce || workspace)) {
