@@ -106,6 +106,7 @@ struct GatFwdOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_ + 2;
     static constexpr bool kReduce = true;
     static constexpr int kLds = 0;
+    static constexpr bool kExpensiveLaneLoad = DROP;  // (the keep bits of an edge: one Philox call)
     const float *attn_row, *attn_col;
     const T *feat;
     T *out;
@@ -225,6 +226,7 @@ struct GatFwdChunkOp {
     static constexpr bool kReduce = true;
     static constexpr int kMaxHeads = 16;
     static constexpr int kLds = kMaxHeads;  // LPR edges x H heads weights per group
+    static constexpr bool kExpensiveLaneLoad = DROP;
     const float *attn_row, *attn_col;
     const T *feat;
     T *out;
@@ -402,6 +404,7 @@ struct GatBwdRowOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_ + 1;
     static constexpr bool kReduce = true;
     static constexpr int kLds = 0;
+    static constexpr bool kExpensiveLaneLoad = DROP;  // (the keep bits of an edge: one Philox call)
     const float *attn_row, *attn_col;
     const T *feat;  // feat / out / grad_out in the layer's dtype (f32, f16, bf16): read natively, fp32 arithmetic
     const float *edge_max, *edge_sum;
@@ -534,6 +537,7 @@ struct GatBwdColOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = 2 * VEC_ + 1;
     static constexpr bool kReduce = true;
     static constexpr int kLds = 0;
+    static constexpr bool kExpensiveLaneLoad = DROP;  // (the keep bits of an edge: one Philox call)
     const float *attn_row, *attn_col;
     const T *feat;
     const float4 *stats;  // [V, H] {attn_row, edge_max, 1 / edge_sum, D} (written by the row pass)

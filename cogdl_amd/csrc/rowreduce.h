@@ -47,6 +47,7 @@
 #pragma once
 #include <algorithm>
 #include <climits>
+#include <type_traits>
 
 #include "common.h"
 
@@ -205,6 +206,17 @@ __device__ __forceinline__ float transpose_reduce(const float (&p)[U], int l) {
     return v[0];
 }
 
+// Operators whose lane_load is arithmetic, not a load (the Philox mask of the dropout GAT functors), declare
+// `static constexpr bool kExpensiveLaneLoad = true`: reduce_edges then prefetches only the column ids of the next chunk.
+template <class Op, class = void>
+struct LaneLoadCost {
+    static constexpr bool expensive = false;
+};
+template <class Op>
+struct LaneLoadCost<Op, std::void_t<decltype(Op::kExpensiveLaneLoad)>> {
+    static constexpr bool expensive = Op::kExpensiveLaneLoad;
+};
+
 // Fold ONE chunk of cnt <= LPR edges (base .. base + cnt) whose column ids / per-edge scalars the lanes already hold.
 template <class Op>
 __device__ __forceinline__ void reduce_chunk(const Op &op, typename Op::Ctx &ctx, typename Op::State &st, int base, int cnt,
@@ -228,20 +240,32 @@ __device__ __forceinline__ void reduce_chunk(const Op &op, typename Op::Ctx &ctx
 }
 
 // Fold edges [start, end) of one row into st, in order.  All lanes of the group execute it.
+// The column ids / per-edge scalars of chunk k+1 are requested BEFORE the gathers of chunk k are issued (round 4): a row of
+// more than LPR edges used to pay three dependent round trips per chunk (ids, then two gather batches), i.e. a third of
+// a medium row's life was the bubble in front of its gathers -- on the R-MAT graphs 80 % of the edges sit in such rows.
+// The loads are unconditional (index clamped into the row): a load inside a per-lane branch makes the compiler park the
+// wave at the join (lesson 1), and a lane past the chunk's end is never read by fetch().
 template <class Op>
 __device__ __forceinline__ void reduce_edges(const Op &op, typename Op::Ctx &ctx, typename Op::State &st,
                                              const int32_t *__restrict__ colind, int start, int end, int sub, int l,
                                              float *lds) {
     constexpr int LPR = Op::LPR;
+    constexpr bool kPrefetchVals = !LaneLoadCost<Op>::expensive;
+    if (start >= end) return;
+    const int last = end - 1;
+    int my_c = colind[min(start + l, last)];
+    typename Op::LaneVals lv{};
+    if constexpr (kPrefetchVals) op.lane_load(ctx, lv, min(start + l, last));
     for (int base = start; base < end; base += LPR) {
         const int cnt = min(LPR, end - base);
-        int my_c = 0;
-        typename Op::LaneVals lv{};
-        if (l < cnt) {
-            my_c = colind[base + l];
-            op.lane_load(ctx, lv, base + l);
-        }
+        const int nidx = min(base + LPR + l, last);  // (past the row's end: its last edge again, an L1 hit, never used)
+        const int next_c = colind[nidx];
+        typename Op::LaneVals next_lv{};
+        if constexpr (kPrefetchVals) op.lane_load(ctx, next_lv, nidx);
+        else op.lane_load(ctx, lv, min(base + l, last));
         reduce_chunk<Op>(op, ctx, st, base, cnt, my_c, lv, sub, l, lds);
+        my_c = next_c;
+        if constexpr (kPrefetchVals) lv = next_lv;
     }
 }
 
@@ -305,9 +329,10 @@ __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSche
     auto load_first_chunk = [&](const Piece &q, int &c, typename Op::LaneVals &lv) {
         c = 0;
         lv = typename Op::LaneVals{};
-        if (l < min(LPR, q.se - q.sb)) {
-            c = s.colind[q.sb + l];
-            op.lane_load(ctx, lv, q.sb + l);
+        if (q.sb < q.se) {  // (group-uniform; the loads themselves are unconditional: index clamped into the slice)
+            const int idx = min(q.sb + l, q.se - 1);
+            c = s.colind[idx];
+            op.lane_load(ctx, lv, idx);
         }
     };
     auto record_of = [&](int p) {
