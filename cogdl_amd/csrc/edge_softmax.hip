@@ -17,6 +17,8 @@
 // row's piece records in chunk order (each piece workgroup redoes that tiny merge itself) and writes the piece.
 #include "rowreduce.h"
 
+#include <type_traits>
+
 namespace cogdl {
 
 // exp of a non-positive difference (value - running max): the hardware exponential (v_exp_f32 of x * log2 e, 1 ulp)
@@ -64,9 +66,11 @@ __device__ __forceinline__ float head_reduce_sum(float v, int h) {
 // elements instead of the 2U of an element-wise online softmax.
 constexpr int kEsUnroll = 4;
 
-__device__ __forceinline__ MaxSum maxsum_strided(const float *__restrict__ a, int64_t i0, int64_t end, int64_t stride) {
+// (T = float, __half or __hip_bfloat16: values are read and written in their own type, all arithmetic is fp32)
+template <typename T>
+__device__ __forceinline__ MaxSum maxsum_strided(const T *__restrict__ a, int64_t i0, int64_t end, int64_t stride) {
     if (i0 + stride >= end) {  // at most one element for this lane (short rows: the common case on small graphs)
-        if (i0 < end) return {a[i0], 1.f};
+        if (i0 < end) return {to_f32<T>(a[i0]), 1.f};
         return {-INFINITY, 0.f};
     }
     MaxSum acc{-INFINITY, 0.f};
@@ -75,7 +79,7 @@ __device__ __forceinline__ MaxSum maxsum_strided(const float *__restrict__ a, in
 #pragma unroll
         for (int u = 0; u < kEsUnroll; ++u) {
             const int64_t idx = i0 + u * stride;
-            v[u] = (idx < end) ? a[idx] : -INFINITY;
+            v[u] = (idx < end) ? to_f32<T>(a[idx]) : -INFINITY;
         }
         float bm = v[0];
 #pragma unroll
@@ -90,7 +94,8 @@ __device__ __forceinline__ MaxSum maxsum_strided(const float *__restrict__ a, in
     return acc;
 }
 
-__device__ __forceinline__ float dot_strided(const float *__restrict__ a, const float *__restrict__ g, int64_t i0,
+template <typename T>
+__device__ __forceinline__ float dot_strided(const T *__restrict__ a, const T *__restrict__ g, int64_t i0,
                                              int64_t end, int64_t stride) {
     float dot = 0.f;
     for (; i0 < end; i0 += stride * kEsUnroll) {
@@ -99,8 +104,8 @@ __device__ __forceinline__ float dot_strided(const float *__restrict__ a, const 
         for (int u = 0; u < kEsUnroll; ++u) {
             const int64_t idx = i0 + u * stride;
             const bool ok = idx < end;
-            v[u] = ok ? a[idx] : 0.f;
-            w[u] = ok ? g[idx] : 0.f;
+            v[u] = ok ? to_f32<T>(a[idx]) : 0.f;
+            w[u] = ok ? to_f32<T>(g[idx]) : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < kEsUnroll; ++u) dot = fmaf(v[u], w[u], dot);
@@ -109,12 +114,18 @@ __device__ __forceinline__ float dot_strided(const float *__restrict__ a, const 
 }
 
 // out = exp(a - mx) * inv   (forward)      out = a * (g - dot)   (backward; mx carries dot)
-template <bool BACKWARD>
-__device__ __forceinline__ void write_strided(const float *__restrict__ a, const float *__restrict__ g,
-                                              float *__restrict__ out, int64_t i0, int64_t end, int64_t stride,
+template <bool BACKWARD, typename T>
+__device__ __forceinline__ void write_strided(const T *__restrict__ a, const T *__restrict__ g,
+                                              T *__restrict__ out, int64_t i0, int64_t end, int64_t stride,
                                               float mx, float inv) {
     if (i0 + stride >= end) {
-        if (i0 < end) out[i0] = BACKWARD ? a[i0] * (g[i0] - mx) : es_exp(a[i0] - mx) * inv;
+        if (i0 < end) {
+            const float av = to_f32<T>(a[i0]);
+            float r;
+            if constexpr (BACKWARD) r = av * (to_f32<T>(g[i0]) - mx);
+            else r = es_exp(av - mx) * inv;
+            out[i0] = from_f32<T>(r);
+        }
         return;
     }
     for (; i0 < end; i0 += stride * kEsUnroll) {
@@ -123,13 +134,13 @@ __device__ __forceinline__ void write_strided(const float *__restrict__ a, const
         for (int u = 0; u < kEsUnroll; ++u) {
             const int64_t idx = i0 + u * stride;
             const bool ok = idx < end;
-            v[u] = ok ? a[idx] : 0.f;
-            if constexpr (BACKWARD) w[u] = ok ? g[idx] : 0.f;
+            v[u] = ok ? to_f32<T>(a[idx]) : 0.f;
+            if constexpr (BACKWARD) w[u] = ok ? to_f32<T>(g[idx]) : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < kEsUnroll; ++u) {
             const int64_t idx = i0 + u * stride;
-            if (idx < end) out[idx] = BACKWARD ? v[u] * (w[u] - mx) : es_exp(v[u] - mx) * inv;
+            if (idx < end) out[idx] = from_f32<T>(BACKWARD ? v[u] * (w[u] - mx) : es_exp(v[u] - mx) * inv);
         }
     }
 }
@@ -308,10 +319,10 @@ __device__ __forceinline__ void edge_softmax_long_stats_block4(const int32_t *__
     }
 }
 
-template <bool BACKWARD>
+template <bool BACKWARD, typename T = float>
 __device__ __forceinline__ void edge_softmax_long_stats_block(const int32_t *__restrict__ rowptr,
-                                                              const float *__restrict__ a,
-                                                              const float *__restrict__ g, int64_t m, int h,
+                                                              const T *__restrict__ a,
+                                                              const T *__restrict__ g, int64_t m, int h,
                                                               const LongRows &lr) {
     __shared__ float red_m[256], red_s[256];
     __shared__ int32_t tbl[kMaxChunksPerBlock + 1];
@@ -380,12 +391,13 @@ __device__ __forceinline__ void edge_softmax_long_stats_block(const int32_t *__r
 
 // Second launch: every piece workgroup merges the records of ITS row in chunk order (a row of 10^5 edges has ~100
 // records of 2H floats: cheaper than a third launch) and writes the piece's outputs.
-template <bool BACKWARD, bool VEC4>
+template <bool BACKWARD, bool VEC4, typename T = float>
 __global__ __launch_bounds__(256) void edge_softmax_long_apply_kernel(const int32_t *__restrict__ rowptr,
-                                                                      const float *__restrict__ a,
-                                                                      const float *__restrict__ g,
-                                                                      float *__restrict__ out, int64_t m, int h,
+                                                                      const T *__restrict__ a,
+                                                                      const T *__restrict__ g,
+                                                                      T *__restrict__ out, int64_t m, int h,
                                                                       LongRows lr) {
+    static_assert(!VEC4 || std::is_same<T, float>::value, "16-byte lanes: fp32 values only");
     __shared__ int32_t tbl[kMaxChunksPerBlock + 1];
     const int64_t c_begin = (int64_t)blockIdx.x * lr.chunks_per_block;
     if (c_begin >= lr.n_chunks) return;
@@ -430,7 +442,7 @@ __global__ __launch_bounds__(256) void edge_softmax_long_apply_kernel(const int3
                 __syncthreads();
                 cached_row = row;
             }
-            if constexpr (VEC4) {  // H a power of two in [4, 64]: 16-byte lanes, heads 4 ci .. 4 ci + 3
+            if constexpr (VEC4 && std::is_same<T, float>::value) {  // H a power of two in [4, 64]: 16-byte lanes, heads 4 ci .. 4 ci + 3
                 float sa4[4], sb4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -537,15 +549,20 @@ __global__ __launch_bounds__(256) void edge_softmax_vec4_kernel(const int32_t *_
 
 // Generic H: one wave per row, lane owns heads lane, lane+64, ...; edges walked sequentially
 // (loads are coalesced across heads).
-template <bool BACKWARD>
+template <bool BACKWARD, typename T = float>
 __global__ __launch_bounds__(256) void edge_softmax_generic_kernel(const int32_t *__restrict__ rowptr,
-                                                                   const float *__restrict__ a,
-                                                                   const float *__restrict__ g,
-                                                                   float *__restrict__ out, int64_t m, int h,
+                                                                   const T *__restrict__ a,
+                                                                   const T *__restrict__ g,
+                                                                   T *__restrict__ out, int64_t m, int h,
                                                                    XcdMap n_rowblocks, LongRows lr, int long_vec4) {
     if (blockIdx.x < lr.n_long_blocks) {
-        if (long_vec4) edge_softmax_long_stats_block4<BACKWARD>(rowptr, a, g, m, h, lr);
-        else edge_softmax_long_stats_block<BACKWARD>(rowptr, a, g, m, h, lr);
+        if constexpr (std::is_same<T, float>::value) {
+            if (long_vec4) {
+                edge_softmax_long_stats_block4<BACKWARD>(rowptr, a, g, m, h, lr);
+                return;
+            }
+        }
+        edge_softmax_long_stats_block<BACKWARD, T>(rowptr, a, g, m, h, lr);
         return;
     }
     const int64_t rb = xcd_remap(blockIdx.x - lr.n_long_blocks, n_rowblocks);
@@ -557,11 +574,11 @@ __global__ __launch_bounds__(256) void edge_softmax_generic_kernel(const int32_t
     if (hi - lo > lr.thresh) return;
     for (int hd = lane; hd < h; hd += kWave) {
         if constexpr (!BACKWARD) {
-            const MaxSum acc = maxsum_strided(a, lo * h + hd, hi * h, h);
-            write_strided<false>(a, g, out, lo * h + hd, hi * h, h, acc.m, 1.f / acc.s);
+            const MaxSum acc = maxsum_strided<T>(a, lo * h + hd, hi * h, h);
+            write_strided<false, T>(a, g, out, lo * h + hd, hi * h, h, acc.m, 1.f / acc.s);
         } else {
-            const float dot = dot_strided(a, g, lo * h + hd, hi * h, h);
-            write_strided<true>(a, g, out, lo * h + hd, hi * h, h, dot, 0.f);
+            const float dot = dot_strided<T>(a, g, lo * h + hd, hi * h, h);
+            write_strided<true, T>(a, g, out, lo * h + hd, hi * h, h, dot, 0.f);
         }
     }
 }
@@ -663,6 +680,31 @@ static int edge_softmax_dispatch(const int32_t *rowptr, const float *a, const fl
     }
 }
 
+// 2-byte values outside the flat kernel's coverage (H not a power of two, H > 64, no workspace, unaligned operands): the
+// generic row kernel + the scalar hub-row path, instantiated for the value type -- values are read and written natively,
+// no fp32 copies of the [E, H] tensors (rounds 1-3 converted them outside the kernel).
+template <bool BACKWARD, typename T>
+static int edge_softmax_dispatch16(const int32_t *rowptr, const T *a, const T *g, T *out, int64_t m, int64_t nnz, int64_t h,
+                                   void *ws, size_t wsb, hipStream_t s) {
+    LongRows lr{};
+    lr.thresh = INT_MAX;
+    if (ws) {
+        if (wsb < rowreduce_workspace_bytes(nnz, 2 * h, es_thresh_scale(h))) return COGDL_HIP_EWORKSPACE;
+        if (!aligned_to(ws, 256)) return COGDL_HIP_EALIGN;
+        plan_long_rows(lr, nnz, es_thresh_scale(h));
+        lr.partial = (float *)((char *)ws + kFoundBytes);
+        lr.rec_stride = 2 * h;
+    }
+    const int64_t nrb = (m + 3) / 4;
+    if (!grid_fits(make_xcd_map(nrb), 4096)) return COGDL_HIP_ERANGE;
+    hipLaunchKernelGGL((edge_softmax_generic_kernel<BACKWARD, T>), dim3(lr.n_long_blocks + xcd_grid(make_xcd_map(nrb))), dim3(256),
+                       0, s, rowptr, a, g, out, m, (int)h, make_xcd_map(nrb), lr, 0);
+    if (lr.n_long_blocks > 0)
+        hipLaunchKernelGGL((edge_softmax_long_apply_kernel<BACKWARD, false, T>), dim3(lr.n_long_blocks), dim3(256), 0, s, rowptr,
+                           a, g, out, m, (int)h, lr);
+    return launch_status();
+}
+
 }  // namespace cogdl
 
 // edge_softmax_flat.hip
@@ -696,8 +738,13 @@ static int edge_softmax_entry(const int32_t *rowptr, const void *a, const void *
     if (!rowptr || !a || !out || (BACKWARD && !g)) return COGDL_HIP_EINVAL;
     if (h > 0x7fffffff || nnz > 0x7fffffff) return COGDL_HIP_ERANGE;
     if (es_use_flat(h, dtype, a, g, out, ws)) return es_flat_launch(BACKWARD, rowptr, a, g, out, m, nnz, h, dtype, ws, wsb, s);
-    // the row kernels: f32 only (H not a power of two, H > 64, unaligned operands, or no workspace)
-    if (dtype != COGDL_HIP_F32) return COGDL_HIP_EUNSUPPORTED;
+    // the row kernels (H not a power of two, H > 64, unaligned operands, or no workspace)
+    if (dtype == COGDL_HIP_F16)
+        return edge_softmax_dispatch16<BACKWARD, __half>(rowptr, (const __half *)a, (const __half *)g, (__half *)out, m, nnz, h, ws,
+                                                         wsb, s);
+    if (dtype == COGDL_HIP_BF16)
+        return edge_softmax_dispatch16<BACKWARD, __hip_bfloat16>(rowptr, (const __hip_bfloat16 *)a, (const __hip_bfloat16 *)g,
+                                                                 (__hip_bfloat16 *)out, m, nnz, h, ws, wsb, s);
     return edge_softmax_dispatch<BACKWARD>(rowptr, (const float *)a, (const float *)g, (float *)out, m, nnz, h, ws, wsb, s);
 }
 

@@ -787,9 +787,10 @@ inline int gat_bwd_vec(int64_t h, int64_t f, int align, int elem_bytes) {
         return vec * elem_bytes <= 16 && align >= vec * elem_bytes && f % vec == 0 && h * f / vec <= kWave &&
                (h == 1 || pow2(f / vec));
     };
-    // fat lanes first: the per-edge attention maths is repeated per lane
+    // fat lanes first: the per-edge attention maths is repeated per lane  (tuning key 4 caps the width: experiments)
+    const int cap = g_tuning[kTuneGatVec] > 0 ? g_tuning[kTuneGatVec] : 8;
     for (int vec = 8; vec > 1; vec >>= 1)
-        if (ok(vec)) return vec;
+        if (vec <= cap && ok(vec)) return vec;
     return (h * f <= kWave && (h == 1 || pow2(f))) ? 1 : 0;
 }
 inline GatBwdGeometry gat_bwd_geometry(int64_t h, int64_t f, int align, int elem_bytes) {

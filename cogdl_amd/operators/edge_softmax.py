@@ -45,13 +45,7 @@ def _launch(fn_name, rowptr, a, g=None):
                       ws_bytes, _lib.stream_of(a_))
 
     out = torch.empty_like(a)
-    rc = call(a, g, out, _lib.DTYPE_CODE[a.dtype])
-    if rc == _lib.EUNSUPPORTED and a.dtype != torch.float32:
-        # 2-byte values with H not a power of two (or > 64): the row kernels are fp32 -- same fp32 arithmetic, the
-        # conversion simply happens outside the kernel
-        out32 = torch.empty(a.shape, dtype=torch.float32, device=dev)
-        rc = call(a.float(), None if g is None else g.float(), out32, _lib.DTYPE_CODE[torch.float32])
-        out = out32.to(a.dtype)
+    rc = call(a, g, out, _lib.DTYPE_CODE[a.dtype])  # (every dtype x every H is a kernel of its own: no conversion route)
     _lib.check(rc, fn_name)
     return out
 

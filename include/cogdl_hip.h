@@ -185,8 +185,8 @@ COGDL_API int cogdl_hip_csr_sddmm(const int32_t *rowptr, const int32_t *colind, 
  * two <= 64 and 16-byte aligned operands the call is ONE streaming pass (every value read from HBM once, written
  * once; rows that cross tile borders are combined inside the launch, csrc/edge_softmax_flat.hip): two launches (a
  * small init kernel + the main kernel), no host synchronisation, hipGraph-capturable.  Other shapes use
- * row-parallel kernels (f32 only: COGDL_HIP_EUNSUPPORTED for 2-byte types there; without a workspace hub rows are
- * reduced sequentially).
+ * row-parallel kernels (every dtype since ABI v5: 2-byte values with H not a power of two / H > 64 are read and written
+ * natively by the generic row kernel; without a workspace hub rows are reduced sequentially).
  * ------------------------------------------------------------------------------------- */
 COGDL_API size_t cogdl_hip_edge_softmax_workspace_bytes(int64_t nnz, int64_t h);
 COGDL_API int cogdl_hip_edge_softmax_fwd(const int32_t *rowptr, const void *values, void *out, int64_t m,

@@ -271,13 +271,48 @@ def test_edge_softmax_flat_kernel_many_short_and_empty_rows(oracle):
         np.testing.assert_allclose(out.cpu().numpy(), oracle.edge_softmax_fwd(rowptr.int(), v), rtol=1e-5, atol=1e-9)
 
 
-def test_edge_softmax_bf16_odd_head_count_goes_through_the_row_kernels(oracle):
-    g = synth.random_csr(80, 80, 9, seed=2)
-    v = rand(g.nnz, 3, seed=1).bfloat16()
-    out = csr_edge_softmax(g.rowptr.to(DEV), v.to(DEV))
-    assert out.dtype == torch.bfloat16
-    np.testing.assert_allclose(out.float().cpu().numpy(), oracle.edge_softmax_fwd(g.rowptr, v.float()), rtol=2.0 ** -7,
-                               atol=1e-30)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("h", [3, 5, 100, 256, 8])
+@pytest.mark.parametrize("graph", ["ragged", "hubs"])
+def test_edge_softmax_16bit_row_kernels_native(oracle, dtype, h, graph, monkeypatch):
+    """2-byte values where the flat kernel does not apply -- H not a power of two (GENConv / DisenGCN call edge_softmax with
+    H = hidden width: layers/deepergcn_layer.py:73, disengcn_layer.py:59), H > 64, or the flat kernel switched off
+    (h = 8 with tuning key 7 bit 2) -- run in the generic row kernel + the scalar hub-row path instantiated for the value
+    type: no fp32 copy of the [E, H] tensors is made anywhere (torch's .float() on a 2-byte CUDA tensor is forbidden
+    for the duration of the call).  Forward and backward against the oracle on the rounded inputs."""
+    from cogdl_amd import _lib
+
+    g = synth.random_csr(80, 80, 9, seed=2) if graph == "ragged" else synth.hub_csr(
+        60, 60, hubs=((3, 129), (4, 1000), (17, 5000), (18, 257)), seed=h)
+    n = g.num_nodes
+    v = rand(g.nnz, h, seed=1, scale=2.0).to(dtype)
+    gr = rand(g.nnz, h, seed=4).to(dtype)
+    if h == 8:
+        _lib.hip().cogdl_hip_set_tuning(7, 4)
+    real_float = torch.Tensor.float
+
+    def no_widening(self, *a, **k):
+        assert not (self.is_cuda and self.element_size() == 2 and self.numel() > 64), "a 16-bit operand was widened on the GPU"
+        return real_float(self, *a, **k)
+
+    monkeypatch.setattr(torch.Tensor, "float", no_widening)
+    try:
+        vd = v.to(DEV).requires_grad_()
+        out = csr_edge_softmax(g.rowptr.to(DEV), vd)
+        out.backward(gr.to(DEV))
+    finally:
+        monkeypatch.setattr(torch.Tensor, "float", real_float)
+        _lib.hip().cogdl_hip_set_tuning(7, 0)
+    assert out.dtype == dtype and vd.grad.dtype == dtype
+    tol = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    want = oracle.edge_softmax_fwd(g.rowptr, v.float())
+    np.testing.assert_allclose(out.detach().float().cpu().numpy(), want, rtol=tol, atol=1e-7 if dtype == torch.float16 else 1e-30)
+    sm = out.detach().float().cpu()
+    want_g = oracle.edge_softmax_bwd(g.rowptr, sm, gr.float())
+    rows_ = torch.repeat_interleave(torch.arange(n), g.degrees())
+    scale_g = _softmax_grad_scale(sm, gr.float(), rows_, n, h)
+    floor = 6e-8 if dtype == torch.float16 else 1e-12
+    assert np.all(np.abs(vd.grad.float().cpu().numpy() - want_g) <= tol * scale_g + floor)
 
 
 def test_edge_softmax_1d_view_like_dispatcher():

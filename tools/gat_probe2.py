@@ -32,3 +32,21 @@ for h, f, dt in ((1, 48, torch.bfloat16), (1, 44, torch.float32), (8, 8, torch.b
         lib.cogdl_hip_set_tuning(5, 0)
         lib.cogdl_hip_set_tuning(4, 0)
         print("fwd H=%d F=%d %s p=%.1f:  %s" % (h, f, str(dt)[6:], p, "   ".join(res)), flush=True)
+
+# backward: vector cap (tuning key 4) -- fat lanes (fewer repeats of the per-edge attention maths) against more, thinner lanes
+# (lower register count per lane, more waves per SIMD)
+from cogdl_amd.operators.fused_gat import fused_gat_dropout_func  # noqa: E402
+for h, f, dt in ((8, 8, torch.bfloat16), (1, 48, torch.bfloat16), (8, 8, torch.float32)):
+    ar, ac = torch.randn(n, h, device=DEV).requires_grad_(), torch.randn(n, h, device=DEV).requires_grad_()
+    feat = torch.randn(n, h, f, device=DEV).to(dt).requires_grad_()
+    gout = torch.randn(n, h, f, device=DEV).to(dt)
+    for p in (0.0, 0.5):
+        res = []
+        for vcap in (0, 4, 2):
+            lib.cogdl_hip_set_tuning(4, vcap)
+            o = fused_gat_dropout_func(ar, ac, g.rowptr, g.colind, 0.2, feat, p, seed=1)
+            ms = timeit(lambda: torch.autograd.grad(o, (ar, ac, feat), gout, retain_graph=True), 5)
+            res.append("vec%s %6.2f ms" % (vcap or "max", ms))
+            del o
+        lib.cogdl_hip_set_tuning(4, 0)
+        print("bwd H=%d F=%d %s p=%.1f:  %s" % (h, f, str(dt)[6:], p, "   ".join(res)), flush=True)

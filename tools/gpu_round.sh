@@ -99,7 +99,7 @@ if has pmccombined; then
     (cd /tmp && timeout -s KILL 400 rocprofv3 --kernel-trace --pmc $c -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmcall_$c" -o pmc -- python "$GRAFT_REPO_ROOT/tools/pmc_probe_ops.py") > gpurun_out/pmcall_$c.log 2>&1
     echo "pmccombined $c rc=$? faults=$(grep -c -i 'memory access fault' gpurun_out/pmcall_$c.log) $(grep done gpurun_out/pmcall_$c.log | tr '\n' ' ')"
   done
-  python tools/pmc_by_kernel.py gpurun_out pmcall_ SpmmOp GatFwd GatBwd SddmmOp MhsddmmOp > gpurun_out/pmcall_summary.json 2> gpurun_out/pmcall_summary.err; head -c 1500 gpurun_out/pmcall_summary.json
+  python tools/pmc_by_kernel.py gpurun_out pmcall_ SpmmOp GatFwd GatBwd SddmmOp MhsddmmOp > gpurun_out/pmcall_summary.json 2> gpurun_out/pmcall_summary.err; python -c "import json; r=json.load(open('gpurun_out/pmcall_summary.json')); [print('%-110s %8.1f us  %7.2f GB  %5.2f TB/s' % (k[:110], v['duration_us_profiled'], v.get('hbm_bytes_per_launch',0)/1e9, v.get('hbm_GBs',0)/1e3)) for k,v in r['kernels'].items() if 'main' in k]"
 fi
 if has nocache_tests; then
   # (stream capture needs the caching allocator's private pools: the hipGraph tests are deselected; failures listed, not -x)
