@@ -150,6 +150,11 @@ def fused_gat_dropout_func(attn_row, attn_col, row_ptr, col_ind, negative_slope,
     if not 0.0 <= p <= 1.0:
         raise ValueError("dropout probability has to be between 0 and 1, but got %s" % p)
     if seed is None:
+        if p > 0.0 and in_feat.is_cuda and torch.cuda.is_current_stream_capturing():
+            # the seed is a kernel ARGUMENT: drawn here it would be frozen into the captured graph and every replay would
+            # drop the same attention entries
+            raise _lib.BackendError("fused_gat_dropout_func inside a hipGraph capture needs an explicit seed per replay "
+                                    "(the seed is passed by value); capture with attn_drop = 0 or step eagerly")
         seed = new_dropout_seed() if p > 0.0 else 0
     return FusedGATFunction.apply(attn_row, attn_col, row_ptr, col_ind, None, None, negative_slope, in_feat, float(p),
                                   int(seed))
