@@ -46,7 +46,12 @@ class GatLayer(torch.nn.Module):
     def forward(self, g, x):
         rowptr, colind, row = g
         h = torch.matmul(x, self.W).view(-1, self.nhead, self.out_feats)
-        h_l, h_r = (self.a_l * h).sum(dim=-1), (self.a_r * h).sum(dim=-1)
+        if self.mode == "fused-dropout":  # (what install(fused_gat_dropout=True) rebinds GATLayer.forward to: cogdl_amd/fused.py)
+            from cogdl_amd.fused import _HeadProjection
+
+            h_l, h_r = _HeadProjection.apply(self.a_l, h), _HeadProjection.apply(self.a_r, h)
+        else:
+            h_l, h_r = (self.a_l * h).sum(dim=-1), (self.a_r * h).sum(dim=-1)
         if self.mode == "fused-dropout":
             out = fused_gat_dropout_func(h_l, h_r, rowptr, colind, self.alpha, h, self.p if self.training else 0.0)
         elif self.mode == "fused":
