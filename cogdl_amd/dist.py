@@ -470,8 +470,10 @@ class Partition:
 
 def partition(rowptr, colind, world, weight=None, order="bfs", balance="edges"):
     """A 1-D vertex partition of a real (GPU-resident, symmetric) CSR graph for ShardedCSR: relabel for locality
-    (`order`: "bfs" | "degree" (hubs first) | "none"), cut the new id range into `world` contiguous ranges (`balance`:
-    "edges" | "rows"), and measure the halo of every rank before and after.  The analogue in the reference is the
+    (`order`: "bfs" | "multilevel" (cogdl_amd/partitioner.py: label-propagation coarsening, greedy graph growing on the
+    coarsest level, label-propagation refinement on the way back -- the parts ARE the ranks' ranges, breadth-first order
+    inside each) | "degree" (hubs first) | "none"), cut the new id range into `world` contiguous ranges (`balance`:
+    "edges" | "rows"; "multilevel" cuts at its part boundaries), and measure the halo of every rank before and after.  The analogue in the reference is the
     METIS partition of ClusteredDataset (cogdl/data/sampler.py:188-243), host-side and for sampling; here every step is
     a HIP kernel (bfs_step, csr2csc for the order, subgraph for the permutation, shard_count for the halos).
     x / y of the vertices follow with x[part.perm]; results come back with out[part.inverse]."""
@@ -491,15 +493,25 @@ def partition(rowptr, colind, world, weight=None, order="bfs", balance="edges"):
         deg = (rp[1:] - rp[:-1])
         key = (int(deg.max()) - deg).int()  # hubs first, ties by id: the stable transpose of vertex -> (max - degree)
         perm = csr2csc(torch.arange(n + 1, dtype=torch.int32, device=dev), key, int(deg.max()) + 1).rowind.long()
+    elif order == "multilevel":
+        from .partitioner import multilevel_partition
+        from .plan import csr2csc
+
+        labels = multilevel_partition(rp, ci, world)
+        perm0 = bfs_order(rp, ci)  # inside a part: breadth-first order (neighbouring rows gather neighbouring columns)
+        inner = csr2csc(torch.arange(n + 1, dtype=torch.int32, device=dev), labels[perm0].int(), world).rowind.long()
+        perm = perm0[inner]        # by (part, breadth-first position)
+        lp_bounds = torch.zeros(world + 1, dtype=torch.long, device=dev)
+        lp_bounds[1:] = torch.cumsum(torch.bincount(labels, minlength=world), 0)
     elif order == "none":
         perm = torch.arange(n, device=dev)
     else:
-        raise ValueError("partition: order must be 'bfs', 'degree' or 'none'")
+        raise ValueError("partition: order must be 'bfs', 'multilevel', 'degree' or 'none'")
     if order == "none":
         rp2, ci2, w2 = rp, ci, weight
     else:
         rp2, ci2, w2 = permute_graph(rp, ci, weight, perm)
-    bounds = cut(rp2)
+    bounds = lp_bounds.cpu() if order == "multilevel" else cut(rp2)
     after = halo_rows(rp2, ci2, bounds)
     return Partition(rp2, ci2, w2, perm, bounds, before, after)
 
