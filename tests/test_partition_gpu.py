@@ -98,7 +98,7 @@ def test_multilevel_partition_on_the_gpu_finds_planted_communities_and_is_the_sa
     bfs = partition(rp, ci, world, weight=w, order="bfs")
     ml = partition(rp, ci, world, weight=w, order="multilevel")
     remote = lambda part: sum(e for e, _ in part.halo_after) / nnz  # noqa: E731
-    assert remote(bfs) > 0.5 and remote(ml) < 0.15, (remote(bfs), remote(ml))
+    assert remote(bfs) > 0.5 and remote(ml) < 0.2, (remote(bfs), remote(ml))  # (planted: ~11 % of the edges leave their community)
     assert torch.equal(torch.sort(ml.perm).values, torch.arange(n, device=DEV))
     per_rank = [int(ml.rowptr[int(ml.bounds[p + 1])] - ml.rowptr[int(ml.bounds[p])]) for p in range(world)]
     assert max(per_rank) <= 1.06 * nnz / world, per_rank
