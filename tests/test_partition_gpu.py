@@ -176,7 +176,7 @@ def test_partition_orders_on_a_power_law_graph_are_valid_and_edge_balanced(order
         assert bool((deg[1:] <= deg[:-1]).all())  # hubs first
 
 
-def _partition_worker(rank, world, port, n, out_dir):
+def _partition_worker(rank, world, port, n, out_dir, order="bfs"):
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -189,7 +189,7 @@ def _partition_worker(rank, world, port, n, out_dir):
 
         torch.cuda.set_device(0)
         g = _hidden_band_graph(n, 6, 300, seed=5)  # the same global graph on every rank; every rank partitions it itself
-        part = partition(g.rowptr.long().to(DEV), g.colind.long().to(DEV), world, weight=g.weight.to(DEV), order="bfs")
+        part = partition(g.rowptr.long().to(DEV), g.colind.long().to(DEV), world, weight=g.weight.to(DEV), order=order)
         rowptr, cols, w = part.shard(rank)
         sh = ShardedCSR(rowptr, cols, w, part.bounds)
         x = torch.randn(n, 24, generator=torch.Generator().manual_seed(5)).to(DEV)
@@ -204,14 +204,15 @@ def _partition_worker(rank, world, port, n, out_dir):
         dist.destroy_process_group()
 
 
-def test_sharded_equals_unsharded_through_the_partitioner(tmp_path, oracle):
+@pytest.mark.parametrize("order", ["bfs", "multilevel"])
+def test_sharded_equals_unsharded_through_the_partitioner(tmp_path, oracle, order):
     """Two ranks on the one GPU: each partitions the global graph (deterministic: both get the same answer), takes its
     shard of the REORDERED graph, runs the sharded SpMM forward + backward on the permuted operands; mapped back through
     the permutation the results equal the unsharded oracle on the original graph."""
     import torch.multiprocessing as mp
 
     n, world = 20000, 2
-    mp.spawn(_partition_worker, args=(world, 29693, n, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_partition_worker, args=(world, 29693 + (order == "multilevel"), n, str(tmp_path), order), nprocs=world, join=True)
     g = _hidden_band_graph(n, 6, 300, seed=5)
     x = torch.randn(n, 24, generator=torch.Generator().manual_seed(5))
     gout = torch.randn(n, 24, generator=torch.Generator().manual_seed(6))
