@@ -74,6 +74,48 @@ def test_fused_gat_forward_and_backward_vs_oracle(oracle, reddit, dtype, tol):
     _close(ac.grad.cpu().numpy(), gr, sr, tol * (4 if dtype != torch.float32 else 1), "grad_attn_col")
 
 
+def test_fused_gat_with_attention_dropout_vs_oracle_bf16(oracle, reddit):
+    """The branch the gat model takes BY DEFAULT (attn_drop 0.5, cogdl/models/nn/gat.py:30; layers/gat_layer.py:72-77) at
+    configs[2]'s true size and dtype: fused_gat_dropout_func in bf16 against the OpenMP oracle's fp64 composition WITH THE
+    SAME MASK (the device mask, whose first two million edges are also checked against the oracle's Philox restatement).
+    The layer's second shape (H = 1 x F = 41: rows padded to 48 inside the operator) rides along in the forward."""
+    from cogdl_amd.operators.fused_gat import edge_dropout_mask, fused_gat_dropout_func
+
+    c = reddit
+    p, seed, tol = 0.5, 20260922, TOL16
+    mask = edge_dropout_mask(c.g.nnz, H, p, seed, DEV)
+    assert np.array_equal(mask[:2_000_000].cpu().numpy(), oracle.edge_dropout_mask(2_000_000, H, p, seed))
+    kept = float((mask > 0).float().mean())
+    assert abs(kept - 0.5) < 1e-3 and float(mask.max()) == 2.0
+    feat, gout = c.feat.bfloat16(), c.gout.bfloat16()
+    ar, ac, ft = c.ar.clone().requires_grad_(), c.ac.clone().requires_grad_(), feat.clone().requires_grad_()
+    out = fused_gat_dropout_func(ar, ac, c.g.rowptr, c.g.colind, 0.2, ft, p, seed)
+    assert out.dtype == torch.bfloat16
+    out.backward(gout)
+    torch.cuda.synchronize()
+    drop = mask.cpu().numpy()
+    del mask
+    h_l, h_r = c.ar.cpu().numpy(), c.ac.cpu().numpy()
+    feat_h, gout_h = feat.float().cpu().numpy(), gout.float().cpu().numpy()
+    want = oracle.gat_fwd(c.rowptr, c.colind, h_l, h_r, feat_h, 0.2, drop=drop)
+    scale = oracle.gat_fwd(c.rowptr, c.colind, h_l, h_r, np.abs(feat_h), 0.2, drop=drop)
+    _close(out.detach().float().cpu().numpy(), want, scale, tol, "fused dropout forward")
+    gf, gl, gr, sf, sl, sr = oracle.gat_bwd(c.rowptr, c.colind, h_l, h_r, feat_h, 0.2, gout_h, scales=True, drop=drop)
+    _close(ft.grad.float().cpu().numpy(), gf, sf, tol, "dropout grad_feat")
+    _close(ar.grad.cpu().numpy(), gl, sl, 4 * tol, "dropout grad_attn_row")
+    _close(ac.grad.cpu().numpy(), gr, sr, 4 * tol, "dropout grad_attn_col")
+    # the second layer's shape, forward only: one head, 41 features (odd: 82-byte rows, padded to 48 by the operator)
+    gen = torch.Generator(device=DEV).manual_seed(41)
+    ar1, ac1 = torch.randn(N, 1, device=DEV, generator=gen), torch.randn(N, 1, device=DEV, generator=gen)
+    f41 = torch.randn(N, 1, 41, device=DEV, generator=gen).bfloat16()
+    out41 = fused_gat_dropout_func(ar1, ac1, c.g.rowptr, c.g.colind, 0.2, f41, p, seed + 1)
+    drop1 = edge_dropout_mask(c.g.nnz, 1, p, seed + 1, DEV).cpu().numpy()
+    f41_h = f41.float().cpu().numpy()
+    want41 = oracle.gat_fwd(c.rowptr, c.colind, ar1.cpu().numpy(), ac1.cpu().numpy(), f41_h, 0.2, drop=drop1)
+    scale41 = oracle.gat_fwd(c.rowptr, c.colind, ar1.cpu().numpy(), ac1.cpu().numpy(), np.abs(f41_h), 0.2, drop=drop1)
+    _close(out41.float().cpu().numpy(), want41, scale41, tol, "fused dropout forward H=1 F=41")
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL32), (torch.bfloat16, TOL16)], ids=["f32", "bf16"])
 @pytest.mark.parametrize("scale_in", [1.0, 10.0], ids=["N(0,1)", "x10"])
 def test_edge_softmax_forward_backward_vs_oracle(oracle, reddit, dtype, tol, scale_in):
