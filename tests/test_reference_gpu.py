@@ -298,6 +298,26 @@ report["cora_acc_gpu"], report["cora_acc_cpu"] = float(res_gpu["test_acc"]), flo
 ds = refpkg.arxiv_like(seed=0)
 res, ms = refpkg.run_experiment(ds, model="gcn", epochs=8, cpu=False, seed=0)
 report["arxiv_losses"], report["arxiv_train_step_ms"] = res["train_losses"], ms
+# ---- 4. experiment(model='gat') -- the reference's gat model with its DEFAULT arguments (attn_drop 0.5, 8 heads) through the
+#         reference's own Trainer, with GATLayer.forward rebound to the fused attention-dropout operator: every training
+#         forward goes through cogdl_hip_gat_dropout_fwd, every evaluation through the plain fused kernel; same experiment on
+#         the unchanged layer beside it (different dropout streams: the trajectories agree in shape, not bitwise)
+import cogdl_amd.operators.fused_gat as fg
+gat_calls = {"train": 0, "eval": 0}
+_raw_fwd = fg.gat_forward
+def counting_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, p=0.0, seed=0):
+    gat_calls["train" if p > 0 else "eval"] += 1
+    return _raw_fwd(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, p, seed)
+fg.gat_forward = counting_forward
+res_plain, _ = refpkg.run_experiment(refpkg.cora_like(seed=0), model="gat", epochs=8, cpu=False, seed=0)
+assert gat_calls["train"] == 0, "the unchanged layer must not reach the dropout kernel"
+cogdl_amd.install(fused_gat_dropout=True)
+res_fused, ms_fused = refpkg.run_experiment(refpkg.cora_like(seed=0), model="gat", epochs=8, cpu=False, seed=0)
+assert gat_calls["train"] >= 8 * 2, gat_calls  # two GATLayers per training step
+assert gat_calls["eval"] >= 2, gat_calls
+cogdl_amd.fused.uninstall()
+fg.gat_forward = _raw_fwd
+report["gat_losses_fused_dropout"], report["gat_losses_unchanged_layer"] = res_fused["train_losses"], res_plain["train_losses"]
 print("RESULT " + json.dumps(report))
 '''
 
@@ -319,6 +339,11 @@ def test_unchanged_reference_layers_and_trainer_run_on_the_hip_operators():
     assert abs(lg[0] - lc[0]) < 0.35 * abs(lc[0]), (lg, lc)
     la = rep["arxiv_losses"]
     assert len(la) == 8 and la[-1] < la[0] and all(x == x for x in la)
+    lf, lp = rep["gat_losses_fused_dropout"], rep["gat_losses_unchanged_layer"]
+    # (random labels, feature dropout 0.6 and attention dropout 0.5: the loss of either run bounces; what is comparable is
+    #  that both are finite, start at the same value up to the dropout draw, and dip below their start)
+    assert len(lf) == len(lp) == 8 and all(x == x and abs(x) < 1e4 for x in lf + lp) and min(lf) < lf[0] and min(lp) < lp[0]
+    assert abs(lf[0] - lp[0]) < 0.35 * abs(lp[0]), (lf, lp)  # same model, same init; only the dropout streams differ
     print("arxiv-shaped Trainer.train_step ms:", rep["arxiv_train_step_ms"])
 
 
