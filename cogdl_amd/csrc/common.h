@@ -42,7 +42,7 @@ inline hipError_t fill_u32_async(void *p, uint32_t v, size_t n_words, hipStream_
 }
 
 // Run-time tuning knobs (cogdl_hip_set_tuning): experiments without recompiling.
-enum Tuning { kTuneXcdStripe = 0, kTuneLongThresh = 1, kTuneRowSort = 2, kTuneLongGrid = 3, kTuneGatVec = 4, kTuneGatOnline = 5, kTuneSpmmVec = 6, kTuneEsScalar = 7, kTuneEsSpin = 8, kTuneEsDebug = 9, kTuneCsr2csc = 10, kTuneSampleRelabel = 11, kTuneWaveSplit = 12, kTuneRowDebug = 13, kTuneCount = 14 };
+enum Tuning { kTuneXcdStripe = 0, kTuneLongThresh = 1, kTuneRowSort = 2, kTuneLongGrid = 3, kTuneGatVec = 4, kTuneGatOnline = 5, kTuneSpmmVec = 6, kTuneEsScalar = 7, kTuneEsSpin = 8, kTuneEsDebug = 9, kTuneCsr2csc = 10, kTuneSampleRelabel = 11, kTuneWaveSplit = 12, kTuneRowDebug = 13, kTuneRowTile = 14, kTuneCount = 15 };
 extern int g_tuning[kTuneCount];
 
 // Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8; observed, used for

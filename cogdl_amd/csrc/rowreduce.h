@@ -82,6 +82,17 @@ struct RowSched {
     int sort_rows;  // deal a workgroup's rows to its lane groups by decreasing length (see rowreduce_main_kernel)
     int wave_split; // > 0: in a skewed workgroup, rows of more than this many edges are reduced by ALL lane groups of their wave
     int debug;      // timing experiments (tuning key 13; WRONG results): 1 = row blocks exit, 2 = long-row workgroups exit
+    int64_t nnz;    // (the row-tile kernel needs a valid edge index for the rows that have none)
+};
+
+// Operators that can run in ROW TILES (rowreduce_tile_kernel) declare `static constexpr int kRowTile = R`.
+template <class Op, class = void>
+struct RowTile {
+    static constexpr int value = 1;
+};
+template <class Op>
+struct RowTile<Op, std::void_t<decltype(Op::kRowTile)>> {
+    static constexpr int value = Op::kRowTile;
 };
 
 // Rows of at most this many edges are always reduced sequentially by one lane group, in CSR order (the reference's
@@ -560,6 +571,108 @@ __global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const 
     op.row_end(ctx, st, row, ok);
 }
 
+// ---- row tiles (round 4) --------------------------------------------------------------------------------------------
+// What bounds the row blocks on graphs with many tiny rows is the dependent chain of a row -- row pointer, column ids,
+// gather, store: three round trips even for ONE edge (169 k one-edge rows take 38 us; half the rows of an R-MAT graph
+// have at most two edges, tools/rowcost_probe.py).  Here a lane group owns R CONSECUTIVE rows and walks their chains
+// together: one load brings the R + 1 row pointers, the R first id chunks are requested at once, and the first
+// UNROLL / R edges of every row are gathered in ONE batch -- three round trips per R rows.  Whatever a row has beyond
+// that is folded afterwards, row by row, in CSR order: per row the arithmetic and its order are those of the plain
+// kernel (bit-identical results); R rows per group also average the row lengths a wave sees.  Operators whose context
+// and hooks do not depend on the row (SpmmOp without attention / epilogue) opt in with kRowTile.
+template <class Op, int R>
+__global__ __launch_bounds__(256) void rowreduce_tile_kernel(const Op op, const RowSched s) {
+    constexpr int LPR = Op::LPR, UNROLL = Op::UNROLL;
+    static_assert(Op::kLds == 0 && UNROLL % R == 0 && kWave % LPR == 0 && R < LPR, "row tiles: plain operators only");
+    constexpr int RPW = kWave / LPR, GPB = RPW * 4, U1 = UNROLL / R;
+    __shared__ float op_lds[1];
+    if (blockIdx.x < s.lr.n_long_blocks) {
+        if (s.debug != 2) rowreduce_long_block<Op>(op, s, op_lds);
+        return;
+    }
+    if (s.debug == 1) return;
+    const int64_t rb = xcd_remap(blockIdx.x - s.lr.n_long_blocks, s.rowblocks);
+    if (rb < 0) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int l = lane % LPR, sub = lane / LPR;
+    const int64_t row0 = (rb * GPB + wave * RPW + sub) * R;
+    // the R + 1 row pointers of the group: one coalesced load (rows past the end read rowptr[m]: empty)
+    const int pv = s.rowptr[min(row0 + min(l, R), s.m)];
+    int st_[R], cnt_[R], en_[R];
+    bool live[R];  // false: a row past the end, or a long row (the long-row workgroups and the combine kernel own it)
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        st_[i] = group_bcast<LPR>(pv, sub, i);
+        en_[i] = group_bcast<LPR>(pv, sub, i + 1);
+        live[i] = row0 + i < s.m && en_[i] - st_[i] <= s.lr.thresh;
+        if (!live[i]) en_[i] = st_[i];
+        cnt_[i] = min(LPR, en_[i] - st_[i]);
+    }
+    typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
+    // phase 0: the first id chunk of every row (unconditional loads; a row without edges reads edge 0 and ignores it)
+    int c_[R];
+    typename Op::LaneVals lv_[R];
+    if (s.nnz > 0) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int idx = cnt_[i] > 0 ? min(st_[i] + l, en_[i] - 1) : 0;
+            c_[i] = s.colind[idx];
+            lv_[i] = typename Op::LaneVals{};
+            op.lane_load(ctx, lv_[i], idx);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            c_[i] = 0;
+            lv_[i] = typename Op::LaneVals{};
+        }
+    }
+    typename Op::State acc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        op.row_load(ctx, row0 + i, live[i]);
+        op.init(ctx, acc[i], row0 + i, live[i]);
+    }
+    // phase 1: the first U1 edges of all R rows in one batch of gathers
+    if (s.nnz > 0) {
+        typename Op::Batch b;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+#pragma unroll
+            for (int k = 0; k < U1; ++k) {
+                const int jj = max(min(k, cnt_[i] - 1), 0);
+                op.fetch(ctx, b, i * U1 + k, group_bcast<LPR>(c_[i], sub, jj), st_[i] + jj, lv_[i], sub, jj);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+#pragma unroll
+            for (int k = 0; k < U1; ++k) op.apply(ctx, acc[i], b, i * U1 + k, k < cnt_[i], st_[i] + k, k);
+        }
+    }
+    // phase 2: what a row has beyond its first U1 edges, row by row, in order
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if (cnt_[i] > U1) {  // (group-uniform)
+            for (int j = U1; j < cnt_[i]; j += UNROLL) {
+                typename Op::Batch b;
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int jj = min(j + u, cnt_[i] - 1);
+                    op.fetch(ctx, b, u, group_bcast<LPR>(c_[i], sub, jj), st_[i] + jj, lv_[i], sub, jj);
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) op.apply(ctx, acc[i], b, u, (j + u) < cnt_[i], st_[i] + j + u, j + u);
+            }
+            if (st_[i] + LPR < en_[i]) reduce_edges<Op>(op, ctx, acc[i], s.colind, st_[i] + LPR, en_[i], sub, l, op_lds);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        if (live[i]) op.row_end(ctx, acc[i], row0 + i, true);
+}
+
 // For every long row merge its piece records in chunk order and finish the row.  The row is combined by the lane
 // group that finds it at its FIRST full chunk (the row's head piece, if any, sits in slot 1 of the chunk before).
 template <class Op>
@@ -626,7 +739,12 @@ __global__ __launch_bounds__(256) void rowreduce_combine_kernel(const Op op, con
 template <class Op>
 static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t nnz,
                             int64_t tiles, void *workspace, size_t workspace_bytes, hipStream_t stream) {
-    constexpr int64_t RPB = (kWave / Op::LPR) * 4;
+    // Row tiles (rowreduce_tile_kernel): operators that allow it, lane groups that tile a wave, several rows per wave.
+    // tuning key 14: 0 = automatic (on), 1 = off, 2 = on
+    constexpr int kTile = (RowTile<Op>::value > 1 && kWave % Op::LPR == 0 && Op::LPR < kWave && Op::LPR > RowTile<Op>::value)
+                              ? RowTile<Op>::value : 1;
+    const bool tile_rows = kTile > 1 && g_tuning[kTuneRowTile] != 1;
+    const int64_t RPB = (int64_t)(kWave / Op::LPR) * 4 * (tile_rows ? kTile : 1);
     const int64_t n_rowblocks = (m + RPB - 1) / RPB;
     if (n_rowblocks == 0) return COGDL_HIP_OK;
     if (tiles > 65535 || tiles < 1) return COGDL_HIP_ERANGE;
@@ -637,6 +755,7 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
     s.rowblocks = make_xcd_map(n_rowblocks);
     s.sort_rows = g_tuning[kTuneRowSort] == 0 ? 1 : 0;
     s.debug = g_tuning[kTuneRowDebug];
+    s.nnz = nnz;
     s.wave_split = wave_split_edges();  // (set to 0 below when the caller asked for sequential rows: no workspace)
     s.lr.thresh = INT_MAX;
     if (nnz > 0 && (!Op::kReduce || workspace)) {
@@ -652,7 +771,12 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
     if (s.lr.thresh == INT_MAX) s.wave_split = 0;  // no workspace = every row sequentially, in the reference's order
     if (!grid_fits(s.rowblocks, s.lr.n_long_blocks)) return COGDL_HIP_ERANGE;
     dim3 grid(s.lr.n_long_blocks + xcd_grid(s.rowblocks), (unsigned)tiles);
-    hipLaunchKernelGGL((rowreduce_main_kernel<Op>), grid, dim3(256), 0, stream, op, s);
+    if constexpr (kTile > 1) {
+        if (tile_rows) hipLaunchKernelGGL((rowreduce_tile_kernel<Op, kTile>), grid, dim3(256), 0, stream, op, s);
+        else hipLaunchKernelGGL((rowreduce_main_kernel<Op>), grid, dim3(256), 0, stream, op, s);
+    } else {
+        hipLaunchKernelGGL((rowreduce_main_kernel<Op>), grid, dim3(256), 0, stream, op, s);
+    }
     if constexpr (Op::kReduce) {
         if (s.lr.n_long_blocks > 0)
             hipLaunchKernelGGL((rowreduce_combine_kernel<Op>), dim3(s.lr.n_long_blocks, (unsigned)tiles), dim3(256), 0,

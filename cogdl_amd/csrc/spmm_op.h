@@ -33,6 +33,8 @@ struct SpmmOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_;
     static constexpr bool kReduce = true;
     static constexpr int kLds = 0;
+    // row tiles (rowreduce_tile_kernel): the context and the hooks of csr_spmm do not depend on the row
+    static constexpr int kRowTile = (WMODE != 2 && !EPI) ? 4 : 1;
     const T *val;      // WMODE 1
     const float *att;  // WMODE 2: [E, heads]
     const T *x;
