@@ -10,7 +10,7 @@ int g_tuning[kTuneCount] = {/*0: xcd stripe*/ 32, /*1: long-row threshold overri
                             /*11: sample_adj relabelling: 0 = hash table of first positions (4 launches), 1 = the rocPRIM sort-based form (~25)*/ 0,
                             /*12: wave-scope split of medium rows: n > 0 = rows of more than n edges in skewed workgroups (off by default)*/ 0,
                             /*13: timing experiments on the row-reduce engine (WRONG results): 1 = the row blocks exit at once, 2 = the long-row workgroups exit at once*/ 0,
-                            /*14: csr_spmm row tiles (several rows per lane group, their first gathers in flight together): 0 = automatic, 1 = off, 2 = on wherever the operator allows*/ 0};
+                            /*14: csr_spmm row tiles (several rows per lane group, their first gathers in flight together): 2 = on wherever the operator allows; off by default (measured slower except for rows of one or two edges)*/ 0};
 }
 
 extern "C" int cogdl_hip_set_tuning(int key, int value) {

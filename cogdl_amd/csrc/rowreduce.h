@@ -740,10 +740,13 @@ template <class Op>
 static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t nnz,
                             int64_t tiles, void *workspace, size_t workspace_bytes, hipStream_t stream) {
     // Row tiles (rowreduce_tile_kernel): operators that allow it, lane groups that tile a wave, several rows per wave.
-    // tuning key 14: 0 = automatic (on), 1 = off, 2 = on
+    // tuning key 14: 2 = on; OFF by default -- measured (profiles/r04_rowtile_ab.txt): 169 k one-edge rows 40.7 -> 31.3 us
+    // (half of what is left above the 19 us of an empty launch), two-edge rows 41 -> 37, but rows of >= 4 edges 4-8 %
+    // slower, arxiv-sized R-MAT F=64 132 -> 145 us, uniform 105 -> 111 us: four rows' remainders walked one after the
+    // other cost more than the shared first round trip saves.
     constexpr int kTile = (RowTile<Op>::value > 1 && kWave % Op::LPR == 0 && Op::LPR < kWave && Op::LPR > RowTile<Op>::value)
                               ? RowTile<Op>::value : 1;
-    const bool tile_rows = kTile > 1 && g_tuning[kTuneRowTile] != 1;
+    const bool tile_rows = kTile > 1 && g_tuning[kTuneRowTile] == 2;
     const int64_t RPB = (int64_t)(kWave / Op::LPR) * 4 * (tile_rows ? kTile : 1);
     const int64_t n_rowblocks = (m + RPB - 1) / RPB;
     if (n_rowblocks == 0) return COGDL_HIP_OK;

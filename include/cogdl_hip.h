@@ -76,7 +76,8 @@ COGDL_API int cogdl_hip_last_hip_error(void);
  * suffice, 6 = digits of at most 6 bits: three passes of whole-line runs for 18-bit ids; both measured slower),
  * key 11 = sampler relabelling (1 = the sort-based form), key 12 = wave-scope split of medium rows in skewed workgroups
  * (<= 0 = off, the default; n > 0 = rows of more than n edges), key 13 = timing experiments on the row-reduce engine
- * (1 = the row blocks exit at once, 2 = the long-row workgroups exit at once -- WRONG results).
+ * (1 = the row blocks exit at once, 2 = the long-row workgroups exit at once -- WRONG results), key 14 = csr_spmm row
+ * tiles (2 = several consecutive rows per lane group with their first gathers in one batch; off by default).
  * Defaults are the measured optima. */
 COGDL_API int cogdl_hip_set_tuning(int key, int value);
 

@@ -397,3 +397,43 @@ def test_wave_scope_split_of_medium_rows(oracle, wave_split_32, k):
     xs = torch.randn(600, k, generator=torch.Generator().manual_seed(3))
     seq = csr_spmm_raw(hubs.rowptr.to(DEV), hubs.colind.to(DEV), hubs.weight.to(DEV), xs.to(DEV), split_long_rows=False)
     assert seq.cpu().numpy().tobytes() == oracle.csr_spmm(hubs.rowptr, hubs.colind, hubs.weight, xs).tobytes()
+
+
+@pytest.mark.parametrize("k", [64, 40, 16, 128])
+@pytest.mark.parametrize("topology", ["rmat", "uniform"])
+def test_row_tiles_are_bit_identical_to_the_plain_kernel(oracle, k, topology):
+    """Tuning key 14 = 2 (off by default: measured slower except on one- and two-edge rows): R = 4 consecutive rows per
+    lane group, row pointers / first id chunks / first gathers of the four rows in flight together.  Per row the arithmetic
+    and its order are the plain kernel's: identical bits, weighted and unweighted, with rows of every length, an
+    accumulating call, a matrix whose last rows do not fill a tile, and a matrix without edges."""
+    from cogdl_amd import _lib
+
+    g = synth.arxiv_like(seed=0, topology=topology)
+    x = torch.randn(g.num_nodes, k, generator=torch.Generator().manual_seed(4))
+    lib = _lib.hip()
+
+    def both(fn):
+        lib.cogdl_hip_set_tuning(14, 2)
+        try:
+            a = fn()
+        finally:
+            lib.cogdl_hip_set_tuning(14, 0)
+        return a, fn()
+
+    a, b = both(lambda: hip_spmm(g.rowptr, g.colind, g.weight, x))
+    assert a.tobytes() == b.tobytes()
+    assert_rows_match(a, oracle.csr_spmm(g.rowptr, g.colind, g.weight, x, nthreads=oracle.num_threads()), g.rowptr, g.nnz,
+                      oracle.csr_spmm_abs(g.rowptr, g.colind, g.weight, x))
+    a, b = both(lambda: hip_spmm(g.rowptr, g.colind, None, x))
+    assert a.tobytes() == b.tobytes()
+    small = synth.random_csr(13, 97, 6, seed=k)  # 13 rows: the last tile is partial; ragged rows, some empty
+    xs = torch.randn(97, k, generator=torch.Generator().manual_seed(5))
+    a, b = both(lambda: hip_spmm(small.rowptr, small.colind, small.weight, xs))
+    assert a.tobytes() == b.tobytes() == oracle.csr_spmm(small.rowptr, small.colind, small.weight, xs).tobytes()
+    base = torch.randn(13, k, generator=torch.Generator().manual_seed(6))
+    a, b = both(lambda: csr_spmm_raw(small.rowptr.to(DEV), small.colind.to(DEV), small.weight.to(DEV), xs.to(DEV),
+                                     out=base.to(DEV).clone()).cpu().numpy())
+    assert a.tobytes() == b.tobytes()
+    empty_rp = torch.zeros(30, dtype=torch.int32)
+    a, b = both(lambda: csr_spmm_raw(empty_rp.to(DEV), torch.zeros(0, dtype=torch.int32, device=DEV), None, xs[:29].to(DEV)).cpu().numpy())
+    assert a.tobytes() == b.tobytes() and not a.any()
