@@ -404,6 +404,7 @@ struct GatBwdRowOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_ + 1;
     static constexpr bool kReduce = true;
     static constexpr int kLds = 0;
+    static constexpr int kMinWaves = (VEC_ == 8) ? 5 : 1;  // 8-element lanes: 90-105 VGPRs, five waves per SIMD fit in 102
     static constexpr bool kExpensiveLaneLoad = DROP;  // (the keep bits of an edge: one Philox call)
     const float *attn_row, *attn_col;
     const T *feat;  // feat / out / grad_out in the layer's dtype (f32, f16, bf16): read natively, fp32 arithmetic
@@ -537,6 +538,8 @@ struct GatBwdColOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = 2 * VEC_ + 1;
     static constexpr bool kReduce = true;
     static constexpr int kLds = 0;
+    // 8-element lanes sit at 133-138 VGPRs: just past the 128 of four waves per SIMD
+    static constexpr int kMinWaves = (VEC_ == 8) ? 4 : 1;
     static constexpr bool kExpensiveLaneLoad = DROP;  // (the keep bits of an edge: one Philox call)
     const float *attn_row, *attn_col;
     const T *feat;

@@ -85,6 +85,17 @@ struct RowSched {
     int64_t nnz;    // (the row-tile kernel needs a valid edge index for the rows that have none)
 };
 
+// Operators may ask for a register budget: `static constexpr int kMinWaves = W` compiles their main kernel for at least W
+// waves per SIMD (512 / W VGPRs per lane).
+template <class Op, class = void>
+struct MinWaves {
+    static constexpr int value = 1;
+};
+template <class Op>
+struct MinWaves<Op, std::void_t<decltype(Op::kMinWaves)>> {
+    static constexpr int value = Op::kMinWaves;
+};
+
 // Operators that can run in ROW TILES (rowreduce_tile_kernel) declare `static constexpr int kRowTile = R`.
 template <class Op, class = void>
 struct RowTile {
@@ -463,7 +474,7 @@ __device__ __forceinline__ bool g_sort_rows(const RowSched &s) { return s.sort_r
 // first so that the (critical-path) hub rows start at once; they cost a graph without hub rows ~17 dependent
 // L2-resident loads in <= 1024 workgroups, overlapped with the row blocks.
 template <class Op>
-__global__ __launch_bounds__(256) void rowreduce_main_kernel(const Op op, const RowSched s) {
+__global__ __launch_bounds__(256, MinWaves<Op>::value) void rowreduce_main_kernel(const Op op, const RowSched s) {
     __shared__ float op_lds[Op::kLds > 0 ? 256 * Op::kLds : 1];  // one buffer for both kinds of workgroup
     if (blockIdx.x < s.lr.n_long_blocks) {
         if (s.debug != 2) rowreduce_long_block<Op>(op, s, op_lds);
