@@ -35,6 +35,8 @@ struct SpmmOp {
     static constexpr int kLds = 0;
     // row tiles (rowreduce_tile_kernel): the context and the hooks of csr_spmm do not depend on the row
     static constexpr int kRowTile = (WMODE != 2 && !EPI) ? 4 : 1;
+    // (kMinWaves = 8, i.e. 64 VGPRs, was tried: arxiv-sized R-MAT F=64 132 -> 122 us but 44 bytes of scratch per lane make
+    //  every other shape 3-10 % slower -- 71 VGPRs / 7 waves per SIMD stay)
     const T *val;      // WMODE 1
     const float *att;  // WMODE 2: [E, heads]
     const T *x;
