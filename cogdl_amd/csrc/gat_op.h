@@ -681,11 +681,10 @@ inline RowGeometry gat_fwd_geometry(int64_t h, int64_t f, int elem_bytes, int al
         vec = w;
         if (forced && w >= forced) break;
     }
-    // One or two heads with a row that fits 8 fat lanes: halve the vector once if that makes the group 16 lanes -- the
-    // chunk-wise softmax (one exponential per edge and head, 16 edges per round) then applies, and it beats 8 lanes of
-    // edge-wise softmax that all repeat the head's arithmetic: Reddit-shaped graph, bf16, H=1 x F=48 (the padded second
-    // layer of the gat model): 2.89 -> 2.39 ms, H=1 x F=64: 2.82 -> 2.35 ms (profiles/r04_gat_probe2.txt).
-    if (!forced && h * 8 <= 16 && vec > 1 && (h * f + vec - 1) / vec <= 8 && (h * f + vec / 2 - 1) / (vec / 2) > 8) vec >>= 1;
+    // (Round 4, first half: one or two heads whose row fits 8 fat lanes ran in 16-lane groups -- chunk-wise softmax -- by
+    //  halving the vector once: H=1 x F=48 bf16 2.89 -> 2.39 ms.  With the next chunk's ids prefetched in reduce_edges the
+    //  8 fat lanes win again: 2.35 vs 2.49 ms, with dropout 2.66 vs 2.85 ms, H=2 x F=32 2.33 vs 2.70 ms
+    //  (tools/gat_h1_probe.py) -- the rule is gone.)
     const int64_t need = (h * f + vec - 1) / vec;
     int lpr = 8;
     while (lpr < kWave && lpr < need) lpr <<= 1;
