@@ -69,6 +69,8 @@ HIP_SIGNATURES = {
     "cogdl_hip_sample_adj": ([_vp, _vp, _i64, _vp, _i64, _i64, _i32, _u64] + [_vp] * 4 + [_i64, _vp, _vp, _sz, _vp], _i32),
     "cogdl_hip_sample_adj_padded": ([_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _u64, _vp] + [_vp] * 4
                                     + [_i64, _vp, _vp, _sz, _vp], _i32),
+    "cogdl_hip_sample_adj_block": ([_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _u64, _vp] + [_vp] * 4
+                                   + [_i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp], _i32),
     "cogdl_hip_add_remaining_self_loops_workspace_bytes": ([_i64, _i64], _sz),
     "cogdl_hip_add_remaining_self_loops": ([_vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp], _i32),
     "cogdl_hip_coo_norm_weights_workspace_bytes": ([_i64], _sz),

@@ -533,28 +533,34 @@ __global__ __launch_bounds__(kScanThreads) void rt_scan_small_kernel(const uint3
 constexpr int kSmThreads = 1024, kSmWaves = 16, kSmItems = 16, kSmTile = kSmThreads * kSmItems;  // 16384 slots
 constexpr int kSmSlotBits = 14, kSmDigit = 7, kSmBins = 1 << kSmDigit;
 
+// ITEMS slots per thread (the tile = 1024 ITEMS slots must hold the edge slots AND the column keys 0 .. n_cols + 1), DB =
+// digit bits of the two LSD passes (2 DB >= the key bits): the 128-seed block of a step (1280 slots) takes 2 items and
+// 6-bit digits instead of 16 and 7 -- the kernel is one workgroup's instruction stream, its time is its length.
+template <int ITEMS, int DB>
 __global__ __launch_bounds__(kSmThreads) void small_transpose_kernel(const int32_t *__restrict__ rowptr,
                                                                    const int32_t *__restrict__ colind, int m, int n_cols,
                                                                    int cap, int padded, int32_t *__restrict__ colptr,
                                                                    int32_t *__restrict__ rowind, int32_t *__restrict__ perm) {
-    __shared__ __attribute__((aligned(16))) uint32_t buf[kSmTile];  // 64 KB: first the histogram, then the reorder buffer
-    __shared__ uint16_t rowof[kSmTile];                             // 32 KB
-    __shared__ uint32_t cnt[kSmWaves][kSmBins];                     // 8 KB
+    constexpr int TILE = kSmThreads * ITEMS, BINS = 1 << DB;
+    static_assert(ITEMS <= kSmItems && DB <= kSmDigit && 2 * DB <= 32 - kSmSlotBits, "tile / digit geometry");
+    __shared__ __attribute__((aligned(16))) uint32_t buf[TILE];  // (16 items: 64 KB) first the histogram, then the reorder buffer
+    __shared__ uint16_t rowof[TILE];                             // (32 KB)
+    __shared__ uint32_t cnt[kSmWaves][BINS];                     // (7-bit digits: 8 KB)
     __shared__ uint32_t dstart[kSmBins];
     __shared__ uint32_t wtot[kSmWaves + 1];
     const int t = threadIdx.x, lane = t & (kWave - 1), w = t >> 6;
     const int valid = padded ? min(max(rowptr[m], 0), cap) : cap;
     const uint32_t pad_key = (uint32_t)n_cols, none_key = (uint32_t)n_cols + 1u;  // (n_cols + 2 <= 16384: 14 key bits)
     // ---- the slots' words; histogram of the columns
-    uint32_t word[kSmItems];
-    for (int i = t; i < kSmTile; i += kSmThreads) {
+    uint32_t word[ITEMS];
+    for (int i = t; i < TILE; i += kSmThreads) {
         buf[i] = 0;
         rowof[i] = 0;
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < kSmItems; ++j) {
-        const int e = w * (kSmItems * kWave) + j * kWave + lane;
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = w * (ITEMS * kWave) + j * kWave + lane;
         uint32_t key = none_key;
         if (e < cap) key = e < valid ? (uint32_t)colind[e] : pad_key;
         if (key > none_key) key = none_key;  // (a column id outside [0, n_cols): sorted behind everything, never written)
@@ -563,15 +569,15 @@ __global__ __launch_bounds__(kSmThreads) void small_transpose_kernel(const int32
     }
     for (int r = t; r < m; r += kSmThreads) {  // a non-empty row marks its first slot (distinct slots: no conflicts)
         const int s0 = rowptr[r], s1 = rowptr[r + 1];
-        if (s0 < s1 && s0 >= 0 && s0 < kSmTile) rowof[s0] = (uint16_t)r;
+        if (s0 < s1 && s0 >= 0 && s0 < TILE) rowof[s0] = (uint16_t)r;
     }
     __syncthreads();
     // ---- colptr = exclusive scan of the histogram over the columns 0 .. n_cols (thread t: 16 consecutive columns)
     {
-        uint32_t h[kSmItems], sum = 0;
+        uint32_t h[ITEMS], sum = 0;
 #pragma unroll
-        for (int i = 0; i < kSmItems; ++i) {
-            h[i] = buf[t * kSmItems + i];
+        for (int i = 0; i < ITEMS; ++i) {
+            h[i] = buf[t * ITEMS + i];
             sum += h[i];
         }
         uint32_t incl = sum;
@@ -585,18 +591,18 @@ __global__ __launch_bounds__(kSmThreads) void small_transpose_kernel(const int32
         uint32_t run = incl - sum;
         for (int ww = 0; ww < w; ++ww) run += wtot[ww];
 #pragma unroll
-        for (int i = 0; i < kSmItems; ++i) {
-            const int c = t * kSmItems + i;
+        for (int i = 0; i < ITEMS; ++i) {
+            const int c = t * ITEMS + i;
             if (c <= n_cols) colptr[c] = (int32_t)run;
             run += h[i];
         }
     }
     // ---- rows: running maximum of the marks in slot order (thread t: the 16 consecutive slots 16 t ..)
     {
-        uint32_t v[kSmItems], mx = 0;
+        uint32_t v[ITEMS], mx = 0;
 #pragma unroll
-        for (int i = 0; i < kSmItems; ++i) {
-            mx = max(mx, (uint32_t)rowof[t * kSmItems + i]);
+        for (int i = 0; i < ITEMS; ++i) {
+            mx = max(mx, (uint32_t)rowof[t * ITEMS + i]);
             v[i] = mx;
         }
         uint32_t incl = mx;
@@ -612,20 +618,20 @@ __global__ __launch_bounds__(kSmThreads) void small_transpose_kernel(const int32
         if (lane == 0) before = 0;
         for (int ww = 0; ww < w; ++ww) before = max(before, wtot[ww]);
 #pragma unroll
-        for (int i = 0; i < kSmItems; ++i) rowof[t * kSmItems + i] = (uint16_t)max(v[i], before);
+        for (int i = 0; i < ITEMS; ++i) rowof[t * ITEMS + i] = (uint16_t)max(v[i], before);
     }
     __syncthreads();  // (buf is free again: the histogram has been read)
     // ---- two stable LSD passes over the 14 key bits
     const uint64_t lt = (1ull << lane) - 1ull;
     for (int pass = 0; pass < 2; ++pass) {
-        const int shift = kSmSlotBits + pass * kSmDigit;
-        for (int i = t; i < kSmWaves * kSmBins; i += kSmThreads) (&cnt[0][0])[i] = 0;
+        const int shift = kSmSlotBits + pass * DB;
+        for (int i = t; i < kSmWaves * BINS; i += kSmThreads) (&cnt[0][0])[i] = 0;
         __syncthreads();
-        uint16_t rank[kSmItems];
+        uint16_t rank[ITEMS];
 #pragma unroll
-        for (int j = 0; j < kSmItems; ++j) {
-            const uint32_t d = (word[j] >> shift) & (kSmBins - 1);
-            const uint64_t peers = match_digit(d, kSmDigit, true);
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint32_t d = (word[j] >> shift) & (BINS - 1);
+            const uint64_t peers = match_digit(d, DB, true);
             const int lower = __popcll(peers & lt);
             const uint32_t before = cnt[w][d];  // (LDS operations of a wave complete in order: read, then the leader's write)
             rank[j] = (uint16_t)(before + lower);
@@ -633,7 +639,7 @@ __global__ __launch_bounds__(kSmThreads) void small_transpose_kernel(const int32
         }
         __syncthreads();
         uint32_t tot = 0;
-        if (t < kSmBins) {  // thread t owns digit t: every wave's start inside the digit's run
+        if (t < BINS) {  // thread t owns digit t: every wave's start inside the digit's run
 #pragma unroll
             for (int ww = 0; ww < kSmWaves; ++ww) {
                 const uint32_t c = cnt[ww][t];
@@ -647,24 +653,24 @@ __global__ __launch_bounds__(kSmThreads) void small_transpose_kernel(const int32
             const uint32_t u = __shfl_up(incl, sft, kWave);
             if (lane >= sft) incl += u;
         }
-        if (t < kSmBins && lane == kWave - 1) wtot[w] = incl;
+        if (t < BINS && lane == kWave - 1) wtot[w] = incl;
         __syncthreads();
-        if (t < kSmBins) dstart[t] = incl - tot + (w == 1 ? wtot[0] : 0u);
+        if (t < BINS) dstart[t] = incl - tot + (w == 1 ? wtot[0] : 0u);
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < kSmItems; ++j) {
-            const uint32_t d = (word[j] >> shift) & (kSmBins - 1);
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint32_t d = (word[j] >> shift) & (BINS - 1);
             buf[dstart[d] + cnt[w][d] + rank[j]] = word[j];
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < kSmItems; ++j) word[j] = buf[w * (kSmItems * kWave) + j * kWave + lane];
+        for (int j = 0; j < ITEMS; ++j) word[j] = buf[w * (ITEMS * kWave) + j * kWave + lane];
         __syncthreads();
     }
     // ---- outputs: position p = 1024 w + 64 j + l of the sorted order
 #pragma unroll
-    for (int j = 0; j < kSmItems; ++j) {
-        const int pos = w * (kSmItems * kWave) + j * kWave + lane;
+    for (int j = 0; j < ITEMS; ++j) {
+        const int pos = w * (ITEMS * kWave) + j * kWave + lane;
         const uint32_t e = word[j] & ((1u << kSmSlotBits) - 1u);
         if (pos < cap && (word[j] >> kSmSlotBits) <= pad_key) {
             perm[pos] = (int32_t)e;
@@ -887,8 +893,16 @@ bool small_transpose_covers(int64_t m, int64_t n_cols, int64_t nnz) {
 // One launch, no workspace.  Preconditions: small_transpose_covers(m, n_cols, nnz).
 int small_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols, int64_t nnz, bool padded,
                     int32_t *colptr, int32_t *rowind, int32_t *perm, hipStream_t s) {
-    hipLaunchKernelGGL(rt::small_transpose_kernel, dim3(1), dim3(rt::kSmThreads), 0, s, rowptr, colind, (int)m, (int)n_cols,
-                       (int)nnz, padded ? 1 : 0, colptr, rowind, perm);
+    const int64_t need = std::max(nnz, n_cols + 2);  // slots and keys one tile must hold
+#define COGDL_SMALL_TRANSPOSE(ITEMS, DB)                                                                                   \
+    hipLaunchKernelGGL((rt::small_transpose_kernel<ITEMS, DB>), dim3(1), dim3(rt::kSmThreads), 0, s, rowptr, colind, (int)m, \
+                       (int)n_cols, (int)nnz, padded ? 1 : 0, colptr, rowind, perm)
+    if (need <= 2048) COGDL_SMALL_TRANSPOSE(2, 6);
+    else if (need <= 4096) COGDL_SMALL_TRANSPOSE(4, 6);
+    else if (need <= 8192) COGDL_SMALL_TRANSPOSE(8, 7);
+    else if (need <= 12288) COGDL_SMALL_TRANSPOSE(12, 7);
+    else COGDL_SMALL_TRANSPOSE(16, 7);
+#undef COGDL_SMALL_TRANSPOSE
     return launch_status();
 }
 

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(kRlThreads) void sample_prep_kernel(const int64_t *
                                                                  const int64_t *__restrict__ node_idx, int64_t batch,
                                                                  const int64_t *__restrict__ batch_count, int64_t num_nodes,
                                                                  int64_t k, int replace, int64_t *__restrict__ out_indptr,
-                                                                 int *__restrict__ flags, HashTable ht) {
+                                                                 int *__restrict__ flags, HashTable ht,
+                                                                 int32_t *__restrict__ rowptr32, float *__restrict__ inv_deg) {
     __shared__ int64_t sh[16 * 12 + 5];
     const int64_t cap = (int64_t)ht.mask + 1;
     for (int64_t i = (int64_t)blockIdx.x * kRlThreads + threadIdx.x; i < cap; i += (int64_t)gridDim.x * kRlThreads) {
@@ -214,12 +215,19 @@ __global__ __launch_bounds__(kRlThreads) void sample_prep_kernel(const int64_t *
         }
 #pragma unroll
         for (int q = 0; q < PI; ++q) c[q] = (sd[q] >= 0 && sd[q] < num_nodes) ? count_for(hi[q] - lo[q], k, replace) : 0;
+        int32_t own[PI];
+#pragma unroll
+        for (int q = 0; q < PI; ++q) own[q] = (int32_t)c[q];
         int64_t total;
         wg1024_strided_exclusive_scan<PI, int64_t>(c, sh, &total);
 #pragma unroll
         for (int q = 0; q < PI; ++q) {
             const int64_t i = base + (int64_t)q * kRlThreads + threadIdx.x;
             if (i <= batch) out_indptr[i] = carry + c[q];
+            if (rowptr32) {  // the block as the SpMM takes it (cogdl_hip_sample_adj_block): no block_prepare launch later
+                if (i <= batch) rowptr32[i] = (int32_t)(carry + c[q]);
+                if (i < batch && inv_deg) inv_deg[i] = own[q] > 0 ? 1.f / (float)own[q] : 0.f;
+            }
         }
         carry += total;
     }
@@ -241,6 +249,7 @@ struct RelabelArgs {
     int64_t *out_indptr, *out_indices, *out_nodes, *out_edges, *out_counts;
     const int *flags;
     HashTable ht;
+    int32_t *col32;               // (cogdl_hip_sample_adj_block: out_indices once more as int32; else NULL)
 };
 
 // Phases A-C of a block of ITEMS * 1024 positions starting at b0, STRIDED: item i of thread t is position
@@ -279,7 +288,10 @@ __device__ __forceinline__ void relabel_block_ranks(const RelabelArgs &a, int64_
 __device__ __forceinline__ void relabel_emit(const RelabelArgs &a, int64_t p, int32_t h, int64_t id, uint32_t key,
                                              int64_t n_nodes, int64_t total) {
     if (h >= 0) {
-        if (p >= a.batch) a.out_indices[p - a.batch] = id;
+        if (p >= a.batch) {
+            a.out_indices[p - a.batch] = id;
+            if (a.col32) a.col32[p - a.batch] = (int32_t)id;
+        }
         if ((int64_t)h == p) a.out_nodes[id] = (int64_t)key;
     }
     if (a.padded) {
@@ -289,6 +301,7 @@ __device__ __forceinline__ void relabel_emit(const RelabelArgs &a, int64_t p, in
             if (j >= total) {
                 a.out_indices[j] = 0;
                 a.out_edges[j] = 0;
+                if (a.col32) a.col32[j] = 0;
             }
             a.out_indptr[a.batch + 1 + j] = total;
         }
@@ -597,6 +610,9 @@ static SampleWs carve(void *base, int64_t batch, int64_t cap_edges, int64_t num_
 
 using namespace cogdl;
 
+extern "C" int cogdl_hip_block_prepare(const int64_t *row_ptr, const int64_t *col, int64_t n_rows, int64_t n_slots,
+                                       int32_t *rowptr32, int32_t *col32, float *inv_deg, void *stream);
+
 extern "C" size_t cogdl_hip_sample_adj_workspace_bytes(int64_t batch, int64_t cap_edges, int64_t num_nodes) {
     if (batch < 0 || cap_edges < 0 || num_nodes < 0) return 0;
     return carve(nullptr, batch, cap_edges, num_nodes).total;
@@ -606,7 +622,8 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
                            int64_t batch, const int64_t *batch_count, int64_t num_neighbors, int replace, uint64_t seed,
                            const uint64_t *seed_dev, int padded, int64_t *out_indptr, int64_t *out_indices,
                            int64_t *out_nodes, int64_t *out_edges, int64_t cap_edges, int64_t *out_counts,
-                           void *workspace, size_t workspace_bytes, void *stream) {
+                           void *workspace, size_t workspace_bytes, void *stream, int32_t *rowptr32 = nullptr,
+                           int32_t *col32 = nullptr, float *inv_deg = nullptr) {
     if (batch < 0 || cap_edges < 0 || num_nodes < 0 || !out_indptr || !out_counts || !workspace) return COGDL_HIP_EINVAL;
     if (batch > 0 && (!indptr || !node_idx || !out_nodes)) return COGDL_HIP_EINVAL;
     if (cap_edges > 0 && (!indices || !out_indices || !out_edges)) return COGDL_HIP_EINVAL;
@@ -629,7 +646,7 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
         HashTable ht{w.tkey, w.tpos, (uint32_t)(w.tcap - 1)};
         const unsigned prep_blocks = (unsigned)std::min<int64_t>(256, std::max<int64_t>(1, w.tcap / (kRlThreads * 8)));
         hipLaunchKernelGGL(sample_prep_kernel, dim3(prep_blocks), dim3(kRlThreads), 0, s, indptr, node_idx, batch, batch_count,
-                           num_nodes, num_neighbors, replace, out_indptr, w.flags, ht);
+                           num_nodes, num_neighbors, replace, out_indptr, w.flags, ht, rowptr32, inv_deg);
         if (len == 0) {
             hipError_t e0 = fill_u32_async(out_counts, 0u, 6, s);
             return e0 == hipSuccess ? launch_status() : fail(e0);
@@ -657,6 +674,7 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
         a.out_counts = out_counts;
         a.flags = w.flags;
         a.ht = ht;
+        a.col32 = col32;
         if (w.n_blocks == 1) {
             hipLaunchKernelGGL(sample_relabel_single_kernel, dim3(1), dim3(kRlThreads), 0, s, a);
         } else {
@@ -674,7 +692,8 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
     if (e != hipSuccess) return fail(e);
     if (len == 0) {
         e = fill_u32_async(out_counts, 0u, 6, s);
-        return e == hipSuccess ? launch_status() : fail(e);
+        if (e != hipSuccess) return fail(e);
+        return rowptr32 ? cogdl_hip_block_prepare(out_indptr, out_indices, 0, 0, rowptr32, col32, inv_deg, stream) : launch_status();
     }
     if (batch > 0)
         hipLaunchKernelGGL(sample_pick_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, s, indptr, indices, node_idx,
@@ -700,6 +719,8 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
     if (e != hipSuccess) return fail(e);
     hipLaunchKernelGGL(sample_relabel_kernel, dim3(blocks), dim3(256), 0, s, w.skeys, w.spos, w.first, w.rank, w.head_of, len,
                        batch, pad_key, out_indptr, out_indices, out_nodes, out_counts, w.flags, padded);
+    if (rowptr32)  // (the sort-based form does not write the int32 block itself)
+        return cogdl_hip_block_prepare(out_indptr, out_indices, batch, cap_edges, rowptr32, col32, inv_deg, stream);
     return launch_status();
 }
 
@@ -722,4 +743,17 @@ extern "C" int cogdl_hip_sample_adj_padded(const int64_t *indptr, const int64_t 
     return sample_adj_impl(indptr, indices, num_nodes, node_idx, batch, batch_count, num_neighbors, replace, seed, seed_dev,
                            1, out_indptr, out_indices, out_nodes, out_edges, cap_edges, out_counts, workspace,
                            workspace_bytes, stream);
+}
+
+extern "C" int cogdl_hip_sample_adj_block(const int64_t *indptr, const int64_t *indices, int64_t num_nodes,
+                                          const int64_t *node_idx, int64_t batch, const int64_t *batch_count,
+                                          int64_t num_neighbors, int replace, uint64_t seed, const uint64_t *seed_dev,
+                                          int64_t *out_indptr, int64_t *out_indices, int64_t *out_nodes,
+                                          int64_t *out_edges, int64_t cap_edges, int64_t *out_counts, int32_t *rowptr32,
+                                          int32_t *col32, float *inv_deg, void *workspace, size_t workspace_bytes,
+                                          void *stream) {
+    if (!rowptr32 || (cap_edges > 0 && !col32)) return COGDL_HIP_EINVAL;
+    return sample_adj_impl(indptr, indices, num_nodes, node_idx, batch, batch_count, num_neighbors, replace, seed, seed_dev,
+                           1, out_indptr, out_indices, out_nodes, out_edges, cap_edges, out_counts, workspace,
+                           workspace_bytes, stream, rowptr32, col32, inv_deg);
 }

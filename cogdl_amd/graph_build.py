@@ -152,6 +152,9 @@ def block_for_spmm(row_ptr, col, n_rows=None, mean=True):
     m = row_ptr.numel() - 1 if n_rows is None else int(n_rows)
     if m < 0 or m > row_ptr.numel() - 1:
         raise _lib.BackendError("block_for_spmm: n_rows = %d outside the block's %d rows" % (m, row_ptr.numel() - 1))
+    ready = getattr(row_ptr, "_cogdl_block32", None)  # sample_adj_padded(block32=True): the sampler wrote it already
+    if ready is not None and ready[0] is col and ready[1].numel() == m + 1:
+        return ready[1], ready[2], (ready[3] if mean else None)
     rp32 = torch.empty(m + 1, dtype=torch.int32, device=dev)
     col32 = torch.empty(col.numel(), dtype=torch.int32, device=dev)
     inv = torch.empty(m, dtype=torch.float32, device=dev) if mean else None

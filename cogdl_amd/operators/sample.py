@@ -111,13 +111,18 @@ def _sampler_threads():
     return max(1, min(int(env), torch.get_num_threads()))
 
 
-def sample_adj_padded(indptr, indices, node_idx, num_neighbors, replace=False, seed=0, seed_dev=None, count=None):
+def sample_adj_padded(indptr, indices, node_idx, num_neighbors, replace=False, seed=0, seed_dev=None, count=None,
+                      counts_out=None, block32=False):
     """sample_adj into buffers of FIXED capacity (GPU graphs only): no size depends on what was sampled and nothing
     synchronises, so the call can sit inside a captured hipGraph (cogdl_amd.graphs.capture / torch.cuda.graph).
 
         node_idx : [B] int64 seed slots, of which `count` (a device int64 scalar tensor; None = all B) are in use
         seed_dev : device int64 scalar tensor added to `seed` on the device at every launch (a captured step bumps it
                    in place between replays); None = `seed` alone
+        counts_out : a [3] int64 tensor on the GPU to receive the counts (a row of a caller's table); None = a new one
+        block32  : also produce the block as the SpMM takes it -- (rowptr int32 [B + 1], col int32 [B*k], 1 / in-degree
+                   float32 [B]) -- in the sampler's own launches (cogdl_hip_sample_adj_block); it is attached to the
+                   returned row_ptr, where graph_build.block_for_spmm finds it instead of launching its conversion
     Returns (row_ptr [B + B*k + 1], col [B*k], nodes [B + B*k], edges [B*k], counts [3] = {N', E', flags}) -- all on the
     GPU, the unused tails filled as cogdl_hip_sample_adj_padded documents (empty rows, index 0).  The valid prefix is
     exactly what sample_adj_c returns for the same seed."""
@@ -140,16 +145,30 @@ def sample_adj_padded(indptr, indices, node_idx, num_neighbors, replace=False, s
     out_indices = torch.empty(cap_e, dtype=torch.long, device=dev)
     out_nodes = torch.empty(b + cap_e, dtype=torch.long, device=dev)
     out_edges = torch.empty(cap_e, dtype=torch.long, device=dev)
-    counts = torch.empty(3, dtype=torch.long, device=dev)
+    if counts_out is None:
+        counts = torch.empty(3, dtype=torch.long, device=dev)
+    else:
+        counts = counts_out
+        if (not torch.is_tensor(counts) or counts.dtype != torch.long or counts.device != dev or counts.numel() != 3
+                or not counts.is_contiguous()):
+            raise _lib.BackendError("sample_adj_padded: counts_out must be a contiguous int64 tensor of 3 elements on %s" % dev)
     lib = _lib.hip()
     ws_bytes = lib.cogdl_hip_sample_adj_workspace_bytes(b, cap_e, n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    head = (_lib.ptr(indptr), _lib.ptr(indices), n, _lib.ptr(node_idx), b, _lib.ptr(count), num_neighbors,
+            int(bool(replace)), int(seed), _lib.ptr(seed_dev), _lib.ptr(out_indptr), _lib.ptr(out_indices),
+            _lib.ptr(out_nodes), _lib.ptr(out_edges), cap_e, _lib.ptr(counts))
     with _lib.on_device(dev):
-        rc = lib.cogdl_hip_sample_adj_padded(_lib.ptr(indptr), _lib.ptr(indices), n, _lib.ptr(node_idx), b,
-                                             _lib.ptr(count), num_neighbors, int(bool(replace)), int(seed),
-                                             _lib.ptr(seed_dev), _lib.ptr(out_indptr), _lib.ptr(out_indices),
-                                             _lib.ptr(out_nodes), _lib.ptr(out_edges), cap_e, _lib.ptr(counts),
-                                             _lib.ptr(ws), ws_bytes, _lib.stream_of(indptr))
+        if block32:
+            rp32 = torch.empty(b + 1, dtype=torch.int32, device=dev)
+            col32 = torch.empty(cap_e, dtype=torch.int32, device=dev)
+            inv = torch.empty(b, dtype=torch.float32, device=dev)
+            rc = lib.cogdl_hip_sample_adj_block(*head, _lib.ptr(rp32), _lib.ptr(col32), _lib.ptr(inv), _lib.ptr(ws), ws_bytes,
+                                                _lib.stream_of(indptr))
+            rp32._cogdl_max_row_edges = num_neighbors  # (csrspmm_block: no row reaches the long-row threshold)
+            out_indptr._cogdl_block32 = (out_indices, rp32, col32, inv)
+        else:
+            rc = lib.cogdl_hip_sample_adj_padded(*head, _lib.ptr(ws), ws_bytes, _lib.stream_of(indptr))
     _lib.check(rc, "sample_adj_padded")
     return out_indptr, out_indices, out_nodes, out_edges, counts
 

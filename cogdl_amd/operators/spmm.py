@@ -169,12 +169,20 @@ class FusedSPMMFunction(torch.autograd.Function):
     gradient), as in CogDL's dispatcher (cogdl/utils/spmm_utils.py:98-109)."""
 
     @staticmethod
-    def forward(ctx, rowptr, colind, feat, edge_weight_csr, out_norm, in_norm, bias, relu, transient=False):
+    def forward(ctx, rowptr, colind, feat, edge_weight_csr, out_norm, in_norm, bias, relu, transient=False,
+                max_row_edges=None):
         rowptr, colind = _lib.csr_structure(rowptr, colind)
         _check_csr(rowptr, colind, feat)
         ctx.transient = bool(transient) or _plan.transient()
         ctx.fp = fingerprint_of(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] and not ctx.transient else None
-        out = csr_spmm_epilogue_raw(rowptr, colind, edge_weight_csr, feat, out_norm, in_norm, bias, relu)
+        # a caller that KNOWS no row reaches the long-row threshold (a sampled block: at most `fanout` edges per row)
+        # saves the launch of the long-row combine kernel; the result is the same either way (no such row is split)
+        split = max_row_edges is None or int(max_row_edges) > _lib.hip().cogdl_hip_long_row_threshold(colind.numel())
+        out = csr_spmm_epilogue_raw(rowptr, colind, edge_weight_csr, feat, out_norm, in_norm, bias, relu,
+                                    split_long_rows=split)
+        side = _plan.early_transpose_stream() if ctx.transient and ctx.needs_input_grad[2] else None
+        # (plan.transient_structures(side_stream=...): the transpose the backward will need starts NOW, on the side stream)
+        ctx.early_plan = csr2csc(rowptr, colind, feat.shape[0], padded=True, stream=side) if side is not None else None
         ctx.n_src, ctx.relu, ctx.has_bias = feat.shape[0], bool(relu), bias is not None
         ctx.save_for_backward(rowptr, colind, edge_weight_csr, out_norm, in_norm, out if relu else None)
         return out
@@ -189,7 +197,12 @@ class FusedSPMMFunction(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[6]:
             grad_bias = g.sum(0)
         if ctx.needs_input_grad[2]:
-            if ctx.transient:  # a structure that is never seen again: transposed here, nothing hashed or cached or read back
+            if ctx.transient and ctx.early_plan is not None:
+                plan = ctx.early_plan
+                torch.cuda.current_stream(g.device).wait_event(plan.ready)
+                w_t = gather_rows(plan.perm, w.detach()) if w is not None else None
+                hubs = True
+            elif ctx.transient:  # a structure that is never seen again: transposed here, nothing hashed or cached or read back
                 plan = csr2csc(rowptr, colind, ctx.n_src, padded=True)
                 w_t = gather_rows(plan.perm, w.detach()) if w is not None else None
                 hubs = True
@@ -199,7 +212,7 @@ class FusedSPMMFunction(torch.autograd.Function):
                 hubs = plan.has_hub_columns()
             grad_feat = csr_spmm_epilogue_raw(plan.colptr, plan.rowind, w_t, g, in_norm, out_norm, None, False,
                                               split_long_rows=hubs)
-        return None, None, grad_feat, None, None, None, grad_bias, None, None
+        return None, None, grad_feat, None, None, None, grad_bias, None, None, None
 
 
 def csrspmm_fused(rowptr, colind, x, csr_data=None, out_norm=None, in_norm=None, bias=None, relu=False):
@@ -208,15 +221,19 @@ def csrspmm_fused(rowptr, colind, x, csr_data=None, out_norm=None, in_norm=None,
     return FusedSPMMFunction.apply(rowptr, colind, x, csr_data, out_norm, in_norm, bias, relu)
 
 
-def csrspmm_block(rowptr, colind, x, csr_data=None, in_norm=None):
+def csrspmm_block(rowptr, colind, x, csr_data=None, in_norm=None, max_row_edges=None):
     """in_norm * (A x) for a SAMPLED block (fp32): a structure that changes with every mini-batch, so the backward
     transposes it on the spot instead of hashing it into the plan cache (no structure hash, no pinned read-back, no
     host synchronisation anywhere -- the call can be captured in a hipGraph, and the transposes of a million
     mini-batches do not pile up in the cache).  `rowptr` may describe fewer edges than `colind` holds
     (rowptr[-1] <= len(colind): the fixed-capacity blocks of sample_adj_padded); the surplus entries are ignored in both
     directions (they only cost time).
-    in_norm = 1 / in-degree gives the mean aggregator (Graph.row_norm, cogdl/data/data.py:240-258)."""
-    return FusedSPMMFunction.apply(rowptr, colind, x, csr_data, None, in_norm, None, False, True)
+    in_norm = 1 / in-degree gives the mean aggregator (Graph.row_norm, cogdl/data/data.py:240-258).
+    max_row_edges: an upper bound of the edges per row when the caller knows one (default: what the sampler attached to
+    `rowptr` -- its fan-out; None = unknown): below the long-row threshold the forward is one launch instead of two."""
+    if max_row_edges is None:
+        max_row_edges = getattr(rowptr, "_cogdl_max_row_edges", None)
+    return FusedSPMMFunction.apply(rowptr, colind, x, csr_data, None, in_norm, None, False, True, max_row_edges)
 
 
 def csrspmm(rowptr, colind, x, csr_data, sym=False, actnn=False):

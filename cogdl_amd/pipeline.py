@@ -23,9 +23,15 @@ from . import plan as _plan
 from .operators.sample import sample_adj_c, sample_adj_padded
 
 
-def gather_rows_by_id(src, ids, out=None):
+GATHER_BAD_ID = 1 << 32  # bit set in a caller's 64-bit flag word by gather_rows_by_id(flag_word=...)
+
+
+def gather_rows_by_id(src, ids, out=None, flag_word=None):
     """out[i] = src[ids[i]] along dim 0.  `src`: a CUDA tensor, or a PINNED CPU tensor (read by the GPU in place);
-    `ids`: CUDA int64 / int32.  Returns a CUDA tensor on ids' device (stream-ordered on its current stream)."""
+    `ids`: CUDA int64 / int32.  Returns a CUDA tensor on ids' device (stream-ordered on its current stream).
+    An id outside the source is reported, not read: by default in a fresh flag (zeroed by one fill launch; check_gather
+    reads it), or -- `flag_word`, an int64 device scalar the caller resets itself, e.g. the sampler's flags of the same
+    step -- as bit GATHER_BAD_ID of that word (no fill launch: a captured step pays per kernel node)."""
     if not ids.is_cuda:
         raise _lib.BackendError("gather_rows_by_id: ids must live on the GPU (got %s)" % ids.device)
     dev = ids.device
@@ -52,12 +58,20 @@ def gather_rows_by_id(src, ids, out=None):
         return out
     if row_bytes % 4:
         raise _lib.BackendError("gather_rows_by_id: rows of %d bytes (must be a multiple of 4)" % row_bytes)
-    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    if flag_word is None:
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        flag_ptr = _lib.ptr(bad)
+    else:
+        if (not torch.is_tensor(flag_word) or flag_word.dtype != torch.long or flag_word.device != dev
+                or flag_word.numel() != 1):
+            raise _lib.BackendError("gather_rows_by_id: flag_word must be an int64 scalar tensor on %s" % dev)
+        bad, flag_ptr = None, flag_word.data_ptr() + 4  # the high half of the little-endian word: bit 32 of its value
     fn = _lib.hip().cogdl_hip_gather_feature_rows if ids.dtype == torch.int64 else _lib.hip().cogdl_hip_gather_feature_rows_i32
     with _lib.on_device(dev):
-        rc = fn(_lib.ptr(ids), src.data_ptr(), _lib.ptr(out), n, row_bytes, n_src, _lib.ptr(bad), _lib.stream_of(ids))
+        rc = fn(_lib.ptr(ids), src.data_ptr(), _lib.ptr(out), n, row_bytes, n_src, flag_ptr, _lib.stream_of(ids))
     _lib.check(rc, "gather_feature_rows")
-    out._cogdl_bad_flag = bad  # checked lazily (BatchPipeline / tests): reading it here would stall the stream
+    if bad is not None:
+        out._cogdl_bad_flag = bad  # checked lazily (BatchPipeline / tests): reading it here would stall the stream
     return out
 
 
@@ -83,7 +97,7 @@ def sample_blocks(indptr, indices, seeds, fanouts):
 HOP_SEED_STRIDE = 0x9E3779B97F4A7C15  # the hops of one batch draw from seeds this far apart
 
 
-def sample_blocks_padded(indptr, indices, seeds, fanouts, seed=0, seed_dev=None):
+def sample_blocks_padded(indptr, indices, seeds, fanouts, seed=0, seed_dev=None, block32=True):
     """sample_blocks with every size fixed by (len(seeds), fanouts) -- nothing depends on what was sampled, nothing
     synchronises: the form a captured step needs (cogdl_amd.graphs.capture).  Hop h samples len(seeds_h) * fanout_h
     edge slots for its seed slots (of which the previous hop's device-side node count are in use).
@@ -91,14 +105,17 @@ def sample_blocks_padded(indptr, indices, seeds, fanouts, seed=0, seed_dev=None)
     Returns (n_id, adjs, counts): n_id [cap] (unused slots hold id 0), adjs = [((row_ptr, col), n_dst_slots), ...]
     innermost block first exactly like sample_blocks -- row_ptr is padded to ALL node slots of the block, col holds
     local ids (< the number of nodes in use) with the unused slots set to 0 behind row_ptr[-1] --, and counts = the
-    per-hop device tensors {nodes, edges, flags} (first hop first) for whoever wants to look (that read synchronises).
-    The in-use prefix of every output equals sample_blocks' result for the same per-hop seeds."""
+    per-hop device tensors {nodes, edges, flags} (first hop first; the rows of ONE [hops, 3] table, `counts[0]._base`)
+    for whoever wants to look (that read synchronises).
+    The in-use prefix of every output equals sample_blocks' result for the same per-hop seeds.  block32: the sampler also
+    writes every block in the SpMM's form (int32 + 1 / in-degree; graph_build.block_for_spmm then launches nothing)."""
     adjs, counts = [], []
     batch, count = seeds, None
+    table = torch.empty((len(fanouts), 3), dtype=torch.long, device=indptr.device)
     for hop, k in enumerate(fanouts):
         hop_seed = (int(seed) + hop * HOP_SEED_STRIDE) % (1 << 64)
         row_ptr, col, nodes, _, cnt = sample_adj_padded(indptr, indices, batch, k, False, seed=hop_seed, seed_dev=seed_dev,
-                                                         count=count)
+                                                         count=count, counts_out=table[hop], block32=block32)
         adjs.append(((row_ptr, col), batch.numel()))
         counts.append(cnt)
         batch, count = nodes, cnt[0:1]
@@ -122,12 +139,16 @@ class CapturedMiniBatchStep:
                           backward and the optimizer, what torch DDP does with its buckets (cogdl/trainer/
                           trainer.py:291-303), as a node of the same graph; `params` = the tensors to average
                           (default: every parameter the optimizer holds)
+        side_stream     : run what does not depend on the forward pass (the seeds' labels, the block transposes of the
+                          backward) on a second stream = a second branch of the captured graph.  Default OFF: measured
+                          on MI355X / ROCm 7.0 the two-branch graph replays SLOWER (1024 seeds 0.354 -> 0.439 ms, 128
+                          seeds 0.272 -> 0.383 ms: a cross-branch dependency costs more than the ~30 us it hides)
     Every step: `loss = step(seeds)` copies the seeds into the static buffer and replays (the returned loss tensor is
     static too: read it when you need it, not every step).  The RNG seed lives in device memory and advances inside the
     graph.  All operators run in plan.transient_structures() mode: nothing is hashed, cached or read back."""
 
     def __init__(self, indptr, indices, x, y, forward, optimizer, initial_seeds, fanouts, loss_fn=None, seed=0, warmup=3,
-                 process_group=None, params=None):
+                 process_group=None, params=None, side_stream=False):
         import torch.nn.functional as F
 
         if process_group is not None:
@@ -153,17 +174,39 @@ class CapturedMiniBatchStep:
 
         self.seeds = initial_seeds.to(device=indptr.device, dtype=torch.long).contiguous().clone()
         self.seed_dev = torch.zeros(1, dtype=torch.long, device=indptr.device)
+        # side_stream: work that does not depend on the forward pass runs BESIDE it, on a second stream (a second branch
+        # of the captured graph): the labels of the seeds, and the transposes the backward will need (launched by the
+        # forward calls, plan.transient_structures(side_stream=...)).
+        side = torch.cuda.Stream(device=indptr.device) if side_stream else None
+        labels = torch.empty(self.seeds.shape, dtype=y.dtype, device=y.device)
+        self._static = (labels, side)  # the captured kernels write `labels` through a raw pointer: it lives as long as the graph
         loss_fn = loss_fn or F.cross_entropy
         fanouts = list(fanouts)
 
         def step():
-            with _plan.transient_structures():
+            main = torch.cuda.current_stream(indptr.device)
+            with _plan.transient_structures(side_stream=side):
+                if side is not None:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        torch.index_select(y, 0, self.seeds, out=labels)
+                    labels_ready = torch.cuda.Event()
+                    labels_ready.record(side)
+                else:
+                    torch.index_select(y, 0, self.seeds, out=labels)
                 n_id, blocks, counts = sample_blocks_padded(indptr, indices, self.seeds, fanouts, seed=seed,
                                                             seed_dev=self.seed_dev)
-                xb = gather_rows_by_id(x, n_id)
+                # (ids straight from the sampler; a bad one would show up in the last hop's flag word, which that hop's
+                #  kernels rewrite on every replay -- no fill launch for a flag of the gather's own)
+                xb = gather_rows_by_id(x, n_id, flag_word=counts[-1][2:3])
                 optimizer.zero_grad(set_to_none=True)
-                loss = loss_fn(forward(xb, blocks), y.index_select(0, self.seeds))
+                logits = forward(xb, blocks)
+                if side is not None:
+                    main.wait_event(labels_ready)  # (not the whole side stream: a transpose may still be running there)
+                loss = loss_fn(logits, labels)
                 loss.backward()
+                if side is not None:
+                    main.wait_stream(side)  # (a transpose no backward asked for must still join before the capture ends)
                 average_gradients()
                 optimizer.step()
                 self.seed_dev.add_(1)
@@ -171,6 +214,7 @@ class CapturedMiniBatchStep:
 
         self._replay = graphs.capture(step, warmup=warmup)
         self.loss, self.counts = self._replay.outputs
+        self.counts_table = self.counts[0]._base  # [hops, 3] = {nodes, edges, flags} per hop: one tensor to accumulate
 
     def __call__(self, seeds):
         self.seeds.copy_(seeds, non_blocking=True)
@@ -180,11 +224,11 @@ class CapturedMiniBatchStep:
     def check(self):
         """Raise if the last replay's sampling was invalid (synchronises): a seed or neighbour id outside the graph."""
         flags = 0
-        for c in self.counts:
-            flags |= int(c[2])
+        for f in self.counts_table[:, 2].tolist():
+            flags |= int(f)
         if flags:
-            raise _lib.BackendError("captured step: sampler flags %d (1 = seed id out of range, 2 = neighbour id out of "
-                                    "range, 4 = capacity exceeded)" % flags)
+            raise _lib.BackendError("captured step: flags %d (1 = seed id out of range, 2 = neighbour id out of range, "
+                                    "4 = capacity exceeded, %d = feature gather met an id outside x)" % (flags, GATHER_BAD_ID))
 
 
 class BatchPipeline:

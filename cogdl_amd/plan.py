@@ -25,13 +25,14 @@ from . import _lib
 
 class CscPlan:
     __slots__ = ("colptr", "rowind", "perm", "m", "n_cols", "nnz", "_val_key", "_val_src", "_val_t",
-                 "_max_col_degree")
+                 "_max_col_degree", "ready", "_ws")
 
     def __init__(self, colptr, rowind, perm, m, n_cols, nnz):
         self.colptr, self.rowind, self.perm = colptr, rowind, perm
         self.m, self.n_cols, self.nnz = m, n_cols, nnz
         self._val_key, self._val_src, self._val_t = None, None, None
         self._max_col_degree = None
+        self.ready, self._ws = None, None  # (csr2csc(stream=...): the event to wait for, the workspace kept until then)
 
     def has_hub_columns(self):
         """Does A^T have rows beyond the long-row threshold?  (One reduction + sync, once per plan.)  When it does not,
@@ -67,9 +68,13 @@ def tensor_key(t):
     return (t.data_ptr(), t._version, t.dtype, tuple(t.shape), tuple(t.stride()), t.device.index)
 
 
-def csr2csc(rowptr, colind, n_cols=None, padded=False):
+def csr2csc(rowptr, colind, n_cols=None, padded=False, stream=None):
     """Stable transpose of the structure -> CscPlan (device tensors, int32).  padded: `colind` is a fixed-capacity
-    buffer of which only the first rowptr[-1] entries (read on the device) are edges (cogdl_hip_csr2csc_padded)."""
+    buffer of which only the first rowptr[-1] entries (read on the device) are edges (cogdl_hip_csr2csc_padded).
+    stream: a torch.cuda.Stream to run the transpose on, forked from the current stream here (it waits for what the
+    current stream has queued so far); the plan then carries `ready`, the event to wait for before reading it, and
+    keeps its workspace until it dies (the buffers are allocated on the CURRENT stream: the caller's ordinary stream
+    owns them, the side stream only computes)."""
     dev = _lib.require_cuda(rowptr, colind)
     m = rowptr.numel() - 1
     nnz = colind.numel()
@@ -85,11 +90,18 @@ def csr2csc(rowptr, colind, n_cols=None, padded=False):
                  else (lib.cogdl_hip_csr2csc_workspace_bytes, lib.cogdl_hip_csr2csc))
     ws_bytes = query(m, n_cols, nnz)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    if stream is not None:
+        stream.wait_stream(torch.cuda.current_stream(dev))
     with _lib.on_device(dev):
         rc = fn(_lib.ptr(rowptr), _lib.ptr(colind), m, n_cols, nnz, _lib.ptr(colptr), _lib.ptr(rowind), _lib.ptr(perm),
-                _lib.ptr(ws), ws_bytes, _lib.stream_of(rowptr))
+                _lib.ptr(ws), ws_bytes, _lib.stream_of(rowptr) if stream is None else stream.cuda_stream)
     _lib.check(rc, "csr2csc")
-    return CscPlan(colptr, rowind, perm, m, n_cols, nnz)
+    plan = CscPlan(colptr, rowind, perm, m, n_cols, nnz)
+    if stream is not None:
+        plan.ready = torch.cuda.Event()
+        plan.ready.record(stream)
+        plan._ws = ws  # (freed with the plan, i.e. after whoever waited for `ready` is done with it)
+    return plan
 
 
 def gather_rows(perm, src):
@@ -153,20 +165,37 @@ def set_tape(tape):
 _TRANSIENT = 0
 
 
+_EARLY_STREAM = None
+
+
+def early_transpose_stream():
+    """The side stream of the enclosing transient_structures(side_stream=...) context, or None."""
+    return _EARLY_STREAM if _TRANSIENT > 0 else None
+
+
 @contextlib.contextmanager
-def transient_structures():
+def transient_structures(side_stream=None):
     """Inside this context the SpMM operators treat every CSR structure they are called with as one they will never
     see again -- the sampled blocks of mini-batch training: nothing is hashed, cached or read back; a backward pass
     transposes its structure on the spot (cogdl_hip_csr2csc_padded, so `colind` may be a fixed-capacity buffer with
     unused slots behind rowptr[-1]).  That makes a whole sampled step free of host synchronisation (capturable in a
     hipGraph) and keeps a million one-off transposes out of the plan cache.  The mode is latched per call in forward:
-    the backward of a call made inside the context is transient wherever it runs."""
-    global _TRANSIENT
+    the backward of a call made inside the context is transient wherever it runs.
+    side_stream: a torch.cuda.Stream on which the transposes are computed EARLY -- launched by the forward call, beside
+    whatever follows it on the ordinary stream, instead of by the backward call in front of its SpMM (a sampled block's
+    transpose is one small workgroup's work: 25-30 us on the critical path of a 0.35 ms step, nothing beside it).  The
+    caller must let the ordinary stream wait for `side_stream` before it ends the step (inside a hipGraph capture an
+    unjoined stream is an error) -- a backward pass does that, a forward-only call does not."""
+    global _TRANSIENT, _EARLY_STREAM
+    prev = _EARLY_STREAM
+    if side_stream is not None:
+        _EARLY_STREAM = side_stream
     _TRANSIENT += 1
     try:
         yield
     finally:
         _TRANSIENT -= 1
+        _EARLY_STREAM = prev
 
 
 def transient():

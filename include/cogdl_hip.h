@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define COGDL_HIP_ABI_VERSION 5
+#define COGDL_HIP_ABI_VERSION 6
 
 /* Exported with default visibility (the library is built -fvisibility=hidden). */
 #if defined(COGDL_HIP_BUILD)
@@ -386,6 +386,17 @@ COGDL_API int cogdl_hip_sample_adj_padded(const int64_t *indptr, const int64_t *
                                 int64_t *out_indptr, int64_t *out_indices, int64_t *out_nodes, int64_t *out_edges,
                                 int64_t cap_edges, int64_t *out_counts, void *workspace, size_t workspace_bytes,
                                 void *stream);
+/* cogdl_hip_sample_adj_padded that ALSO leaves the block as the SpMM takes it -- rowptr32 [batch + 1] (the seed rows
+ * only: the rows a layer keeps, graphsage.py:99), col32 [cap_edges] (local ids, 0 behind E') and, unless NULL,
+ * inv_deg [batch] = 1 / sampled in-degree (0 for an empty row: Graph.row_norm, cogdl/data/data.py:240-258) -- written by
+ * the sampler's own kernels: what cogdl_hip_block_prepare would produce from out_indptr / out_indices, without its
+ * launch (a captured mini-batch step pays per dependent kernel node, not per byte). */
+COGDL_API int cogdl_hip_sample_adj_block(const int64_t *indptr, const int64_t *indices, int64_t num_nodes,
+                               const int64_t *node_idx, int64_t batch, const int64_t *batch_count,
+                               int64_t num_neighbors, int replace, uint64_t seed, const uint64_t *seed_dev,
+                               int64_t *out_indptr, int64_t *out_indices, int64_t *out_nodes, int64_t *out_edges,
+                               int64_t cap_edges, int64_t *out_counts, int32_t *rowptr32, int32_t *col32,
+                               float *inv_deg, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Graph preprocessing on the GPU (what cogdl.data.Graph does once per graph before its first SpMM), int64 COO in and out:

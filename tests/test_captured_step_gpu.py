@@ -133,6 +133,72 @@ def test_block_for_spmm_equals_the_torch_expressions(n_rows):
         block_for_spmm(row_ptr.int(), col, n_rows)
 
 
+@pytest.mark.parametrize("relabel", [0, 1], ids=["hash-relabel", "sort-relabel"])
+@pytest.mark.parametrize("b,k,in_use", [(300, 4, None), (100, 10, 37), (2000, 10, None), (64, 0, None), (50, 5, 0)])
+def test_sampler_writes_the_block_in_the_spmm_form_itself(b, k, in_use, relabel):
+    """cogdl_hip_sample_adj_block = cogdl_hip_sample_adj_padded + cogdl_hip_block_prepare without the second launch:
+    int32 row pointer of the seed rows, int32 local ids, 1 / in-degree; block_for_spmm picks it up."""
+    from cogdl_amd.graph_build import block_for_spmm
+
+    indptr, indices = _graph(6000, 7, seed=b + k)
+    seeds = torch.randperm(6000, device=DEV)[:b]
+    count = None if in_use is None else torch.tensor([in_use], device=DEV)
+    table = torch.full((2, 3), -7, dtype=torch.long, device=DEV)
+    _lib.hip().cogdl_hip_set_tuning(11, relabel)
+    try:
+        plain = sample_adj_padded(indptr, indices, seeds, k, seed=77, count=count)
+        row_ptr, col, nodes, edges, counts = sample_adj_padded(indptr, indices, seeds, k, seed=77, count=count,
+                                                               counts_out=table[1], block32=True)
+    finally:
+        _lib.hip().cogdl_hip_set_tuning(11, 0)
+    for got, want in zip((row_ptr, col, nodes, edges, counts), plain):
+        assert torch.equal(got, want)
+    assert counts.data_ptr() == table[1].data_ptr() and table[0].tolist() == [-7, -7, -7]  # the caller's row, only that row
+    want_rp, want_col, want_inv = block_for_spmm(plain[0], plain[1], b)  # (one block_prepare launch)
+    rp, c32, inv = block_for_spmm(row_ptr, col, b)                        # (nothing launched: the sampler's tensors)
+    assert rp.data_ptr() == row_ptr._cogdl_block32[1].data_ptr()
+    assert torch.equal(rp, want_rp) and torch.equal(c32, want_col) and torch.equal(inv, want_inv)
+    assert block_for_spmm(row_ptr, col, b, mean=False)[2] is None
+    assert getattr(rp, "_cogdl_max_row_edges") == k
+    # another row count is not what the sampler prepared: the ordinary conversion answers
+    if b > 10:
+        rp2, _, _ = block_for_spmm(row_ptr, col, 10)
+        assert rp2.numel() == 11 and torch.equal(rp2, row_ptr[:11].int())
+
+
+def test_csrspmm_block_with_a_row_bound_is_one_launch_and_the_same_result():
+    indptr, indices = _graph(20000, 12, seed=3)
+    seeds = torch.randperm(20000, device=DEV)[:512]
+    row_ptr, col, nodes, _, counts = sample_adj_padded(indptr, indices, seeds, 10, seed=4, block32=True)
+    from cogdl_amd.graph_build import block_for_spmm
+
+    rp, c32, inv = block_for_spmm(row_ptr, col, 512)
+    x = torch.randn(nodes.numel(), 100, device=DEV, requires_grad=True)
+    out = csrspmm_block(rp, c32, x, None, inv)  # the sampler's bound (10 edges per row) travels with rp
+    g = torch.randn_like(out)
+    out.backward(g)
+    x2 = x.detach().clone().requires_grad_()
+    out2 = csrspmm_block(rp.clone(), c32, x2, None, inv)  # no bound known: long-row path planned, combine kernel launched
+    out2.backward(g)
+    assert torch.equal(out, out2) and torch.equal(x.grad, x2.grad)
+    out3 = csrspmm_block(rp.clone(), c32, x.detach(), None, inv, max_row_edges=10 ** 6)  # a bound above the threshold: ignored
+    assert torch.equal(out3, out.detach())
+
+
+def test_gather_reports_a_bad_id_in_the_callers_flag_word():
+    from cogdl_amd.pipeline import GATHER_BAD_ID
+
+    x = torch.randn(100, 12, device=DEV)
+    word = torch.tensor([0, 6, 0], device=DEV)  # {., flags, .}: bits already set stay
+    ids = torch.tensor([3, 99, 0], device=DEV)
+    out = gather_rows_by_id(x, ids, flag_word=word[1:2])
+    assert torch.equal(out, x[ids]) and word.tolist() == [0, 6, 0] and not hasattr(out, "_cogdl_bad_flag")
+    gather_rows_by_id(x, torch.tensor([3, 100], device=DEV), flag_word=word[1:2])
+    assert word.tolist() == [0, 6 | GATHER_BAD_ID, 0]
+    with pytest.raises(_lib.BackendError):
+        gather_rows_by_id(x, ids, flag_word=torch.zeros(1, dtype=torch.int32, device=DEV))
+
+
 def test_padded_sampler_and_transpose_replay_correctly_above_a_million_slots():
     """Above 1 M keys rocPRIM's default sort is onesweep, which clears its state with hipMemsetAsync (memset nodes do not
     replay reliably): the fixed-capacity entry points keep the merge sort, so a captured graph stays right at any size."""
@@ -271,6 +337,33 @@ def test_captured_step_in_training_mode_keeps_the_sampler_flags_clean():
         seen.add((int(step.counts[0][0]), int(step.counts[1][0])))
     assert len(seen) > 1  # different seeds and a moving RNG seed: the replays sample different frontiers
     assert int(step.seed_dev) == 3 + 6  # 3 warm-up runs (the capture pass records, it does not execute) + 6 replays
+
+
+def test_captured_step_with_the_side_branch_equals_the_single_stream_step():
+    """side_stream=True: the labels and the block transposes run on a second branch of the captured graph (launched from
+    the forward calls); same numbers as everything on one stream, replay after replay."""
+    n, b = 30000, 256
+    indptr, indices = _graph(n, 14, seed=6)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x_all = torch.randn(n, 32, device=DEV, generator=gen)
+    y_all = torch.randint(0, 7, (n,), device=DEV, generator=gen)
+    order = torch.randperm(n, device=DEV, generator=gen)
+    m_a, m_b = _models()
+    m_a.eval(), m_b.eval()  # (dropout off: number for number)
+    runs = []
+    for model, side in ((m_a, True), (m_b, False)):
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+        step = CapturedMiniBatchStep(indptr, indices, x_all, y_all, model.forward_padded, opt, order[:b], [10, 10], seed=5,
+                                     side_stream=side)
+        losses = []
+        for i in range(5):
+            losses.append(float(step(order[i * b:(i + 1) * b])))
+            step.check()
+        runs.append((losses, [p.detach().clone() for p in model.parameters()], step.counts_table.clone()))
+    assert runs[0][0] == runs[1][0]
+    for pa, pb in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(pa, pb)
+    assert torch.equal(runs[0][2], runs[1][2]) and int(runs[0][2][:, 2].sum()) == 0
 
 
 REFERENCE_SCRIPT = r'''

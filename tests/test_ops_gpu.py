@@ -49,7 +49,14 @@ def test_csr2csc_bit_exact(oracle, csc_algo, m, n_cols, deg):
 @pytest.mark.parametrize("m,n_cols,nnz,kind", [(16000, 16382, 16384, "uniform"), (3, 16382, 16384, "hub-rows"),
                                                (9000, 40, 16384, "hub-columns"), (12000, 12000, 9000, "empty-rows"),
                                                (1, 1, 16384, "one-cell"), (65535, 200, 5000, "max-rows"),
-                                               (700, 16383, 16000, "one-column-too-many"), (500, 900, 16385, "one-slot-too-many")])
+                                               (700, 16383, 16000, "one-column-too-many"), (500, 900, 16385, "one-slot-too-many"),
+                                               # the smaller tiles of the same kernel (2 / 4 / 8 / 12 slots per thread), each
+                                               # at its upper edge in slots or in columns, and one step beyond it
+                                               (128, 1408, 1280, "128-seed-block"), (300, 2046, 2048, "tile-2-full"),
+                                               (300, 2047, 1500, "tile-4-by-columns"), (900, 4094, 4096, "tile-4-full"),
+                                               (40, 100, 4097, "tile-8-by-slots"), (2000, 8190, 8192, "tile-8-full"),
+                                               (1024, 11264, 10240, "1024-seed-block"), (5000, 12286, 12288, "tile-12-full"),
+                                               (5000, 12287, 12000, "tile-16-by-columns")])
 def test_csr2csc_small_single_workgroup_kernel(oracle, m, n_cols, nnz, kind):
     """The one-launch LDS transpose of csrc/radix_transpose.hip (default tuning, up to 16384 slots and 16382 columns) at
     its boundaries -- full tile, a row of thousands of edges, forty columns taking everything, runs of empty rows, the

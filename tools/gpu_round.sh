@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc pmc2 pmcops ops epoch e2e sampler hunt gat pmccombined nocache_tests
+# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc pmc2 pmcops ops epoch e2e sampler hunt gat pmccombined nocache_tests timeline
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -105,4 +105,11 @@ if has nocache_tests; then
   # (stream capture needs the caching allocator's private pools: the hipGraph tests are deselected; failures listed, not -x)
   PYTORCH_NO_CUDA_MEMORY_CACHING=1 timeout -s KILL 1800 python -m pytest tests -m gpu -q --tb=line -p no:cacheprovider -k "not captur and not replay and not hipgraph and not graph_launch" > gpurun_out/pytest_nocache.log 2>&1; echo "nocache pytest rc=$?" >> gpurun_out/pytest_nocache.log
   grep -E "^FAILED|^ERROR|passed|failed|rc=" gpurun_out/pytest_nocache.log | tail -25
+fi
+if has timeline; then
+  rm -rf gpurun_out/prof_tl
+  (cd /tmp && timeout 500 rocprofv3 --kernel-trace -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_tl" -o tl -- python "$GRAFT_REPO_ROOT/tools/sage_bench.py" --captured --steps 60 --warmup 10) > gpurun_out/timeline.log 2>&1
+  python tools/step_timeline.py "$(find gpurun_out/prof_tl -name '*kernel_trace.csv' | head -1)" > gpurun_out/captured_step_timeline.txt 2>&1
+  (timeout 300 python tools/sage_bench.py --captured --steps 200 --warmup 20 2>&1 | tail -1; timeout 300 python tools/sage_bench.py --captured --batch 128 --steps 200 --warmup 20 2>&1 | tail -1; timeout 300 python tools/sage_bench.py --captured --steps 200 --warmup 20 --side-stream 2>&1 | tail -1; timeout 300 python tools/sage_bench.py --captured --batch 128 --steps 200 --warmup 20 --side-stream 2>&1 | tail -1) > gpurun_out/captured_ms.txt 2>&1
+  cut -c1-140 gpurun_out/captured_step_timeline.txt | tail -70; grep -o '"ms_per_step": [0-9.]*' gpurun_out/captured_ms.txt
 fi

@@ -82,25 +82,25 @@ def captured_training(args, dev, n, indptr, indices, x_all, y_all, model, gen, g
     order = torch.randperm(n, device=dev, generator=gen)  # distinct seeds per batch, as a DataLoader over the train set gives
     model.train()
     step = CapturedMiniBatchStep(indptr, indices, x_all, y_all, model.forward_padded, opt, order[:b], [10, 10], seed=20240 + int(os.environ.get("RANK", 0)),
-                                 process_group=group)  # replicas: the gradient all-reduce is a node of the captured graph
+                                 process_group=group, side_stream=args.side_stream)  # replicas: the gradient all-reduce is a node of the captured graph
     n_batches = n // b
     for i in range(args.warmup):
         step(order[(i % n_batches) * b:(i % n_batches + 1) * b])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    nodes = torch.zeros((), dtype=torch.long, device=dev)
-    edges = torch.zeros((), dtype=torch.long, device=dev)
+    acc = torch.zeros_like(step.counts_table)  # {nodes, edges, flags} per hop, summed over the steps: one launch per step
     for i in range(args.steps):
         k = (args.warmup + i) % n_batches
         loss = step(order[k * b:(k + 1) * b])
-        nodes += step.counts[-1][0]
-        edges += step.counts[0][1] + step.counts[1][1]
+        acc += step.counts_table
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     step.check()
     if not bool(torch.isfinite(loss)):
         raise SystemExit("captured step: loss %s" % float(loss))
-    return dt, b * args.steps, int(nodes), int(edges)
+    if int(acc[:, 2].sum()):
+        raise SystemExit("captured step: a replay raised flags (per-hop sums %s)" % acc[:, 2].tolist())
+    return dt, b * args.steps, int(acc[-1, 0]), int(acc[:, 1].sum())
 
 
 def main():
@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--pipeline", action="store_true", help="sample + gather batch i+1 on a side stream while batch i trains")
     ap.add_argument("--captured", action="store_true",
                     help="fixed-capacity blocks, the whole step (sampling included) replayed as one hipGraph (single GPU)")
+    ap.add_argument("--side-stream", action="store_true",
+                    help="--captured: labels and block transposes on a second branch of the captured graph (A/B; slower on ROCm 7.0)")
     ap.add_argument("--inference", action="store_true", help="also time layer-wise full-neighbour inference over all nodes")
     ap.add_argument("--torch-linear", action="store_true",
                     help="keep torch / hipBLASLt for the SAGE layers' Linear (default: cogdl_amd.linear = install(linear=True): "
