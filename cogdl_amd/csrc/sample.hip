@@ -179,6 +179,8 @@ __device__ __forceinline__ void wg1024_strided_exclusive_scan(V (&v)[N], V *sh, 
     for (int q = 0; q < N; ++q) v[q] = sh[q * 16 + w] + incl[q] - v[q];
 }
 
+typedef int64_t I64x2 __attribute__((ext_vector_type(2), aligned(8)));
+
 // prep: block 0 -- flags = 0, per-seed counts and their exclusive scan -> out_indptr (int64; out_indptr[batch] = total);
 // every block -- its share of the hash table set to empty.
 __global__ __launch_bounds__(kRlThreads) void sample_prep_kernel(const int64_t *__restrict__ indptr,
@@ -210,8 +212,11 @@ __global__ __launch_bounds__(kRlThreads) void sample_prep_kernel(const int64_t *
             const int64_t i = base + (int64_t)q * kRlThreads + threadIdx.x;
             const bool ok = sd[q] >= 0 && sd[q] < num_nodes;
             if (i < valid && !ok) bad = 1;
-            lo[q] = ok ? indptr[sd[q]] : 0;
-            hi[q] = ok ? indptr[sd[q] + 1] : 0;
+            // indptr[s] and indptr[s + 1] in ONE 16-byte request (8-byte aligned): this workgroup issues a random gather per
+            // entry from a single CU, and that CU's request rate is what the kernel's time is made of
+            const I64x2 pr = *reinterpret_cast<const I64x2 *>(indptr + (ok ? sd[q] : 0));
+            lo[q] = ok ? pr.x : 0;
+            hi[q] = ok ? pr.y : 0;
         }
 #pragma unroll
         for (int q = 0; q < PI; ++q) c[q] = (sd[q] >= 0 && sd[q] < num_nodes) ? count_for(hi[q] - lo[q], k, replace) : 0;
@@ -378,16 +383,20 @@ __global__ __launch_bounds__(kRlThreads) void sample_relabel_hash_kernel(const R
 
 // |Q| <= kRlTile1: ONE workgroup, one launch, two round trips to memory: the ranks of the block travel through LDS
 // (16-bit: ranks < kRlTile1), nothing is re-read from global memory.
+// ITEMS positions per thread (|Q| <= 1024 ITEMS): the first hop of a 128-seed step has 1408 positions, not 16384 -- one
+// workgroup's gathers leave from one CU, so the kernel's time is its number of requests.
+template <int ITEMS>
 __global__ __launch_bounds__(kRlThreads) void sample_relabel_single_kernel(const RelabelArgs a) {
-    __shared__ int32_t sh[16 * kRlItems1 + 5];
-    __shared__ uint16_t lrank16[kRlTile1];
+    static_assert(ITEMS <= kRlItems1, "at most kRlTile1 positions");
+    __shared__ int32_t sh[16 * ITEMS + 5];
+    __shared__ uint16_t lrank16[kRlThreads * ITEMS];
     const int fl = *a.flags;
-    int32_t hp[kRlItems1], rk[kRlItems1], tot;
-    uint32_t ky[kRlItems1];
+    int32_t hp[ITEMS], rk[ITEMS], tot;
+    uint32_t ky[ITEMS];
     int64_t total;
-    relabel_block_ranks<kRlItems1>(a, 0, hp, ky, rk, total, sh, &tot);
+    relabel_block_ranks<ITEMS>(a, 0, hp, ky, rk, total, sh, &tot);
 #pragma unroll
-    for (int i = 0; i < kRlItems1; ++i) lrank16[i * kRlThreads + threadIdx.x] = (uint16_t)rk[i];
+    for (int i = 0; i < ITEMS; ++i) lrank16[i * kRlThreads + threadIdx.x] = (uint16_t)rk[i];
     __syncthreads();
     const int64_t n_nodes = tot;
     if (threadIdx.x == 0) {
@@ -396,7 +405,7 @@ __global__ __launch_bounds__(kRlThreads) void sample_relabel_single_kernel(const
         a.out_counts[2] = fl;
     }
 #pragma unroll
-    for (int i = 0; i < kRlItems1; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int64_t p = (int64_t)i * kRlThreads + threadIdx.x;
         if (p < a.len) {
             const int64_t id = hp[i] >= 0 ? (int64_t)lrank16[hp[i]] : 0;
@@ -676,7 +685,11 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
         a.ht = ht;
         a.col32 = col32;
         if (w.n_blocks == 1) {
-            hipLaunchKernelGGL(sample_relabel_single_kernel, dim3(1), dim3(kRlThreads), 0, s, a);
+            if (len <= 2 * kRlThreads) hipLaunchKernelGGL(sample_relabel_single_kernel<2>, dim3(1), dim3(kRlThreads), 0, s, a);
+            else if (len <= 4 * kRlThreads) hipLaunchKernelGGL(sample_relabel_single_kernel<4>, dim3(1), dim3(kRlThreads), 0, s, a);
+            else if (len <= 8 * kRlThreads) hipLaunchKernelGGL(sample_relabel_single_kernel<8>, dim3(1), dim3(kRlThreads), 0, s, a);
+            else if (len <= 12 * kRlThreads) hipLaunchKernelGGL(sample_relabel_single_kernel<12>, dim3(1), dim3(kRlThreads), 0, s, a);
+            else hipLaunchKernelGGL(sample_relabel_single_kernel<kRlItems1>, dim3(1), dim3(kRlThreads), 0, s, a);
         } else {
             hipLaunchKernelGGL(sample_first_kernel, dim3((unsigned)w.n_blocks), dim3(kRlThreads), 0, s, a);
             hipLaunchKernelGGL(sample_relabel_hash_kernel, dim3((unsigned)w.n_blocks), dim3(kRlThreads), 0, s, a, w.n_blocks);
