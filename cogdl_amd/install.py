@@ -36,7 +36,8 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
 _finder = None
 
 
-def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False, fused_gat_dropout=False, structure_memo=False):
+def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False, fused_gat_dropout=False, structure_memo=False,
+            metis=False):
     """Idempotent.  Returns the list of cogdl module names that are now served by cogdl_amd.
     fused_norm=True rebinds the dispatcher function `cogdl.utils.spmm_utils.spmm` itself (opt-in: that is no longer the
     unchanged dispatcher) to cogdl_amd.fused.spmm, which folds `out_norm * x` / `in_norm * x` into the kernel.
@@ -52,6 +53,8 @@ def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False, f
     structure_memo=True rebinds the two properties Graph.row_indptr / Graph.col_indices (opt-in, same caveat) so that the
     `.int()` copies the dispatcher makes on every call, and the content hash this library takes of them, happen once per
     structure (cogdl_amd/structure_memo.py).
+    metis=True registers cogdl_amd.metis_compat as the module `metis` when the real package cannot be imported, so that
+    ClusteredDataset / ClusteredLoader (cogdl/data/sampler.py:188-262) partition on the GPU instead of exiting.
     linear=True additionally routes torch.nn.functional.linear -- i.e. the unchanged nn.Linear inside every CogDL
     layer -- through cogdl_amd.linear (hand-written MFMA weight gradient for full-graph shapes)."""
     global _finder
@@ -93,6 +96,11 @@ def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False, f
         from . import structure_memo as _memo
 
         _memo.install()
+    if metis and "metis" not in sys.modules:
+        try:
+            importlib.import_module("metis")  # the real one wins where it exists
+        except Exception:  # (ImportError, or the wrapper's RuntimeError when libmetis is missing)
+            sys.modules["metis"] = importlib.import_module("cogdl_amd.metis_compat")
     su = sys.modules.get("cogdl.utils.spmm_utils")
     if su is not None:  # force the dispatcher to re-resolve the callables
         for k in ("spmm_flag", "mh_spmm_flag", "fused_gat_flag", "spmm_cpu_flag"):

@@ -203,10 +203,14 @@ def initial_partition(level, world, cap, gen, spmm, tries=6):
     return best
 
 
-def multilevel_partition(rowptr, colind, world, seed=0, slack=1.03, spmm=None, info=None):
+def multilevel_partition(rowptr, colind, world, seed=0, slack=1.03, spmm=None, info=None, balance="edges"):
     """labels [N] int64 in [0, world) for the symmetric graph (rowptr, colind); see the module docstring.
     spmm: (rowptr int32, colind int32, weight f32, dense [n, world]) -> [n, world] (default: cogdl_hip_csr_spmm; tests
-    inject a CPU stand-in).  info: optional dict that receives the level sizes and the cut after every phase."""
+    inject a CPU stand-in).  info: optional dict that receives the level sizes and the cut after every phase.
+    balance: "edges" (vertex weight = degree + 1: what a shard's SpMM time follows) or "vertices" (unit weights: METIS's
+    default, what ClusterGCN's equally sized clusters want)."""
+    if balance not in ("edges", "vertices"):
+        raise ValueError("balance must be 'edges' or 'vertices'")
     spmm = spmm or _default_spmm
     dev = rowptr.device
     gen = torch.Generator(device=dev).manual_seed(seed)
@@ -214,7 +218,7 @@ def multilevel_partition(rowptr, colind, world, seed=0, slack=1.03, spmm=None, i
     n = rp.numel() - 1
     if world <= 1 or n == 0:
         return torch.zeros(n, dtype=torch.long, device=dev)
-    vw = (rp[1:] - rp[:-1]).to(torch.float32) + 1.0
+    vw = (rp[1:] - rp[:-1]).to(torch.float32) + 1.0 if balance == "edges" else torch.ones(n, dtype=torch.float32, device=dev)
     levels = [_Level(rp, ci, torch.ones(ci.numel(), dtype=torch.float32, device=dev), vw)]
     maps = []
     cap = slack * float(vw.sum()) / world

@@ -281,3 +281,37 @@ def test_partition_world_1_is_the_identity_cut():
     assert part.bounds.tolist() == [0, 5000] and part.halo_after == [(0, 0)] and part.halo_fraction() == 0.0
     rp, ci, w = part.shard(0)
     assert torch.equal(rp, g.rowptr.long().to(DEV)) and torch.equal(ci, g.colind.long().to(DEV)) and w is None
+
+
+def test_metis_compatible_part_graph_balances_vertices_and_counts_the_cut():
+    """cogdl_amd.metis_compat.part_graph: the `metis` package's call shape (adjacency list or (xadj, adjncy), nparts, seed)
+    -> (edgecuts, parts) with unit vertex weights; what it rejects it rejects loudly."""
+    from cogdl_amd import _lib, metis_compat
+
+    k, size = 12, 300
+    n = k * size
+    gen = torch.Generator().manual_seed(11)
+    comm = torch.arange(n) // size
+    src = torch.arange(n).repeat_interleave(6)
+    dst = comm[src] * size + torch.randint(0, size, (src.numel(),), generator=gen)
+    extra_s, extra_d = torch.arange(0, n, 5), torch.randint(0, n, (n // 5,), generator=gen)
+    shuffle = torch.randperm(n, generator=gen)
+    g = synth.finalize(shuffle[torch.cat([src, extra_s])], shuffle[torch.cat([dst, extra_d])], n, norm=None, self_loops=False)
+    xadj, adjncy = g.rowptr.long().numpy(), g.colind.long().numpy()
+    adj_list = np.split(adjncy, xadj[1:-1])
+    cut, parts = metis_compat.part_graph(adj_list, 12, seed=1)
+    assert isinstance(cut, int) and isinstance(parts, list) and len(parts) == n and set(parts) <= set(range(12))
+    parts_t = torch.tensor(parts)
+    sizes = torch.bincount(parts_t, minlength=12)
+    assert int(sizes.max()) <= 1.04 * size + 1 and int(sizes.min()) > 0, sizes.tolist()
+    rows = torch.repeat_interleave(torch.arange(n), g.rowptr.long()[1:] - g.rowptr.long()[:-1])
+    assert cut == int((parts_t[rows] != parts_t[g.colind.long()]).sum()) // 2
+    rnd = torch.randint(0, 12, (n,), generator=gen)
+    assert cut < 0.3 * (int((rnd[rows] != rnd[g.colind.long()]).sum()) // 2)
+    cut2, parts2 = metis_compat.part_graph((xadj, adjncy), 12, seed=1)  # the (xadj, adjncy) form; deterministic for a seed
+    assert cut2 == cut and parts2 == parts
+    assert metis_compat.part_graph(adj_list, 1) == (0, [0] * n) and metis_compat.part_graph([], 4) == (0, [])
+    with pytest.raises(_lib.BackendError):
+        metis_compat.part_graph(adj_list, 4, tpwgts=[0.25] * 4)
+    with pytest.raises(_lib.BackendError):
+        metis_compat.part_graph([np.array([1]), np.array([5])], 2)

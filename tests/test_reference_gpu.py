@@ -397,3 +397,79 @@ def test_reference_trainer_distributed_world1_rccl_on_the_hip_operators(tmp_path
     assert rep["metrics"] and all(0.0 <= v <= 1.0 for v in rep["metrics"].values()), rep
     pids = {int(f.split(".")[1]) for f in os.listdir(str(marks))}
     assert len(pids) >= 2, "csr_spmm ran in %d process(es): the spawned DDP rank did not use the HIP operators" % len(pids)
+
+
+CLUSTER_SCRIPT = r'''
+import json, os, sys
+import numpy as np
+if not hasattr(np, "int"):
+    np.int = int  # (the reference still spells the alias numpy 1.24 removed: cogdl/data/sampler.py:236)
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT)
+from tools import refpkg
+refpkg.setup(install=True)
+import torch
+import cogdl_amd
+assert "metis" not in sys.modules
+cogdl_amd.install(metis=True)
+import metis
+from cogdl.data.sampler import ClusteredDataset, ClusteredLoader
+
+# 40 planted communities of 100 nodes (dense inside, a few links across), node ids shuffled
+import tempfile
+from cogdl.data import Graph
+from cogdl.datasets import NodeDataset
+gen = torch.Generator().manual_seed(3)
+n_comm, size = 40, 100
+n = n_comm * size
+ids = torch.randperm(n, generator=gen)
+inside = torch.randint(0, size, (2, n * 6), generator=gen) + (torch.randint(0, n_comm, (n * 6,), generator=gen) * size)
+across = torch.randint(0, n, (2, n // 4), generator=gen)
+ei = ids[torch.cat([inside, across], 1)]
+ei = ei[:, ei[0] != ei[1]]
+ei = torch.unique(torch.cat([ei, ei.flip(0)], 1), dim=1)
+g = Graph(x=torch.randn(n, 8, generator=gen), edge_index=ei, y=torch.randint(0, 4, (n,), generator=gen))
+ds = NodeDataset(path=os.path.join(tempfile.mkdtemp(prefix="cogdl_ds_"), "data.pt"), data=g, metric="accuracy")
+torch.cuda.set_device(0)
+loader = ClusteredLoader(ds, n_cluster=40, method="metis", batch_size=4)
+cds = loader.dataset
+assert isinstance(cds, ClusteredDataset) and ClusteredDataset.partition_tool is metis
+sizes = [len(c) for c in cds.clusters]
+allnodes = np.sort(np.concatenate(cds.clusters))
+part = np.empty(n, dtype=np.int64)
+for k, c in enumerate(cds.clusters):
+    part[c] = k
+row, col = g.edge_index
+cut = int((part[row.numpy()] != part[col.numpy()]).sum()) // 2
+rnd = np.random.RandomState(0).randint(0, 40, n)
+cut_rnd = int((rnd[row.numpy()] != rnd[col.numpy()]).sum()) // 2
+batches = 0
+nodes_seen = 0
+for sub in loader:
+    batches += 1
+    nodes_seen += sub.num_nodes
+    assert sub.batch.numel() == sub.num_nodes
+print("RESULT " + json.dumps({"module": metis.__name__, "sizes": sizes, "covers": bool((allnodes == np.arange(n)).all()),
+                              "cut": cut, "cut_random": cut_rnd, "edges": int(row.numel()) // 2, "batches": batches,
+                              "nodes_seen": nodes_seen}))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(refpkg.STAGED, "cogdl")),
+                    reason="staged reference package absent (make -C oracle ref in the build container)")
+def test_reference_clustergcn_loader_partitions_through_the_gpu_partitioner(tmp_path):
+    """The reference's ClusterGCN loader (cogdl/data/sampler.py:188-262) UNCHANGED on a box without METIS:
+    install(metis=True) serves `import metis` from cogdl_amd.metis_compat, ClusteredDataset.preprocess calls
+    metis.part_graph(adjacency_list, n_cluster, seed=1), the clusters come from the GPU multilevel partitioner: every
+    node in exactly one cluster, equal sizes within the slack, a cut far below a random assignment's (planted
+    communities: most of the 6 % cross links are all that is cut), and the loader yields the cluster-batch subgraphs."""
+    script = tmp_path / "cluster.py"
+    script.write_text(CLUSTER_SCRIPT)
+    proc = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert proc.returncode == 0 and lines, proc.stdout[-3000:] + proc.stderr[-5000:]
+    rep = json.loads(lines[-1][7:])
+    assert rep["module"] == "cogdl_amd.metis_compat" and rep["covers"] and sum(rep["sizes"]) == 4000
+    assert max(rep["sizes"]) <= 1.04 * 100 + 1 and min(rep["sizes"]) >= 50, rep["sizes"]
+    assert rep["cut"] < 0.25 * rep["cut_random"], rep
+    assert rep["batches"] == 10 and rep["nodes_seen"] == 4000
