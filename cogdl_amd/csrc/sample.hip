@@ -202,10 +202,12 @@ __global__ __launch_bounds__(kRlThreads) void sample_prep_kernel(const int64_t *
     constexpr int PI = 12;  // entries per thread and trip (12 k: a 1024-seed second hop in one trip; strided: entry q * 1024 + t), their gathers in flight together
     for (int64_t base = 0; base <= batch; base += (int64_t)kRlThreads * PI) {  // entry `batch` (count 0) receives the total
         int64_t sd[PI], lo[PI], hi[PI], c[PI];
+        // (the seed ids are requested before `valid` -- another load -- is known: one dependent round trip less)
 #pragma unroll
         for (int q = 0; q < PI; ++q) {
             const int64_t i = base + (int64_t)q * kRlThreads + threadIdx.x;
-            sd[q] = i < valid ? node_idx[i] : -1;
+            const int64_t v = batch > 0 ? node_idx[min(i, batch - 1)] : -1;
+            sd[q] = i < valid ? v : -1;
         }
 #pragma unroll
         for (int q = 0; q < PI; ++q) {
@@ -442,12 +444,16 @@ __global__ __launch_bounds__(256) void sample_pick_kernel(const int64_t *__restr
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
     if (i >= batch) return;
+    // everything that does not depend on another load is requested first (each dependent round trip is ~2 us of a chain
+    // of five): the seed id and its output offsets next to the count of seeds in use and the RNG seed word
+    const int64_t s = node_idx[i];
+    const int64_t off = out_indptr[i], cnt = out_indptr[i + 1] - off;
+    const uint64_t seed_add = seed_dev ? *seed_dev : 0;  // (a captured graph re-reads it on every replay; `seed` then is a per-call offset)
     if (i >= valid_seeds(batch_count, batch)) {  // an unused seed slot: sorts last, gets no local id
         if (lane == 0) keys[i] = pad_key;
         return;
     }
-    if (seed_dev) seed += *seed_dev;  // (a captured graph re-reads it on every replay; `seed` then is a per-call offset)
-    const int64_t s = node_idx[i];
+    seed += seed_add;
     if (s < 0 || s >= num_nodes) {  // flagged by the count kernel; its count is 0
         if (lane == 0) keys[i] = pad_key;
         return;
@@ -456,8 +462,8 @@ __global__ __launch_bounds__(256) void sample_pick_kernel(const int64_t *__restr
         keys[i] = (uint32_t)s;
         if (ht.key) slots[i] = ht_insert(ht, (uint32_t)s, (uint32_t)i);
     }
-    const int64_t start = indptr[s], deg = indptr[s + 1] - start;
-    const int64_t off = out_indptr[i], cnt = out_indptr[i + 1] - off;
+    const I64x2 pr = *reinterpret_cast<const I64x2 *>(indptr + s);
+    const int64_t start = pr.x, deg = pr.y - start;
     auto emit = [&](int64_t j, int64_t pos) {
         if (off + j >= cap_edges) {
             atomicOr(flags, 4);
