@@ -937,12 +937,26 @@ bool es_flat_covers(int64_t h, int dtype, const void *a, const void *g, const vo
 }
 
 static bool es_flat_small16() { return (g_tuning[kTuneEsDebug] & 4) != 0; }  // 16-bit values: the half-size tiles
-static int64_t es_flat_tile_elems(bool bwd, int elem_bytes) {
-    if (elem_bytes == 4 || es_flat_small16()) return bwd ? esf::TileSize<true, 4>::value : esf::TileSize<false, 4>::value;
-    return bwd ? esf::TileSize<true, 2>::value : esf::TileSize<false, 2>::value;
+// Small problems (fewer full-size tiles than the chip has workgroup slots: an arxiv-sized graph with one or two heads)
+// run in QUARTER-size tiles: four times the workgroups, a quarter of the serial work in each, 16 KB of LDS instead of 40 --
+// with full-size tiles an arxiv-sized H = 1 call is 293 workgroups on 256 CUs, each walking ~600 rows through LDS.
+// Measured (tools/es_small_ab.py, arxiv-sized R-MAT graph, forward): H = 1 fp32 65 -> 39 us, bf16 121 -> 48 us, H = 2
+// 64 -> 47 / 80 -> 45 us; at H = 8 (2441 full tiles: the chip is full either way) quarter tiles are SLOWER (69 -> 78 us
+// forward, 69 -> 98 backward: four times the pieces per row), hence the bound.  A function of (nnz, h) only, so that the
+// workspace query and the launch agree.  Tuning key 9 bit 6 = off (A/B runs, tests of the full-size tiles on small graphs).
+constexpr int kSmallDiv = 4;
+static bool es_flat_small_problem(int64_t nnz, int64_t h) {
+    if (g_tuning[kTuneEsDebug] & 64) return false;
+    return nnz * h < (int64_t)1024 * esf::TileSize<false, 4>::value;
+}
+static int64_t es_flat_tile_elems(bool bwd, int elem_bytes, bool small) {
+    int64_t t;
+    if (elem_bytes == 4 || es_flat_small16()) t = bwd ? esf::TileSize<true, 4>::value : esf::TileSize<false, 4>::value;
+    else t = bwd ? esf::TileSize<true, 2>::value : esf::TileSize<false, 2>::value;
+    return small ? t / kSmallDiv : t;
 }
 static int64_t es_flat_tiles(int64_t nnz, int64_t h, bool bwd, int elem_bytes = 4) {
-    const int64_t tile_e = es_flat_tile_elems(bwd, elem_bytes) / h;
+    const int64_t tile_e = es_flat_tile_elems(bwd, elem_bytes, es_flat_small_problem(nnz, h)) / h;
     return (nnz + tile_e - 1) / tile_e;
 }
 
@@ -968,7 +982,8 @@ int es_flat_launch(bool bwd, const int32_t *rowptr, const void *a, const void *g
     p.nnz = nnz;
     p.h = (int)h;
     const int elem_bytes = dtype == COGDL_HIP_F32 ? 4 : 2;
-    p.tile_e = (int)(es_flat_tile_elems(bwd, elem_bytes) / h);
+    const bool small = es_flat_small_problem(nnz, h);
+    p.tile_e = (int)(es_flat_tile_elems(bwd, elem_bytes, small) / h);
     p.n_tiles = es_flat_tiles(nnz, h, bwd, elem_bytes);
     p.stats = (unsigned *)ws;
     p.tinfo = (esf::TileInfo *)((char *)ws + 256);
@@ -979,6 +994,19 @@ int es_flat_launch(bool bwd, const int32_t *rowptr, const void *a, const void *g
     constexpr int F32F = esf::TileSize<false, 4>::value, F32B = esf::TileSize<true, 4>::value;  // 8192 / 4096 elements
     constexpr int B16F = esf::TileSize<false, 2>::value, B16B = esf::TileSize<true, 2>::value;  // 16384 / 8192
     const bool small16 = es_flat_small16();
+    if (small && !small16) {  // quarter-size tiles, six to eight workgroups per CU
+        constexpr int D = kSmallDiv;
+        switch (dtype) {
+            case COGDL_HIP_F32:
+                return bwd ? esf::launch_typed<float, true, F32B / D, 6>(p, s) : esf::launch_typed<float, false, F32F / D, 6, true>(p, s);
+            case COGDL_HIP_F16:
+                return bwd ? esf::launch_typed<__half, true, B16B / D, 6>(p, s) : esf::launch_typed<__half, false, B16F / D, 6, true>(p, s);
+            case COGDL_HIP_BF16:
+                return bwd ? esf::launch_typed<__hip_bfloat16, true, B16B / D, 6>(p, s)
+                           : esf::launch_typed<__hip_bfloat16, false, B16F / D, 6, true>(p, s);
+            default: return COGDL_HIP_EDTYPE;
+        }
+    }
     // forward: exp(v - max_piece) of single-row tiles kept in registers (one exponential per element; measured on the
     // Reddit-shaped graph: fp32 1.68 -> 1.62 ms, bf16 1.41 -> 1.37 ms, the latter despite 65 spilled registers per lane);
     // tuning key 9 bit 3 switches it off for A/B runs

@@ -204,12 +204,23 @@ def _softmax_grad_scale(sm, gr, rows_, n, h):
 FLAT_HUBS = [((3, 1023), (4, 1025), (17, 9000), (18, 2048), (40, 5)), ((0, 20000),), ((58, 3000), (59, 4100))]
 
 
+@pytest.fixture(params=[0, 64], ids=["small-problem-tiles", "full-size-tiles"])
+def es_tiles(request):
+    """Graphs of test size are "small problems" for the flat kernel (quarter-size tiles); tuning key 9 bit 6 runs the same
+    cases through the full-size tiles that only true-size graphs would otherwise reach."""
+    from cogdl_amd import _lib
+
+    _lib.hip().cogdl_hip_set_tuning(9, request.param)
+    yield request.param
+    _lib.hip().cogdl_hip_set_tuning(9, 0)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("hubs", FLAT_HUBS, ids=["mixed", "one-huge-first-row", "hubs-at-the-end"])
 @pytest.mark.parametrize("h", [1, 2, 8, 64])
-def test_edge_softmax_flat_kernel_rows_across_tiles(oracle, hubs, h, dtype):
-    """The flat kernel against the oracle on rows that span 1..40 tiles, every I/O dtype (inputs rounded to the dtype
-    first, fp32 arithmetic inside, one rounding on store)."""
+def test_edge_softmax_flat_kernel_rows_across_tiles(oracle, hubs, h, dtype, es_tiles):
+    """The flat kernel against the oracle on rows that span 1..160 tiles, every I/O dtype (inputs rounded to the dtype
+    first, fp32 arithmetic inside, one rounding on store), in both tile sizes."""
     if h == 64:
         hubs = tuple((r, min(d, 3000)) for r, d in hubs)
     g = synth.hub_csr(60, 60, hubs=hubs, seed=h)
@@ -235,7 +246,7 @@ def test_edge_softmax_flat_kernel_rows_across_tiles(oracle, hubs, h, dtype):
 
 
 @pytest.mark.parametrize("spin", [0, -1], ids=["exchange", "forced-timeout-escape"])
-def test_edge_softmax_flat_kernel_super_long_rows_and_timeout_escape(oracle, spin):
+def test_edge_softmax_flat_kernel_super_long_rows_and_timeout_escape(oracle, spin, es_tiles):
     """H = 64: a tile is 128 edges (64 backward), so rows beyond 512 tiles = 65,536 (32,768) edges take the init kernel's
     record path (no waiting); tuning key 8 = -1 makes every cross-tile wait give up at once, which exercises the recompute-from-global
     escape on ordinary multi-tile rows."""
@@ -263,7 +274,7 @@ def test_edge_softmax_flat_kernel_super_long_rows_and_timeout_escape(oracle, spi
     assert np.all(np.abs(vd.grad.cpu().numpy() - want_g) <= 1e-5 * _softmax_grad_scale(sm, gr, rows_, 40, h) + 1e-12)
 
 
-def test_edge_softmax_flat_kernel_many_short_and_empty_rows(oracle):
+def test_edge_softmax_flat_kernel_many_short_and_empty_rows(oracle, es_tiles):
     """Tiles with hundreds of rows (more than one rowptr chunk per tile), empty rows, degree-1 rows, H = 1."""
     gen = torch.Generator().manual_seed(0)
     deg = torch.randint(0, 4, (40000,), generator=gen)
