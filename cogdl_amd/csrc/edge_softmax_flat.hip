@@ -566,6 +566,18 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
     const int count = (int)((e1 - e0) * h);
     const bool full = count == TILE;
 
+    // Phase stamps (tuning key 9 bit 7, measurement only): thread 0 of every 61st one-row tile adds the 10 ns ticks it spent
+    // between the marks to stats[8 + k], stats[15] counts the tiles.  The waits are forced at the marks.
+    const bool stamp = (p.debug & 128) && t == 0 && (c % 61) == 17;
+    long long tk = stamp ? wall_clock64() : 0;
+    auto mark = [&](int k) {
+        if (stamp) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const long long now = wall_clock64();
+            atomicAdd(p.stats + 8 + k, (unsigned)(now - tk));
+            tk = now;
+        }
+    };
     // ---- 1. the tile's values, 16 bytes per lane per load, all loads in flight before anything waits ------------
     uint4 ra[NV];
     uint4 rg[BWD ? NV : 1];
@@ -594,6 +606,7 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
         constexpr bool FULL = decltype(full_c)::value;
         // ================= the whole tile is one piece of one row: everything stays in registers =================
         const bool partial = hs < e0 || he > e1;
+        mark(0);  // loads + tile record landed (thread 0's)
         float x[V];
         float pv[(KEEP_P && !BWD) ? NV : 1][V];
         float2 piece = make_float2(0.f, 0.f);  // this thread's view: statistics of head t % h (threads < h publish)
@@ -629,6 +642,7 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
                 }
             }
             wg_slot_reduce<V, true>(mxs, h, red);
+            mark(1);  // maximum pass + workgroup reduction
 #pragma unroll
             for (int k = 0; k < V; ++k) x[k] = 0.f;
 #pragma unroll
@@ -652,6 +666,7 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
             }
         }
         __syncthreads();
+        mark(2);  // exp pass + workgroup reduction
         if (t < h) piece = pstat[t];
         float2 tot = piece;
         if (partial) {
@@ -664,6 +679,7 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
             facm[0][t] = tot.x;
         }
         __syncthreads();
+        mark(3);  // publish + wait for the other pieces + merge
         float f[V], fm[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -695,6 +711,8 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
                     if (i0 + k < count) out[b0 + i0 + k] = from_f32<T>(o[k]);
             }
         }
+        mark(4);  // scale + stores (issued and acknowledged)
+        if (stamp) atomicAdd(p.stats + 15, 1u);
                 };
         if (full) one_row_tile(std::true_type{});
         else one_row_tile(std::false_type{});
@@ -891,6 +909,7 @@ __global__ __launch_bounds__(kThreads) void es_flat_init_kernel(const Params p) 
     const int64_t seg = blockIdx.x;
     const int64_t c_lo = seg * kKMax, c_hi = min(p.n_tiles, c_lo + kKMax);
     if (seg == 0 && t == 0) st_agent(p.stats, 0u);
+    if (seg == 0 && t < 16 && (p.debug & 128)) st_agent(p.stats + 8 + t, 0u);  // phase stamps (tuning key 9 bit 7)
     for (int64_t i = c_lo * 2 * p.h + t; i < c_hi * 2 * p.h; i += kThreads) st_rec(p.rec + i, 0.f, 0.f);
     const int64_t L = (int64_t)kKMax * p.tile_e;
     if (p.nnz <= L) return;  // no row can be super-long (uniform)
@@ -989,7 +1008,7 @@ int es_flat_launch(bool bwd, const int32_t *rowptr, const void *a, const void *g
     p.tinfo = (esf::TileInfo *)((char *)ws + 256);
     p.rec = (float2 *)((char *)ws + 256 + es_flat_info_bytes(nnz, h));
     p.long_edges = (int64_t)esf::kKMax * p.tile_e;
-    p.debug = (g_tuning[kTuneEsDebug] & (1 | 16)) | (g_tuning[kTuneEsSpin] < 0 ? 2 : 0);
+    p.debug = (g_tuning[kTuneEsDebug] & (1 | 16 | 128)) | (g_tuning[kTuneEsSpin] < 0 ? 2 : 0);
     p.spin_limit = g_tuning[kTuneEsSpin] > 0 ? (unsigned)g_tuning[kTuneEsSpin] : esf::kSpinLimit;
     constexpr int F32F = esf::TileSize<false, 4>::value, F32B = esf::TileSize<true, 4>::value;  // 8192 / 4096 elements
     constexpr int B16F = esf::TileSize<false, 2>::value, B16B = esf::TileSize<true, 2>::value;  // 16384 / 8192
