@@ -199,7 +199,8 @@ class FusedSPMMFunction(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             if ctx.transient and ctx.early_plan is not None:
                 plan = ctx.early_plan
-                torch.cuda.current_stream(g.device).wait_event(plan.ready)
+                if plan.ready is not None:  # (None: a block without rows -- nothing was launched)
+                    torch.cuda.current_stream(g.device).wait_event(plan.ready)
                 w_t = gather_rows(plan.perm, w.detach()) if w is not None else None
                 hubs = True
             elif ctx.transient:  # a structure that is never seen again: transposed here, nothing hashed or cached or read back
