@@ -165,6 +165,47 @@ def rebalance(level, labels, world, cap, gen, spmm, rounds=8):
     return labels
 
 
+def force_balance(level, labels, world, cap, max_rounds=64):
+    """What rebalance() could not place (hub neighbourhoods: every well-connected part is full as well) goes to the LIGHTEST
+    parts, connection or not: an overfull part sheds its lightest vertices, one per open part and round, until no part
+    exceeds `cap` or nothing fits any more (a single vertex heavier than a part's share stays where it is)."""
+    dev = labels.device
+    for _ in range(max_rounds):
+        size = torch.zeros(world, dtype=torch.float32, device=dev).index_add_(0, labels, level.vw)
+        over = size > cap
+        if not bool(over.any()):
+            break
+        cand = torch.nonzero(over[labels]).flatten()  # vertices of overfull parts, lightest first within their part
+        cand = cand[torch.argsort(level.vw[cand])]
+        part_of = labels[cand]
+        # per overfull part: only as many of its vertices as its excess needs (prefix by weight)
+        order = torch.argsort(part_of, stable=True)
+        cand, part_of = cand[order], part_of[order]
+        w = level.vw[cand]
+        cum = torch.cumsum(w, 0)
+        start = torch.zeros(world, dtype=torch.float32, device=dev)
+        first = torch.ones_like(part_of, dtype=torch.bool)
+        first[1:] = part_of[1:] != part_of[:-1]
+        start[part_of[first]] = (cum - w)[first]
+        shed = (cum - start[part_of]) - w < (size - cap)[part_of]  # weight shed BEFORE this vertex is still short of the excess
+        cand, w = cand[shed], w[shed]
+        if cand.numel() == 0:
+            break
+        room = cap - size
+        targets = torch.argsort(room, descending=True)  # the lightest parts first
+        k = min(int(cand.numel()), int((room > 0).sum()))
+        if k == 0:
+            break
+        heavy_first = torch.argsort(w, descending=True)[:k]  # heaviest movers to the roomiest parts
+        mv, tg = cand[heavy_first], targets[:k]
+        fits = level.vw[mv] <= room[tg]
+        if not bool(fits.any()):
+            break
+        labels = labels.clone()
+        labels[mv[fits]] = tg[fits]
+    return labels
+
+
 def initial_partition(level, world, cap, gen, spmm, tries=6):
     """Coarsest level: greedy graph growing from several seeds, each refined; the best cut wins."""
     dev = level.rowptr.device
@@ -219,6 +260,11 @@ def multilevel_partition(rowptr, colind, world, seed=0, slack=1.03, spmm=None, i
     if world <= 1 or n == 0:
         return torch.zeros(n, dtype=torch.long, device=dev)
     vw = (rp[1:] - rp[:-1]).to(torch.float32) + 1.0 if balance == "edges" else torch.ones(n, dtype=torch.float32, device=dev)
+    if n <= 8 * world:
+        # fewer than eight vertices per part: nothing for a multilevel scheme to work with (its coarsest level must hold
+        # several vertices per part) -- contiguous weight-balanced blocks in the given order
+        cum = torch.cumsum(vw, 0)
+        return torch.clamp(((cum - 0.5 * vw) * (world / float(vw.sum()))).floor(), 0, world - 1).long()
     levels = [_Level(rp, ci, torch.ones(ci.numel(), dtype=torch.float32, device=dev), vw)]
     maps = []
     cap = slack * float(vw.sum()) / world
@@ -246,6 +292,7 @@ def multilevel_partition(rowptr, colind, world, seed=0, slack=1.03, spmm=None, i
     for lv, cluster_of in zip(reversed(levels[:-1]), reversed(maps)):
         labels = refine(lv, labels[cluster_of], world, cap, REFINE_SWEEPS, gen, spmm)
         labels = rebalance(lv, labels, world, cap, gen, spmm)
+    labels = force_balance(levels[0], labels, world, cap)
     if info is not None:
         info["cut"] = cut_weight(levels[0], labels)
         size = torch.zeros(world, dtype=torch.float32, device=dev).index_add_(0, labels, vw)

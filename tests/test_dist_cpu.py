@@ -455,3 +455,27 @@ def test_multilevel_partitioner_on_a_lattice_with_long_links_and_on_a_structurel
     labels = multilevel_partition(rp, ci, world, spmm=_torch_spmm, info=info)
     assert info["imbalance"] <= 1.06, info
     assert _remote_fraction(rp, ci, labels) <= _remote_fraction(rp, ci, (torch.arange(20000) * world) // 20000) + 0.01
+
+
+@pytest.mark.parametrize("topology", ["uniform", "rmat"])
+def test_multilevel_partitioner_keeps_many_small_parts_balanced(topology):
+    """ClusterGCN-sized requests (hundreds of parts): unit vertex weights stay within the slack on a skewed graph too --
+    what rebalance() cannot place next to its neighbours goes to the lightest parts (force_balance) --, edge weights within
+    the slack or the heaviest single vertex, and fewer than eight vertices per part falls back to contiguous blocks."""
+    from cogdl_amd import synth
+    from cogdl_amd.partitioner import multilevel_partition
+
+    n = 3000
+    g = synth.scaled(n, 8, seed=1, topology=topology, norm=None, self_loops=False)
+    rp, ci = g.rowptr.long(), g.colind.long()
+    deg = (rp[1:] - rp[:-1]).float() + 1.0
+    for world in (60, 250, 1000):
+        for balance, vw in (("vertices", torch.ones(n)), ("edges", deg)):
+            labels = multilevel_partition(rp, ci, world, spmm=_torch_spmm, balance=balance)
+            assert labels.shape == (n,) and int(labels.min()) >= 0 and int(labels.max()) < world
+            size = torch.zeros(world).index_add_(0, labels, vw)
+            mean = float(vw.sum()) / world
+            bound = max(1.04 * mean, float(vw.max())) + (float(vw.max()) if world == 1000 else 0.0)  # (blocks: one vertex of slop)
+            assert float(size.max()) <= bound, (topology, world, balance, float(size.max()) / mean)
+    with pytest.raises(ValueError):
+        multilevel_partition(rp, ci, 4, spmm=_torch_spmm, balance="nodes")
