@@ -69,8 +69,10 @@ COGDL_API int cogdl_hip_last_hip_error(void);
  * the row kernels, bit 1: 4-byte lanes in the hub-row path, bit 2: row kernels instead of the flat streaming kernel;
  * 0 = flat kernel where it applies, 16-byte lanes where the layout allows), key 8 = polls before the flat edge_softmax
  * kernel's cross-tile wait gives up and recomputes the row statistics itself (0 = default 4096; negative: every
- * wait gives up at once -- tests of that escape path), key 9 = timing experiments (bit 0: the flat edge_softmax kernel
- * skips its cross-tile exchange -- WRONG results), key 10 = csr2csc algorithm (0 = automatic: the hand-written
+ * wait gives up at once -- tests of that escape path), key 9 = flat edge_softmax experiments (bit 0: the kernel
+ * skips its cross-tile exchange -- WRONG results; bit 2: half-size tiles for 16-bit values; bit 3: no kept exp values in
+ * the forward; bit 4: one 16-bit element per LDS access; bit 6: full-size tiles for under-filled launches too; bit 7:
+ * wall-clock phase stamps of one-row tiles in the workspace header, tools/es_phase_probe.py), key 10 = csr2csc algorithm (0 = automatic: the hand-written
  * two-payload radix sort from 256 k edge slots on, 1 = always the rocPRIM sort + row look-up pipeline, 2 = always the radix sort, 3 = the radix sort with packed
  * intermediate records wherever two passes suffice -- by default only from 16 M slots on, 5 = MSD-first where two passes
  * suffice, 6 = digits of at most 6 bits: three passes of whole-line runs for 18-bit ids; both measured slower),
