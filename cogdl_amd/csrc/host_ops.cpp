@@ -102,19 +102,55 @@ void counting_sort_by_row(const int64_t *row, int64_t nnz, int64_t num_nodes, in
 }
 
 // ---------------------------------------------------------------- CPU SpMM rows
+constexpr int kPrefetchAhead = 8;
+constexpr int kColBlock = 64;  // floats a row's accumulator holds in registers (8 AVX2 vectors)
+
+// out[i, :] = sum_e val[e] * dense[colind[e], :] for the rows [r0, r1): every column's sum is taken in CSR edge order with
+// a separately rounded multiply and add (-ffp-contract=off) -- the arithmetic of the reference's loop
+// (operators/spmm/spmm_cpu.cpp:39-58 as it is shipped), bit for bit.  Columns are walked in blocks of kColBlock whose
+// partial sums stay in registers across the row's edges (the plain loop stores and reloads the output row once per edge:
+// a store-forwarding chain per column); the gathered rows are random 4k-byte reads out of a matrix far larger than the
+// caches, so the row kPrefetchAhead edges ahead (across row boundaries: colind is one array) is requested on the first
+// column block's pass.
 __attribute__((target_clones("avx2", "default"))) void spmm_rows(const int32_t *rowptr, const int32_t *colind,
                                                                   const float *val, const float *dense, float *out,
-                                                                  int64_t r0, int64_t r1, int64_t k) {
+                                                                  int64_t r0, int64_t r1, int64_t k, int64_t nnz_total) {
+    const int64_t k_blocked = k / kColBlock * kColBlock;
     for (int64_t i = r0; i < r1; ++i) {
         float *__restrict__ o = out + i * k;
-        for (int64_t t = 0; t < k; ++t) o[t] = 0.f;
-        for (int32_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-            const float *__restrict__ b = dense + (int64_t)colind[e] * k;
-            if (val) {
-                const float v = val[e];
-                for (int64_t t = 0; t < k; ++t) o[t] = o[t] + v * b[t];
-            } else {
-                for (int64_t t = 0; t < k; ++t) o[t] = o[t] + b[t];
+        const int32_t e0 = rowptr[i], e1 = rowptr[i + 1];
+        for (int64_t cb = 0; cb < k_blocked; cb += kColBlock) {
+            float acc[kColBlock];
+            for (int t = 0; t < kColBlock; ++t) acc[t] = 0.f;
+            for (int32_t e = e0; e < e1; ++e) {
+                const float *__restrict__ b = dense + (int64_t)colind[e] * k + cb;
+                if (cb == 0 && e + kPrefetchAhead < nnz_total) {
+                    const char *nb = (const char *)(dense + (int64_t)colind[e + kPrefetchAhead] * k);
+                    for (int64_t off = 0; off < k * (int64_t)sizeof(float); off += 64) __builtin_prefetch(nb + off, 0, 1);
+                }
+                if (val) {
+                    const float v = val[e];
+                    for (int t = 0; t < kColBlock; ++t) acc[t] = acc[t] + v * b[t];
+                } else {
+                    for (int t = 0; t < kColBlock; ++t) acc[t] = acc[t] + b[t];
+                }
+            }
+            for (int t = 0; t < kColBlock; ++t) o[cb + t] = acc[t];
+        }
+        if (k_blocked < k) {  // the last k % kColBlock columns: the plain loop
+            for (int64_t t = k_blocked; t < k; ++t) o[t] = 0.f;
+            for (int32_t e = e0; e < e1; ++e) {
+                const float *__restrict__ b = dense + (int64_t)colind[e] * k;
+                if (k_blocked == 0 && e + kPrefetchAhead < nnz_total) {
+                    const char *nb = (const char *)(dense + (int64_t)colind[e + kPrefetchAhead] * k);
+                    for (int64_t off = 0; off < k * (int64_t)sizeof(float); off += 64) __builtin_prefetch(nb + off, 0, 1);
+                }
+                if (val) {
+                    const float v = val[e];
+                    for (int64_t t = k_blocked; t < k; ++t) o[t] = o[t] + v * b[t];
+                } else {
+                    for (int64_t t = k_blocked; t < k; ++t) o[t] = o[t] + b[t];
+                }
             }
         }
     }
@@ -328,7 +364,7 @@ int cogdl_host_csr_spmm_f32(const int32_t *rowptr, const int32_t *colind, const 
     const int64_t work = (nnz + m) * k;
     int t = (int)std::min<int64_t>(nthreads, std::max<int64_t>(1, work / (1 << 16)));
     if (t <= 1) {
-        spmm_rows(rowptr, colind, val, dense, out, 0, m, k);
+        spmm_rows(rowptr, colind, val, dense, out, 0, m, k, nnz);
         return COGDL_HOST_OK;
     }
     std::vector<int64_t> cut((size_t)t + 1, 0);
@@ -344,7 +380,7 @@ int cogdl_host_csr_spmm_f32(const int32_t *rowptr, const int32_t *colind, const 
     }
     std::vector<std::thread> pool;
     for (int i = 0; i < t; ++i)
-        pool.emplace_back(spmm_rows, rowptr, colind, val, dense, out, cut[(size_t)i], cut[(size_t)i + 1], k);
+        pool.emplace_back(spmm_rows, rowptr, colind, val, dense, out, cut[(size_t)i], cut[(size_t)i + 1], k, nnz);
     for (auto &th : pool) th.join();
     return COGDL_HOST_OK;
 }

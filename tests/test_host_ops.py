@@ -123,3 +123,18 @@ def test_spmm_cpu_bit_exact_vs_reference(golden, oracle):
     x = torch.randn(g.num_nodes, 64, generator=torch.Generator().manual_seed(0))
     got = spmm_cpu(g.rowptr, g.colind, g.weight, x)
     assert got.numpy().tobytes() == oracle.csr_spmm(g.rowptr, g.colind, g.weight, x).tobytes()
+
+
+@pytest.mark.parametrize("k", [1, 7, 63, 64, 65, 100, 128, 130, 200])
+@pytest.mark.parametrize("weighted", [True, False], ids=["weighted", "unit-weights"])
+def test_spmm_cpu_column_blocks_keep_the_reference_arithmetic(oracle, k, weighted, monkeypatch):
+    """The host SpMM walks the columns in register-resident blocks of 64 (+ a plain remainder loop) and prefetches ahead:
+    every width around the block size, with and without weights, one thread and several, byte for byte the oracle
+    (= the reference's loop, operators/spmm/spmm_cpu.cpp:39-58: a separately rounded multiply and add per edge, CSR order)."""
+    g = synth.scaled(3000, 9, seed=k, topology="rmat")  # (hub rows and empty rows)
+    x = torch.randn(g.num_nodes, k, generator=torch.Generator().manual_seed(k))
+    w = g.weight if weighted else None
+    want = oracle.csr_spmm(g.rowptr, g.colind, g.weight if weighted else torch.ones_like(g.weight), x).tobytes()
+    for threads in ("1", "5"):
+        monkeypatch.setenv("COGDL_AMD_CPU_THREADS", threads)
+        assert spmm_cpu(g.rowptr, g.colind, w, x).numpy().tobytes() == want
