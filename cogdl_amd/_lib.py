@@ -23,6 +23,7 @@ HIP_SIGNATURES = {
     "cogdl_hip_strerror": ([_i32], ctypes.c_char_p),
     "cogdl_hip_last_hip_error": ([], _i32),
     "cogdl_hip_set_tuning": ([_i32, _i32], _i32),
+    "cogdl_hip_probe_read_stream": ([_vp, _sz, _vp, _vp], _i32),
     "cogdl_hip_csr_spmm_workspace_bytes": ([_i64, _i64, _i32], _sz),
     "cogdl_hip_long_row_threshold": ([_i64], _i32),
     "cogdl_hip_exact_row_edges": ([_i64], _i32),
@@ -86,7 +87,24 @@ HIP_SIGNATURES = {
     "cogdl_hip_shard_count": ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp], _i32),
     "cogdl_hip_shard_fill": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64] + [_vp] * 8 + [_vp, _sz, _vp], _i32),
     "cogdl_hip_bfs_step": ([_vp, _vp, _i64, _vp, _i32, _vp, _vp], _i32),
+    # 64-bit CSR (ABI v7); the segment table is passed by address (ctypes.addressof(Segments))
+    "cogdl_hip_csr_segments": ([_vp, _i64, _i64, _i64, _vp, _vp, _vp], _i32),
+    "cogdl_hip_csr_rebase_rowptr": ([_vp, _vp, _vp, _vp], _i32),
+    "cogdl_hip_csr_spmm_i64_workspace_bytes": ([_vp, _i64, _i32], _sz),
+    "cogdl_hip_csr_spmm_i64": ([_vp] * 6 + [_i64, _i32, _vp, _sz, _vp], _i32),
+    "cogdl_hip_csr_sddmm_i64": ([_vp] * 6 + [_i64, _vp], _i32),
+    "cogdl_hip_csr2csc_i64_workspace_bytes": ([_vp, _i64], _sz),
+    "cogdl_hip_csr2csc_i64": ([_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp], _i32),
+    "cogdl_hip_gather_rows_i64": ([_vp, _vp, _vp, _i64, _i64, _i32, _vp], _i32),
 }
+
+MAX_SEGMENTS = 64  # COGDL_HIP_MAX_SEGMENTS
+
+
+class Segments(ctypes.Structure):
+    """cogdl_hip_segments (include/cogdl_hip.h): the row cuts of a 64-bit CSR."""
+    _fields_ = [("n", ctypes.c_int32), ("row", ctypes.c_int64 * (MAX_SEGMENTS + 1)),
+                ("edge", ctypes.c_int64 * (MAX_SEGMENTS + 1))]
 
 HOST_SIGNATURES = {
     "cogdl_host_strerror": ([_i32], ctypes.c_char_p),

@@ -25,6 +25,9 @@ inline int launch_status() {
     return COGDL_HIP_OK;
 }
 
+// bigcsr.hip: a segment table is well-formed and every segment fits the 32-bit kernels
+int segments_valid(const cogdl_hip_segments *seg);
+
 inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 // Stream-ordered fill of 32-bit words.  A kernel, not hipMemsetAsync: inside a captured hipGraph the small memsets of
@@ -42,7 +45,7 @@ inline hipError_t fill_u32_async(void *p, uint32_t v, size_t n_words, hipStream_
 }
 
 // Run-time tuning knobs (cogdl_hip_set_tuning): experiments without recompiling.
-enum Tuning { kTuneXcdStripe = 0, kTuneLongThresh = 1, kTuneRowSort = 2, kTuneLongGrid = 3, kTuneGatVec = 4, kTuneGatOnline = 5, kTuneSpmmVec = 6, kTuneEsScalar = 7, kTuneEsSpin = 8, kTuneEsDebug = 9, kTuneCsr2csc = 10, kTuneSampleRelabel = 11, kTuneWaveSplit = 12, kTuneRowDebug = 13, kTuneRowTile = 14, kTuneCount = 15 };
+enum Tuning { kTuneXcdStripe = 0, kTuneLongThresh = 1, kTuneRowSort = 2, kTuneLongGrid = 3, kTuneGatVec = 4, kTuneGatOnline = 5, kTuneSpmmVec = 6, kTuneEsScalar = 7, kTuneEsSpin = 8, kTuneEsDebug = 9, kTuneCsr2csc = 10, kTuneSampleRelabel = 11, kTuneWaveSplit = 12, kTuneRowDebug = 13, kTuneRowTile = 14, kTuneSegmentEdges = 15, kTuneCount = 16 };
 extern int g_tuning[kTuneCount];
 
 // Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8; observed, used for

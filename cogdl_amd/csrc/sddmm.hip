@@ -121,11 +121,25 @@ extern "C" int cogdl_hip_csr_sddmm(const int32_t *rowptr, const int32_t *colind,
     if (m < 0 || k < 0 || nnz < 0) return COGDL_HIP_EINVAL;
     if (m == 0) return COGDL_HIP_OK;
     if (!rowptr || !d1 || !d2 || !out) return COGDL_HIP_EINVAL;
-    if (k > 0x7fffffff || nnz > 0x7fffffff) return COGDL_HIP_ERANGE;
+    if (k > 0x7fffffff || nnz > COGDL_HIP_SEGMENT_MAX_EDGES) return COGDL_HIP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
     if (k == 0) return COGDL_HIP_EINVAL;
     SddmmArgs a{rowptr, colind, d1, d2, out, m, k, nnz};
     if (k % 4 == 0 && aligned_to(d1, 16) && aligned_to(d2, 16)) return dispatch_sddmm<4>(a, nullptr, 0, s);
     if (k % 2 == 0 && aligned_to(d1, 8) && aligned_to(d2, 8)) return dispatch_sddmm<2>(a, nullptr, 0, s);
     return dispatch_sddmm<1>(a, nullptr, 0, s);
+}
+
+extern "C" int cogdl_hip_csr_sddmm_i64(const int32_t *rowptr32, const cogdl_hip_segments *seg, const int32_t *colind,
+                                       const float *d1, const float *d2, float *out, int64_t k, void *stream) {
+    int rc = segments_valid(seg);
+    if (rc != COGDL_HIP_OK) return rc;
+    for (int s = 0; s < seg->n; ++s) {
+        const int64_t r0 = seg->row[s], e0 = seg->edge[s];
+        if (seg->edge[s + 1] == e0) continue;
+        rc = cogdl_hip_csr_sddmm(rowptr32 + r0 + s, colind + e0, d1 + r0 * k, d2, out + e0, seg->row[s + 1] - r0, k,
+                                 seg->edge[s + 1] - e0, stream);
+        if (rc != COGDL_HIP_OK) return rc;
+    }
+    return COGDL_HIP_OK;
 }

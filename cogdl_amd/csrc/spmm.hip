@@ -79,7 +79,8 @@ static int check_args(const int32_t *rowptr, const void *x, const void *out, int
     if (m < 0 || k < 0 || nnz < 0) return COGDL_HIP_EINVAL;
     if (m == 0 || k == 0) return COGDL_HIP_OK;
     if (!rowptr || !x || !out) return COGDL_HIP_EINVAL;
-    if (k > 0x7fffffff || nnz > 0x7fffffff) return COGDL_HIP_ERANGE;
+    // (the engine's `int` edge arithmetic looks up to one chunk past a row's end: base + LPR + lane, start + thresh - 1)
+    if (k > 0x7fffffff || nnz > COGDL_HIP_SEGMENT_MAX_EDGES) return COGDL_HIP_ERANGE;
     return COGDL_HIP_OK;
 }
 
@@ -144,6 +145,33 @@ extern "C" int cogdl_hip_csr_spmm_acc(const int32_t *rowptr, const int32_t *coli
                                       void *out, int64_t m, int64_t k, int64_t nnz, int dtype, void *workspace,
                                       size_t workspace_bytes, void *stream) {
     return csr_spmm_entry(rowptr, colind, val, x, out, m, k, nnz, dtype, 1, workspace, workspace_bytes, stream);
+}
+
+// ---- 64-bit CSR: one launch per row segment (bigcsr.hip) ---------------------------------------------------------------
+extern "C" size_t cogdl_hip_csr_spmm_i64_workspace_bytes(const cogdl_hip_segments *seg, int64_t k, int dtype) {
+    if (segments_valid(seg) != COGDL_HIP_OK) return 0;
+    size_t need = 0;
+    for (int s = 0; s < seg->n; ++s)
+        need = std::max(need, cogdl_hip_csr_spmm_workspace_bytes(seg->edge[s + 1] - seg->edge[s], k, dtype));
+    return need;
+}
+
+extern "C" int cogdl_hip_csr_spmm_i64(const int32_t *rowptr32, const cogdl_hip_segments *seg, const int32_t *colind,
+                                      const void *val, const void *x, void *out, int64_t k, int dtype, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    int rc = segments_valid(seg);
+    if (rc != COGDL_HIP_OK) return rc;
+    if (k < 0) return COGDL_HIP_EINVAL;
+    if (dtype != COGDL_HIP_F32 && dtype != COGDL_HIP_F16 && dtype != COGDL_HIP_BF16) return COGDL_HIP_EDTYPE;
+    const size_t es = (size_t)elem_bytes_of(dtype);
+    for (int s = 0; s < seg->n; ++s) {
+        const int64_t r0 = seg->row[s], e0 = seg->edge[s];
+        rc = csr_spmm_entry(rowptr32 + r0 + s, colind ? colind + e0 : nullptr, val ? (const char *)val + (size_t)e0 * es : nullptr, x,
+                            out ? (char *)out + (size_t)r0 * (size_t)k * es : nullptr, seg->row[s + 1] - r0, k,
+                            seg->edge[s + 1] - e0, dtype, 0, workspace, workspace_bytes, stream);
+        if (rc != COGDL_HIP_OK) return rc;
+    }
+    return COGDL_HIP_OK;
 }
 
 extern "C" int cogdl_hip_mhspmm(const int32_t *rowptr, const int32_t *colind, const float *att, const void *feat,

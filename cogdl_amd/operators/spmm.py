@@ -11,6 +11,8 @@ Differences from the reference, all deliberate (SURVEY.md section 7 "hard parts"
   * unweighted + not sym no longer calls csr2csc(None) (operators/spmm.py:75).
   * failures raise BackendError instead of silently falling back to torch.scatter_add.
   * actnn=True (activation quantisation, third_party/actnn absent) is rejected loudly.
+  * an int64 `rowptr` (with int32 `colind`) selects the 64-bit CSR path (cogdl_amd/bigcsr.py): graphs of 2^31 edges
+    and more, which the reference's `.int()` cast cannot express.
 """
 import os
 
@@ -241,6 +243,12 @@ def csrspmm(rowptr, colind, x, csr_data, sym=False, actnn=False):
     if actnn:
         raise _lib.BackendError("actnn=True needs the ActNN quantiser (third_party/actnn is an empty submodule "
                                 "in the reference); not supported by the HIP backend")
+    if rowptr.dtype == torch.int64:
+        # 64-bit CSR (cogdl_amd/bigcsr.py): `graph.row_indptr` itself instead of `.int()` -- the only way to express a
+        # graph of 2^31 edges or more (the reference's cast wraps, cogdl/utils/spmm_utils.py:106)
+        from ..bigcsr import BigSPMMFunction
+
+        return BigSPMMFunction.apply(rowptr, colind, x, csr_data)
     return SPMMFunction.apply(rowptr, colind, x, csr_data, sym)
 
 

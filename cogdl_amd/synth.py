@@ -176,3 +176,84 @@ def hub_csr(m, n_cols, base_deg=5, hubs=((3, 129), (4, 1000), (17, 5000), (18, 2
     colind = torch.randint(0, n_cols, (nnz,), generator=g)
     w = torch.randn(nnz, generator=g) if weighted else None
     return CSRGraph(rowptr.int(), colind.int(), w, m, n_cols)
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] at FULL size on one GPU: ogbn-papers100M's shape (111,059,956 nodes, 1,615,685,872 directed
+# citation pairs).  Built on the device in row buckets so that no single torch op sees 2^31 elements and the
+# temporaries stay a few GB; returns a 64-bit CSR (int64 row pointers, int32 column ids) -- what cogdl_amd/bigcsr.py runs.
+PAPERS_NODES, PAPERS_PAIRS = 111_059_956, 1_615_685_872
+
+
+def rmat_pairs_i32(num_nodes, num_pairs, seed, device, chunk=1 << 27):
+    """rmat_pairs in chunks, as int32 ids (num_nodes < 2^31): 8 bytes per pair instead of 16 + temporaries."""
+    src = torch.empty(num_pairs, dtype=torch.int32, device=device)
+    dst = torch.empty(num_pairs, dtype=torch.int32, device=device)
+    for i, lo in enumerate(range(0, num_pairs, chunk)):
+        n = min(chunk, num_pairs - lo)
+        s, d = rmat_pairs(num_nodes, n, seed * 1_000_003 + i, device=device)
+        src[lo:lo + n] = s
+        dst[lo:lo + n] = d
+        del s, d
+    return src, dst
+
+
+class BigCSRGraph:
+    """64-bit CSR container: rowptr int64 [N+1], colind int32 [nnz], weight fp32 [nnz] (device tensors)."""
+
+    def __init__(self, rowptr, colind, weight, num_nodes):
+        self.rowptr, self.colind, self.weight, self.num_nodes = rowptr, colind, weight, num_nodes
+
+    @property
+    def nnz(self):
+        return int(self.colind.numel())
+
+
+def big_csr_from_pairs(src, dst, num_nodes, symmetrise, buckets=16):
+    """int32 pairs on the device -> BigCSRGraph with row = aggregation target (dst), column ids ascending inside a row
+    (the order CogDL's coalesce leaves, cogdl/datasets/ogb.py:50-55), multi-edges KEPT (so the edge count is the pair
+    count: 1.6e9 directed, 3.2e9 symmetrised -- R-MAT draws duplicates, the dataset has none) and
+    w = d^-1/2[row] * d^-1/2[col] with d = the row's edge count (sym_norm, cogdl/data/data.py:260-274)."""
+    dev = src.device
+    deg = torch.bincount(dst, minlength=num_nodes)
+    if symmetrise:
+        deg += torch.bincount(src, minlength=num_nodes)
+    rowptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(deg, 0, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    dinv = deg.to(torch.float32).pow_(-0.5)
+    dinv[torch.isinf(dinv)] = 0
+    del deg
+    colind = torch.empty(nnz, dtype=torch.int32, device=dev)
+    weight = torch.empty(nnz, dtype=torch.float32, device=dev)
+    # buckets of about nnz / buckets edges each (cut by edge count, not by rows: R-MAT rows are skewed towards low ids)
+    targets = torch.arange(1, buckets, device=dev, dtype=torch.int64) * (nnz // buckets)
+    cuts = [0] + sorted(set(int(r) for r in (torch.searchsorted(rowptr, targets, right=True) - 1).tolist())) + [num_nodes]
+    cuts = sorted(set(cuts))
+    for r0, r1 in zip(cuts, cuts[1:]):
+        sel = (dst >= r0) & (dst < r1)
+        key = dst[sel].long() * num_nodes + src[sel].long()
+        if symmetrise:
+            sel = (src >= r0) & (src < r1)
+            key = torch.cat([key, src[sel].long() * num_nodes + dst[sel].long()])
+        del sel
+        key = torch.sort(key).values
+        e0, e1 = int(rowptr[r0]), int(rowptr[r1])
+        assert key.numel() == e1 - e0
+        row, col = key // num_nodes, key % num_nodes
+        del key
+        colind[e0:e1] = col
+        weight[e0:e1] = dinv[row] * dinv[col]
+        del row, col
+    return BigCSRGraph(rowptr, colind, weight, num_nodes)
+
+
+def papers100m_like(device, symmetrise=True, seed=0, num_nodes=PAPERS_NODES, num_pairs=PAPERS_PAIRS):
+    """ogbn-papers100M's shape as one 64-bit CSR on `device`: directed (1.6e9 edges) or symmetrised as CogDL feeds it
+    to GCN (3.2e9 edges > 2^31).  Smaller (num_nodes, num_pairs) give the same construction at test sizes."""
+    src, dst = rmat_pairs_i32(num_nodes, num_pairs, seed, device)
+    g = big_csr_from_pairs(src, dst, num_nodes, symmetrise)
+    del src, dst
+    if torch.device(device).type == "cuda":
+        torch.cuda.empty_cache()
+    return g

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define COGDL_HIP_ABI_VERSION 6
+#define COGDL_HIP_ABI_VERSION 7
 
 /* Exported with default visibility (the library is built -fvisibility=hidden). */
 #if defined(COGDL_HIP_BUILD)
@@ -82,6 +82,10 @@ COGDL_API int cogdl_hip_last_hip_error(void);
  * tiles (2 = several consecutive rows per lane group with their first gathers in one batch; off by default).
  * Defaults are the measured optima. */
 COGDL_API int cogdl_hip_set_tuning(int key, int value);
+/* Measurement hook (bench.py `roofline.measured_read_GBs`, SURVEY.md section 8d: the box's own roof beside the spec
+ * peak): one read-only pass over `bytes` of device memory in 16-byte vectors; sink: COGDL_HIP_PROBE_BLOCKS * 16 bytes. */
+#define COGDL_HIP_PROBE_BLOCKS 8192
+COGDL_API int cogdl_hip_probe_read_stream(const void *p, size_t bytes, void *sink, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * csr_spmm:  out[i,:] = sum_{e in row i, CSR order} val[e] * x[colind[e],:]
@@ -124,6 +128,56 @@ COGDL_API int cogdl_hip_csr_spmm_acc(const int32_t *rowptr, const int32_t *colin
 COGDL_API int cogdl_hip_csr_spmm_variant(const int32_t *rowptr, const int32_t *colind, const void *val,
                                const void *x, void *out, int64_t m, int64_t k, int64_t nnz, int dtype,
                                int variant, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * 64-bit CSR ("big CSR", ABI v7): graphs of 2^31 edges and more -- ogbn-papers100M as CogDL feeds it to GCN
+ * (symmetrised + coalesced, cogdl/datasets/ogb.py:50-55: 3.2e9 edges).  The reference cannot represent them: the
+ * dispatcher casts row pointers to int32 (utils/spmm_utils.py:106), csr_spmm_cpu walks `int` edge offsets and
+ * `int ik = i * k` (operators/spmm/spmm_cpu.cpp:24-33), the CUDA kernels take `int nnz` (spmm_kernel.cu:534-594).
+ * Row pointers are int64, column ids stay int32.  The rows are cut into SEGMENTS of about 2^29 edges; each segment is
+ * one launch of the 32-bit kernels on a rebased int32 copy of its row pointers (csrc/bigcsr.hip), so results are
+ * those of cogdl_hip_csr_spmm row for row (same summation order, same long-row rule with the SEGMENT's edge count).
+ *   1. cogdl_hip_csr_segments(rowptr64, m, nnz, 0, &seg, scratch, stream)      -- plan time; SYNCHRONISES `stream`
+ *   2. cogdl_hip_csr_rebase_rowptr(rowptr64, &seg, rowptr32, stream)           -- rowptr32: [m + seg.n] int32
+ *   3. cogdl_hip_csr_spmm_i64 / cogdl_hip_csr_sddmm_i64 / cogdl_hip_csr2csc_i64 with (rowptr32, &seg)
+ * Segment s covers rows [row[s], row[s+1]) = edges [edge[s], edge[s+1]); its rebased row pointers are
+ * rowptr32[row[s] + s .. row[s+1] + s] (rows + 1 entries, starting at 0).
+ * ------------------------------------------------------------------------------------- */
+#define COGDL_HIP_MAX_SEGMENTS 64
+#define COGDL_HIP_SEGMENT_MAX_EDGES 0x7ff00000ll /* what one 32-bit launch takes (2^31 - 2^20) */
+typedef struct cogdl_hip_segments {
+    int32_t n;
+    int64_t row[COGDL_HIP_MAX_SEGMENTS + 1];
+    int64_t edge[COGDL_HIP_MAX_SEGMENTS + 1];
+} cogdl_hip_segments;
+/* max_edges: target edges per segment (0 = default: tuning key 15, else 2^29; capped at 2^30).  scratch: device,
+ * >= 2 * (COGDL_HIP_MAX_SEGMENTS + 1) * 8 bytes.  rowptr[m] must equal nnz (COGDL_HIP_EINVAL otherwise); a single row
+ * of more than COGDL_HIP_SEGMENT_MAX_EDGES edges is COGDL_HIP_ERANGE. */
+COGDL_API int cogdl_hip_csr_segments(const int64_t *rowptr, int64_t m, int64_t nnz, int64_t max_edges,
+                                     cogdl_hip_segments *out, void *scratch, void *stream);
+COGDL_API int cogdl_hip_csr_rebase_rowptr(const int64_t *rowptr, const cogdl_hip_segments *seg, int32_t *rowptr32,
+                                          void *stream);
+/* csr_spmm over all segments (x: [n_src, k], out: [row[n], k], colind / val: [edge[n]]).  Workspace as cogdl_hip_csr_spmm,
+ * sized for the largest segment by the query below; NULL = every row sequential. */
+COGDL_API size_t cogdl_hip_csr_spmm_i64_workspace_bytes(const cogdl_hip_segments *seg, int64_t k, int dtype);
+COGDL_API int cogdl_hip_csr_spmm_i64(const int32_t *rowptr32, const cogdl_hip_segments *seg, const int32_t *colind,
+                                     const void *val, const void *x, void *out, int64_t k, int dtype, void *workspace,
+                                     size_t workspace_bytes, void *stream);
+/* csr_sddmm over all segments (d1: [row[n], k], d2: [n_src, k], out: [edge[n]] fp32). */
+COGDL_API int cogdl_hip_csr_sddmm_i64(const int32_t *rowptr32, const cogdl_hip_segments *seg, const int32_t *colind,
+                                      const float *d1, const float *d2, float *out, int64_t k, void *stream);
+/* Stable transpose -> colptr [n_cols + 1] int64, rowind [nnz] int32, and either or both of
+ *   perm [nnz] int64 (CSR position of CSC entry j; may be NULL: 8 bytes per edge are 26 GB at 3.2e9 edges) and
+ *   val_t [nnz] = val[perm] (val_bytes in {2, 4}; val and val_t both NULL or both given),
+ * ordered inside a column by ascending CSR position like cogdl_hip_csr2csc.  Every segment is transposed by
+ * cogdl_hip_csr2csc (twice: column counts, then entries) and merged. */
+COGDL_API size_t cogdl_hip_csr2csc_i64_workspace_bytes(const cogdl_hip_segments *seg, int64_t n_cols);
+COGDL_API int cogdl_hip_csr2csc_i64(const int32_t *rowptr32, const cogdl_hip_segments *seg, const int32_t *colind,
+                                    int64_t n_cols, int64_t *colptr, int32_t *rowind, int64_t *perm, const void *val,
+                                    void *val_t, int val_bytes, void *workspace, size_t workspace_bytes, void *stream);
+/* out[i, 0:h] = src[perm[i], 0:h] with 64-bit positions (elem_bytes in {2,4}). */
+COGDL_API int cogdl_hip_gather_rows_i64(const int64_t *perm, const void *src, void *out, int64_t n, int64_t h,
+                                        int elem_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * csr_spmm with a fused normalisation / bias / activation epilogue (fp32):

@@ -356,3 +356,14 @@ def ref_spmm_cpu(kind="asshipped"):
 def ref_sampler():
     """The reference's sampler module (cogdl/operators/sample/sample.cpp)."""
     return _load_ext("sampler", os.path.join(_HERE, "_ref", "sampler.so"))
+
+
+def ref_gpu_op(name):
+    """A CUDA operator of the reference built for gfx950 by the reference's own JIT recipe (oracle/Makefile `ref`,
+    oracle/build_ref_gpu_ops.py): 'scatter_max' (scatter_max_fp / scatter_max_bp) or 'mhspmm' (mhspmm).  GPU box only;
+    used by tests/golden/make_golden_gpu.py to produce reference outputs, never by the product."""
+    return _load_ext(name, os.path.join(_HERE, "_ref", "jit", name, name + ".so"))
+
+
+def ref_gpu_op_available(name):
+    return os.path.exists(os.path.join(_HERE, "_ref", "jit", name, name + ".so"))

@@ -1,0 +1,162 @@
+"""The 64-bit CSR path (cogdl_amd/bigcsr.py, csrc/bigcsr.hip) at sizes the oracle finishes in seconds: the segment
+size is forced down (max_edges / tuning key 15) so that small graphs are cut into many segments -- the code that a
+3.2e9-edge graph runs, cut where it is cheap to check.  Index outputs bit-exact; csr_spmm bit-exact for rows up to the
+long-row threshold (128 edges for these sizes), 1e-5 beyond (re-association at piece borders, as the 32-bit operator).
+The full-size graph is tests/test_config5_full_gpu.py."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from cogdl_amd import _lib, synth
+from cogdl_amd.bigcsr import BigCsr, clear_plans, gather_rows_i64
+from cogdl_amd.operators.spmm import csr_spmm_raw, csrspmm
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rand(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def big(g, max_edges, n_cols=None):
+    return BigCsr(g.rowptr.long().to(DEV), g.colind.to(DEV), n_cols=g.n_cols if n_cols is None else n_cols, max_edges=max_edges)
+
+
+def check_rows(got, want, deg, exact_upto):
+    short = deg <= exact_upto
+    assert got[short].tobytes() == want[short].tobytes()
+    if (~short).any():
+        np.testing.assert_allclose(got[~short], want[~short], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("max_edges", [1 << 29, 5000, 700, 64])
+@pytest.mark.parametrize("f", [128, 40, 7])
+def test_segmented_spmm_matches_oracle(oracle, max_edges, f):
+    g = synth.hub_csr(3000, 2500, base_deg=6, seed=3)
+    x = rand(g.n_cols, f, seed=1)
+    plan = big(g, max_edges)
+    rows, edges = plan.segment_rows(), plan.segment_edges()
+    assert rows[0] == 0 and rows[-1] == g.num_nodes and edges[-1] == g.nnz
+    assert all(b > a for a, b in zip(rows, rows[1:]))
+    rp = g.rowptr.long().numpy()
+    assert [int(rp[r]) for r in rows] == edges
+    if max_edges == 64:  # rows longer than the target make longer segments; equal cuts collapse
+        assert plan.n_segments < (g.nnz + 63) // 64
+    elif max_edges < (1 << 29):
+        assert plan.n_segments >= g.nnz // max_edges
+    # the rebased row pointers, segment by segment
+    r32 = plan.rowptr32.cpu().numpy()
+    for s in range(plan.n_segments):
+        seg = r32[rows[s] + s: rows[s + 1] + s + 1]
+        assert np.array_equal(seg, rp[rows[s]: rows[s + 1] + 1] - edges[s])
+    out = plan.spmm(g.weight.to(DEV), x.to(DEV)).cpu().numpy()
+    want = oracle.csr_spmm(g.rowptr, g.colind, g.weight, x)
+    check_rows(out, want, g.degrees().numpy(), 128)
+    # unweighted, and every row sequential (no workspace): bit-exact everywhere
+    out = plan.spmm(None, x.to(DEV), split_long_rows=False).cpu().numpy()
+    assert out.tobytes() == oracle.csr_spmm(g.rowptr, g.colind, None, x).tobytes()
+
+
+def test_one_segment_equals_the_32_bit_operator():
+    g = synth.arxiv_like(seed=1, topology="rmat")
+    x = rand(g.num_nodes, 64, seed=2).to(DEV)
+    gd = g.to(DEV)
+    plan = BigCsr(gd.rowptr.long(), gd.colind)
+    assert plan.n_segments == 1
+    assert torch.equal(plan.spmm(gd.weight, x), csr_spmm_raw(gd.rowptr, gd.colind, gd.weight, x))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_segmented_spmm_16_bit(dtype):
+    g = synth.random_csr(4000, 3000, 9, seed=5)
+    x = rand(g.n_cols, 64, seed=3).to(DEV).to(dtype)
+    gd = g.to(DEV)
+    w = gd.weight.to(dtype)
+    got = big(g, 3000).spmm(w, x)
+    assert torch.equal(got, csr_spmm_raw(gd.rowptr, gd.colind, w, x, split_long_rows=False))
+
+
+@pytest.mark.parametrize("max_edges", [1 << 29, 4096, 300])
+@pytest.mark.parametrize("shape", [(3000, 2500), (500, 70000), (9000, 40)])
+def test_transpose_i64_bit_exact(oracle, max_edges, shape):
+    m, n_cols = shape
+    g = synth.hub_csr(m, n_cols, base_deg=5, seed=m)
+    plan = big(g, max_edges)
+    t, perm, val_t = plan.transpose(g.weight.to(DEV), keep_perm=True)
+    colptr, rowind, w_t, perm_ref = oracle.csr2csc(g.rowptr, g.colind, g.weight, n_cols=n_cols)
+    assert t.rowptr.dtype == torch.int64 and perm.dtype == torch.int64
+    assert np.array_equal(t.rowptr.cpu().numpy(), colptr)
+    assert np.array_equal(t.colind.cpu().numpy(), rowind)
+    assert np.array_equal(perm.cpu().numpy(), perm_ref)
+    assert val_t.cpu().numpy().tobytes() == np.asarray(w_t, dtype=np.float32).tobytes()
+    assert torch.equal(gather_rows_i64(perm, g.weight.to(DEV)), val_t)
+    assert t.m == n_cols and t.n_cols == m
+    # without perm / without values
+    t2, perm2, v2 = plan.transpose(None, keep_perm=False)
+    assert perm2 is None and v2 is None and torch.equal(t2.colind, t.colind) and torch.equal(t2.rowptr, t.rowptr)
+    half = g.weight.to(DEV).half()
+    _, _, vh = plan.transpose(half, keep_perm=False)
+    assert torch.equal(vh, half[perm])
+
+
+def test_autograd_through_csrspmm_int64(oracle):
+    """csrspmm with an int64 rowptr = the 64-bit path: forward, grad_x (cached 64-bit transpose), grad_w (segmented
+    sddmm) against the oracle's csr_spmm / csr2csc / csr_sddmm."""
+    clear_plans()
+    _lib.hip().cogdl_hip_set_tuning(15, 2000)
+    try:
+        g = synth.random_csr(3000, 3000, 8, seed=11)
+        x, gout = rand(g.n_cols, 32, seed=4), rand(g.num_nodes, 32, seed=5)
+        rowptr64, colind = g.rowptr.long().to(DEV), g.colind.to(DEV)
+        w_const = g.weight.to(DEV)
+        xd = x.to(DEV).requires_grad_()
+        out = csrspmm(rowptr64, colind, xd, w_const, True)
+        out.backward(gout.to(DEV))
+        assert out.detach().cpu().numpy().tobytes() == oracle.csr_spmm(g.rowptr, g.colind, g.weight, x).tobytes()
+        colptr, rowind, w_t, _ = oracle.csr2csc(g.rowptr, g.colind, g.weight)
+        assert xd.grad.cpu().numpy().tobytes() == oracle.csr_spmm(colptr, rowind, w_t, gout).tobytes()
+        from cogdl_amd.bigcsr import plan_of
+
+        plan = plan_of(rowptr64, colind, g.n_cols)
+        assert plan.n_segments > 5 and plan._transposed[1] is None  # constant weights: fused into the transpose, no perm kept
+        # learned weights: perm is built, grad_w from the segmented sddmm
+        wd = g.weight.to(DEV).requires_grad_()
+        xd.grad = None
+        out = csrspmm(rowptr64, colind, xd, wd, True)
+        out.backward(gout.to(DEV))
+        assert xd.grad.cpu().numpy().tobytes() == oracle.csr_spmm(colptr, rowind, w_t, gout).tobytes()
+        np.testing.assert_allclose(wd.grad.cpu().numpy(), oracle.csr_sddmm(g.rowptr, g.colind, gout, x), rtol=1e-5, atol=1e-6)
+        assert plan._transposed[1] is not None
+    finally:
+        _lib.hip().cogdl_hip_set_tuning(15, 0)
+        clear_plans()
+
+
+def test_empty_and_degenerate_structures():
+    z = torch.zeros(1, dtype=torch.int64, device=DEV)
+    e = torch.zeros(0, dtype=torch.int32, device=DEV)
+    plan = BigCsr(z, e, n_cols=5)
+    assert plan.n_segments == 0 and plan.spmm(None, torch.ones(5, 4, device=DEV)).shape == (0, 4)
+    rowptr = torch.zeros(11, dtype=torch.int64, device=DEV)  # rows without edges
+    plan = BigCsr(rowptr, e, n_cols=5)
+    out = plan.spmm(None, torch.ones(5, 4, device=DEV))
+    assert out.shape == (10, 4) and float(out.abs().sum()) == 0.0
+    t, perm, _ = plan.transpose()
+    assert t.m == 5 and int(t.rowptr.abs().sum()) == 0 and perm.numel() == 0
+    with pytest.raises(_lib.BackendError):  # rowptr[m] != nnz
+        BigCsr(torch.tensor([0, 3], dtype=torch.int64, device=DEV), torch.zeros(2, dtype=torch.int32, device=DEV))
+    with pytest.raises(_lib.BackendError):
+        BigCsr(torch.tensor([0, 2], dtype=torch.int32, device=DEV), torch.zeros(2, dtype=torch.int32, device=DEV))
+
+
+def test_int32_entry_points_refuse_what_they_cannot_address():
+    """The 32-bit entry points return ERANGE above COGDL_HIP_SEGMENT_MAX_EDGES (no launch, pointers never read)."""
+    lib = _lib.hip()
+    one = torch.zeros(4, dtype=torch.int32, device=DEV)
+    f = torch.zeros(4, device=DEV)
+    rc = lib.cogdl_hip_csr_spmm(one.data_ptr(), one.data_ptr(), None, f.data_ptr(), f.data_ptr(), 1, 1, 1 << 31, 0, None, 0, None)
+    assert rc == 6
+    assert ctypes.sizeof(_lib.Segments) == 8 + 2 * 8 * (_lib.MAX_SEGMENTS + 1)
