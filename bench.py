@@ -332,7 +332,38 @@ def bench_single(args):
         result["weak_scaling_base"] = base
         if "roofline" in base:  # the HBM-RESIDENT number: X of the shard is 7.1 GB, far beyond L2 + Infinity Cache
             result["roofline"]["hbm_resident"] = base.pop("roofline")
+    # the box's own roofs beside the spec peak: fractions of a spec number are not comparable across boxes
+    try:
+        from tools.papers_bench import measured_roofs
+
+        roofs = measured_roofs(dev)
+        result["roofline"].update({k: roofs[k] for k in ("measured_copy_GBs", "measured_read_GBs", "torch_copy_GBs", "kernel_copy_GBs")})
+        result["roofline"]["measured_what"] = roofs["what"]
+        result["roofline"]["frac_of_measured_copy"] = achieved / roofs["measured_copy_GBs"]
+        hr = result["roofline"].get("hbm_resident")
+        if isinstance(hr, dict) and "achieved" in hr:
+            hr["frac_of_measured_copy"] = hr["achieved"] / roofs["measured_copy_GBs"]
+            hr["frac_of_measured_read"] = hr["achieved"] / roofs["measured_read_GBs"]
+            hr["frac_of_measured"] = hr["frac_of_measured_copy"]
+    except Exception as e:
+        result["roofline"]["measured_error"] = repr(e)[:300]
+    if not args.no_papers:
+        result["configs4_papers_1gpu"] = papers_leg()
     return result
+
+
+def papers_leg(budget_s=300):
+    """`configs4_papers_1gpu`: BASELINE.json configs[4] at FULL size on this one GPU (tools/papers_bench.py, child
+    interpreter): the papers100M-shaped graph -- 111,059,956 nodes, 1.6e9 directed / 3.2e9 symmetrised R-MAT edges generated
+    on the device, F = 128 fp32 -- through csrspmm with 64-bit row pointers: forward, backward and forward + backward,
+    GEdges/s, algorithmic bytes / time against the spec peak and the roofs measured on this box, peak memory.  The N = 1
+    end of north_star's 1 -> 8 curve.  An error or a timeout is reported, it cannot take the line down."""
+    from cogdl_amd.dist import _child_leg
+
+    r = _child_leg([os.path.join(ROOT, "tools", "papers_bench.py"), "--steps", "3"], 6, budget_s)
+    if "error" in r:
+        r["error"] = r["error"][-400:]
+    return r
 
 
 def gat_leg(budget_s=300):
@@ -452,6 +483,7 @@ def main():
     ap.add_argument("--no-gat", action="store_true", help="skip the configs2_gat leg (GAT on the Reddit-shaped graph, bf16)")
     ap.add_argument("--no-trainer", action="store_true", help="skip the reference-Trainer epoch legs (gnn_epoch.trainer_ms)")
     ap.add_argument("--no-shard-base", action="store_true", help="skip the weak_scaling_base leg (the sharded path at world size 1)")
+    ap.add_argument("--no-papers", action="store_true", help="skip the configs4_papers_1gpu leg (papers100M-shaped graph at full size on this GPU)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc passes for roofline.traffic")
     ap.add_argument("--sharded", action="store_true", help="run the N>1 workload (vertex-sharded SpMM) even at world size 1")
     ap.add_argument("--shard-nodes", type=int, default=0, help="N>1: nodes per GPU (default: papers100M/8)")

@@ -24,6 +24,7 @@ HIP_SIGNATURES = {
     "cogdl_hip_last_hip_error": ([], _i32),
     "cogdl_hip_set_tuning": ([_i32, _i32], _i32),
     "cogdl_hip_probe_read_stream": ([_vp, _sz, _vp, _vp], _i32),
+    "cogdl_hip_probe_copy_stream": ([_vp, _vp, _sz, _vp], _i32),
     "cogdl_hip_csr_spmm_workspace_bytes": ([_i64, _i64, _i32], _sz),
     "cogdl_hip_long_row_threshold": ([_i64], _i32),
     "cogdl_hip_exact_row_edges": ([_i64], _i32),
@@ -51,6 +52,7 @@ HIP_SIGNATURES = {
     "cogdl_hip_scatter_max_bwd_csc": ([_vp] * 5 + [_i64, _i64, _i64, _vp, _sz, _vp], _i32),
     "cogdl_hip_gspmm_workspace_bytes": ([_i64, _i64], _sz),
     "cogdl_hip_gspmm": ([_vp] * 5 + [_i32, _vp, _i32, _i32, _vp, _i64, _i64, _i64, _vp, _sz, _vp], _i32),
+    "cogdl_hip_gspmm_edge_grad": ([_vp] * 7 + [_i32, _i32, _vp, _vp, _i64, _i64, _vp], _i32),
     "cogdl_hip_gat_fwd_workspace_bytes": ([_i64, _i64, _i64, _i32], _sz),
     "cogdl_hip_gat_fwd": ([_vp] * 5 + [_f32] + [_vp] * 3 + [_i64, _i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_gat_bwd_workspace_bytes": ([_i64, _i64, _i64, _i64, _i64, _i32], _sz),

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void merge_segment_kernel(const int32_t *__res
     __shared__ int64_t off[256];
     const int64_t c0 = (int64_t)blockIdx.x * 256;
     const int nc = (int)min((int64_t)256, n_cols - c0);
-    if ((int)threadIdx.x <= nc) cp[threadIdx.x] = colptr_s[c0 + threadIdx.x];
+    for (int i = threadIdx.x; i <= nc; i += 256) cp[i] = colptr_s[c0 + i];  // nc + 1 <= 257 entries
     __syncthreads();
     if ((int)threadIdx.x < nc) {
         const int64_t c = c0 + threadIdx.x;

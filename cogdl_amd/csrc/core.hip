@@ -15,30 +15,57 @@ int g_tuning[kTuneCount] = {/*0: xcd stripe*/ 32, /*1: long-row threshold overri
 }
 
 namespace cogdl {
-// Measurement hook (bench.py: the box's read roof beside the spec peak): every lane streams 16-byte vectors, four in
-// flight, and folds them into one word per workgroup -- read-only HBM traffic, nothing else.
-__global__ __launch_bounds__(256) void read_stream_kernel(const uint4 *__restrict__ p, size_t n_vec, uint32_t *__restrict__ sink) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Measurement hooks (bench.py: the box's own read / copy roofs beside the spec peak).  A workgroup
+// owns contiguous 32 KiB tiles (8 x 16-byte vectors per lane, all eight requested before the first is used) and strides
+// over the buffer; the read kernel folds what it loads into one word per wave so that the loads cannot be elided.
+constexpr int kProbeUnroll = 8;
+typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void read_stream_kernel(const U32x4 *__restrict__ p, size_t n_vec, uint32_t *__restrict__ sink) {
+    const size_t tile = (size_t)256 * kProbeUnroll;
     uint32_t acc = 0;
-    for (; i + 3 * stride < n_vec; i += 4 * stride) {
-        const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
-        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
-    }
-    for (; i < n_vec; i += stride) {
-        const uint4 a = p[i];
-        acc ^= a.x ^ a.y ^ a.z ^ a.w;
+    for (size_t base = (size_t)blockIdx.x * tile; base < n_vec; base += (size_t)gridDim.x * tile) {
+        U32x4 v[kProbeUnroll];
+#pragma unroll
+        for (int j = 0; j < kProbeUnroll; ++j) {
+            const size_t i = base + (size_t)j * 256 + threadIdx.x;
+            v[j] = i < n_vec ? __builtin_nontemporal_load(p + i) : U32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int j = 0; j < kProbeUnroll; ++j) acc ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
     }
 #pragma unroll
     for (int s = kWave / 2; s > 0; s >>= 1) acc ^= __shfl_xor(acc, s, kWave);
     if ((threadIdx.x & (kWave - 1)) == 0) sink[blockIdx.x * 4 + (threadIdx.x >> 6)] = acc;
 }
+__global__ __launch_bounds__(256) void copy_stream_kernel(const U32x4 *__restrict__ p, U32x4 *__restrict__ q, size_t n_vec) {
+    const size_t tile = (size_t)256 * kProbeUnroll;
+    for (size_t base = (size_t)blockIdx.x * tile; base < n_vec; base += (size_t)gridDim.x * tile) {
+        U32x4 v[kProbeUnroll];
+#pragma unroll
+        for (int j = 0; j < kProbeUnroll; ++j) {
+            const size_t i = base + (size_t)j * 256 + threadIdx.x;
+            v[j] = i < n_vec ? __builtin_nontemporal_load(p + i) : U32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int j = 0; j < kProbeUnroll; ++j) {
+            const size_t i = base + (size_t)j * 256 + threadIdx.x;
+            if (i < n_vec) __builtin_nontemporal_store(v[j], q + i);
+        }
+    }
+}
 }  // namespace cogdl
 
 extern "C" int cogdl_hip_probe_read_stream(const void *p, size_t bytes, void *sink, void *stream) {
     if (!p || !sink || !cogdl::aligned_to(p, 16)) return COGDL_HIP_EINVAL;
-    hipLaunchKernelGGL(cogdl::read_stream_kernel, dim3(COGDL_HIP_PROBE_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const uint4 *)p,
+    hipLaunchKernelGGL(cogdl::read_stream_kernel, dim3(COGDL_HIP_PROBE_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const cogdl::U32x4 *)p,
                        bytes / 16, (uint32_t *)sink);
+    return cogdl::launch_status();
+}
+
+extern "C" int cogdl_hip_probe_copy_stream(const void *src, void *dst, size_t bytes, void *stream) {
+    if (!src || !dst || !cogdl::aligned_to(src, 16) || !cogdl::aligned_to(dst, 16)) return COGDL_HIP_EINVAL;
+    hipLaunchKernelGGL(cogdl::copy_stream_kernel, dim3(COGDL_HIP_PROBE_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const cogdl::U32x4 *)src,
+                       (cogdl::U32x4 *)dst, bytes / 16);
     return cogdl::launch_status();
 }
 

@@ -28,7 +28,7 @@ struct GspmmOp {
     const float *w;         // [E] or NULL
     float *out;             // [m, k]
     int k;
-    int op;         // COGDL_HIP_GSPMM_{ADD,SUB,MUL}
+    int op;         // COGDL_HIP_GSPMM_{ADD,SUB,MUL,WMUL}
     int ef_scalar;  // efeat is [E]: one value per edge, broadcast over the columns
     int mean;
 
@@ -92,8 +92,9 @@ struct GspmmOp {
             else if (!ef) msg = b.v[u][i];
             else if (op == COGDL_HIP_GSPMM_ADD) msg = b.v[u][i] + b.e[u][i];
             else if (op == COGDL_HIP_GSPMM_SUB) msg = b.v[u][i] - b.e[u][i];
+            else if (op == COGDL_HIP_GSPMM_WMUL) msg = (w ? b.v[u][i] * b.w[u] : b.v[u][i]) * b.e[u][i];  // weight first
             else msg = b.v[u][i] * b.e[u][i];
-            if (w) msg = msg * b.w[u];
+            if (w && op != COGDL_HIP_GSPMM_WMUL) msg = msg * b.w[u];
             s.acc[i] = s.acc[i] + (valid ? msg : 0.f);
         }
     }
@@ -179,7 +180,8 @@ extern "C" int cogdl_hip_gspmm(const int32_t *rowptr, const int32_t *colind, con
     if (m < 0 || k < 0 || nnz < 0) return COGDL_HIP_EINVAL;
     if (m == 0 || k == 0) return COGDL_HIP_OK;
     if (!rowptr || !out || (!x && !efeat) || (nnz > 0 && !colind)) return COGDL_HIP_EINVAL;
-    if (op < COGDL_HIP_GSPMM_ADD || op > COGDL_HIP_GSPMM_MUL) return COGDL_HIP_EINVAL;
+    if (op < COGDL_HIP_GSPMM_ADD || op > COGDL_HIP_GSPMM_WMUL) return COGDL_HIP_EINVAL;
+    if (op == COGDL_HIP_GSPMM_WMUL && (!x || !efeat)) return COGDL_HIP_EINVAL;
     if (!x && efeat_is_scalar) return COGDL_HIP_EINVAL;  // scatter_add of a scalar per edge: pass it as [E, 1], k = 1
     if (k > 0x7fffffff || nnz > 0x7fffffff) return COGDL_HIP_ERANGE;
     GspmmArgs a{rowptr, colind, eid, x, efeat, weight, out, m, nnz, (int)k, op, efeat_is_scalar ? 1 : 0, mean ? 1 : 0};
@@ -191,5 +193,106 @@ extern "C" int cogdl_hip_gspmm(const int32_t *rowptr, const int32_t *colind, con
         case 4: return gspmm_lpr<4>(a, g.lpr, workspace, workspace_bytes, s);
         case 2: return gspmm_lpr<2>(a, g.lpr, workspace, workspace_bytes, s);
         default: return gspmm_lpr<1>(a, g.lpr, workspace, workspace_bytes, s);
+    }
+}
+
+// ---- per-edge gradients of the family (the backward of src_op_e_aggr_coo, cogdl/operators/ops.py:43-52) ----------------
+// For every edge e = (r <- c) of the caller's COO list, from the upstream gradient G [m, k]:
+//     g   = G[r, :] * scale[r]                       (scale: 1 / deg for op2 == mean, NULL for sum)
+//     gw[e]    = sum_k (x[c, k] OP ef[e, k]) * g[k]                               (gradient of the edge weight)
+//     ge[e, :] = { MUL: (g * w[e]) * x[c, :] ;  ADD: g * w[e] ;  SUB: -(g * w[e]) }   (gradient of the edge feature;
+//                                                                  summed over k into ge[e] when ef is one scalar per edge)
+// with autograd's own roundings in autograd's order (g, then * w, then * x), so a [E, k] result equals the torch
+// composition bit for bit.  No [E, k] temporaries: the gathered rows live in registers.  One lane group per edge,
+// edge-parallel (no reduction over edges); the sums over k are per-lane column-order partials + one butterfly.
+template <int VEC, int LPR>
+__global__ __launch_bounds__(256) void gspmm_edge_grad_kernel(const int64_t *__restrict__ row, const int64_t *__restrict__ col,
+                                                              const float *__restrict__ G, const float *__restrict__ scale,
+                                                              const float *__restrict__ w, const float *__restrict__ x,
+                                                              const float *__restrict__ ef, int ef_scalar, int op,
+                                                              float *__restrict__ ge, float *__restrict__ gw, int64_t n_edges,
+                                                              int k) {
+    constexpr int GPB = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    const int64_t g0 = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
+    for (int64_t e = g0; e < n_edges; e += (int64_t)gridDim.x * GPB) {
+        const int64_t r = row[e], c = col[e];
+        const float sc = scale ? scale[r] : 1.f;
+        const float we = w ? w[e] : 1.f;
+        const float es = (ef && ef_scalar) ? ef[e] : 0.f;
+        float acc_w = 0.f, acc_e = 0.f;
+        for (int c0 = l * VEC; c0 < k; c0 += LPR * VEC) {
+            float gv[VEC], xv[VEC], ev[VEC], out[VEC];
+            load_vec<float, VEC>(G + r * (int64_t)k + c0, gv);
+            if (x) load_vec<float, VEC>(x + c * (int64_t)k + c0, xv);
+            if (ef && !ef_scalar) load_vec<float, VEC>(ef + e * (int64_t)k + c0, ev);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float g = scale ? gv[i] * sc : gv[i];
+                if (gw) {
+                    const float efv = ef_scalar ? es : ev[i];
+                    const float m = op == COGDL_HIP_GSPMM_MUL ? xv[i] * efv : (op == COGDL_HIP_GSPMM_SUB ? xv[i] - efv : xv[i] + efv);
+                    acc_w = acc_w + m * g;
+                }
+                const float gm = w ? g * we : g;
+                out[i] = op == COGDL_HIP_GSPMM_MUL ? gm * xv[i] : (op == COGDL_HIP_GSPMM_SUB ? -gm : gm);
+                acc_e = acc_e + out[i];
+            }
+            if (ge && !ef_scalar) store_vec<float, VEC>(ge + e * (int64_t)k + c0, out);
+        }
+        if (gw) {
+            const float t = group_sum<LPR>(acc_w);
+            if (l == 0) gw[e] = t;
+        }
+        if (ge && ef_scalar) {
+            const float t = group_sum<LPR>(acc_e);
+            if (l == 0) ge[e] = t;
+        }
+    }
+}
+
+template <int VEC>
+static int launch_edge_grad(int lpr, dim3 grid, hipStream_t s, const int64_t *row, const int64_t *col, const float *G,
+                            const float *scale, const float *w, const float *x, const float *ef, int ef_scalar, int op, float *ge,
+                            float *gw, int64_t n_edges, int k) {
+#define EG(L) hipLaunchKernelGGL((gspmm_edge_grad_kernel<VEC, L>), grid, dim3(256), 0, s, row, col, G, scale, w, x, ef, ef_scalar, op, ge, gw, n_edges, k)
+    switch (lpr) {
+        case 4: EG(4); break;
+        case 8: EG(8); break;
+        case 16: EG(16); break;
+        case 32: EG(32); break;
+        default: EG(64); break;
+    }
+#undef EG
+    return launch_status();
+}
+
+extern "C" int cogdl_hip_gspmm_edge_grad(const int64_t *row, const int64_t *col, const float *grad, const float *scale,
+                                         const float *weight, const float *x, const float *efeat, int efeat_is_scalar, int op,
+                                         float *grad_efeat, float *grad_weight, int64_t n_edges, int64_t k, void *stream) {
+    if (n_edges < 0 || k < 0) return COGDL_HIP_EINVAL;
+    if (n_edges == 0 || k == 0 || (!grad_efeat && !grad_weight)) return COGDL_HIP_OK;
+    if (!row || !col || !grad) return COGDL_HIP_EINVAL;
+    if (op < COGDL_HIP_GSPMM_ADD || op > COGDL_HIP_GSPMM_MUL) return COGDL_HIP_EINVAL;
+    if ((op == COGDL_HIP_GSPMM_MUL || grad_weight) && !x) return COGDL_HIP_EINVAL;
+    if (grad_weight && !efeat) return COGDL_HIP_EINVAL;
+    if (efeat_is_scalar && !efeat) return COGDL_HIP_EINVAL;
+    if (k > 0x7fffffff) return COGDL_HIP_ERANGE;
+    uintptr_t v = reinterpret_cast<uintptr_t>(grad);
+    if (x) v |= reinterpret_cast<uintptr_t>(x);
+    if (efeat && !efeat_is_scalar) v |= reinterpret_cast<uintptr_t>(efeat);
+    if (grad_efeat && !efeat_is_scalar) v |= reinterpret_cast<uintptr_t>(grad_efeat);
+    if (v % 4 != 0) return COGDL_HIP_EALIGN;
+    const int vec = (k % 4 == 0 && v % 16 == 0) ? 4 : (k % 2 == 0 && v % 8 == 0) ? 2 : 1;
+    const int64_t need = (k + vec - 1) / vec;
+    int lpr = 4;
+    while (lpr < kWave && lpr < need) lpr <<= 1;
+    const int64_t groups_per_block = 256 / lpr;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n_edges + groups_per_block - 1) / groups_per_block, 1 << 16);
+    hipStream_t s = (hipStream_t)stream;
+    switch (vec) {
+        case 4: return launch_edge_grad<4>(lpr, dim3(blocks), s, row, col, grad, scale, weight, x, efeat, efeat_is_scalar ? 1 : 0, op, grad_efeat, grad_weight, n_edges, (int)k);
+        case 2: return launch_edge_grad<2>(lpr, dim3(blocks), s, row, col, grad, scale, weight, x, efeat, efeat_is_scalar ? 1 : 0, op, grad_efeat, grad_weight, n_edges, (int)k);
+        default: return launch_edge_grad<1>(lpr, dim3(blocks), s, row, col, grad, scale, weight, x, efeat, efeat_is_scalar ? 1 : 0, op, grad_efeat, grad_weight, n_edges, (int)k);
     }
 }

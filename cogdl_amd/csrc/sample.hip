@@ -216,7 +216,10 @@ __global__ __launch_bounds__(kRlThreads) void sample_prep_kernel(const int64_t *
             if (i < valid && !ok) bad = 1;
             // indptr[s] and indptr[s + 1] in ONE 16-byte request (8-byte aligned): this workgroup issues a random gather per
             // entry from a single CU, and that CU's request rate is what the kernel's time is made of
-            const I64x2 pr = *reinterpret_cast<const I64x2 *>(indptr + (ok ? sd[q] : 0));
+            // (a graph without nodes has a one-entry indptr: the unconditional 16-byte load of indptr[0..1] would read 8 bytes
+            //  past it -- every seed is invalid there, nothing is loaded; the test is uniform)
+            I64x2 pr{0, 0};
+            if (num_nodes > 0) pr = *reinterpret_cast<const I64x2 *>(indptr + (ok ? sd[q] : 0));
             lo[q] = ok ? pr.x : 0;
             hi[q] = ok ? pr.y : 0;
         }

@@ -167,20 +167,21 @@ class ShardedCSR:
         self.backend = backend or HipBackend()
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         dev = colind_global.device
-        bounds = bounds.to(device=dev, dtype=torch.long).contiguous()
-        if bounds.numel() != self.world + 1:
-            raise _lib.BackendError("ShardedCSR: %d partition bounds for %d ranks" % (bounds.numel(), self.world))
-        blist = bounds.tolist()
-        lo, hi = blist[self.rank], blist[self.rank + 1]
-        self.n_local = hi - lo
-        if rowptr.numel() != self.n_local + 1:
-            raise _lib.BackendError("ShardedCSR: rowptr has %d entries, this rank owns %d rows" % (rowptr.numel(), self.n_local))
-        if weight is not None and weight.numel() != colind_global.numel():
-            raise _lib.BackendError("ShardedCSR: %d weights for %d edges" % (weight.numel(), colind_global.numel()))
         # A rank that raised here on its own would leave its peers blocked in the exchanges below: every rank validates
-        # and splits locally, the ranks agree on the outcome with one all-reduce, and then ALL of them raise or none.
+        # and splits locally -- ALL checks, the cheap shape checks included --, the ranks agree on the outcome with one
+        # all-reduce, and then ALL of them raise or none.
         err = None
         try:
+            bounds = bounds.to(device=dev, dtype=torch.long).contiguous()
+            if bounds.numel() != self.world + 1:
+                raise _lib.BackendError("ShardedCSR: %d partition bounds for %d ranks" % (bounds.numel(), self.world))
+            blist = bounds.tolist()
+            lo, hi = blist[self.rank], blist[self.rank + 1]
+            self.n_local = hi - lo
+            if rowptr.numel() != self.n_local + 1:
+                raise _lib.BackendError("ShardedCSR: rowptr has %d entries, this rank owns %d rows" % (rowptr.numel(), self.n_local))
+            if weight is not None and weight.numel() != colind_global.numel():
+                raise _lib.BackendError("ShardedCSR: %d weights for %d edges" % (weight.numel(), colind_global.numel()))
             if colind_global.is_cuda and isinstance(self.backend, HipBackend):
                 halo_ids, cut = self._split_hip(rowptr, colind_global, weight, bounds, lo, hi, blist[-1])
             else:  # CPU tensors (gloo tests, HostBackend): the same split with torch expressions

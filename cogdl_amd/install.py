@@ -91,11 +91,15 @@ def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False, f
     if fused_gat_dropout:
         from . import fused as _fused
 
-        _fused.install_gat_dropout()
+        _import_target("cogdl.layers.gat_layer", "fused_gat_dropout")  # (the finder above already serves cogdl.operators.*)
+        if not _fused.install_gat_dropout():
+            raise _lib_error("install(fused_gat_dropout=True): GATLayer.forward could not be rebound")
     if structure_memo:
         from . import structure_memo as _memo
 
-        _memo.install()
+        _import_target("cogdl.data.data", "structure_memo")
+        if not _memo.install():
+            raise _lib_error("install(structure_memo=True): Graph.row_indptr / col_indices could not be rebound")
     if metis and "metis" not in sys.modules:
         try:
             importlib.import_module("metis")  # the real one wins where it exists
@@ -115,6 +119,21 @@ def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False, f
     return [_PREFIX + op for op in REPLACED]
 
 
+
+
+def _lib_error(msg):
+    from ._lib import BackendError
+
+    return BackendError(msg)
+
+
+def _import_target(name, flag):
+    """The opt-in rebinds patch a cogdl module: import it now (install() may be called before `import cogdl`) instead of
+    silently doing nothing; an installation without cogdl gets an error naming the flag, not the slow path."""
+    try:
+        importlib.import_module(name)
+    except ImportError as e:
+        raise _lib_error("install(%s=True) needs the cogdl package (importing %s failed: %s)" % (flag, name, e)) from e
 
 
 _GRAPH_BUILD_NAMES = ("coo2csr_index", "add_remaining_self_loops", "symmetric_normalization", "row_normalization")

@@ -24,6 +24,7 @@ from ..plan import tensor_key
 _lib.hip()
 
 _OPS = {"add": 0, "sub": 1, "mul": 2}  # COGDL_HIP_GSPMM_*
+_OPS_WMUL = 3  # COGDL_HIP_GSPMM_WMUL: (x * weight) * efeat, autograd's rounding order in the backward of "mul"
 
 
 # --------------------------------------------------------------------------------------------- destination plans
@@ -215,28 +216,41 @@ class _SrcOpEdgeAggr(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
+        """Fused (no [E, F] temporaries): grad_x = the same gspmm kernel over the SOURCE-sorted view of the edges (rows =
+        sources, gathered operand = the upstream gradient rows, autograd's rounding order: COGDL_HIP_GSPMM_WMUL); grad of
+        the edge features / edge weights = one per-edge kernel (cogdl_hip_gspmm_edge_grad).  Per element the edges are
+        added in the caller's edge order: what index_add_ does on the CPU (the reference's gradients, bit for bit, while
+        a source has at most `long-row threshold` out-edges); on a GPU the reference's scatter has no order at all."""
         n_feat, e_feat, weight, row, col = ctx.saved_tensors
-        if ctx.mean:
-            grad = grad * _deg_inv(ctx.plan).view(-1, 1)
-        g_msg = grad.index_select(0, row)  # d out / d (message * weight)
-        g_w = None
-        if ctx.has_w:
-            if ctx.needs_input_grad[2]:
-                g_w = (op_src_edge(ctx.op1, n_feat.index_select(0, col), e_feat) * g_msg).sum(dim=1)
-            g_msg = g_msg * weight.view(-1, 1)
-        g_x = g_e = None
+        grad = grad.contiguous()
+        scale = _deg_inv(ctx.plan) if ctx.mean else None
+        op = _OPS[ctx.op1]
+        ef_scalar = e_feat.shape[1] == 1 and n_feat.shape[1] != 1
+        k = n_feat.shape[1]
+        g_x = g_e = g_w = None
         if ctx.needs_input_grad[0]:
-            d_src = g_msg * e_feat if ctx.op1 == "mul" else g_msg
-            g_x = scatter_add(d_src.contiguous(), col, n_feat.shape[0])
-        if ctx.needs_input_grad[1]:
+            gs = grad * scale.view(-1, 1) if scale is not None else grad  # [n, k]: autograd's `grad * deg_inv`
+            splan = edge_plan(col, n_feat.shape[0])  # source-sorted view (memoised like the destination plan)
+            dst_sorted = splan.colind(row)
             if ctx.op1 == "mul":
-                g_e = g_msg * n_feat.index_select(0, col)
-            elif ctx.op1 == "sub":
-                g_e = -g_msg
-            else:
-                g_e = g_msg
-            if e_feat.shape[1] == 1 and g_e.shape[1] != 1:
-                g_e = g_e.sum(dim=1, keepdim=True)
+                g_x = _gspmm(splan, dst_sorted, gs, e_feat, ef_scalar, weight, _OPS_WMUL, False, k)
+            else:  # d msg / d src = 1: the message is the gradient row alone (times the weight)
+                g_x = _gspmm(splan, dst_sorted, gs, None, False, weight, 0, False, k)
+        need_e, need_w = ctx.needs_input_grad[1], ctx.has_w and ctx.needs_input_grad[2]
+        if need_e or need_w:
+            dev = grad.device
+            e = row.numel()
+            if need_e:
+                g_e = torch.empty((e, 1) if ef_scalar else (e, k), dtype=torch.float32, device=dev)
+            if need_w:
+                g_w = torch.empty(e, dtype=torch.float32, device=dev)
+            with _lib.on_device(dev):
+                rc = _lib.hip().cogdl_hip_gspmm_edge_grad(_lib.ptr(row.contiguous()), _lib.ptr(col.contiguous()), _lib.ptr(grad), _lib.ptr(scale),
+                                                          _lib.ptr(weight), _lib.ptr(n_feat), _lib.ptr(e_feat), int(ef_scalar),
+                                                          op, _lib.ptr(g_e), _lib.ptr(g_w), e, k, _lib.stream_of(grad))
+            _lib.check(rc, "gspmm_edge_grad")
+            if need_e and e_feat.shape[1] == 1 and not ef_scalar:  # k == 1: [E, 1] either way
+                g_e = g_e.view(e, 1)
         return g_x, g_e, g_w, None, None, None, None
 
 

@@ -92,6 +92,11 @@ def csr2csc(rowptr, colind, n_cols=None, padded=False, stream=None):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     if stream is not None:
         stream.wait_stream(torch.cuda.current_stream(dev))
+        # the buffers belong to the CURRENT stream's pool but are written on `stream`: tell the caching allocator, so that
+        # a plan dropped without anybody waiting for `ready` (a forward whose backward never runs) cannot have its memory
+        # handed out again while the side-stream transpose is still writing it
+        for t in (colptr, rowind, perm, ws):
+            t.record_stream(stream)
     with _lib.on_device(dev):
         rc = fn(_lib.ptr(rowptr), _lib.ptr(colind), m, n_cols, nnz, _lib.ptr(colptr), _lib.ptr(rowind), _lib.ptr(perm),
                 _lib.ptr(ws), ws_bytes, _lib.stream_of(rowptr) if stream is None else stream.cuda_stream)

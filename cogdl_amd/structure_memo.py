@@ -28,7 +28,7 @@ _orig = {}
 
 class StructureMemo:
     """rowptr32 / colind32 of ONE structure + its fingerprint (hashed on first use, then reused)."""
-    __slots__ = ("src", "src_version", "rowptr32", "colind32", "_fp")
+    __slots__ = ("src", "src_version", "rowptr32", "colind32", "_fp", "_fp_versions")
 
     def __init__(self):
         # The int64 SOURCE tensors are held, not just their addresses: a freed source's address can be handed to a new
@@ -38,6 +38,7 @@ class StructureMemo:
         self.src_version = [None, None]
         self.rowptr32 = self.colind32 = None
         self._fp = {}
+        self._fp_versions = None  # (_version of rowptr32, colind32) the memoised hash was taken at
 
     def __reduce__(self):  # pickled with its Graph (Trainer.dist_train spawns ranks): events / pinned buffers stay behind
         return (StructureMemo, ())
@@ -46,10 +47,14 @@ class StructureMemo:
         """The Fingerprint of (rowptr, colind) if those are the memoised tensors, else None."""
         if rowptr is not self.rowptr32 or colind is not self.colind32:
             return None
+        versions = (rowptr._version, colind._version)
+        if versions != self._fp_versions:  # an in-place edit of the cached int32 copies: the old hash (and the cached
+            self._fp, self._fp_versions = {}, versions  # transpose it keys) no longer describes them
         fp = self._fp.get(n_cols)
         if fp is None:
             fp = Fingerprint(rowptr, colind, n_cols)
-            self._fp = {n_cols: fp}
+            if fp.event is not None:  # (made under hipGraph-capture replay: nothing was hashed -- not worth remembering,
+                self._fp = {n_cols: fp}  # a later eager lookup would find no key behind it)
         return fp
 
 

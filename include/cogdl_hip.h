@@ -84,8 +84,10 @@ COGDL_API int cogdl_hip_last_hip_error(void);
 COGDL_API int cogdl_hip_set_tuning(int key, int value);
 /* Measurement hook (bench.py `roofline.measured_read_GBs`, SURVEY.md section 8d: the box's own roof beside the spec
  * peak): one read-only pass over `bytes` of device memory in 16-byte vectors; sink: COGDL_HIP_PROBE_BLOCKS * 16 bytes. */
-#define COGDL_HIP_PROBE_BLOCKS 8192
+#define COGDL_HIP_PROBE_BLOCKS 4096
 COGDL_API int cogdl_hip_probe_read_stream(const void *p, size_t bytes, void *sink, void *stream);
+/* ... and one 16-byte-vector copy of `bytes` from src to dst (`roofline.measured_copy_GBs` counts read + written bytes). */
+COGDL_API int cogdl_hip_probe_copy_stream(const void *src, void *dst, size_t bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * csr_spmm:  out[i,:] = sum_{e in row i, CSR order} val[e] * x[colind[e],:]
@@ -313,11 +315,26 @@ COGDL_API int cogdl_hip_scatter_max_bwd_csc(const int32_t *colptr, const int32_t
  * fp32; per output element the edges are added in row order with every step rounded like the torch expression, so
  * rows up to the long-row threshold equal a sequential CPU scatter_add_ bit for bit.  No atomics (deterministic).
  * ------------------------------------------------------------------------------------- */
-enum { COGDL_HIP_GSPMM_ADD = 0, COGDL_HIP_GSPMM_SUB = 1, COGDL_HIP_GSPMM_MUL = 2 };
+/* WMUL: (x * weight) * efeat -- the rounding order of autograd's chain for the MUL operator's source gradient (x := the
+ * upstream gradient rows over the SOURCE-sorted view of the edges), so that the fused backward equals the torch one bit
+ * for bit; needs x and efeat. */
+enum { COGDL_HIP_GSPMM_ADD = 0, COGDL_HIP_GSPMM_SUB = 1, COGDL_HIP_GSPMM_MUL = 2, COGDL_HIP_GSPMM_WMUL = 3 };
 COGDL_API size_t cogdl_hip_gspmm_workspace_bytes(int64_t nnz, int64_t k);
 COGDL_API int cogdl_hip_gspmm(const int32_t *rowptr, const int32_t *colind, const int32_t *eid, const float *x,
                     const float *efeat, int efeat_is_scalar, const float *weight, int op, int mean, float *out,
                     int64_t m, int64_t k, int64_t nnz, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Per-edge gradients of the family (autograd of src_op_e_aggr_coo, ops.py:43-52) without [E, k] temporaries, over the
+ * caller's COO list (row = destination, col = source, int64 as CogDL keeps them), from the upstream gradient grad [m, k]:
+ *   g = grad[row[e], :] * scale[row[e]]            (scale [m]: 1 / deg for "mean", NULL for "sum")
+ *   grad_weight[e]   = sum_k (x[col[e], k] OP efeat[e, k]) * g[k]                     ([E]; NULL = not wanted)
+ *   grad_efeat[e, :] = MUL: (g * weight[e]) * x[col[e], :];  ADD: g * weight[e];  SUB: -(g * weight[e])
+ *                      ([E, k], or [E] summed over k when efeat_is_scalar; NULL = not wanted; weight NULL = 1)
+ * with autograd's roundings in autograd's order (bit-identical to the torch composition for [E, k] outputs).
+ * op: COGDL_HIP_GSPMM_ADD | SUB | MUL.  fp32. */
+COGDL_API int cogdl_hip_gspmm_edge_grad(const int64_t *row, const int64_t *col, const float *grad, const float *scale,
+                              const float *weight, const float *x, const float *efeat, int efeat_is_scalar, int op,
+                              float *grad_efeat, float *grad_weight, int64_t n_edges, int64_t k, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused GAT attention + aggregation (no [E,H] tensor is materialised in forward):

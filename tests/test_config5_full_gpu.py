@@ -28,16 +28,23 @@ def oracle_rows(oracle, g, rows, x):
     pos = torch.cat([torch.arange(int(a), int(b), device=g.colind.device) for a, b in zip(rp[0], rp[1])])
     cols, w = g.colind[pos].long(), g.weight[pos]
     uniq, inv = torch.unique(cols, return_inverse=True)
-    want = oracle.csr_spmm(torch.from_numpy(small_rowptr).int(), inv.int().cpu(), w.cpu(), x[uniq].cpu())
-    return want, deg
+    small = (torch.from_numpy(small_rowptr).int(), inv.int().cpu(), w.cpu(), x[uniq].cpu())
+    return small, deg
 
 
-def compare(got, want, deg, exact_upto):
+def compare(oracle, got, small, deg, exact_upto):
+    """Rows summed sequentially (<= the long-row threshold): bit-identical to the oracle's fp32 loop.  Longer rows are
+    re-associated at piece borders -- and a hub row of 10^6 edges is where the ORACLE's own sequential fp32 sum drifts
+    (~sqrt(n) eps of the terms' magnitude): those are compared with the float64 sum, within (1e-5 + 2e-7 sqrt(deg)) of
+    sum |w x|."""
+    want = oracle.csr_spmm(*small)
     short = deg <= exact_upto
     assert short.sum() > 0
     assert got[short].tobytes() == want[short].tobytes(), "sequentially summed rows must be bit-identical to the oracle"
     if (~short).any():
-        np.testing.assert_allclose(got[~short], want[~short], rtol=1e-5, atol=1e-6)
+        want64, scale = oracle.csr_spmm_f64(*small), oracle.csr_spmm_abs(*small)
+        tol = (1e-5 + 2e-7 * np.sqrt(deg[~short]))[:, None] * scale[~short] + 1e-6
+        assert np.all(np.abs(got[~short] - want64[~short]) <= tol)
 
 
 @pytest.mark.timeout(900)
@@ -65,14 +72,14 @@ def test_papers100m_full_size_symmetrised_on_one_gpu(oracle):
     rows = torch.cat([torch.randint(0, n, (3000,), device=DEV, generator=gen), torch.topk(deg_all, 2).indices, borders,
                       torch.tensor([0, n - 1], device=DEV)]).unique()
     del deg_all
-    want, deg = oracle_rows(oracle, g, rows, x.detach())
-    compare(out.detach()[rows].cpu().numpy(), want, deg, exact)
+    small, deg = oracle_rows(oracle, g, rows, x.detach())
+    compare(oracle, out.detach()[rows].cpu().numpy(), small, deg, exact)
 
     # ---- backward: grad_x = A^T grad_out with grad_out := out (no fourth 57 GB tensor), on sampled columns
     gout = out.detach()
     out.backward(gout)
     del out
-    cols = torch.cat([torch.randint(0, n, (1500,), device=DEV, generator=gen), torch.tensor([0, 1, n - 1], device=DEV)]).unique()
+    cols = torch.cat([torch.randint(0, n, (1500,), device=DEV, generator=gen), torch.tensor([0, n - 1], device=DEV)]).unique()
     pos = []
     step = 1 << 28
     mark = torch.zeros(n, dtype=torch.bool, device=DEV)
@@ -90,10 +97,10 @@ def test_papers100m_full_size_symmetrised_on_one_gpu(oracle):
     small_rowptr = np.zeros(cols.numel() + 1, dtype=np.int64)
     np.cumsum(cnt.cpu().numpy(), out=small_rowptr[1:])
     uniq, inv = torch.unique(e_rows, return_inverse=True)
-    want = oracle.csr_spmm(torch.from_numpy(small_rowptr).int(), inv.int().cpu(), g.weight[pos].cpu(), gout[uniq].cpu())
+    small = (torch.from_numpy(small_rowptr).int(), inv.int().cpu(), g.weight[pos].cpu(), gout[uniq].cpu())
     t, _ = plan.transposed(g.weight)
     exact_t = min(_lib.hip().cogdl_hip_exact_row_edges(int(e)) for e in np.diff(t.segment_edges()))
-    compare(x.grad[cols].cpu().numpy(), want, np.diff(small_rowptr), exact_t)
+    compare(oracle, x.grad[cols].cpu().numpy(), small, np.diff(small_rowptr), exact_t)
     # the transpose's structure on the same sample: column c of A = row c of A^T, sources ascending
     tp = t.rowptr[torch.cat([cols, cols + 1])].cpu().numpy().reshape(2, -1)
     assert np.array_equal(tp[1] - tp[0], np.diff(small_rowptr))

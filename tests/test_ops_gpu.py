@@ -407,6 +407,27 @@ def test_scatter_max_all_negative_rows_are_true_max(oracle):
     assert np.array_equal(out.cpu().numpy(), quirk)
 
 
+def test_scatter_max_and_mhspmm_against_the_reference_cuda_kernels_golden(golden):
+    """The HIP operators against OUTPUTS OF THE REFERENCE'S OWN CUDA KERNELS (scatter_max.cu:5-28, multiheadSpmm.cu:6-51;
+    JIT-built for gfx950 by the reference's recipe and run on an MI355X: tests/golden/make_golden_gpu.py).  scatter_max:
+    value and argmax identical wherever the reference kernel defines them (row maximum above its FLT_MIN start), and in
+    reference-exact mode the value everywhere; mhspmm: 1e-5 (the reference build contracts to FMA)."""
+    z = golden("scatter_max")
+    for name in sorted({k[: -len("_rowptr")] for k in z if k.endswith("_rowptr")}):
+        rp, ci, x = (torch.from_numpy(z[name + "_" + f]).to(DEV) for f in ("rowptr", "colind", "feat"))
+        out, idx = scatter_max_fp(rp, ci, x)
+        valid = z[name + "_argmax_valid"]
+        assert np.array_equal(out.cpu().numpy()[valid], z[name + "_out"][valid]), name
+        assert np.array_equal(idx.cpu().numpy()[valid], z[name + "_argmax"][valid]), name
+        exact = scatter_max(rp, ci, x, reference_exact=True)
+        assert exact.cpu().numpy().tobytes() == z[name + "_out"].tobytes(), name
+    z = golden("mhspmm")
+    for name in sorted({k[: -len("_rowptr")] for k in z if k.endswith("_rowptr")}):
+        rp, ci, att, feat = (torch.from_numpy(z[name + "_" + f]).to(DEV) for f in ("rowptr", "colind", "att", "feat"))
+        got = mhspmm_raw(rp, ci, att, feat)
+        np.testing.assert_allclose(got.cpu().numpy().reshape(z[name + "_out"].shape), z[name + "_out"], rtol=1e-5, atol=1e-5, err_msg=name)
+
+
 # ---------------------------------------------------------------------------------- fused GAT
 @pytest.fixture(params=[0, 1, 2], ids=["auto", "edgewise-softmax", "chunkwise-softmax"])
 def gat_kernel(request):

@@ -28,28 +28,36 @@ def b_alg(nnz, m, f):
 
 
 def measured_roofs(dev, gib=1):
-    """The box's own roofs: a 1 GiB device-to-device copy (read + write) and a read-only 16-byte stream
-    over the same buffer, best of 5, far beyond L2 + Infinity Cache."""
+    """The box's own roofs: a 1 GiB device-to-device copy (read + write bytes; torch's copy_ and this
+    library's 16-byte-vector copy kernel, the better of the two) and a read-only 16-byte stream over the same buffer,
+    best of 7, far beyond L2 + Infinity Cache."""
     from cogdl_amd import _lib
 
     n = gib * (1 << 30) // 4
     a = torch.randn(n, device=dev)
     b = torch.empty_like(a)
-    sink = torch.empty(8192 * 4, dtype=torch.int32, device=dev)
+    sink = torch.empty(4096 * 4, dtype=torch.int32, device=dev)
     lib = _lib.hip()
-    best_copy = best_read = 1e9
+    best = {"torch_copy": 1e9, "copy": 1e9, "read": 1e9}
     for _ in range(7):
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        e0.record()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
         b.copy_(a)
-        e1.record()
-        rc = lib.cogdl_hip_probe_read_stream(a.data_ptr(), n * 4, sink.data_ptr(), _lib.stream_of(a))
-        e2.record()
+        ev[1].record()
+        rc1 = lib.cogdl_hip_probe_copy_stream(a.data_ptr(), b.data_ptr(), n * 4, _lib.stream_of(a))
+        ev[2].record()
+        rc2 = lib.cogdl_hip_probe_read_stream(a.data_ptr(), n * 4, sink.data_ptr(), _lib.stream_of(a))
+        ev[3].record()
         torch.cuda.synchronize()
-        _lib.check(rc, "probe_read_stream")
-        best_copy, best_read = min(best_copy, e0.elapsed_time(e1)), min(best_read, e1.elapsed_time(e2))
-    return {"measured_copy_GBs": 2 * n * 4 / (best_copy * 1e-3) / 1e9, "measured_read_GBs": n * 4 / (best_read * 1e-3) / 1e9,
-            "what": "%d GiB torch D2D copy (read + write bytes) / read-only uint4 stream (cogdl_hip_probe_read_stream), best of 7" % gib}
+        _lib.check(rc1, "probe_copy_stream")
+        _lib.check(rc2, "probe_read_stream")
+        for key, i in (("torch_copy", 0), ("copy", 1), ("read", 2)):
+            best[key] = min(best[key], ev[i].elapsed_time(ev[i + 1]))
+    gbs = {k: (2 if "copy" in k else 1) * n * 4 / (v * 1e-3) / 1e9 for k, v in best.items()}
+    return {"measured_copy_GBs": max(gbs["copy"], gbs["torch_copy"]), "measured_read_GBs": gbs["read"],
+            "torch_copy_GBs": gbs["torch_copy"], "kernel_copy_GBs": gbs["copy"],
+            "what": "%d GiB device-to-device copy (read + written bytes; torch copy_ / cogdl_hip_probe_copy_stream, the better) and a "
+                    "read-only 16-byte-vector stream (cogdl_hip_probe_read_stream), best of 7" % gib}
 
 
 def run(g, feat, steps, dev, roofs):
@@ -101,7 +109,22 @@ def run(g, feat, steps, dev, roofs):
     ach2 = 2 * bytes_alg / (step_ms * 1e-3) / 1e9
     res["forward_backward"] = {"ms": step_ms, "GEdges_s": 2 * g.nnz / (step_ms * 1e-3) / 1e9, "achieved_GBs": ach2,
                                "frac": ach2 / HBM_PEAK_GBS, "frac_of_measured_read": ach2 / roofs["measured_read_GBs"]}
+    # the backward SpMM alone (A^T on the cached 64-bit transpose), event timed like the forward
+    t, w_t = plan.transposed(g.weight)
+    xd = x.detach()
+    with torch.no_grad():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            out = t.spmm(w_t, xd)
+            del out
+        e1.record()
+        torch.cuda.synchronize()
+    bwd_ms = e0.elapsed_time(e1) / steps
+    res["backward_alone"] = {"ms": bwd_ms, "achieved_GBs": bytes_alg / (bwd_ms * 1e-3) / 1e9,
+                             "frac": bytes_alg / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "segments": t.n_segments}
     res["peak_allocated_GB"] = torch.cuda.max_memory_allocated() / 1e9
+    del t, w_t, xd
     del x, plan
     clear_plans()
     torch.cuda.empty_cache()
