@@ -126,6 +126,12 @@ inline int pick_long_thresh(int64_t nnz) {
     if (g_tuning[kTuneLongThresh] > 0) return g_tuning[kTuneLongThresh];
     int t = 128;
     while (t < 1024 && (int64_t)t * 32768 < nnz) t <<= 1;
+    // Launches of 2^28 edges and more (the row segments of a 64-bit CSR, csrc/bigcsr.hip; a papers100M shard): 512.  Round 5,
+    // symmetrised papers100M-shaped graph (3.2e9 edges, 7 segments, F = 128 fp32) on the MI355X, forward ms by threshold:
+    // 256: 347, 512: 345, 1024: 384, 2048: 474, 4096: 460, 16384: 571 (profiles/r05_papers_threshold.txt) -- a row of
+    // ~1000 edges is 125 dependent gather batches of ONE wave; by the time such rows are common (hub-heavy graphs at this
+    // scale) four waves on contiguous slices finish them sooner than the wave's neighbours can hide them.
+    if (nnz >= ((int64_t)1 << 28)) t = 512;
     return t;
 }
 inline int64_t n_chunks_for(int64_t nnz, int thresh) { return (nnz + thresh - 1) / thresh; }

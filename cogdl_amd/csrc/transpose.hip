@@ -1,91 +1,19 @@
-// transpose.hip -- csr2csc (stable CSR transpose) and row gathers for gfx950.
+// transpose.hip -- csr2csc (stable CSR transpose), COO -> CSR index, row gathers and the structure hash for gfx950.
 // Replaces the reference's cuSPARSE call (cogdl/operators/spmm/spmm_kernel.cu:514-532,
-// cusparseCsr2cscEx2 ALG1: handle created per call and leaked, cudaMalloc/cudaFree per call)
-// From 256 k edge slots on the transpose is the hand-written two-payload radix sort of radix_transpose.hip; below that
-// (and under tuning key 10 = 1) this file's allocation-free, stream-ordered, deterministic rocPRIM pipeline:
-//   1. stable LSD radix sort of (key = colind[e], value = e) restricted to the
-//      ceil(log2(n_cols)) significant key bits (rocPRIM device primitive, header-only) -> perm
-//   2. colptr from the sorted keys by boundary detection (no atomics)
-//   3. rowind[j] = row owning CSR position perm[j] (binary search in rowptr, L2 resident)
-// Traffic ~ nnz * (4+4) * 2 per radix pass + nnz * 12; all integer, HBM/L2 bound.
+// cusparseCsr2cscEx2 ALG1: handle created per call and leaked, cudaMalloc/cudaFree per call).
+// Every size is hand-written since round 5 (rounds 1-4 kept a rocPRIM radix/merge sort + row look-up pipeline for 16 k ..
+// 256 k edge slots and for coo2csr_index):
+//   * up to 16 k slots and columns: ONE single-workgroup launch, everything in LDS (radix_transpose.hip: small_transpose);
+//   * above: the two-payload LSD radix sort of radix_transpose.hip (sorts the slots by column id, carrying the CSR
+//     position and the row; 9-bit digits);
+//   * coo2csr_index (stable sort of the edges by source row, cogdl/utils/graph_utils.py:133-142) IS that transpose of a
+//     one-row matrix whose column ids are the rows: colptr = row_ptr, perm = the order -- no second sort in the library.
+// All integer, HBM/L2 bound, allocation-free, stream-ordered, deterministic, hipGraph-capturable.
 #include "common.h"
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
 
 namespace cogdl {
 
-static unsigned key_bits(int64_t n_cols) {
-    unsigned b = 1;
-    while (b < 32 && (int64_t(1) << b) < n_cols) ++b;
-    return b;
-}
-
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-// (Tried: a 9-bit-digit onesweep configuration -- two passes instead of three for column ids of up to 18 bits.  With 512
-// bins the default rank algorithm needs 262 KB of LDS; the `match` algorithm fits but runs each pass slower: 4.6 ms vs
-// 3.7 ms for the whole transpose of the Reddit-shaped graph.  rocPRIM's tuned default stays.)
-// capturable: the merge sort at every size -- above 1 M keys rocPRIM's default is onesweep, whose hipMemsetAsync calls
-// become memset nodes in a captured hipGraph, and those were seen not to replay (common.h: fill_u32_async).
-using CapturableSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                        rocprim::default_config, (size_t)1 << 40>;
-static hipError_t sort_pairs(void *temp, size_t &temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
-                             int32_t *perm_out, int64_t nnz, unsigned bits, hipStream_t s, bool capturable = false) {
-    rocprim::counting_iterator<int32_t> iota(0);
-    if (capturable)
-        return rocprim::radix_sort_pairs<CapturableSortConfig>(temp, temp_bytes, keys_in, keys_out, iota, perm_out,
-                                                               (size_t)nnz, 0u, bits, s);
-    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, iota, perm_out, (size_t)nnz, 0u, bits, s);
-}
-
-// colptr[c] = number of sorted keys < c (lower bound), one thread per column: fully
-// parallel even when most columns are empty (sampled blocks), no atomics.
-__global__ void colptr_from_sorted_keys(const uint32_t *__restrict__ keys, int32_t *__restrict__ colptr,
-                                        int64_t nnz, int64_t n_cols) {
-    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c <= n_cols;
-         c += (int64_t)gridDim.x * blockDim.x) {
-        int64_t lo = 0, hi = nnz;  // first position whose key >= c
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if ((int64_t)keys[mid] < c) lo = mid + 1; else hi = mid;
-        }
-        colptr[c] = (int32_t)lo;
-    }
-}
-
-// rowind[j] = the row that owns CSR position perm[j].  A full binary search of rowptr per element is 18-27 dependent
-// L2 loads (measured: 1.9 ms of the 4.7 ms transpose of the Reddit-shaped graph).  A coarse table -- the row of every
-// 128th edge, nnz/128 entries, L2 resident -- narrows the search to the rows that intersect one 128-edge block
-// (one row for hubs, a few cache-line-adjacent rowptr entries otherwise).
-constexpr int kCoarseShift = 7;
-
-__device__ __forceinline__ int64_t row_search(const int32_t *__restrict__ rowptr, int64_t lo, int64_t hi, int64_t e) {
-    while (hi - lo > 1) {  // invariant: rowptr[lo] <= e < rowptr[hi]; empty rows share their successor's offset
-        const int64_t mid = (lo + hi) >> 1;
-        if (rowptr[mid] <= e) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-__global__ void coarse_rows_kernel(const int32_t *__restrict__ rowptr, int64_t m, int64_t nnz,
-                                   int32_t *__restrict__ coarse, int64_t n_coarse) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_coarse) return;
-    const int64_t e = b << kCoarseShift;
-    coarse[b] = e < nnz ? (int32_t)row_search(rowptr, 0, m, e) : (int32_t)(m - 1);
-}
-
-__global__ void rowind_from_perm(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ perm,
-                                 const int32_t *__restrict__ coarse, int32_t *__restrict__ rowind, int64_t nnz,
-                                 int64_t m) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nnz) return;
-    const int32_t e = perm[j];
-    const int64_t b = e >> kCoarseShift;
-    // the row of edge b*128 is <= the wanted row, the row of edge (b+1)*128 is >= it
-    rowind[j] = (int32_t)row_search(rowptr, coarse[b], min(m, (int64_t)coarse[b + 1] + 1), e);
-}
 
 // ---- COO -> CSR on the GPU (coo2csr_index) ------------------------------------------------------------------------
 __global__ void keys_from_rows64(const int64_t *__restrict__ row, uint32_t *__restrict__ keys, int64_t nnz,
@@ -97,21 +25,18 @@ __global__ void keys_from_rows64(const int64_t *__restrict__ row, uint32_t *__re
     }
 }
 
-// row_ptr[r] (int64) = number of sorted keys < r; perm widened to int64 in the same launch
-__global__ void rowptr64_and_perm64(const uint32_t *__restrict__ keys, const int32_t *__restrict__ perm32,
-                                    int64_t *__restrict__ row_ptr, int64_t *__restrict__ perm, int64_t nnz,
-                                    int64_t num_nodes) {
+// colptr / perm of the one-row transpose, widened to the int64 the callers keep (cogdl/data/data.py: row_ptr, perm)
+__global__ void widen_i32_to_i64_kernel(const int32_t *__restrict__ a, int64_t *__restrict__ a64, int64_t na,
+                                        const int32_t *__restrict__ b, int64_t *__restrict__ b64, int64_t nb) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (int64_t r = tid; r <= num_nodes; r += stride) {
-        int64_t lo = 0, hi = nnz;  // first position whose key >= r
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if ((int64_t)keys[mid] < r) lo = mid + 1; else hi = mid;
-        }
-        row_ptr[r] = lo;
-    }
-    for (int64_t i = tid; i < nnz; i += stride) perm[i] = perm32[i];
+    for (int64_t i = tid; i < na; i += stride) a64[i] = a[i];
+    for (int64_t i = tid; i < nb; i += stride) b64[i] = b[i];
+}
+
+// colptr of a structure without edges
+__global__ void zero_i32_kernel(int32_t *__restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0;
 }
 
 template <typename E>
@@ -202,44 +127,43 @@ int small_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int
                     int32_t *colptr, int32_t *rowind, int32_t *perm, hipStream_t s);
 }
 
-static size_t rocprim_csr2csc_bytes(int64_t n_cols, int64_t nnz) {
-    size_t temp = 0;
-    (void)sort_pairs(nullptr, temp, nullptr, nullptr, nullptr, nnz, key_bits(n_cols), nullptr);
-    return align_up((size_t)nnz * sizeof(uint32_t), 256) + align_up(temp, 256) +
-           align_up((size_t)((nnz >> kCoarseShift) + 2) * sizeof(int32_t), 256) + 256;
-}
-
 extern "C" size_t cogdl_hip_csr2csc_workspace_bytes(int64_t m, int64_t n_cols, int64_t nnz) {
     (void)m;
     if (nnz <= 0) return 256;
-    return std::max(rocprim_csr2csc_bytes(n_cols, nnz), radix_transpose_workspace_bytes(n_cols, nnz, false));
+    return radix_transpose_workspace_bytes(n_cols, nnz, false);
 }
 
 // Fixed-capacity blocks (sample_adj_padded): colind holds `nnz` slots of which only the first rowptr[m] are edges.  The
 // surplus gets the key n_cols -- behind every real column, so colptr[n_cols] = rowptr[m] and no column reaches it.
-__global__ void padded_keys_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind, int64_t m,
-                                   int64_t nnz, uint32_t n_cols, uint32_t *__restrict__ keys) {
-    const int64_t valid = rowptr[m];
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x)
-        keys[e] = e < valid ? (uint32_t)colind[e] : n_cols;
-}
-
 extern "C" size_t cogdl_hip_csr2csc_padded_workspace_bytes(int64_t m, int64_t n_cols, int64_t nnz) {
-    size_t extra = 0;  // the merge sort's scratch where it exceeds the default algorithm's
-    if (nnz > 0) {
-        size_t t_default = 0, t_merge = 0;
-        (void)sort_pairs(nullptr, t_default, nullptr, nullptr, nullptr, nnz, key_bits(n_cols + 1), nullptr);
-        (void)sort_pairs(nullptr, t_merge, nullptr, nullptr, nullptr, nnz, key_bits(n_cols + 1), nullptr, true);
-        if (t_merge > t_default) extra = align_up(t_merge - t_default, 256);
-    }
     (void)m;
-    return std::max(rocprim_csr2csc_bytes(n_cols + 1, nnz) + extra + align_up((size_t)std::max<int64_t>(nnz, 0) * sizeof(uint32_t), 256),
-                    radix_transpose_workspace_bytes(n_cols, nnz, true));
+    if (nnz <= 0) return 256;
+    return radix_transpose_workspace_bytes(n_cols, nnz, true);
 }
 
 static int csr2csc_impl(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols, int64_t nnz,
                         int32_t *colptr, int32_t *rowind, int32_t *perm, void *workspace, size_t workspace_bytes,
-                        void *stream, bool padded);
+                        void *stream, bool padded) {
+    if (m < 0 || n_cols < 0 || nnz < 0 || !colptr) return COGDL_HIP_EINVAL;
+    if (nnz > COGDL_HIP_SEGMENT_MAX_EDGES) return COGDL_HIP_ERANGE;
+    hipStream_t s = (hipStream_t)stream;
+    if (nnz == 0) {
+        hipLaunchKernelGGL(zero_i32_kernel, dim3((unsigned)std::min<int64_t>((n_cols + 256) / 256, 4096)), dim3(256), 0, s, colptr,
+                           n_cols + 1);
+        return launch_status();
+    }
+    if (!rowptr || !colind || !rowind || !perm) return COGDL_HIP_EINVAL;
+    if (m == 0) return padded ? COGDL_HIP_ERANGE : COGDL_HIP_EINVAL;  // edges without rows
+    if (padded && n_cols >= 0x7fffffff) return COGDL_HIP_ERANGE;
+    // Up to 16 k slots and columns (the sampled blocks of a mini-batch step): one single-workgroup launch, everything in
+    // LDS (radix_transpose.hip: small_transpose_kernel); no workspace.
+    // (tuning key 10 >= 2: the radix sort at every size -- tests and A/B runs)
+    if (g_tuning[kTuneCsr2csc] < 2 && small_transpose_covers(m, n_cols, nnz)) return small_transpose(rowptr, colind, m, n_cols, nnz, padded, colptr, rowind, perm, s);
+    if (!workspace) return COGDL_HIP_EINVAL;
+    if (workspace_bytes < radix_transpose_workspace_bytes(n_cols, nnz, padded)) return COGDL_HIP_EWORKSPACE;
+    if (!aligned_to(workspace, 256)) return COGDL_HIP_EALIGN;
+    return radix_transpose(rowptr, colind, m, n_cols, nnz, padded, colptr, rowind, perm, workspace, s);
+}
 
 extern "C" int cogdl_hip_csr2csc_padded(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols,
                                         int64_t nnz, int32_t *colptr, int32_t *rowind, int32_t *perm, void *workspace,
@@ -251,63 +175,6 @@ extern "C" int cogdl_hip_csr2csc(const int32_t *rowptr, const int32_t *colind, i
                                  int64_t nnz, int32_t *colptr, int32_t *rowind, int32_t *perm, void *workspace,
                                  size_t workspace_bytes, void *stream) {
     return csr2csc_impl(rowptr, colind, m, n_cols, nnz, colptr, rowind, perm, workspace, workspace_bytes, stream, false);
-}
-
-static int csr2csc_impl(const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t n_cols, int64_t nnz,
-                        int32_t *colptr, int32_t *rowind, int32_t *perm, void *workspace, size_t workspace_bytes,
-                        void *stream, bool padded) {
-    if (m < 0 || n_cols < 0 || nnz < 0 || !colptr) return COGDL_HIP_EINVAL;
-    if (nnz > 0x7fffffff) return COGDL_HIP_ERANGE;
-    hipStream_t s = (hipStream_t)stream;
-    if (nnz == 0) {
-        hipLaunchKernelGGL(colptr_from_sorted_keys, dim3(64), dim3(256), 0, s, (const uint32_t *)nullptr, colptr, nnz, n_cols);
-        return launch_status();
-    }
-    if (!rowptr || !colind || !rowind || !perm || !workspace) return COGDL_HIP_EINVAL;
-    if (workspace_bytes < (padded ? cogdl_hip_csr2csc_padded_workspace_bytes(m, n_cols, nnz)
-                                  : cogdl_hip_csr2csc_workspace_bytes(m, n_cols, nnz)))
-        return COGDL_HIP_EWORKSPACE;
-    if (!aligned_to(workspace, 256)) return COGDL_HIP_EALIGN;
-    if (padded && (m == 0 || n_cols >= 0x7fffffff)) return COGDL_HIP_ERANGE;
-    // The hand-written sort (radix_transpose.hip) from 256 k edge slots on: below that a transpose is ~10 launches either
-    // way and rocPRIM's merge sort has the shorter ones (51 k slots: 69 vs 69 us alone, but inside the captured
-    // mini-batch step +0.02 ms per step with the radix sort at every size: its 8192-slot tiles leave a 100 k-slot block
-    // to 14 workgroups with a long serial chain each; 2.5 M slots: 198 vs 112 us the other way).
-    const bool radix = g_tuning[kTuneCsr2csc] >= 2 || (g_tuning[kTuneCsr2csc] == 0 && nnz >= (1 << 18));
-    if (radix && m > 0) {
-        return radix_transpose(rowptr, colind, m, n_cols, nnz, padded, colptr, rowind, perm, workspace, s);
-    }
-    // Up to 16 k slots and columns (the sampled blocks of a mini-batch step): one single-workgroup launch, everything in
-    // LDS (radix_transpose.hip: small_transpose_kernel).  tuning key 10 = 1 keeps the rocPRIM pipeline for A/B runs.
-    if (g_tuning[kTuneCsr2csc] != 1 && small_transpose_covers(m, n_cols, nnz))
-        return small_transpose(rowptr, colind, m, n_cols, nnz, padded, colptr, rowind, perm, s);
-    const uint32_t *keys_in = (const uint32_t *)colind;
-    if (padded) {  // (the key buffer sits in front of the ordinary layout)
-        uint32_t *keys = (uint32_t *)workspace;
-        workspace = (char *)workspace + align_up((size_t)nnz * sizeof(uint32_t), 256);
-        hipLaunchKernelGGL(padded_keys_kernel, dim3((unsigned)std::min<int64_t>((nnz + 255) / 256, 4096)), dim3(256), 0, s,
-                           rowptr, colind, m, nnz, (uint32_t)n_cols, keys);
-        keys_in = keys;
-    }
-    uint32_t *keys_sorted = (uint32_t *)workspace;
-    char *temp = (char *)workspace + align_up((size_t)nnz * sizeof(uint32_t), 256);
-    size_t temp_bytes = 0;
-    const unsigned bits = key_bits(padded ? n_cols + 1 : n_cols);
-    (void)sort_pairs(nullptr, temp_bytes, nullptr, nullptr, nullptr, nnz, bits, nullptr, padded);
-    hipError_t e = sort_pairs(temp, temp_bytes, keys_in, keys_sorted, perm, nnz, bits, s, padded);
-    if (e != hipSuccess) {
-        g_last_hip_error = (int)e;
-        return COGDL_HIP_ELAUNCH;
-    }
-    const unsigned blocks = (unsigned)((nnz + 255) / 256);
-    const unsigned cblocks = (unsigned)std::min<int64_t>((n_cols + 256) / 256, 1 << 20);
-    int32_t *coarse = (int32_t *)(temp + align_up(temp_bytes, 256));
-    const int64_t n_coarse = (nnz >> kCoarseShift) + 2;
-    hipLaunchKernelGGL(coarse_rows_kernel, dim3((unsigned)((n_coarse + 255) / 256)), dim3(256), 0, s, rowptr, m, nnz, coarse,
-                       n_coarse);
-    hipLaunchKernelGGL(colptr_from_sorted_keys, dim3(cblocks), dim3(256), 0, s, keys_sorted, colptr, nnz, n_cols);
-    hipLaunchKernelGGL(rowind_from_perm, dim3(blocks), dim3(256), 0, s, rowptr, perm, coarse, rowind, nnz, m);
-    return launch_status();
 }
 
 extern "C" int cogdl_hip_gather_rows(const int32_t *perm, const void *src, void *out, int64_t n, int64_t h,
@@ -342,19 +209,48 @@ extern "C" int cogdl_hip_csr_fingerprint(const int32_t *rowptr, const int32_t *c
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// coo2csr_index: the edges as ONE row of a [1 x num_nodes] matrix whose column ids are the source rows -- its stable
+// transpose has colptr = row_ptr and perm = the stable order.  Workspace: keys | rowptr2 | colptr32 | rowind (unused
+// payload) | perm32 | the transpose's own scratch.
+namespace {
+struct CooLayout {
+    size_t off_keys, off_rowptr2, off_colptr, off_rowind, off_perm, off_inner, inner, total;
+};
+CooLayout coo_layout(int64_t nnz, int64_t num_nodes) {
+    CooLayout L{};
+    const size_t kb = align_up((size_t)std::max<int64_t>(nnz, 1) * sizeof(uint32_t), 256);
+    size_t o = 0;
+    L.off_keys = o;
+    o += kb;
+    L.off_rowptr2 = o;
+    o += 256;
+    L.off_colptr = o;
+    o += align_up((size_t)(num_nodes + 1) * sizeof(int32_t), 256);
+    L.off_rowind = o;
+    o += kb;
+    L.off_perm = o;
+    o += kb;
+    L.off_inner = o;
+    L.inner = align_up(cogdl_hip_csr2csc_workspace_bytes(1, num_nodes, nnz), 256);
+    L.total = o + L.inner;
+    return L;
+}
+__global__ void one_row_rowptr_kernel(int32_t *rowptr2, int32_t nnz) {
+    rowptr2[0] = 0;
+    rowptr2[1] = nnz;
+}
+}  // namespace
+
 extern "C" size_t cogdl_hip_coo2csr_index_workspace_bytes(int64_t nnz, int64_t num_nodes) {
     if (nnz <= 0) return 256;
-    size_t temp = 0;
-    (void)sort_pairs(nullptr, temp, nullptr, nullptr, nullptr, nnz, key_bits(num_nodes), nullptr);
-    return 2 * align_up((size_t)nnz * sizeof(uint32_t), 256) + align_up((size_t)nnz * sizeof(int32_t), 256) +
-           align_up(temp, 256) + 256;
+    return coo_layout(nnz, num_nodes).total;
 }
 
 extern "C" int cogdl_hip_coo2csr_index(const int64_t *row, int64_t nnz, int64_t num_nodes, int64_t *row_ptr,
                                        int64_t *perm, int *bad_flag, void *workspace, size_t workspace_bytes,
                                        void *stream) {
     if (nnz < 0 || num_nodes < 0 || !row_ptr || !bad_flag) return COGDL_HIP_EINVAL;
-    if (nnz > 0x7fffffff || num_nodes > 0xffffffffll) return COGDL_HIP_ERANGE;
+    if (nnz > COGDL_HIP_SEGMENT_MAX_EDGES || num_nodes >= 0x7fffffff) return COGDL_HIP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
     if (nnz > 0 && (!row || !perm || !workspace)) return COGDL_HIP_EINVAL;
     if (workspace_bytes < cogdl_hip_coo2csr_index_workspace_bytes(nnz, num_nodes)) return COGDL_HIP_EWORKSPACE;
@@ -364,25 +260,35 @@ extern "C" int cogdl_hip_coo2csr_index(const int64_t *row, int64_t nnz, int64_t 
         g_last_hip_error = (int)e;
         return COGDL_HIP_ELAUNCH;
     }
-    const size_t kb = align_up((size_t)nnz * sizeof(uint32_t), 256);
-    uint32_t *keys = (uint32_t *)workspace;
-    uint32_t *keys_sorted = (uint32_t *)((char *)workspace + kb);
-    int32_t *perm32 = (int32_t *)((char *)workspace + 2 * kb);
-    char *temp = (char *)workspace + 2 * kb + align_up((size_t)nnz * sizeof(int32_t), 256);
-    const unsigned eblocks = (unsigned)std::min<int64_t>((nnz + 255) / 256, 1 << 16);
-    if (nnz > 0) {
-        hipLaunchKernelGGL(keys_from_rows64, dim3(eblocks), dim3(256), 0, s, row, keys, nnz, num_nodes, bad_flag);
-        size_t temp_bytes = 0;
-        const unsigned bits = key_bits(num_nodes);
-        (void)sort_pairs(nullptr, temp_bytes, nullptr, nullptr, nullptr, nnz, bits, nullptr);
-        e = sort_pairs(temp, temp_bytes, keys, keys_sorted, perm32, nnz, bits, s);
+    if (nnz > 0 && num_nodes == 0) {  // every id is out of range
+        e = fill_u32_async(bad_flag, 1u, 1, s);
+        if (e == hipSuccess) e = fill_u32_async(row_ptr, 0u, 2, s);
         if (e != hipSuccess) {
             g_last_hip_error = (int)e;
             return COGDL_HIP_ELAUNCH;
         }
+        return launch_status();
     }
+    if (nnz == 0) {
+        e = fill_u32_async(row_ptr, 0u, (size_t)(num_nodes + 1) * 2, s);
+        if (e != hipSuccess) {
+            g_last_hip_error = (int)e;
+            return COGDL_HIP_ELAUNCH;
+        }
+        return launch_status();
+    }
+    const CooLayout L = coo_layout(nnz, num_nodes);
+    char *ws = (char *)workspace;
+    uint32_t *keys = (uint32_t *)(ws + L.off_keys);
+    int32_t *rowptr2 = (int32_t *)(ws + L.off_rowptr2), *colptr32 = (int32_t *)(ws + L.off_colptr);
+    int32_t *rowind = (int32_t *)(ws + L.off_rowind), *perm32 = (int32_t *)(ws + L.off_perm);
+    const unsigned eblocks = (unsigned)std::min<int64_t>((nnz + 255) / 256, 1 << 16);
+    hipLaunchKernelGGL(keys_from_rows64, dim3(eblocks), dim3(256), 0, s, row, keys, nnz, num_nodes, bad_flag);
+    hipLaunchKernelGGL(one_row_rowptr_kernel, dim3(1), dim3(1), 0, s, rowptr2, (int32_t)nnz);
+    int rc = csr2csc_impl(rowptr2, (const int32_t *)keys, 1, num_nodes, nnz, colptr32, rowind, perm32, ws + L.off_inner, L.inner,
+                          stream, false);
+    if (rc != COGDL_HIP_OK) return rc;
     const unsigned blocks = (unsigned)std::min<int64_t>((std::max(nnz, num_nodes + 1) + 255) / 256, 1 << 16);
-    hipLaunchKernelGGL(rowptr64_and_perm64, dim3(blocks), dim3(256), 0, s, keys_sorted, perm32, row_ptr, perm, nnz,
-                       num_nodes);
+    hipLaunchKernelGGL(widen_i32_to_i64_kernel, dim3(blocks), dim3(256), 0, s, colptr32, row_ptr, num_nodes + 1, perm32, perm, nnz);
     return launch_status();
 }

@@ -62,8 +62,8 @@ def test_sample_adj_padded_rejects_what_has_no_fixed_capacity():
     assert int(counts[2]) & 1  # a seed outside the graph is flagged, not fatal on the device
 
 
-@pytest.mark.parametrize("algo", [0, 1, 2, 3, 5], ids=["default-by-size", "rocprim-pipeline", "radix-transpose",
-                                                        "radix-transpose-packed-records", "radix-transpose-msd-first"])
+@pytest.mark.parametrize("algo", [0, 2, 3, 5], ids=["default-by-size", "radix-transpose",
+                                                     "radix-transpose-packed-records", "radix-transpose-msd-first"])
 @pytest.mark.parametrize("surplus", [0, 1, 777, 20000])
 @pytest.mark.parametrize("n_cols", [500, 6000], ids=["one-radix-pass", "two-radix-passes"])
 def test_csr2csc_padded_ignores_the_slots_behind_the_last_row(surplus, algo, n_cols):
@@ -200,8 +200,9 @@ def test_gather_reports_a_bad_id_in_the_callers_flag_word():
 
 
 def test_padded_sampler_and_transpose_replay_correctly_above_a_million_slots():
-    """Above 1 M keys rocPRIM's default sort is onesweep, which clears its state with hipMemsetAsync (memset nodes do not
-    replay reliably): the fixed-capacity entry points keep the merge sort, so a captured graph stays right at any size."""
+    """A captured graph must stay right at any size: the sampler's sort-based relabelling keeps rocPRIM's merge sort there
+    (above 1 M keys its default is onesweep, which clears its state with hipMemsetAsync -- memset nodes do not replay
+    reliably), the transpose is this library's radix sort (kernels only, no memset)."""
     n = 400000
     indptr, indices = _graph(n, 12, seed=8)
     seeds = torch.randperm(n, device=DEV)[:120000]

@@ -21,12 +21,12 @@ def rand(*shape, seed=0, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------ csr2csc
-@pytest.fixture(params=[0, 1, 2, 3, 5, 6], ids=["default-by-size", "rocprim-pipeline", "radix-transpose", "radix-transpose-packed-records", "radix-transpose-msd-first", "radix-transpose-6-bit-digits"])
+@pytest.fixture(params=[0, 2, 3, 5, 6], ids=["default-by-size", "radix-transpose", "radix-transpose-packed-records", "radix-transpose-msd-first", "radix-transpose-6-bit-digits"])
 def csc_algo(request):
     """csr2csc's implementations (tuning key 10; the default picks by size: one single-workgroup launch up to 16 k slots
-    and columns, the rocPRIM pipeline up to 256 k slots, the radix transpose above): the rocPRIM sort + row look-up, and the
-    hand-written two-payload radix sort (csrc/radix_transpose.hip) -- LSD, with packed intermediate records from 16 M slots on (3: at
-    any size); 5: MSD-first where two passes suffice (column ids of 10..18 bits)."""
+    and columns, the radix transpose above -- the rocPRIM pipeline of rounds 1-4 is gone): the hand-written two-payload radix
+    sort (csrc/radix_transpose.hip) at every size (2) -- LSD, with packed intermediate records from 16 M slots on (3: at
+    any size); 5: MSD-first where two passes suffice (column ids of 10..18 bits); 6: digits of at most 6 bits."""
     from cogdl_amd import _lib
 
     _lib.hip().cogdl_hip_set_tuning(10, request.param)
@@ -60,7 +60,7 @@ def test_csr2csc_bit_exact(oracle, csc_algo, m, n_cols, deg):
 def test_csr2csc_small_single_workgroup_kernel(oracle, m, n_cols, nnz, kind):
     """The one-launch LDS transpose of csrc/radix_transpose.hip (default tuning, up to 16384 slots and 16382 columns) at
     its boundaries -- full tile, a row of thousands of edges, forty columns taking everything, runs of empty rows, the
-    largest row count -- and just beyond them (those go to the rocPRIM pipeline); plain and fixed-capacity form."""
+    largest row count -- and just beyond them (those go to the radix transpose); plain and fixed-capacity form."""
     from cogdl_amd import _lib
 
     _lib.hip().cogdl_hip_set_tuning(10, 0)

@@ -254,3 +254,25 @@ def test_mhspmm_oracle_equals_the_reference_cuda_kernel(golden, oracle):
     for name, c in _gpu_cases(golden("mhspmm"), ("rowptr", "colind", "att", "feat", "out")):
         got = oracle.mhspmm(c["rowptr"], c["colind"], c["att"], c["feat"])
         np.testing.assert_allclose(got, c["out"], rtol=1e-5, atol=1e-5, err_msg=name)
+
+
+def test_mhsddmm_and_mhtranspose_oracles_follow_from_the_pinned_mhspmm(golden, oracle):
+    """The reference's mhsddmm / mhtranspose kernels are warp-32 shuffle code / a cuSPARSE call and cannot run on wave64
+    (oracle/README.md), so no reference output pins them directly.  What can be had: on the SAME inputs whose mhspmm
+    output the reference's kernel produced (mhspmm.npz), oracle_mhsddmm equals the float64 autograd gradient of that
+    function with respect to the attention (MHSPMMFunction.backward computes exactly this, cogdl/operators/mhspmm.py:56-66),
+    and oracle_mhtranspose is the permutation att[perm] with the oracle's (separately pinned) stable csr2csc perm."""
+    for name, c in _gpu_cases(golden("mhspmm"), ("rowptr", "colind", "att", "feat", "out")):
+        rowptr, colind = c["rowptr"].astype(np.int64), c["colind"].astype(np.int64)
+        row = torch.repeat_interleave(torch.arange(len(rowptr) - 1), torch.from_numpy(np.diff(rowptr)))
+        att = torch.from_numpy(c["att"]).double().requires_grad_()
+        feat = torch.from_numpy(c["feat"]).double()
+        msg = att.unsqueeze(-1) * feat[torch.from_numpy(colind)]
+        out = torch.zeros(feat.shape, dtype=torch.float64).index_add_(0, row, msg)
+        np.testing.assert_allclose(out.detach().numpy(), c["out"], rtol=1e-5, atol=1e-5, err_msg=name)  # the pinned function
+        gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(3)).double()
+        (out * gout).sum().backward()
+        got = oracle.mhsddmm(c["rowptr"], c["colind"], gout.float().numpy(), c["feat"])
+        np.testing.assert_allclose(got, att.grad.numpy(), rtol=1e-5, atol=1e-5, err_msg=name)
+        _, _, _, perm = oracle.csr2csc(c["rowptr"], c["colind"], None, n_cols=feat.shape[0])
+        assert oracle.mhtranspose(perm, c["att"]).tobytes() == c["att"][perm].tobytes(), name

@@ -123,7 +123,10 @@ SPARSE_ENTRIES = ("cogdl_hip_csr_spmm", "cogdl_hip_csr_spmm_variant", "cogdl_hip
 NO_SPARSE_ON_GPU = {"correct_smooth_mlp", "sign"}  # (an MLP on features; SIGN propagates once, on the CPU, before training)
 # Default-argument GAT models apply nn.Dropout to the attention: the two legs draw different masks (see FP16 above), so
 # their losses agree only as far as two dropout draws do.  The *_nodrop legs are the exact comparison of the same operators.
-LOOSE = {"gat": 0.5, "drgat": 0.5, "revgat": 0.5}
+LOOSE = {"gat": 0.5, "drgat": 0.5, "revgat": 0.5,
+         # 14 GENConv layers with a learned softmax temperature: the sum order of edge_softmax / scatter_add is amplified
+         # layer by layer (1.1e-3 on the first loss; deepergcn, 3 such layers, is bit-equal)
+         "revgen": 5e-3}
 
 
 def _run(script, *args, timeout=2400):
