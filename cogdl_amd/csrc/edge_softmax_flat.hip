@@ -81,6 +81,7 @@ struct Params {
     int info_per_wave;   // init kernel: 1 = one wave per tile (64-ary search), 0 = one thread per tile (binary search)
 };
 
+
 // ---- agent-scope accesses (write-through stores / L1-bypassing loads; see the file header) ---------------------
 __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -539,7 +540,11 @@ __device__ __forceinline__ void wg_slot_reduce(float (&x)[V], int h, float *red)
 //   KEEP_P       forward, tiles inside ONE row: exp(v - max_piece) of the thread's elements stays in fp32 registers and the
 //                output is p * exp(max_piece - max_row) / sum_row -- one exponential per element instead of two, at the
 //                price of TILE / 256 more live registers (the default forward; tuning key 9 bit 3 = off, A/B runs)
-template <typename T, bool BWD, int TILE, int WPE, bool KEEP_P = false>
+//   SPLIT        (round 5, opt-in experiment: tuning key 9 bit 8, measured slower -- see es_flat_launch) the tiles that lie inside ONE row -- and the partial pieces of rows that
+//                cross tile borders -- are left to es_stream_kernel (below): this kernel returns at once on a one-row tile
+//                (its tile record is read BEFORE the value loads are issued), publishes the statistics of its partial
+//                pieces without waiting for anybody, and does not store those pieces.  No wait is left in this kernel.
+template <typename T, bool BWD, int TILE, int WPE, bool KEEP_P = false, bool SPLIT = false>
 __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) {
     constexpr int V = VecOf<T>::V;
     constexpr int NV = TILE / (kThreads * V);  // 16-byte vectors per thread (per array): 8 forward, 4 + 4 backward
@@ -578,6 +583,11 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
             tk = now;
         }
     };
+    TileInfo ti_early{};
+    if constexpr (SPLIT) {
+        ti_early = p.tinfo[c];
+        if (ti_early.r_first == ti_early.r_last) return;  // a one-row tile: es_stream_kernel's
+    }
     // ---- 1. the tile's values, 16 bytes per lane per load, all loads in flight before anything waits ------------
     uint4 ra[NV];
     uint4 rg[BWD ? NV : 1];
@@ -596,7 +606,7 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
         }
     }
     // ---- 2. the rows of the tile (precomputed by the init kernel) ----------------------------------------------
-    const TileInfo ti = p.tinfo[c];
+    const TileInfo ti = SPLIT ? ti_early : p.tinfo[c];
     const int64_t r_first = ti.r_first, r_last = ti.r_last;
     const int64_t hs = ti.hs, he = ti.he, ts = ti.ts, te = ti.te;
 
@@ -812,10 +822,12 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
     // ---- row totals of the partial pieces -> what the store step applies to their (still raw) values ---------------
     //   forward : out = exp(v - max_row) / sum_row          (facm = max_row, fac = 1 / sum_row)
     //   backward: out = a * (g - dot_row)                   (fac = dot_row)
-    if (head_partial && !head_halo) {
+    // (SPLIT: the exchanged pieces are finished by es_stream_kernel -- nothing to wait for here, and nothing of them is stored)
+    const bool skip_head = SPLIT && head_partial && !head_halo, skip_tail = SPLIT && tail_partial && !tail_halo;
+    if (!SPLIT && head_partial && !head_halo) {
         if (!row_totals<BWD>(p, hs, he, mrg, head_tot)) head_tot = wg_piece_global<T, BWD>(a, g, hs * h, he * h, h, red);
     }
-    if (tail_partial && !tail_halo) {
+    if (!SPLIT && tail_partial && !tail_halo) {
         if (!row_totals<BWD>(p, ts, te, mrg, tail_tot)) tail_tot = wg_piece_global<T, BWD>(a, g, ts * h, te * h, h, red);
     }
     if (t < h) {
@@ -846,12 +858,177 @@ __global__ __launch_bounds__(kThreads, WPE) void es_flat_kernel(const Params p) 
                 }
             }
         }
+        if constexpr (SPLIT) {
+            const bool in_head = skip_head && i0 < head_end, in_tail = skip_tail && i0 + V > tail_begin;
+            if (in_head || in_tail) {  // (part of) the vector belongs to a piece es_stream_kernel writes
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const int i = i0 + k;
+                    const bool skipped = (skip_head && i < head_end) || (skip_tail && i >= tail_begin);
+                    if (!skipped && i < count) out[b0 + i] = from_f32<T>(o[k]);
+                }
+                continue;
+            }
+        }
         if (full) {
             store_vec<T, V>(out + b0 + i0, o);
         } else {
 #pragma unroll
             for (int k = 0; k < V; ++k)
                 if (i0 + k < count) out[b0 + i0 + k] = from_f32<T>(o[k]);
+        }
+    }
+}
+
+// =====================================================================================================================
+// stream kernel (round 5, forward; OPT-IN, measured slower than the one-kernel form: see es_flat_launch): the one-row tiles
+// and the exchanged partial pieces of a SPLIT launch.
+// What bounded the one-row tiles inside es_flat_kernel was not memory but concurrency: a tile held its 32 KB in registers
+// across the cross-tile exchange (publish, two or three polling rounds, merge: half of an fp32 tile's life, DESIGN
+// section 8) next to a 32 KB LDS buffer it never used, four workgroups per CU.  Here a one-row tile
+//   1. streams its values ONCE for the online (max, sum) of its piece -- two batches of four 16-byte vectors, ~40 VGPRs,
+//      nothing kept --, publishes the piece record,
+//   2. waits for the row's other pieces (row_totals, as before),
+//   3. reads the tile AGAIN -- 32 KB it read microseconds ago: L2 / Infinity Cache, not HBM -- and stores
+//      exp(v - max_row) / sum_row.
+// 4 KB of LDS and <= 64 VGPRs: eight workgroups per CU hide the exchange.  A multi-row tile's workgroup finishes the
+// tile's exchanged partial pieces (head / tail of rows that cross the tile border; es_flat_kernel<SPLIT> published their
+// statistics and left them unwritten): totals, then the piece re-read element-wise (row pieces start at multiples of h
+// elements, not of 16 bytes) -- a small fraction of the array.  Waits only concern records of THIS kernel's one-row tiles
+// (published before their workgroup waits) or of the previous kernel: bounded as before, same time-out escape.
+template <typename T>
+__global__ __launch_bounds__(kThreads, 7) void es_stream_kernel(const Params p) {
+    constexpr int V = VecOf<T>::V;
+    constexpr int kBatch = 16 / V;            // 16-byte vectors in flight per thread and batch (16 unpacked values: 64 VGPRs hold)
+    __shared__ float red[4 * kWave];
+    __shared__ float2 mrg[kThreads];
+    __shared__ float2 pstat[kWave];
+    __shared__ float fac[kWave], facm[kWave];
+    const int t = threadIdx.x;
+    const T *__restrict__ a = (const T *)p.a;
+    T *__restrict__ out = (T *)p.out;
+    const int h = p.h;
+    const int64_t c = blockIdx.x;
+    const TileInfo ti = p.tinfo[c];
+    const int64_t e0 = c * p.tile_e, e1 = min(p.nnz, e0 + p.tile_e);
+    const int64_t b0 = e0 * h;
+    const int count = (int)((e1 - e0) * h);
+    const int tile_elems = p.tile_e * h;
+    const int nv = tile_elems / (kThreads * V);  // vectors per thread of a full tile (8; 2 for quarter tiles)
+    const bool full = count == tile_elems;
+    if (ti.r_first != ti.r_last) {
+        // ---- exchanged partial pieces of a multi-row tile -------------------------------------------------------------
+        const int64_t halo_max = p.tile_e / 4;
+        for (int which = 0; which < 2; ++which) {
+            const int64_t rs = which == 0 ? ti.hs : ti.ts, re = which == 0 ? ti.he : ti.te;
+            const bool partial = which == 0 ? rs < e0 : re > e1;
+            if (!partial || (re - rs) <= halo_max) continue;  // (workgroup-uniform)
+            float2 tot;
+            if (!row_totals<false>(p, rs, re, mrg, tot)) tot = wg_piece_global<T, false>(a, nullptr, rs * h, re * h, h, red);
+            __syncthreads();  // (fac / facm of the previous piece have been read)
+            if (t < h) {
+                fac[t] = 1.f / tot.y;
+                facm[t] = tot.x;
+            }
+            __syncthreads();
+            const int64_t lo = max(rs, e0) * h, hi = min(re, e1) * h;
+            for (int64_t i = lo + t; i < hi; i += kThreads) {
+                const int hd = (int)(i & (h - 1));
+                out[i] = from_f32<T>(es_exp(to_f32<T>(a[i]) - facm[hd]) * fac[hd]);
+            }
+        }
+        return;
+    }
+    // ---- a tile inside ONE row ------------------------------------------------------------------------------------------
+    const bool partial = ti.hs < e0 || ti.he > e1;
+    float mx[V], sm[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        mx[k] = -INFINITY;
+        sm[k] = 0.f;
+    }
+    for (int j0 = 0; j0 < nv; j0 += kBatch) {  // pass 1: online (max, sum) per slot (slot k of thread t = head (t*V + k) % h)
+        uint4 r[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int j = min(j0 + u, nv - 1);
+            if (full) r[u] = *reinterpret_cast<const uint4 *>(a + b0 + (int64_t)(j * kThreads + t) * V);
+            else r[u] = load16_guarded<T>(a + b0, (j * kThreads + t) * V, count);
+        }
+        float v[kBatch][V];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) unpack16<T>(r[u], v[u]);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float bm = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const bool valid = (j0 + u < nv) && (full || ((j0 + u) * kThreads + t) * V + k < count);
+                v[u][k] = valid ? v[u][k] : -INFINITY;
+                bm = fmaxf(bm, v[u][k]);
+            }
+            const float mn = fmaxf(mx[k], bm);
+            float acc = (sm[k] == 0.f) ? 0.f : sm[k] * es_exp(mx[k] - mn);
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) acc += (v[u][k] == -INFINITY) ? 0.f : es_exp(v[u][k] - mn);
+            sm[k] = acc;
+            mx[k] = mn;
+        }
+    }
+    float gm[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) gm[k] = mx[k];
+    wg_slot_reduce<V, true>(gm, h, red);
+#pragma unroll
+    for (int k = 0; k < V; ++k) sm[k] = (sm[k] == 0.f) ? 0.f : sm[k] * es_exp(mx[k] - gm[k]);
+    wg_slot_reduce<V, false>(sm, h, red);
+    if (t * V < h || (h < V && t == 0)) {
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            if (t * V + k < h) pstat[t * V + k] = make_float2(gm[k], sm[k]);
+    }
+    __syncthreads();
+    float2 piece = make_float2(0.f, 0.f);
+    if (t < h) piece = pstat[t];
+    float2 tot = piece;
+    if (partial) {
+        if (ti.he - ti.hs <= p.long_edges) publish<false>(p, c, 0, piece);  // super-long rows: published by the init kernel
+        if (!row_totals<false>(p, ti.hs, ti.he, mrg, tot)) tot = wg_piece_global<T, false>(a, nullptr, ti.hs * h, ti.he * h, h, red);
+    }
+    if (t < h) {
+        fac[t] = 1.f / tot.y;
+        facm[t] = tot.x;
+    }
+    __syncthreads();
+    float f[V], fm[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        f[k] = fac[(t * V + k) & (h - 1)];
+        fm[k] = facm[(t * V + k) & (h - 1)];
+    }
+    for (int j0 = 0; j0 < nv; j0 += kBatch) {  // pass 2: the tile again (L2 / Infinity Cache), scaled, stored
+        uint4 r[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int j = min(j0 + u, nv - 1);
+            if (full) r[u] = *reinterpret_cast<const uint4 *>(a + b0 + (int64_t)(j * kThreads + t) * V);
+            else r[u] = load16_guarded<T>(a + b0, (j * kThreads + t) * V, count);
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            if (j0 + u >= nv) continue;
+            const int i0 = ((j0 + u) * kThreads + t) * V;
+            float va[V], o[V];
+            unpack16<T>(r[u], va);
+#pragma unroll
+            for (int k = 0; k < V; ++k) o[k] = es_exp(va[k] - fm[k]) * f[k];
+            if (full) {
+                store_vec<T, V>(out + b0 + i0, o);
+            } else {
+#pragma unroll
+                for (int k = 0; k < V; ++k)
+                    if (i0 + k < count) out[b0 + i0 + k] = from_f32<T>(o[k]);
+            }
         }
     }
 }
@@ -935,13 +1112,20 @@ __global__ __launch_bounds__(kThreads) void es_flat_init_kernel(const Params p) 
 }
 
 template <typename T, bool BWD, int TILE, int WPE, bool KEEP_P = false>
-static int launch_typed(Params &p, hipStream_t s) {
+static int launch_typed(Params &p, hipStream_t s, bool split = false) {
     const int64_t n_seg = (p.n_tiles + kKMax - 1) / kKMax;
     p.info_per_wave = p.n_tiles < 16384 ? 1 : 0;
     const int64_t n_info = p.info_per_wave ? (p.n_tiles + 3) / 4 : (p.n_tiles + kThreads - 1) / kThreads;
     if (n_seg + n_info > 0x7fffffff || p.n_tiles > 0x7fffffff) return COGDL_HIP_ERANGE;
     p.n_seg = (int)n_seg;
     hipLaunchKernelGGL((es_flat_init_kernel<T, BWD>), dim3((unsigned)(n_seg + n_info)), dim3(kThreads), 0, s, p);
+    if constexpr (!BWD) {
+        if (split) {  // three launches: multi-row tiles through LDS (no waits), then one-row tiles + exchanged pieces streamed
+            hipLaunchKernelGGL((es_flat_kernel<T, false, TILE, WPE, false, true>), dim3((unsigned)p.n_tiles), dim3(kThreads), 0, s, p);
+            hipLaunchKernelGGL((es_stream_kernel<T>), dim3((unsigned)p.n_tiles), dim3(kThreads), 0, s, p);
+            return launch_status();
+        }
+    }
     hipLaunchKernelGGL((es_flat_kernel<T, BWD, TILE, WPE, KEEP_P>), dim3((unsigned)p.n_tiles), dim3(kThreads), 0, s, p);
     return launch_status();
 }
@@ -1030,10 +1214,18 @@ int es_flat_launch(bool bwd, const int32_t *rowptr, const void *a, const void *g
     // Reddit-shaped graph: fp32 1.68 -> 1.62 ms, bf16 1.41 -> 1.37 ms, the latter despite 65 spilled registers per lane);
     // tuning key 9 bit 3 switches it off for A/B runs
     if (!bwd && !(g_tuning[kTuneEsDebug] & 8) && !small16) {
+        // The two-kernel form (round 5: one-row tiles and exchanged pieces streamed twice by es_stream_kernel at 7 workgroups
+        // per CU instead of held in registers across the exchange) is OPT-IN, tuning key 9 bit 8: measured on the MI355X it
+        // loses -- Reddit-shaped graph, H = 8, forward: fp32 1674 -> 2512 us, bf16 1474 -> 1899 us; H = 1: 331 -> 441 us
+        // (profiles/r05_es_split_ab.txt).  The second read of a tile does not come out of L2: seven resident tiles of 32 KB
+        // per CU are 7 MB per XCD against 4 MB of L2, and a hit in the Infinity Cache crosses the same fabric as an HBM
+        // read -- three passes over the array instead of two is the 1.5x that was measured.  Fitting L2 means four tiles per
+        // CU or smaller tiles, i.e. the occupancy of the one-kernel form or more pieces per row (measured slower in round 3).
+        const bool split = (g_tuning[kTuneEsDebug] & 256) != 0;
         switch (dtype) {
-            case COGDL_HIP_F32: return esf::launch_typed<float, false, F32F, 4, true>(p, s);
-            case COGDL_HIP_F16: return esf::launch_typed<__half, false, B16F, 4, true>(p, s);
-            case COGDL_HIP_BF16: return esf::launch_typed<__hip_bfloat16, false, B16F, 4, true>(p, s);
+            case COGDL_HIP_F32: return esf::launch_typed<float, false, F32F, 4, true>(p, s, split);
+            case COGDL_HIP_F16: return esf::launch_typed<__half, false, B16F, 4, true>(p, s, split);
+            case COGDL_HIP_BF16: return esf::launch_typed<__hip_bfloat16, false, B16F, 4, true>(p, s, split);
             default: return COGDL_HIP_EDTYPE;
         }
     }

@@ -72,7 +72,8 @@ COGDL_API int cogdl_hip_last_hip_error(void);
  * wait gives up at once -- tests of that escape path), key 9 = flat edge_softmax experiments (bit 0: the kernel
  * skips its cross-tile exchange -- WRONG results; bit 2: half-size tiles for 16-bit values; bit 3: no kept exp values in
  * the forward; bit 4: one 16-bit element per LDS access; bit 6: full-size tiles for under-filled launches too; bit 7:
- * wall-clock phase stamps of one-row tiles in the workspace header, tools/es_phase_probe.py), key 10 = csr2csc algorithm (0 = automatic: one single-workgroup launch up
+ * wall-clock phase stamps of one-row tiles in the workspace header, tools/es_phase_probe.py; bit 8: the forward's two-kernel
+ * form -- one-row tiles streamed twice by a second kernel instead of held in registers across the exchange; measured slower), key 10 = csr2csc algorithm (0 = automatic: one single-workgroup launch up
  * to 16 k edge slots and columns, the hand-written two-payload radix sort above; 1 = as 0 (the rocPRIM sort pipeline of
  * rounds 1-4 was removed in round 5); 2 = the radix sort at every size; 3 = the radix sort with packed
  * intermediate records wherever two passes suffice -- by default only from 16 M slots on, 5 = MSD-first where two passes

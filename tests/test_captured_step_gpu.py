@@ -468,3 +468,14 @@ def test_reference_graphsage_model_trains_in_a_captured_step():
     rep = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("REPORT ")][-1][7:])
     assert abs(rep["eager"][0] - rep["ref_loss"]) <= 1e-5 * max(1.0, abs(rep["ref_loss"]))
     np.testing.assert_allclose(rep["captured"], rep["eager"], rtol=1e-6)
+
+
+def test_sampling_from_a_graph_without_nodes_flags_every_seed_and_reads_nothing():
+    """Round-4 advisor: sample_prep's unconditional 16-byte load of indptr[0..1] read 8 bytes past a ONE-entry indptr
+    (num_nodes == 0, batch > 0).  Every seed is invalid there: flagged, nothing loaded, an empty block comes back."""
+    indptr = torch.zeros(1, dtype=torch.long, device=DEV)
+    indices = torch.zeros(0, dtype=torch.long, device=DEV)
+    row_ptr, col, nodes, edges, counts = sample_adj_padded(indptr, indices, torch.tensor([0, 5, 2], device=DEV), 3)
+    torch.cuda.synchronize()
+    assert int(counts[2]) & 1 and int(counts[1]) == 0  # flagged, no edges
+    assert int(row_ptr[:4].abs().sum()) == 0

@@ -328,7 +328,7 @@ def test_any_rank_vote_is_the_same_on_every_rank():
         assert all("VOTE " + want in o for o in outs), (yes, outs)
 
 
-def _bad_shard_worker(rank, world, port, out_dir):
+def _bad_shard_worker(rank, world, port, out_dir, kind="rowptr"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -342,10 +342,15 @@ def _bad_shard_worker(rank, world, port, out_dir):
         lo, hi = int(bounds[rank]), int(bounds[rank + 1])
         e0, e1 = int(g.rowptr[lo]), int(g.rowptr[hi])
         rowptr = (g.rowptr[lo:hi + 1] - g.rowptr[lo]).long()
-        if rank == 1:  # ONE rank holds a row pointer that runs backwards
+        weight = g.weight[e0:e1]
+        if rank == 1 and kind == "rowptr":  # ONE rank holds a row pointer that runs backwards
             rowptr[3] = rowptr[5] + 2
+        if rank == 1 and kind == "rows":    # ... or one entry too few (round-4 advisor: the cheap shape checks raised locally)
+            rowptr = rowptr[:-1]
+        if rank == 1 and kind == "weights":
+            weight = weight[:-3]
         try:
-            ShardedCSR(rowptr, g.colind[e0:e1].long(), g.weight[e0:e1], bounds, backend=OracleBackend())
+            ShardedCSR(rowptr, g.colind[e0:e1].long(), weight, bounds, backend=OracleBackend())
             msg = "no error"
         except _lib.BackendError as e:
             msg = str(e)
@@ -362,6 +367,16 @@ def test_an_invalid_shard_on_one_rank_stops_every_rank_instead_of_hanging_the_ex
     m0, m1 = (open(os.path.join(str(tmp_path), "bad%d.txt" % r)).read() for r in (0, 1))
     assert "rowptr must start at 0, be non-decreasing" in m1
     assert "another rank rejected its shard" in m0
+
+
+@pytest.mark.parametrize("kind,text", [("rows", "rowptr has"), ("weights", "weights for")])
+def test_a_shape_error_on_one_rank_stops_every_rank_too(tmp_path, kind, text):
+    """Round-4 advisor: the per-rank SHAPE checks (row count, weight length, number of bounds) still raised locally, in
+    front of the all-reduce their peers were about to enter.  They feed the same agreement now."""
+    mp.spawn(_bad_shard_worker, args=(2, 29690 if kind == "rows" else 29692, str(tmp_path), kind), nprocs=2, join=True)
+    m0, m1 = (open(os.path.join(str(tmp_path), "bad%d.txt" % r)).read() for r in (0, 1))
+    assert text in m1, m1
+    assert "another rank rejected its shard" in m0, m0
 
 
 def test_predict_scaling_model():

@@ -204,10 +204,11 @@ def _softmax_grad_scale(sm, gr, rows_, n, h):
 FLAT_HUBS = [((3, 1023), (4, 1025), (17, 9000), (18, 2048), (40, 5)), ((0, 20000),), ((58, 3000), (59, 4100))]
 
 
-@pytest.fixture(params=[0, 64], ids=["small-problem-tiles", "full-size-tiles"])
+@pytest.fixture(params=[0, 64, 64 | 256], ids=["small-problem-tiles", "full-size-tiles", "full-size-tiles-split-forward"])
 def es_tiles(request):
     """Graphs of test size are "small problems" for the flat kernel (quarter-size tiles); tuning key 9 bit 6 runs the same
-    cases through the full-size tiles that only true-size graphs would otherwise reach."""
+    cases through the full-size tiles that only true-size graphs would otherwise reach.  Bit 8 selects the forward's
+    two-kernel form (round 5, opt-in: one-row tiles and exchanged pieces streamed by es_stream_kernel; measured slower)."""
     from cogdl_amd import _lib
 
     _lib.hip().cogdl_hip_set_tuning(9, request.param)

@@ -58,3 +58,51 @@ def test_memo_pickles_empty():
     _StructIndex(torch.arange(3, dtype=torch.int64), memo, 0).int()
     back = pickle.loads(pickle.dumps(memo))
     assert isinstance(back, StructureMemo) and back.rowptr32 is None and back.colind32 is None
+
+
+def test_fingerprint_memo_follows_the_versions_of_the_int32_copies(monkeypatch):
+    """Round-4 advisor: the memoised Fingerprint was vouched for by tensor identity only -- an in-place edit of the cached
+    int32 copy reused the stale hash (and the cached transpose it keys).  And a Fingerprint made under hipGraph-capture
+    replay (nothing hashed: no event) must not be remembered for a later eager lookup."""
+    import cogdl_amd.structure_memo as sm
+
+    made = []
+
+    class FakeFingerprint:
+        def __init__(self, rowptr, colind, n_cols):
+            self.event = object() if not made or made[-1] != "replay" else None
+            made.append("fp")
+
+    monkeypatch.setattr(sm, "Fingerprint", FakeFingerprint)
+    memo = StructureMemo()
+    rp = _StructIndex(torch.tensor([0, 1, 2], dtype=torch.int64), memo, 0).int()
+    ci = _StructIndex(torch.tensor([1, 0], dtype=torch.int64), memo, 1).int()
+    a = memo.fingerprint(rp, ci, 2)
+    assert memo.fingerprint(rp, ci, 2) is a and made == ["fp"]
+    ci[0] = 0  # in-place edit of the cached copy: its version moves, the hash is taken again
+    b = memo.fingerprint(rp, ci, 2)
+    assert b is not a and made == ["fp", "fp"] and memo.fingerprint(rp, ci, 2) is b
+    rp.add_(0)
+    made.append("replay")  # the next Fingerprint is built as under tape replay: event None
+    c = memo.fingerprint(rp, ci, 2)
+    assert c.event is None
+    d = memo.fingerprint(rp, ci, 2)  # not memoised: a fresh one (with an event) is made for the eager lookup
+    assert d is not c and d.event is not None and memo.fingerprint(rp, ci, 2) is d
+    assert memo.fingerprint(rp.clone(), ci, 2) is None  # not the memoised tensors at all
+
+
+def test_install_opt_in_rebinds_fail_loudly_without_their_target(monkeypatch):
+    """Round-4 advisor: install(structure_memo=True) / install(fused_gat_dropout=True) before `import cogdl` silently did
+    nothing.  They import their target module now; where cogdl is not importable at all they raise, naming the flag."""
+    import importlib
+    import sys
+
+    import cogdl_amd
+    from cogdl_amd import _lib
+
+    if "cogdl" in sys.modules or importlib.util.find_spec("cogdl") is not None:
+        pytest.skip("cogdl is importable here")
+    for flag in ("structure_memo", "fused_gat_dropout"):
+        with pytest.raises(_lib.BackendError, match=flag):
+            cogdl_amd.install(**{flag: True})
+    cogdl_amd.uninstall()
