@@ -21,7 +21,11 @@ power-law topology and on a shard far beyond the caches) and cpu_baseline (the r
 /root/reference by oracle/Makefile, timed on this host's cores; N=1 only).  The N = 1 line also carries configs3_sage: the
 captured GraphSAGE mini-batch step of configs[3] on this GPU (child interpreter), the base of the replica legs, and
 configs2_gat: the GAT training step of configs[2] (Reddit-shaped graph, bf16) with the model's default arguments through
-the fused attention-dropout operator, beside the unchanged layer's time and the per-kernel roofline fractions.
+the fused attention-dropout operator, beside the unchanged layer's time and the per-kernel roofline fractions;
+configs4_papers_1gpu (round 5): BASELINE configs[4] at FULL size on this one GPU -- the papers100M-shaped graph, 1.6e9 directed
+and 3.2e9 symmetrised edges, F = 128 fp32, through csrspmm with 64-bit row pointers (tools/papers_bench.py): the N = 1 end of
+the 1 -> 8 curve; and roofline.measured_copy_GBs / measured_read_GBs: the box's own roofs, measured in the same run
+(fractions of the 8 TB/s spec number are not comparable across boxes).
 """
 import argparse
 import json
@@ -199,8 +203,12 @@ def trainer_epoch(budget_s=240):
     if not refpkg.available():
         return None
     out = {}
+    # arxiv_example_*: the model of the reference's ogbn-arxiv example (3 GCNLayers, hidden 256, batch-norm; examples/ogb/arxiv/
+    # gnn.py:148-156), the configuration BASELINE.md section 3 timed at 5.94 s per training step on the CPU
     for key, argv in (("gpu", ["gpu", "30"]), ("gpu_mfma_linear", ["gpu", "30", "linear"]),
-                      ("gpu_mfma_linear_structure_memo", ["gpu", "30", "linear", "memo"]), ("cpu_reference", ["cpu", "3"])):
+                      ("gpu_mfma_linear_structure_memo", ["gpu", "30", "linear", "memo"]), ("cpu_reference", ["cpu", "3"]),
+                      ("arxiv_example_gpu", ["gpu", "30", "example"]),
+                      ("arxiv_example_gpu_mfma_linear", ["gpu", "30", "linear", "example"])):
         try:
             proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trainer_epoch.py")] + argv,
                                   capture_output=True, text=True, timeout=budget_s)

@@ -45,7 +45,7 @@ inline hipError_t fill_u32_async(void *p, uint32_t v, size_t n_words, hipStream_
 }
 
 // Run-time tuning knobs (cogdl_hip_set_tuning): experiments without recompiling.
-enum Tuning { kTuneXcdStripe = 0, kTuneLongThresh = 1, kTuneRowSort = 2, kTuneLongGrid = 3, kTuneGatVec = 4, kTuneGatOnline = 5, kTuneSpmmVec = 6, kTuneEsScalar = 7, kTuneEsSpin = 8, kTuneEsDebug = 9, kTuneCsr2csc = 10, kTuneSampleRelabel = 11, kTuneWaveSplit = 12, kTuneRowDebug = 13, kTuneRowTile = 14, kTuneSegmentEdges = 15, kTuneCount = 16 };
+enum Tuning { kTuneXcdStripe = 0, kTuneLongThresh = 1, kTuneRowSort = 2, kTuneLongGrid = 3, kTuneGatVec = 4, kTuneGatOnline = 5, kTuneSpmmVec = 6, kTuneEsScalar = 7, kTuneEsSpin = 8, kTuneEsDebug = 9, kTuneCsr2csc = 10, kTuneSampleRelabel = 11, kTuneWaveSplit = 12, kTuneRowDebug = 13, kTuneRowTile = 14, kTuneSegmentEdges = 15, kTuneRowQueue = 16, kTuneCount = 17 };
 extern int g_tuning[kTuneCount];
 
 // Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8; observed, used for
@@ -101,6 +101,20 @@ __device__ __forceinline__ void load_vec(const T *p, float (&dst)[VEC]) {
     using Raw = typename RawVec<sizeof(T) * VEC>::type;
     union { Raw raw; T e[VEC]; } u;
     u.raw = *reinterpret_cast<const Raw *>(p);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) dst[i] = to_f32<T>(u.e[i]);
+}
+
+// The same in two steps: the raw vector as loaded (16-bit types: half the registers of their fp32 values while the load is
+// in flight), unpacked where it is used.
+template <typename T, int VEC>
+__device__ __forceinline__ typename RawVec<sizeof(T) * VEC>::type load_raw(const T *p) {
+    return *reinterpret_cast<const typename RawVec<sizeof(T) * VEC>::type *>(p);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void unpack_raw(const typename RawVec<sizeof(T) * VEC>::type &raw, float (&dst)[VEC]) {
+    union { typename RawVec<sizeof(T) * VEC>::type raw; T e[VEC]; } u;
+    u.raw = raw;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) dst[i] = to_f32<T>(u.e[i]);
 }

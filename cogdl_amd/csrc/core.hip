@@ -11,7 +11,8 @@ int g_tuning[kTuneCount] = {/*0: xcd stripe*/ 32, /*1: long-row threshold overri
                             /*12: wave-scope split of medium rows: n > 0 = rows of more than n edges in skewed workgroups (off by default)*/ 0,
                             /*13: timing experiments on the row-reduce engine (WRONG results): 1 = the row blocks exit at once, 2 = the long-row workgroups exit at once*/ 0,
                             /*14: csr_spmm row tiles (several rows per lane group, their first gathers in flight together): 2 = on wherever the operator allows; off by default (measured slower except for rows of one or two edges)*/ 0,
-                            /*15: 64-bit CSR: edges per row segment (0 = default 2^29; tests use tiny values)*/ 0};
+                            /*15: 64-bit CSR: edges per row segment (0 = default 2^29; tests use tiny values)*/ 0,
+                            /*16: csr_spmm row queue: a workgroup owns n x as many rows and its waves pull them from an LDS counter (0 = off)*/ 0};
 }
 
 namespace cogdl {

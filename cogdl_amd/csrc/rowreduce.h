@@ -83,6 +83,7 @@ struct RowSched {
     int wave_split; // > 0: in a skewed workgroup, rows of more than this many edges are reduced by ALL lane groups of their wave
     int debug;      // timing experiments (tuning key 13; WRONG results): 1 = row blocks exit, 2 = long-row workgroups exit
     int64_t nnz;    // (the row-tile kernel needs a valid edge index for the rows that have none)
+    int queue;      // rowreduce_queue_kernel: wave-units of rows per wave handed out by the workgroup's queue (0: not used)
 };
 
 // Operators may ask for a register budget: `static constexpr int kMinWaves = W` compiles their main kernel for at least W
@@ -104,6 +105,17 @@ struct RowTile {
 template <class Op>
 struct RowTile<Op, std::void_t<decltype(Op::kRowTile)>> {
     static constexpr int value = Op::kRowTile;
+};
+
+// Operators that may run through the per-workgroup ROW QUEUE (rowreduce_queue_kernel) declare `static constexpr bool
+// kRowQueue = true` (their hooks must not contain workgroup barriers: the waves of a workgroup walk different rows).
+template <class Op, class = void>
+struct RowQueue {
+    static constexpr bool value = false;
+};
+template <class Op>
+struct RowQueue<Op, std::void_t<decltype(Op::kRowQueue)>> {
+    static constexpr bool value = Op::kRowQueue;
 };
 
 // Rows of at most this many edges are always reduced sequentially by one lane group, in CSR order (the reference's
@@ -690,6 +702,64 @@ __global__ __launch_bounds__(256) void rowreduce_tile_kernel(const Op op, const 
         if (live[i]) op.row_end(ctx, acc[i], row0 + i, true);
 }
 
+// ---- row queue (round 5) ---------------------------------------------------------------------------------------------
+// What the degree-sorted dealing of rowreduce_main_kernel cannot fix on skewed graphs is the imbalance BETWEEN waves and
+// between workgroups: a workgroup lives as long as its longest row while its other waves finished their 5-edge rows long
+// ago (arxiv-sized R-MAT graph, F = 64: row blocks alone 107 us, 77 us with rows and columns relabelled by degree,
+// profiles/r04_longpath_probe.txt).  Here a workgroup owns `queue` times as many consecutive rows and its four waves PULL
+// wave-units of RPW rows from a counter in LDS until the pool is empty: a wave that drew a 100-edge row simply takes fewer
+// units.  Per row nothing changes -- one lane group, CSR order, the operator's own hooks (bit-identical results); long rows
+// are skipped as before.  One LDS atomic per unit; no barrier after the first.
+template <class Op>
+__global__ __launch_bounds__(256, MinWaves<Op>::value) void rowreduce_queue_kernel(const Op op, const RowSched s) {
+    __shared__ float op_lds[Op::kLds > 0 ? 256 * Op::kLds : 1];
+    __shared__ int q_next;
+    if (blockIdx.x < s.lr.n_long_blocks) {
+        if (s.debug != 2) rowreduce_long_block<Op>(op, s, op_lds);
+        return;
+    }
+    if (s.debug == 1) return;
+    constexpr int LPR = Op::LPR;
+    constexpr int RPW = kWave / LPR;
+    const int64_t rb = xcd_remap(blockIdx.x - s.lr.n_long_blocks, s.rowblocks);
+    if (rb < 0) return;
+    if (threadIdx.x == 0) q_next = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1);
+    const int l = lane % LPR;
+    const bool lane_on = (kWave % LPR == 0) || lane / LPR < RPW;
+    const int sub = lane_on ? lane / LPR : 0;
+    const int n_units = s.queue * 4;
+    const int64_t row0 = rb * (int64_t)n_units * RPW;
+    float *const my_lds = op_lds + (threadIdx.x / LPR) * LPR * Op::kLds;
+    typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
+    for (;;) {
+        int u = 0;
+        if (lane == 0) u = atomicAdd(&q_next, 1);
+        u = __builtin_amdgcn_readfirstlane(u);  // (lane 0 is the first active lane)
+        if (u >= n_units) break;
+        const int64_t row = row0 + (int64_t)u * RPW + sub;
+        if (row0 + (int64_t)u * RPW >= s.m) break;  // (wave-uniform: the pool's tail lies behind the last row)
+        bool ok = lane_on && row < s.m;
+        int start = 0, end = 0;
+        if (ok) {
+            start = s.rowptr[row];
+            end = s.rowptr[row + 1];
+        }
+        if constexpr (LPR == kWave) {
+            start = __builtin_amdgcn_readfirstlane(start);
+            end = __builtin_amdgcn_readfirstlane(end);
+        }
+        if (end - start <= s.lr.thresh) {  // (group-uniform) a long row is the long-row workgroups' and the combine kernel's
+            op.row_load(ctx, row, ok);
+            typename Op::State st;
+            op.init(ctx, st, row, ok);
+            reduce_edges<Op>(op, ctx, st, s.colind, start, end, sub, l, my_lds);
+            op.row_end(ctx, st, row, ok);
+        }
+    }
+}
+
 // For every long row merge its piece records in chunk order and finish the row.  The row is combined by the lane
 // group that finds it at its FIRST full chunk (the row's head piece, if any, sits in slot 1 of the chunk before).
 template <class Op>
@@ -764,7 +834,9 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
     constexpr int kTile = (RowTile<Op>::value > 1 && kWave % Op::LPR == 0 && Op::LPR < kWave && Op::LPR > RowTile<Op>::value)
                               ? RowTile<Op>::value : 1;
     const bool tile_rows = kTile > 1 && g_tuning[kTuneRowTile] == 2;
-    const int64_t RPB = (int64_t)(kWave / Op::LPR) * 4 * (tile_rows ? kTile : 1);
+    // Row queue (rowreduce_queue_kernel): tuning key 16 = wave-units per wave (0 = off)
+    const int queue = (RowQueue<Op>::value && !tile_rows) ? std::min(std::max(g_tuning[kTuneRowQueue], 0), 64) : 0;
+    const int64_t RPB = (int64_t)(kWave / Op::LPR) * 4 * (tile_rows ? kTile : 1) * (queue > 0 ? queue : 1);
     const int64_t n_rowblocks = (m + RPB - 1) / RPB;
     if (n_rowblocks == 0) return COGDL_HIP_OK;
     if (tiles > 65535 || tiles < 1) return COGDL_HIP_ERANGE;
@@ -776,6 +848,7 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
     s.sort_rows = g_tuning[kTuneRowSort] == 0 ? 1 : 0;
     s.debug = g_tuning[kTuneRowDebug];
     s.nnz = nnz;
+    s.queue = queue;
     s.wave_split = wave_split_edges();  // (set to 0 below when the caller asked for sequential rows: no workspace)
     s.lr.thresh = INT_MAX;
     if (nnz > 0 && (!Op::kReduce || workspace)) {
@@ -791,12 +864,20 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
     if (s.lr.thresh == INT_MAX) s.wave_split = 0;  // no workspace = every row sequentially, in the reference's order
     if (!grid_fits(s.rowblocks, s.lr.n_long_blocks)) return COGDL_HIP_ERANGE;
     dim3 grid(s.lr.n_long_blocks + xcd_grid(s.rowblocks), (unsigned)tiles);
-    if constexpr (kTile > 1) {
-        if (tile_rows) hipLaunchKernelGGL((rowreduce_tile_kernel<Op, kTile>), grid, dim3(256), 0, stream, op, s);
-        else hipLaunchKernelGGL((rowreduce_main_kernel<Op>), grid, dim3(256), 0, stream, op, s);
-    } else {
-        hipLaunchKernelGGL((rowreduce_main_kernel<Op>), grid, dim3(256), 0, stream, op, s);
+    bool launched = false;
+    if constexpr (RowQueue<Op>::value) {
+        if (queue > 0) {
+            hipLaunchKernelGGL((rowreduce_queue_kernel<Op>), grid, dim3(256), 0, stream, op, s);
+            launched = true;
+        }
     }
+    if constexpr (kTile > 1) {
+        if (!launched && tile_rows) {
+            hipLaunchKernelGGL((rowreduce_tile_kernel<Op, kTile>), grid, dim3(256), 0, stream, op, s);
+            launched = true;
+        }
+    }
+    if (!launched) hipLaunchKernelGGL((rowreduce_main_kernel<Op>), grid, dim3(256), 0, stream, op, s);
     if constexpr (Op::kReduce) {
         if (s.lr.n_long_blocks > 0)
             hipLaunchKernelGGL((rowreduce_combine_kernel<Op>), dim3(s.lr.n_long_blocks, (unsigned)tiles), dim3(256), 0,

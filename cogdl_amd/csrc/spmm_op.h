@@ -6,6 +6,12 @@
 namespace cogdl {
 
 constexpr int kDefaultUnroll = 8;
+// (Round 5, tried: batches of 16 gathers in flight for 16-bit features -- they move half the bytes per gathered row, so at the
+//  fp32 depth a lane group keeps half the bytes in flight -- with the batch held as RAW vectors.  Slower on every graph and
+//  width, 5-35 %: arxiv-sized R-MAT bf16 F = 64 125 -> 147 us, F = 128 190 -> 224, F = 256 207 -> 281; uniform F = 64 57 -> 66;
+//  Reddit-shaped F = 128 2.93 -> 3.11 ms (profiles/r05_unroll16_ab.txt): the compiler unpacks early, the kernels grow from
+//  78-82 to 84-119 VGPRs (one to two waves per SIMD fewer), and a chunk of LPR <= 32 edges has only one or two batches to
+//  begin with.  The batch keeps the raw vectors (free for fp32, never worse for 16-bit); the depth stays 8.)
 
 template <bool EXACT>
 __device__ __forceinline__ float mul_add(float acc, float w, float v) {
@@ -35,6 +41,7 @@ struct SpmmOp {
     static constexpr int kLds = 0;
     // row tiles (rowreduce_tile_kernel): the context and the hooks of csr_spmm do not depend on the row
     static constexpr int kRowTile = (WMODE != 2 && !EPI) ? 4 : 1;
+    static constexpr bool kRowQueue = (WMODE != 2 && !EPI);  // rowreduce_queue_kernel (tuning key 16): csr_spmm only
     // (kMinWaves = 8, i.e. 64 VGPRs, was tried: arxiv-sized R-MAT F=64 132 -> 122 us but 44 bytes of scratch per lane make
     //  every other shape 3-10 % slower -- 71 VGPRs / 7 waves per SIMD stay)
     const T *val;      // WMODE 1
@@ -57,8 +64,9 @@ struct SpmmOp {
         float w;
         int id;
     };
+    using Raw = typename RawVec<sizeof(T) * VEC>::type;
     struct Batch {
-        float v[UNROLL][VEC];
+        Raw v[UNROLL];  // as loaded; unpacked in apply()
         float w[UNROLL];
         float s[EPI ? UNROLL : 1];
     };
@@ -95,16 +103,18 @@ struct SpmmOp {
         }
         else b.w[u] = 1.f;
         if constexpr (EPI) b.s[u] = epi.src_scale ? epi.src_scale[col] : 1.f;
-        load_vec<T, VEC>(c.xcol + (int64_t)col * k, b.v[u]);
+        b.v[u] = load_raw<T, VEC>(c.xcol + (int64_t)col * k);
     }
     // Strictly in CSR order.  acc + 0*0 == acc exactly (acc is never -0), so masked slots are no-ops;
     // selecting v (not only w) to zero keeps inf/nan out.
     __device__ __forceinline__ void apply(const Ctx &, State &s, const Batch &b, int u, bool valid, int64_t,
                                           int) const {
+        float xv[VEC];
+        unpack_raw<T, VEC>(b.v[u], xv);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            float vv = valid ? b.v[u][i] : 0.f;
-            if constexpr (EPI) vv = valid ? b.s[u] * b.v[u][i] : 0.f;  // (out_norm * x)[col, :], rounded like the reference's product
+            float vv = valid ? xv[i] : 0.f;
+            if constexpr (EPI) vv = valid ? b.s[u] * xv[i] : 0.f;  // (out_norm * x)[col, :], rounded like the reference's product
             if constexpr (WMODE != 0) s.acc[i] = mul_add<EXACT>(s.acc[i], valid ? b.w[u] : 0.f, vv);
             else s.acc[i] = s.acc[i] + vv;
         }
@@ -165,23 +175,28 @@ static int launch_spmm(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s
 
 // (VEC, LPR) choice: as many lanes per row as the row has VEC-wide columns (whole-wave rows are the
 // fastest: scalar column broadcast, no inter-row divergence inside a wave), VEC as small as that allows.
-template <typename T, int VEC, int WMODE, bool EPI = false>
-static int dispatch_lpr(const SpmmArgs<T> &a, int lpr, void *ws, size_t wsb, hipStream_t s) {
+template <typename T, int VEC, int WMODE, bool EPI, int UNROLL>
+static int dispatch_lpr_u(const SpmmArgs<T> &a, int lpr, void *ws, size_t wsb, hipStream_t s) {
     if constexpr (WMODE != 2 && !EPI) {  // lane groups that do not divide the wave (spmm_geometry: narrow_groups)
         switch (lpr) {
-            case 10: return launch_spmm<T, VEC, 10, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
-            case 12: return launch_spmm<T, VEC, 12, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
-            case 20: return launch_spmm<T, VEC, 20, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
+            case 10: return launch_spmm<T, VEC, 10, UNROLL, WMODE, true, EPI>(a, ws, wsb, s);
+            case 12: return launch_spmm<T, VEC, 12, UNROLL, WMODE, true, EPI>(a, ws, wsb, s);
+            case 20: return launch_spmm<T, VEC, 20, UNROLL, WMODE, true, EPI>(a, ws, wsb, s);
             default: break;
         }
     }
     switch (lpr) {
-        case 4: return launch_spmm<T, VEC, 4, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
-        case 8: return launch_spmm<T, VEC, 8, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
-        case 16: return launch_spmm<T, VEC, 16, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
-        case 32: return launch_spmm<T, VEC, 32, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
-        default: return launch_spmm<T, VEC, 64, kDefaultUnroll, WMODE, true, EPI>(a, ws, wsb, s);
+        case 4: return launch_spmm<T, VEC, 4, UNROLL, WMODE, true, EPI>(a, ws, wsb, s);
+        case 8: return launch_spmm<T, VEC, 8, UNROLL, WMODE, true, EPI>(a, ws, wsb, s);
+        case 16: return launch_spmm<T, VEC, 16, UNROLL, WMODE, true, EPI>(a, ws, wsb, s);
+        case 32: return launch_spmm<T, VEC, 32, UNROLL, WMODE, true, EPI>(a, ws, wsb, s);
+        default: return launch_spmm<T, VEC, 64, UNROLL, WMODE, true, EPI>(a, ws, wsb, s);
     }
+}
+
+template <typename T, int VEC, int WMODE, bool EPI = false>
+static int dispatch_lpr(const SpmmArgs<T> &a, int lpr, void *ws, size_t wsb, hipStream_t s) {
+    return dispatch_lpr_u<T, VEC, WMODE, EPI, kDefaultUnroll>(a, lpr, ws, wsb, s);
 }
 
 static int pointer_alignment(const void *a, const void *b) {

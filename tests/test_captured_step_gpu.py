@@ -474,7 +474,9 @@ def test_sampling_from_a_graph_without_nodes_flags_every_seed_and_reads_nothing(
     """Round-4 advisor: sample_prep's unconditional 16-byte load of indptr[0..1] read 8 bytes past a ONE-entry indptr
     (num_nodes == 0, batch > 0).  Every seed is invalid there: flagged, nothing loaded, an empty block comes back."""
     indptr = torch.zeros(1, dtype=torch.long, device=DEV)
-    indices = torch.zeros(0, dtype=torch.long, device=DEV)
+    with pytest.raises(_lib.BackendError):  # (no edge array at all: refused before any launch)
+        sample_adj_padded(indptr, torch.zeros(0, dtype=torch.long, device=DEV), torch.tensor([0, 5, 2], device=DEV), 3)
+    indices = torch.zeros(1, dtype=torch.long, device=DEV)  # a non-null edge array: the kernels run with num_nodes == 0
     row_ptr, col, nodes, edges, counts = sample_adj_padded(indptr, indices, torch.tensor([0, 5, 2], device=DEV), 3)
     torch.cuda.synchronize()
     assert int(counts[2]) & 1 and int(counts[1]) == 0  # flagged, no edges
