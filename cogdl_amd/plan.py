@@ -272,6 +272,35 @@ def fingerprint_of(rowptr, colind, n_cols):
     return Fingerprint(rowptr, colind, n_cols)
 
 
+# Debug mode (COGDL_AMD_VERIFY_PLANS=1, or plan.VERIFY_HITS = True): a cache hit is trusted on sizes + a 64-bit content hash;
+# a collision would hand the backward a WRONG transpose silently.  With the mode on every hit is checked against the
+# structure of the call (O(nnz) torch work + one synchronisation per hit: for debugging, not for training).
+VERIFY_HITS = os.environ.get("COGDL_AMD_VERIFY_PLANS", "0") == "1"
+
+
+def verify_plan(plan, rowptr, colind):
+    """Is `plan` the stable transpose of (rowptr, colind)?  Necessary and sufficient: the sizes agree, the columns of the
+    CSR positions perm lists are exactly the plan's column runs (colind[perm] == repeat(arange(n_cols), diff(colptr))),
+    perm ascends inside every column (stability; then it is a permutation), and rowind names the row that owns each
+    position."""
+    m, nnz = rowptr.numel() - 1, colind.numel()
+    ok = plan.m == m and plan.nnz == nnz and plan.colptr.numel() == plan.n_cols + 1
+    if ok and nnz:
+        perm = plan.perm.long()
+        counts = (plan.colptr[1:] - plan.colptr[:-1]).long()
+        cols = torch.repeat_interleave(torch.arange(plan.n_cols, device=colind.device), counts)
+        ok = cols.numel() == nnz and bool((colind.long()[perm] == cols).all())
+        if ok and nnz > 1:
+            same_col = cols[1:] == cols[:-1]
+            ok = bool((perm[1:] > perm[:-1])[same_col].all())
+        if ok:
+            rows = torch.searchsorted(rowptr.long(), perm, right=True) - 1
+            ok = bool((rows == plan.rowind.long()).all())
+    if not ok:
+        raise _lib.BackendError("plan cache: the cached transpose does not belong to this structure (m=%d, nnz=%d): a "
+                                "fingerprint collision or a structure edited in place behind the cache" % (m, nnz))
+
+
 class PlanCache:
     def __init__(self, budget_bytes=None):
         if budget_bytes is None:
@@ -305,6 +334,8 @@ class PlanCache:
         if plan is not None:
             self.lru.move_to_end(key)
             self.hits += 1
+            if VERIFY_HITS:
+                verify_plan(plan, rowptr, colind)
             return plan
         self.misses += 1
         plan = csr2csc(rowptr, colind, n_cols)
