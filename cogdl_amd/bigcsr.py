@@ -165,7 +165,7 @@ def gather_rows_i64(perm, src):
 
 # plans by tensor identity (the key holds references to both tensors: their addresses cannot be recycled while it lives)
 _BIG_PLANS = {}
-_BIG_PLANS_MAX = 8
+_BIG_PLANS_MAX = 4  # (a plan pins its graph's index tensors: clear_plans() releases them)
 
 
 def plan_of(rowptr, colind, n_cols):

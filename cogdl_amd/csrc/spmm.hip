@@ -45,6 +45,12 @@ RowGeometry spmm_geometry(int64_t k, int64_t unit, int elem_bytes, int align, bo
         return l;
     };
     while (vec > 1 && (vec / 2) * elem_bytes >= 4 && lanes(vec) < 16) vec /= 2;  // >= 16 lanes per row
+    // (Round 5: is that still right where every gather is an HBM access?  On one eighth of the papers100M-shaped symmetrised
+    //  graph -- X = 7.1 GB -- 16-byte lanes / two rows per wave looked 6 % faster, 36.9 vs 39.1 ms; at FULL size, A/B in one
+    //  process on one box (tuning key 6 = -2 against a build with the rule "operands beyond 512 MiB keep 16-byte lanes"):
+    //  symmetrised 327-330 vs 333-338 ms, but the DIRECTED graph -- 14.5 edges per row instead of 29 -- 201-202 vs 138-139 ms
+    //  with the wider lanes: two rows of different length per wave cost more than the bytes in flight buy.  The rule stays
+    //  size-independent; profiles/r05_papers_variants.txt.)
     while (vec > 1 && (vec / 2) * elem_bytes >= 8 && k / vec >= 32) vec /= 2;  // wide rows: 8-byte lanes
     if (g_tuning[kTuneSpmmVec] > 0)  // experiments: cap the vector width
         while (vec > g_tuning[kTuneSpmmVec]) vec /= 2;
