@@ -371,6 +371,13 @@ def papers_leg(budget_s=300):
     r = _child_leg([os.path.join(ROOT, "tools", "papers_bench.py"), "--steps", "3"], 6, budget_s)
     if "error" in r:
         r["error"] = r["error"][-400:]
+    try:  # HBM-side traffic of this leg's kernel: collected once per round under rocprofv3 --pmc (tools/gpu_pmc_papers.sh), not in this run
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_papers.json")))
+        r["traffic_committed_profile"] = {"source": "profiles/r05_pmc_papers.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the directed leg; NOT measured in this run)",
+                                          "hbm_side_bytes_per_pass": prof["reading"]["hbm_side_bytes_per_pass_GB"] * 1e9,
+                                          "algorithmic_bytes_per_pass": prof["reading"]["algorithmic_bytes_per_pass_GB"] * 1e9}
+    except Exception:
+        pass
     return r
 
 
