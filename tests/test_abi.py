@@ -61,3 +61,22 @@ def test_gpu_ops_refuse_cpu_tensors():
     colind = torch.tensor([0], dtype=torch.int32)
     with pytest.raises(_lib.BackendError):
         csrspmm(rowptr, colind, torch.ones(1, 4), torch.ones(1))
+
+
+def test_segments_struct_layout_matches_the_c_header(tmp_path):
+    """cogdl_hip_segments crosses the boundary by address: the ctypes mirror (cogdl_amd/_lib.py: Segments) must have the
+    layout the C compiler gives the header's struct (plain C: the header must also compile as C)."""
+    import subprocess
+
+    from cogdl_amd import _lib
+
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "cogdl_hip.h"\n#include "cogdl_host.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %d %lld\\n", sizeof(cogdl_hip_segments), offsetof(cogdl_hip_segments, row), '
+                   'offsetof(cogdl_hip_segments, edge), COGDL_HIP_MAX_SEGMENTS, (long long)COGDL_HIP_SEGMENT_MAX_EDGES); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    size, off_row, off_edge, max_seg, max_edges = (int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split())
+    assert size == ctypes.sizeof(_lib.Segments)
+    assert off_row == _lib.Segments.row.offset and off_edge == _lib.Segments.edge.offset
+    assert max_seg == _lib.MAX_SEGMENTS and max_edges == 2 ** 31 - 2 ** 20
