@@ -839,7 +839,7 @@ int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int
         const unsigned dgrid2 = (unsigned)(((t2max + kXcds - 1) / kXcds) * kXcds);
         hipLaunchKernelGGL((rt_downsweep_kernel<false, 2, true>), dim3(dgrid2), dim3(kThreads), 0, s, p);
         const unsigned cb = (unsigned)std::min<int64_t>((n_cols + 256) / 256, 1 << 20);
-        hipLaunchKernelGGL(rt_colptr_msd_kernel, dim3(cb), dim3(256), 0, s, p, (const uint32_t *)scanned, lbits, n_cols, colptr);
+        if (colptr) hipLaunchKernelGGL(rt_colptr_msd_kernel, dim3(cb), dim3(256), 0, s, p, (const uint32_t *)scanned, lbits, n_cols, colptr);
         return launch_status();
     }
     for (int pass = 0; pass < g.n_pass; ++pass) {
@@ -878,6 +878,7 @@ int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int
         }
     }
     const unsigned cb = (unsigned)std::min<int64_t>((n_cols + 256) / 256, 1 << 20);
+    if (!colptr) return launch_status();  // (a caller that only wants the stable order: the sampler's position sort)
     if (packed)
         hipLaunchKernelGGL(rt_colptr_perm_kernel, dim3(cb), dim3(256), 0, s, colind, perm, rowptr, m, padded ? 1 : 0, nnz,
                            n_cols, colptr);

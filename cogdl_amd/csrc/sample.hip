@@ -17,23 +17,30 @@
 //      its 16 k-position block; kernel `relabel` adds the block prefixes.  Four launches per call (three when Q fits one
 //      block) instead of the ~25 of the sort-based form -- a captured mini-batch step is bound by its count of dependent
 //      kernel nodes, not by their work.
-//      Round 1-2 form (tuning key 11 = 1, kept for A/B tests): stable radix sort of (node id, position in Q) (rocPRIM);
+//      Round 1-2 form (tuning key 11 = 1, kept for A/B tests and for frontiers beyond 6.7e7 positions): stable sort of the positions
+//      in Q by node id (rocPRIM's radix sort until round 5, this library's radix transpose of a one-row matrix since);
 //      the head of every run of equal ids is that node's first occurrence; an exclusive scan of the first-occurrence
 //      flags over Q gives the local ids; a running maximum over the sorted order hands every duplicate its head.
 // Integer work, latency bound at mini-batch sizes; int64 in and out like the reference.
 #include "common.h"
 
-#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
 
 namespace cogdl {
 
-// The fixed-capacity entry point must be capturable in a hipGraph at ANY size: rocPRIM switches from merge sort to
-// onesweep above 1 M keys, and onesweep clears its histograms / look-back state with hipMemsetAsync -- memset nodes that
-// were seen not to replay (common.h: fill_u32_async).  Padded mode keeps the merge sort at every size.
-using CapturableSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                        rocprim::default_config, (size_t)1 << 40>;
+// The sort of the round 1-2 form is this library's own since round 5 (transpose.hip: sort_positions_by_key = the radix
+// transpose of a one-row matrix; kernels only, so the fixed-capacity entry point stays capturable in a hipGraph at any
+// size -- rocPRIM's onesweep clears its state with hipMemsetAsync, memset nodes that were seen not to replay).
+size_t sort_positions_workspace_bytes(int64_t n_keys, int64_t len);
+int sort_positions_by_key(const uint32_t *keys, int64_t len, int64_t n_keys, int32_t *perm_out, void *workspace,
+                          size_t workspace_bytes, hipStream_t s);
+
+// skeys[j] = keys[spos[j]] (the sorted keys of the position sort)
+__global__ void sample_gather_keys_kernel(const uint32_t *__restrict__ keys, const int32_t *__restrict__ spos,
+                                          uint32_t *__restrict__ skeys, int64_t len) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < len; j += (int64_t)gridDim.x * blockDim.x)
+        skeys[j] = keys[spos[j]];
+}
 constexpr int kSampleMaxK = 1024;  // without replacement: chosen set of one seed lives in LDS
 
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -581,15 +588,9 @@ struct SampleWs {
 static SampleWs carve(void *base, int64_t batch, int64_t cap_edges, int64_t num_nodes) {
     const int64_t len = batch + cap_edges;
     SampleWs w{};
-    size_t sort_t = 0, scan_t = 0, scan64_t = 0, max_t = 0;
-    rocprim::counting_iterator<int32_t> iota(0);
-    (void)rocprim::radix_sort_pairs(nullptr, sort_t, (uint32_t *)nullptr, (uint32_t *)nullptr, iota, (int32_t *)nullptr,
-                                    (size_t)std::max<int64_t>(len, 1), 0u, sample_key_bits(num_nodes) + 1, nullptr);
-    size_t sort_m = 0;
-    (void)rocprim::radix_sort_pairs<CapturableSortConfig>(nullptr, sort_m, (uint32_t *)nullptr, (uint32_t *)nullptr, iota,
-                                                          (int32_t *)nullptr, (size_t)std::max<int64_t>(len, 1), 0u,
-                                                          sample_key_bits(num_nodes) + 1, nullptr);
-    sort_t = std::max(sort_t, sort_m);
+    size_t scan_t = 0, scan64_t = 0, max_t = 0;
+    // (keys are node ids < 2^bits plus the padding key 2^bits: 2^bits + 1 key values)
+    const size_t sort_t = sort_positions_workspace_bytes(((int64_t)1 << sample_key_bits(num_nodes)) + 1, std::max<int64_t>(len, 1));
     (void)rocprim::exclusive_scan(nullptr, scan_t, (int32_t *)nullptr, (int32_t *)nullptr, int32_t(0),
                                   (size_t)std::max<int64_t>(len, 1), rocprim::plus<int32_t>(), nullptr);
     (void)rocprim::exclusive_scan(nullptr, scan64_t, (int32_t *)nullptr, (int64_t *)nullptr, int64_t(0),
@@ -724,13 +725,12 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
     if (cap_edges > 0)
         hipLaunchKernelGGL(sample_pad_kernel, dim3((unsigned)std::min<int64_t>((cap_edges + 255) / 256, 1024)), dim3(256), 0, s,
                            out_indptr, batch, cap_edges, w.keys, pad_key, padded, out_indices, out_edges);
-    rocprim::counting_iterator<int32_t> iota(0);
-    tb = w.temp_bytes;
-    e = padded ? rocprim::radix_sort_pairs<CapturableSortConfig>(w.temp, tb, w.keys, w.skeys, iota, w.spos, (size_t)len, 0u,
-                                                                 sample_key_bits(num_nodes) + 1, s)
-               : rocprim::radix_sort_pairs(w.temp, tb, w.keys, w.skeys, iota, w.spos, (size_t)len, 0u,
-                                           sample_key_bits(num_nodes) + 1, s);
-    if (e != hipSuccess) return fail(e);
+    {
+        const int rc = sort_positions_by_key(w.keys, len, ((int64_t)1 << sample_key_bits(num_nodes)) + 1, w.spos, w.temp, w.temp_bytes, s);
+        if (rc != COGDL_HIP_OK) return rc;
+        hipLaunchKernelGGL(sample_gather_keys_kernel, dim3((unsigned)std::min<int64_t>((len + 255) / 256, 1 << 16)), dim3(256), 0, s,
+                           w.keys, w.spos, w.skeys, len);
+    }
     const unsigned blocks = (unsigned)((len + 255) / 256);
     hipLaunchKernelGGL(sample_mark_kernel, dim3(blocks), dim3(256), 0, s, w.skeys, w.spos, len, pad_key, w.first, w.head);
     tb = w.temp_bytes;

@@ -209,6 +209,45 @@ extern "C" int cogdl_hip_csr_fingerprint(const int32_t *rowptr, const int32_t *c
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Stable sort of POSITIONS by a 32-bit key (keys[i] < n_keys): perm_out[j] = the position holding the j-th smallest key, equal
+// keys in ascending position -- the transpose of a one-row matrix without its colptr.  For the sampler's sort-based
+// relabelling (sample.hip), which used rocPRIM's radix sort until round 5.  Workspace: rowptr2 | rowind (unused payload) |
+// colptr (only for the single-workgroup kernel, which always writes it) | the transpose's own scratch.
+namespace cogdl {
+size_t sort_positions_workspace_bytes(int64_t n_keys, int64_t len) {
+    if (len <= 0) return 256;
+    size_t o = 256 + align_up((size_t)len * sizeof(int32_t), 256);
+    if (small_transpose_covers(1, n_keys, len)) o += align_up((size_t)(n_keys + 1) * sizeof(int32_t), 256);
+    return o + align_up(radix_transpose_workspace_bytes(n_keys, len, false), 256);
+}
+
+namespace {
+__global__ void one_row_rowptr_kernel2(int32_t *rowptr2, int32_t nnz) {
+    rowptr2[0] = 0;
+    rowptr2[1] = nnz;
+}
+}  // namespace
+
+int sort_positions_by_key(const uint32_t *keys, int64_t len, int64_t n_keys, int32_t *perm_out, void *workspace,
+                          size_t workspace_bytes, hipStream_t s) {
+    if (len <= 0) return COGDL_HIP_OK;
+    if (!keys || !perm_out || !workspace) return COGDL_HIP_EINVAL;
+    if (len > COGDL_HIP_SEGMENT_MAX_EDGES || n_keys >= 0x7fffffff) return COGDL_HIP_ERANGE;
+    if (workspace_bytes < sort_positions_workspace_bytes(n_keys, len)) return COGDL_HIP_EWORKSPACE;
+    char *ws = (char *)workspace;
+    int32_t *rowptr2 = (int32_t *)ws;
+    int32_t *rowind = (int32_t *)(ws + 256);
+    char *rest = ws + 256 + align_up((size_t)len * sizeof(int32_t), 256);
+    hipLaunchKernelGGL(one_row_rowptr_kernel2, dim3(1), dim3(1), 0, s, rowptr2, (int32_t)len);
+    if (g_tuning[kTuneCsr2csc] < 2 && small_transpose_covers(1, n_keys, len)) {
+        int32_t *colptr = (int32_t *)rest;
+        return small_transpose(rowptr2, (const int32_t *)keys, 1, n_keys, len, false, colptr, rowind, perm_out, s);
+    }
+    if (small_transpose_covers(1, n_keys, len)) rest += align_up((size_t)(n_keys + 1) * sizeof(int32_t), 256);
+    return radix_transpose(rowptr2, (const int32_t *)keys, 1, n_keys, len, false, nullptr, rowind, perm_out, rest, s);
+}
+}  // namespace cogdl
+
 // coo2csr_index: the edges as ONE row of a [1 x num_nodes] matrix whose column ids are the source rows -- its stable
 // transpose has colptr = row_ptr and perm = the stable order.  Workspace: keys | rowptr2 | colptr32 | rowind (unused
 // payload) | perm32 | the transpose's own scratch.
