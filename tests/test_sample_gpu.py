@@ -21,7 +21,7 @@ def T(a):
 @pytest.fixture(autouse=True, params=[0, 1], ids=["relabel-hash", "relabel-sort"])
 def relabel_algo(request):
     """Both relabelling forms of csrc/sample.hip (tuning key 11): the hash table of first positions (default, 3-4
-    launches) and the rocPRIM sort-based pipeline of rounds 1-2 (~25 launches)."""
+    launches) and the sort-based pipeline of rounds 1-2 (~25 launches; its sort is the library's radix transpose since round 5, rocPRIM's before)."""
     from cogdl_amd import _lib
 
     _lib.hip().cogdl_hip_set_tuning(11, request.param)
