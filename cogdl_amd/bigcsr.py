@@ -141,10 +141,13 @@ class BigCsr:
             return t, gather_rows_i64(perm, w.detach())
         key = tensor_key(w)
         if key != self._val_key or self._val_src is None:
-            if perm is None:  # a different constant weight tensor: transposed again with its values fused
-                _, _, val_t = self.transpose(w.detach(), keep_perm=False)
-            else:
-                val_t = gather_rows_i64(perm, w.detach())
+            if perm is None:
+                # a SECOND constant weight tensor on this structure (a caller that re-creates its weights per call, e.g. the
+                # dispatcher's `csr_data.half()` under fp16): build the permutation once and gather from now on, instead
+                # of transposing the structure again for every new tensor
+                t, perm, _ = self.transpose(None, keep_perm=True)
+                self._transposed = (t, perm)
+            val_t = gather_rows_i64(perm, w.detach())
             self._val_key, self._val_src, self._val_t = key, w.detach(), val_t
         return t, self._val_t
 

@@ -126,6 +126,16 @@ def test_autograd_through_csrspmm_int64(oracle):
 
         plan = plan_of(rowptr64, colind, g.n_cols)
         assert plan.n_segments > 5 and plan._transposed[1] is None  # constant weights: fused into the transpose, no perm kept
+        # a fresh (equal) constant weight tensor per call, as the dispatcher's csr_data.half() makes: the permutation is built
+        # ONCE and reused -- no second transpose per new tensor
+        for _ in range(2):
+            xd.grad = None
+            csrspmm(rowptr64, colind, xd, g.weight.to(DEV), True).backward(gout.to(DEV))
+            assert xd.grad.cpu().numpy().tobytes() == oracle.csr_spmm(colptr, rowind, w_t, gout).tobytes()
+        t_first = plan._transposed[0]
+        assert plan._transposed[1] is not None
+        csrspmm(rowptr64, colind, xd, g.weight.to(DEV), True).backward(gout.to(DEV))
+        assert plan._transposed[0] is t_first
         # learned weights: perm is built, grad_w from the segmented sddmm
         wd = g.weight.to(DEV).requires_grad_()
         xd.grad = None
