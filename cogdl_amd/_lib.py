@@ -116,6 +116,7 @@ HOST_SIGNATURES = {
     "cogdl_host_sample_adj_mt": ([_vp, _vp, _i64, _vp, _i64, _i64, _i32, _u64] + [_vp] * 4 + [_i64, _i64, _vp, _i32], _i32),
     "cogdl_host_subgraph": ([_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp], _i32),
     "cogdl_host_csr_spmm_f32": ([_vp] * 5 + [_i64, _i64, _i32], _i32),
+    "cogdl_host_csr_spmm_f32_i64": ([_vp] * 5 + [_i64, _i64, _i32], _i32),
 }
 
 EUNSUPPORTED = 7  # COGDL_HIP_EUNSUPPORTED

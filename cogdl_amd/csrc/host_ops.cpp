@@ -112,17 +112,20 @@ constexpr int kColBlock = 64;  // floats a row's accumulator holds in registers 
 // a store-forwarding chain per column); the gathered rows are random 4k-byte reads out of a matrix far larger than the
 // caches, so the row kPrefetchAhead edges ahead (across row boundaries: colind is one array) is requested on the first
 // column block's pass.
-__attribute__((target_clones("avx2", "default"))) void spmm_rows(const int32_t *rowptr, const int32_t *colind,
-                                                                  const float *val, const float *dense, float *out,
-                                                                  int64_t r0, int64_t r1, int64_t k, int64_t nnz_total) {
+// P = the row pointer type: int32 (what CogDL passes) or int64 (graphs of 2^31 edges and more; the reference's `int` loop,
+// spmm_cpu.cpp:24-33, overflows there -- and at i * k >= 2^31 already)
+template <typename P>
+static inline __attribute__((always_inline)) void spmm_rows_body(const P *rowptr, const int32_t *colind, const float *val,
+                                                                  const float *dense, float *out, int64_t r0, int64_t r1,
+                                                                  int64_t k, int64_t nnz_total) {
     const int64_t k_blocked = k / kColBlock * kColBlock;
     for (int64_t i = r0; i < r1; ++i) {
         float *__restrict__ o = out + i * k;
-        const int32_t e0 = rowptr[i], e1 = rowptr[i + 1];
+        const P e0 = rowptr[i], e1 = rowptr[i + 1];
         for (int64_t cb = 0; cb < k_blocked; cb += kColBlock) {
             float acc[kColBlock];
             for (int t = 0; t < kColBlock; ++t) acc[t] = 0.f;
-            for (int32_t e = e0; e < e1; ++e) {
+            for (P e = e0; e < e1; ++e) {
                 const float *__restrict__ b = dense + (int64_t)colind[e] * k + cb;
                 if (cb == 0 && e + kPrefetchAhead < nnz_total) {
                     const char *nb = (const char *)(dense + (int64_t)colind[e + kPrefetchAhead] * k);
@@ -139,7 +142,7 @@ __attribute__((target_clones("avx2", "default"))) void spmm_rows(const int32_t *
         }
         if (k_blocked < k) {  // the last k % kColBlock columns: the plain loop
             for (int64_t t = k_blocked; t < k; ++t) o[t] = 0.f;
-            for (int32_t e = e0; e < e1; ++e) {
+            for (P e = e0; e < e1; ++e) {
                 const float *__restrict__ b = dense + (int64_t)colind[e] * k;
                 if (k_blocked == 0 && e + kPrefetchAhead < nnz_total) {
                     const char *nb = (const char *)(dense + (int64_t)colind[e + kPrefetchAhead] * k);
@@ -154,6 +157,51 @@ __attribute__((target_clones("avx2", "default"))) void spmm_rows(const int32_t *
             }
         }
     }
+}
+
+__attribute__((target_clones("avx2", "default"))) void spmm_rows(const int32_t *rowptr, const int32_t *colind,
+                                                                  const float *val, const float *dense, float *out,
+                                                                  int64_t r0, int64_t r1, int64_t k, int64_t nnz_total) {
+    spmm_rows_body<int32_t>(rowptr, colind, val, dense, out, r0, r1, k, nnz_total);
+}
+__attribute__((target_clones("avx2", "default"))) void spmm_rows64(const int64_t *rowptr, const int32_t *colind,
+                                                                    const float *val, const float *dense, float *out,
+                                                                    int64_t r0, int64_t r1, int64_t k, int64_t nnz_total) {
+    spmm_rows_body<int64_t>(rowptr, colind, val, dense, out, r0, r1, k, nnz_total);
+}
+
+// rows split over the threads at equal (edges + rows) boundaries
+template <typename P, typename F>
+int spmm_threads(const P *rowptr, const int32_t *colind, const float *val, const float *dense, float *out, int64_t m,
+                 int64_t k, int nthreads, F rows_fn) {
+    if (m < 0 || k < 0) return COGDL_HOST_EINVAL;
+    if (m == 0 || k == 0) return COGDL_HOST_OK;
+    if (!rowptr || !dense || !out) return COGDL_HOST_EINVAL;
+    const int64_t nnz = rowptr[m];
+    if (nthreads < 1) nthreads = 1;
+    // a thread per ~64k edge-columns of work at most
+    const int64_t work = (nnz + m) * k;
+    int t = (int)std::min<int64_t>(nthreads, std::max<int64_t>(1, work / (1 << 16)));
+    if (t <= 1) {
+        rows_fn(rowptr, colind, val, dense, out, 0, m, k, nnz);
+        return COGDL_HOST_OK;
+    }
+    std::vector<int64_t> cut((size_t)t + 1, 0);
+    cut[(size_t)t] = m;
+    for (int i = 1; i < t; ++i) {
+        const int64_t target = (nnz + m) * i / t;  // balance edges + rows
+        int64_t lo = 0, hi = m;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) / 2;
+            if ((int64_t)rowptr[mid] + mid < target) lo = mid + 1; else hi = mid;
+        }
+        cut[(size_t)i] = std::max(lo, cut[(size_t)i - 1]);
+    }
+    std::vector<std::thread> pool;
+    for (int i = 0; i < t; ++i)
+        pool.emplace_back(rows_fn, rowptr, colind, val, dense, out, cut[(size_t)i], cut[(size_t)i + 1], k, nnz);
+    for (auto &th : pool) th.join();
+    return COGDL_HOST_OK;
 }
 
 }  // namespace
@@ -355,34 +403,12 @@ int cogdl_host_subgraph(const int64_t *indptr, const int64_t *indices, int64_t n
 
 int cogdl_host_csr_spmm_f32(const int32_t *rowptr, const int32_t *colind, const float *val, const float *dense,
                             float *out, int64_t m, int64_t k, int nthreads) {
-    if (m < 0 || k < 0) return COGDL_HOST_EINVAL;
-    if (m == 0 || k == 0) return COGDL_HOST_OK;
-    if (!rowptr || !dense || !out) return COGDL_HOST_EINVAL;
-    const int64_t nnz = rowptr[m];
-    if (nthreads < 1) nthreads = 1;
-    // a thread per ~64k edge-columns of work at most; rows split at equal-nnz boundaries
-    const int64_t work = (nnz + m) * k;
-    int t = (int)std::min<int64_t>(nthreads, std::max<int64_t>(1, work / (1 << 16)));
-    if (t <= 1) {
-        spmm_rows(rowptr, colind, val, dense, out, 0, m, k, nnz);
-        return COGDL_HOST_OK;
-    }
-    std::vector<int64_t> cut((size_t)t + 1, 0);
-    cut[(size_t)t] = m;
-    for (int i = 1; i < t; ++i) {
-        const int64_t target = (nnz + m) * i / t;  // balance edges + rows
-        int64_t lo = 0, hi = m;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) / 2;
-            if ((int64_t)rowptr[mid] + mid < target) lo = mid + 1; else hi = mid;
-        }
-        cut[(size_t)i] = std::max(lo, cut[(size_t)i - 1]);
-    }
-    std::vector<std::thread> pool;
-    for (int i = 0; i < t; ++i)
-        pool.emplace_back(spmm_rows, rowptr, colind, val, dense, out, cut[(size_t)i], cut[(size_t)i + 1], k, nnz);
-    for (auto &th : pool) th.join();
-    return COGDL_HOST_OK;
+    return spmm_threads(rowptr, colind, val, dense, out, m, k, nthreads, spmm_rows);
+}
+
+int cogdl_host_csr_spmm_f32_i64(const int64_t *rowptr, const int32_t *colind, const float *val, const float *dense,
+                                float *out, int64_t m, int64_t k, int nthreads) {
+    return spmm_threads(rowptr, colind, val, dense, out, m, k, nthreads, spmm_rows64);
 }
 
 }  // extern "C"

@@ -257,14 +257,15 @@ def spmm_cpu(rowptr, colind, csr_data, x):
     for name, t in (("rowptr", rowptr), ("colind", colind), ("csr_data", csr_data), ("x", x)):
         if t is not None and t.device.type != "cpu":
             raise _lib.BackendError("spmm_cpu: %s must be a CPU tensor" % name)
-    if rowptr.dtype != torch.int32 or colind.dtype != torch.int32 or x.dtype != torch.float32:
-        raise _lib.BackendError("spmm_cpu expects int32 indices and float32 features")
+    if rowptr.dtype not in (torch.int32, torch.int64) or colind.dtype != torch.int32 or x.dtype != torch.float32:
+        raise _lib.BackendError("spmm_cpu expects int32 (or int64 row pointer) indices and float32 features")
     rowptr, colind, x = rowptr.contiguous(), colind.contiguous(), x.contiguous()
     val = None if csr_data is None else csr_data.contiguous().float()
     m, k = rowptr.numel() - 1, x.shape[1]
     out = torch.empty((m, k), dtype=torch.float32)
     nthreads = int(os.environ.get("COGDL_AMD_CPU_THREADS", torch.get_num_threads()))
-    rc = _lib.host().cogdl_host_csr_spmm_f32(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(val), _lib.ptr(x),
-                                             _lib.ptr(out), m, k, nthreads)
+    # (an int64 row pointer = a graph of 2^31 edges and more, which the reference's `int` loop cannot walk)
+    fn = _lib.host().cogdl_host_csr_spmm_f32 if rowptr.dtype == torch.int32 else _lib.host().cogdl_host_csr_spmm_f32_i64
+    rc = fn(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(val), _lib.ptr(x), _lib.ptr(out), m, k, nthreads)
     _lib.check_host(rc, "csr_spmm_cpu")
     return out

@@ -82,6 +82,10 @@ COGDL_HOST_API int cogdl_host_subgraph(const int64_t *indptr, const int64_t *ind
  * with fp32 multiply then add (bit-identical to the reference).  int32 indices, 64-bit offsets. */
 COGDL_HOST_API int cogdl_host_csr_spmm_f32(const int32_t *rowptr, const int32_t *colind, const float *val,
                                            const float *dense, float *out, int64_t m, int64_t k, int nthreads);
+/* The same with int64 row pointers: graphs of 2^31 edges and more on the host (the reference's `int key` / `int ik = i * k`
+ * loop, spmm_cpu.cpp:24-33, overflows at 2^31 edges and already at 16.7 M rows x 128 columns).  Same arithmetic. */
+COGDL_HOST_API int cogdl_host_csr_spmm_f32_i64(const int64_t *rowptr, const int32_t *colind, const float *val,
+                                               const float *dense, float *out, int64_t m, int64_t k, int nthreads);
 
 #ifdef __cplusplus
 }

@@ -138,3 +138,6 @@ def test_spmm_cpu_column_blocks_keep_the_reference_arithmetic(oracle, k, weighte
     for threads in ("1", "5"):
         monkeypatch.setenv("COGDL_AMD_CPU_THREADS", threads)
         assert spmm_cpu(g.rowptr, g.colind, w, x).numpy().tobytes() == want
+        # int64 row pointers (cogdl_host_csr_spmm_f32_i64: graphs of 2^31 edges and more, where the reference's `int` loop
+        # -- spmm_cpu.cpp:24-33 -- overflows): the same arithmetic
+        assert spmm_cpu(g.rowptr.long(), g.colind, w, x).numpy().tobytes() == want
