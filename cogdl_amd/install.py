@@ -37,7 +37,7 @@ _finder = None
 
 
 def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False, fused_gat_dropout=False, structure_memo=False,
-            metis=False):
+            metis=False, big_graphs=False):
     """Idempotent.  Returns the list of cogdl module names that are now served by cogdl_amd.
     fused_norm=True rebinds the dispatcher function `cogdl.utils.spmm_utils.spmm` itself (opt-in: that is no longer the
     unchanged dispatcher) to cogdl_amd.fused.spmm, which folds `out_norm * x` / `in_norm * x` into the kernel.
@@ -53,6 +53,8 @@ def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False, f
     structure_memo=True rebinds the two properties Graph.row_indptr / Graph.col_indices (opt-in, same caveat) so that the
     `.int()` copies the dispatcher makes on every call, and the content hash this library takes of them, happen once per
     structure (cogdl_amd/structure_memo.py).
+    big_graphs=True rebinds the dispatcher function `spmm` (opt-in, like fused_norm) to cogdl_amd.big_dispatch's front: GPU
+    graphs of 2^31 edges and more keep their int64 row pointer on the way to csrspmm (the reference's `.int()` wraps there).
     metis=True registers cogdl_amd.metis_compat as the module `metis` when the real package cannot be imported, so that
     ClusteredDataset / ClusteredLoader (cogdl/data/sampler.py:188-262) partition on the GPU instead of exiting.
     linear=True additionally routes torch.nn.functional.linear -- i.e. the unchanged nn.Linear inside every CogDL
@@ -94,6 +96,12 @@ def install(linear=False, fused_gat=True, fused_norm=False, narrow_side=False, f
         _import_target("cogdl.layers.gat_layer", "fused_gat_dropout")  # (the finder above already serves cogdl.operators.*)
         if not _fused.install_gat_dropout():
             raise _lib_error("install(fused_gat_dropout=True): GATLayer.forward could not be rebound")
+    if big_graphs:
+        from . import big_dispatch as _big
+
+        _import_target("cogdl.utils.spmm_utils", "big_graphs")
+        if not _big.install():
+            raise _lib_error("install(big_graphs=True): cogdl.utils.spmm_utils.spmm could not be rebound")
     if structure_memo:
         from . import structure_memo as _memo
 
@@ -161,6 +169,8 @@ def _rebind_graph_build():
 
 
 def uninstall():
+    if "cogdl_amd.big_dispatch" in sys.modules:
+        sys.modules["cogdl_amd.big_dispatch"].uninstall()
     if "cogdl_amd.structure_memo" in sys.modules:
         sys.modules["cogdl_amd.structure_memo"].uninstall()
     if "cogdl_amd.linear" in sys.modules:

@@ -1,0 +1,101 @@
+"""install(big_graphs=True): the unchanged reference GCNLayer / Trainer on a Graph whose aggregation goes through the 64-bit
+CSR path (cogdl_amd/big_dispatch.py -> csrspmm with the int64 row pointer -> cogdl_amd/bigcsr.py).  A graph of 2^31 edges
+inside a cogdl.data.Graph (edge_index alone would be 51 GB) is not something a test builds: the size threshold is lowered
+to 1 edge and the segment size to 200 edges, so that an ordinary graph takes exactly the code a 3.2e9-edge graph would --
+the full-size run of the operators themselves is tests/test_config5_full_gpu.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools import refpkg  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+SCRIPT = r'''
+import json, os, sys
+import numpy as np
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT)
+from tools import refpkg
+refpkg.setup(install=True)
+import torch
+import cogdl, cogdl_amd
+from cogdl.data import Graph
+from cogdl.layers import GCNLayer
+from cogdl.utils import spmm_utils
+from cogdl_amd import _lib, big_dispatch, bigcsr
+
+DEV = "cuda:0"
+GOLD = os.path.join(ROOT, "tests", "golden")
+z = dict(np.load(os.path.join(GOLD, "gcn_layer.npz")))
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+rp = T(z["row_indptr"]); deg = rp[1:] - rp[:-1]
+row, col = torch.repeat_interleave(torch.arange(deg.numel()), deg), T(z["col_indices"])
+g = Graph(edge_index=(row, col), edge_weight=T(z["edge_weight"]), num_nodes=row.max().item() + 1).to(DEV)
+layer = GCNLayer(32, 16).to(DEV)
+with torch.no_grad():
+    layer.linear.weight.copy_(T(z["W"])); layer.linear.bias.copy_(T(z["b"]))
+
+def run():
+    layer.zero_grad()
+    x = T(z["x"]).to(DEV).requires_grad_()
+    out = layer(g, x)
+    (out * T(z["G"]).to(DEV)).sum().backward()
+    return [t.detach().cpu().numpy() for t in (out, x.grad, layer.linear.weight.grad, layer.linear.bias.grad)]
+
+plain = run()                       # the unchanged dispatcher: int32 path
+cogdl_amd.install(big_graphs=True)
+import cogdl.layers.gcn_layer as gl
+assert getattr(spmm_utils.spmm, "_cogdl_amd_big", False) and getattr(gl.spmm, "_cogdl_amd_big", False)
+assert run()[0].tobytes() == plain[0].tobytes()   # below the threshold: forwarded to the reference's function
+calls = {"big": 0}
+_spmm = bigcsr.BigCsr.spmm
+def counted(self, *a, **k):
+    calls["big"] += 1
+    calls["segments"] = self.n_segments
+    return _spmm(self, *a, **k)
+bigcsr.BigCsr.spmm = counted
+big_dispatch.BIG_EDGES = 1
+_lib.hip().cogdl_hip_set_tuning(15, 200)
+big = run()
+assert calls["big"] >= 2 and calls["segments"] >= 2, calls     # forward and backward went through the segmented kernels
+for a, b, name in zip(big, plain, ("out", "grad_x", "grad_W", "grad_b")):
+    np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6, err_msg=name)
+np.testing.assert_allclose(big[0], z["out_train"], rtol=1e-4, atol=1e-5)      # the reference's own CPU output
+np.testing.assert_allclose(big[1], z["grad_x"], rtol=1e-4, atol=1e-5)
+c1 = big_dispatch._colind32(g); assert big_dispatch._colind32(g) is c1          # one int32 copy per structure
+# fp16 through the same front (the dispatcher halves the weights per call: the plan builds its permutation once)
+with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+    oh = layer(g, T(z["x"]).to(DEV))
+assert oh.dtype == torch.float16
+np.testing.assert_allclose(oh.float().cpu().numpy(), z["out_train"], rtol=5e-2, atol=5e-2)
+# the reference Trainer end to end on the 64-bit path
+before = calls["big"]
+ds = refpkg.cora_like(seed=0)
+res, ms = refpkg.run_experiment(ds, model="gcn", epochs=4, cpu=False, seed=0)
+assert calls["big"] - before >= 4 * 4, calls
+losses_big = res["train_losses"]
+big_dispatch.BIG_EDGES = 2 ** 31 - 2 ** 20
+res2, _ = refpkg.run_experiment(refpkg.cora_like(seed=0), model="gcn", epochs=4, cpu=False, seed=0)
+_lib.hip().cogdl_hip_set_tuning(15, 0)
+cogdl_amd.uninstall()
+print("RESULT " + json.dumps({"losses_big": losses_big, "losses_plain": res2["train_losses"], "calls": calls}))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(refpkg.STAGED, "cogdl")),
+                    reason="staged reference package absent (make -C oracle ref in the build container)")
+def test_unchanged_reference_layer_and_trainer_on_the_64_bit_path():
+    proc = subprocess.run([sys.executable, "-c", SCRIPT, ROOT], capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert proc.returncode == 0 and lines, proc.stdout[-3000:] + proc.stderr[-5000:]
+    rep = json.loads(lines[-1][7:])
+    lb, lp = rep["losses_big"], rep["losses_plain"]
+    assert len(lb) == len(lp) == 4
+    for a, b in zip(lb, lp):  # same seeds, same dropout stream, same per-row arithmetic: the same trajectory
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (lb, lp)

@@ -148,6 +148,21 @@ for fin, fout in ((8, 32), (32, 8), (16, 16)):
     assert torch.allclose(xT.grad, xN.grad, rtol=1e-4, atol=1e-5), (fin, fout)
     for pa, pb in zip(twin.parameters(), layer.parameters()):
         assert torch.allclose(pa.grad, pb.grad, rtol=1e-4, atol=1e-5), (fin, fout)
+# 10. install(big_graphs=True): the 64-bit front of the dispatcher is in place everywhere `spmm` is held by name; CPU tensors
+#     (and GPU graphs below 2^31 edges) are forwarded to the reference's own function, bit for bit; uninstall restores it
+cogdl_amd.install(big_graphs=True)
+import cogdl_amd.big_dispatch as big_dispatch
+import cogdl.layers.gcn_layer as gcn_mod
+assert getattr(spmm_utils.spmm, "_cogdl_amd_big", False) and getattr(gcn_mod.spmm, "_cogdl_amd_big", False)
+with torch.no_grad():
+    y3 = spmm_utils.spmm(g, x.detach())
+assert torch.equal(y3, y)
+big_dispatch.BIG_EDGES = 1                                    # even "big" CPU graphs stay on the reference's path
+with torch.no_grad():
+    assert torch.equal(spmm_utils.spmm(g, x.detach()), y)
+big_dispatch.BIG_EDGES = 2 ** 31 - 2 ** 20
+big_dispatch.uninstall()
+assert not getattr(spmm_utils.spmm, "_cogdl_amd_big", False) and not getattr(gcn_mod.spmm, "_cogdl_amd_big", False)
 shutil.rmtree(scratch, ignore_errors=True)
 print("INSTALL-OK", served)
 '''
