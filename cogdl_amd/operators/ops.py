@@ -244,8 +244,11 @@ class _SrcOpEdgeAggr(torch.autograd.Function):
                 g_e = torch.empty((e, 1) if ef_scalar else (e, k), dtype=torch.float32, device=dev)
             if need_w:
                 g_w = torch.empty(e, dtype=torch.float32, device=dev)
+            # (bound to locals: a temporary copy of a strided row / col would go back to the caching allocator as soon as its
+            #  address is taken, and the second copy would most likely reuse the first one's block before the launch)
+            row_c, col_c = row.contiguous(), col.contiguous()
             with _lib.on_device(dev):
-                rc = _lib.hip().cogdl_hip_gspmm_edge_grad(_lib.ptr(row.contiguous()), _lib.ptr(col.contiguous()), _lib.ptr(grad), _lib.ptr(scale),
+                rc = _lib.hip().cogdl_hip_gspmm_edge_grad(_lib.ptr(row_c), _lib.ptr(col_c), _lib.ptr(grad), _lib.ptr(scale),
                                                           _lib.ptr(weight), _lib.ptr(n_feat), _lib.ptr(e_feat), int(ef_scalar),
                                                           op, _lib.ptr(g_e), _lib.ptr(g_w), e, k, _lib.stream_of(grad))
             _lib.check(rc, "gspmm_edge_grad")

@@ -184,6 +184,33 @@ def test_gradcheck_like_against_torch_composition():
             assert torch.allclose(a.grad, b.grad, rtol=1e-4, atol=1e-5), op1
 
 
+def test_backward_with_strided_row_and_col_of_an_edge_list():
+    """Regression: row = ei[:, 0], col = ei[:, 1] of an [E, 2] edge list are both NON-contiguous.
+    The backward's per-edge kernel used to take the address of two temporary `.contiguous()` copies; the second copy
+    reused the block the first had just given back, so the kernel read the source ids as destinations.  Gradients must
+    equal those of the same call on contiguous index tensors, bit for bit."""
+    n, e, k = 700, 9000, 24
+    row, col = _coo(n, e, seed=21)
+    ei = torch.stack([row, col], dim=1).to(DEV)  # [E, 2]: both columns have stride 2
+    r_s, c_s = ei[:, 0], ei[:, 1]
+    assert not r_s.is_contiguous() and not c_s.is_contiguous()
+    r_c, c_c = r_s.contiguous(), c_s.contiguous()
+    gen = torch.Generator().manual_seed(8)
+    x0, e0, w0 = (torch.randn(n, k, generator=gen).to(DEV), torch.randn(e, k, generator=gen).to(DEV),
+                  torch.rand(e, generator=gen).to(DEV))
+    G = torch.randn(n, k, generator=gen).to(DEV)
+    for op1 in ("add", "mul"):
+        grads = []
+        for r, c in ((r_c, c_c), (r_s, c_s)):
+            ops.clear_plans()
+            xa, ea, wa = (t.clone().requires_grad_() for t in (x0, e0, w0))
+            torch.cuda.empty_cache()
+            (ops.src_op_e_aggr_coo(op1, "sum", xa, ea, r, c, data=wa) * G).sum().backward()
+            grads.append((xa.grad, ea.grad, wa.grad))
+        for a, b in zip(*grads):
+            assert torch.equal(a, b), op1
+
+
 def test_fresh_source_ids_on_a_fixed_destination_list(oracle):
     """Regression (ADVICE medium): `col` resampled every step against a persistent `row` tensor (negative sampling).
     Each step's `col` dies with its frame and the allocator recycles its address for the next one; the plan's sorted
