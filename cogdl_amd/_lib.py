@@ -30,6 +30,12 @@ HIP_SIGNATURES = {
     "cogdl_hip_exact_row_edges": ([_i64], _i32),
     "cogdl_hip_csr_spmm": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_csr_spmm_acc": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
+    "cogdl_hip_csr_spmm_xcd_workspace_bytes": ([_i64, _i64, _i32], _sz),
+    "cogdl_hip_csr_spmm_xcd": ([_vp] * 4 + [_i64, _i64, _i32, _i32, _vp, _sz, _vp], _i32),
+    "cogdl_hip_gat_fwd_xcd_workspace_bytes": ([_i64, _i64, _i64, _i32], _sz),
+    "cogdl_hip_gat_fwd_xcd": ([_vp] * 4 + [_f32, _f32, _u64] + [_vp] * 3 + [_i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),
+    "cogdl_hip_gat_bwd_xcd_workspace_bytes": ([_i64, _i64, _i64, _i64, _i64, _i32], _sz),
+    "cogdl_hip_gat_bwd_xcd": ([_vp] * 5 + [_f32, _f32, _u64] + [_vp] * 8 + [_sz, _i64, _i64, _i64, _i64, _i32, _vp], _i32),
     "cogdl_hip_csr_spmm_variant": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_csr_spmm_epilogue": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _sz, _vp], _i32),
     "cogdl_hip_csr2csc_workspace_bytes": ([_i64, _i64, _i64], _sz),

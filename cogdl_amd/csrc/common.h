@@ -128,6 +128,26 @@ __device__ __forceinline__ void store_vec(T *p, const float (&src)[VEC]) {
     *reinterpret_cast<Raw *>(p) = u.raw;
 }
 
+// Address of the lane's piece of row `col` of a row-major table: table + col * row_bytes + lane_elems elements.
+//   A24 = false   ONE v_mad_u64_u32 (unsigned 32 x 32 -> 64 multiply with the lane's 64-bit base as addend) where
+//                 `base + (int64_t)col * k` in ELEMENTS compiles to a signed 64-bit multiply-add plus a 64-bit shift-add: two
+//                 multi-cycle vector instructions per gather in kernels bound by VALU issue on hub-heavy graphs (round 6).
+//                 col >= 0, row_bytes < 2^32.
+//   A24 = true    tables of < 2^24 rows of < 2^24 bytes, < 4 GiB in all (what an XCD-partitioned plan is built for,
+//                 cogdl_amd/xcdplan.py: wanted()): a 32-bit byte offset from ONE full-rate v_mad_u32_u24 (col * row_bytes +
+//                 the lane's own offset), added to the table's UNIFORM base by the load itself (global_load ... v_off, s[base]).
+//                 v_mad_u64_u32 is a quarter-rate instruction; the fused GAT kernels issue two gathers per edge.
+template <bool A24, typename T>
+__device__ __forceinline__ const T *gather_row(const T *table, int lane_elems, int col, uint32_t row_bytes) {
+    if constexpr (A24) {
+        const uint32_t off = __umul24((uint32_t)col, row_bytes) + (uint32_t)lane_elems * (uint32_t)sizeof(T);
+        return reinterpret_cast<const T *>(reinterpret_cast<const char *>(table) + off);
+    } else {
+        return reinterpret_cast<const T *>(reinterpret_cast<const char *>(table + lane_elems) +
+                                           (uint64_t)(uint32_t)col * (uint64_t)row_bytes);
+    }
+}
+
 // Butterfly reductions inside an aligned group of WIDTH lanes (WIDTH power of two <= 64).
 template <int WIDTH>
 __device__ __forceinline__ float group_sum(float v) {

@@ -6,13 +6,13 @@ thread_local int g_last_hip_error = 0;
 int g_tuning[kTuneCount] = {/*0: xcd stripe*/ 32, /*1: long-row threshold override (0 = automatic)*/ 0, /*2: 1 = no degree-sorted row assignment inside a workgroup*/ 0,
                             /*3: max long-row workgroups*/ 1024, /*4: fused-GAT vector cap*/ 0,
                             /*5: fused-GAT forward kernel*/ 0, /*6: spmm vector cap (<0: force)*/ 0, /*7: edge_softmax scalar lanes only*/ 0, /*8: edge_softmax flat kernel: polls before a wait gives up (0 = default)*/ 0, /*9: edge_softmax flat kernel experiments: bit 0 = no cross-tile exchange (WRONG results, timing only), bit 2 = 16-bit values in half-size tiles at 6 workgroups per CU, bit 3 = forward recomputes the exponential instead of keeping it in registers*/ 0,
-                            /*10: csr2csc: 0 = automatic (one single-workgroup launch up to 16 k slots, the radix sort above), 1 = as 0 (the rocPRIM pipeline of rounds 1-4 is gone), 2 = the radix sort at every size, 3 = radix, packed records at any size, 5 = radix, MSD-first two-pass order*/ 0,
+                            /*10: csr2csc: 0 = automatic (one single-workgroup launch up to 16 k slots, the radix sort above), 2 = the radix sort at every size, 3 = radix, packed records at any size*/ 0,
                             /*11: sample_adj relabelling: 0 = hash table of first positions (4 launches), 1 = the sort-based form of rounds 1-2 (~25 launches; its sort is this library's radix transpose since round 5)*/ 0,
-                            /*12: wave-scope split of medium rows: n > 0 = rows of more than n edges in skewed workgroups (off by default)*/ 0,
+                            /*12: retired (round 4's wave-scope split of medium rows, removed in round 6)*/ 0,
                             /*13: timing experiments on the row-reduce engine (WRONG results): 1 = the row blocks exit at once, 2 = the long-row workgroups exit at once*/ 0,
-                            /*14: csr_spmm row tiles (several rows per lane group, their first gathers in flight together): 2 = on wherever the operator allows; off by default (measured slower except for rows of one or two edges)*/ 0,
+                            /*14: retired (round 4's csr_spmm row tiles, removed in round 6)*/ 0,
                             /*15: 64-bit CSR: edges per row segment (0 = default 2^29; tests use tiny values)*/ 0,
-                            /*16: csr_spmm row queue: a workgroup owns n x as many rows and its waves pull them from an LDS counter (0 = off)*/ 0};
+                            /*16: retired (round 5's per-workgroup row queue, removed in round 6)*/ 0};
 }
 
 namespace cogdl {

@@ -170,6 +170,109 @@ extern "C" int cogdl_hip_gat_dropout_bwd(const int32_t *rowptr, const int32_t *c
                          h, f, nnz, dtype, &d, stream);
 }
 
+// ---- XCD-partitioned plans (rowreduce.h: virtual rows) ------------------------------------------------------------------
+extern "C" size_t cogdl_hip_gat_fwd_xcd_workspace_bytes(int64_t n_parts, int64_t h, int64_t f, int dtype) {
+    if (h <= 0 || f <= 0) return 256;
+    const RowGeometry g = gat_fwd_geometry(h, f, dtype == COGDL_HIP_F32 ? 4 : 2, 16);
+    return vrows_workspace_bytes(n_parts, g.tiles * (g.vec + 2) * g.lpr);
+}
+
+extern "C" int cogdl_hip_gat_fwd_xcd(const cogdl_hip_vrows *plan, const float *attn_row, const float *attn_col,
+                                     const void *feat, float negative_slope, float p, uint64_t seed, void *out,
+                                     float *edge_max, float *edge_sum, int64_t v, int64_t h, int64_t f, int dtype,
+                                     void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = vrows_valid(plan);
+    if (rc != COGDL_HIP_OK) return rc;
+    const int32_t dummy = 0;
+    rc = check_fwd(&dummy, attn_row, attn_col, feat, out, edge_max, edge_sum, v, h, f, plan->nnz);
+    if (rc != COGDL_HIP_OK) return rc < 0 ? COGDL_HIP_OK : rc;
+    if (!(p >= 0.f && p <= 1.f)) return COGDL_HIP_EINVAL;
+    // (the plan kernels address the gathered tables with 24 x 24 -> 32-bit offsets, common.h: gather_row; the caller
+    //  vouches for the column ids -- < 2^24 source rows, tables below 4 GiB: cogdl_amd/xcdplan.py wanted())
+    if (h * f * 4 >= (1 << 24)) return COGDL_HIP_EUNSUPPORTED;
+    GatFwdArgs a{nullptr, nullptr, attn_row, attn_col, feat, negative_slope, out, edge_max, edge_sum, v, h, f, plan->nnz,
+                 GatDrop{}, plan};
+    if (p > 0.f) {
+        if (h > 64) return COGDL_HIP_EUNSUPPORTED;
+        if (!plan->eid && plan->nnz > 0) return COGDL_HIP_EINVAL;  // (the mask is a function of the CSR position)
+        a.drop = make_drop(p, seed, plan->eid);
+        return gat_fwd_drop(a, dtype, workspace, workspace_bytes, (hipStream_t)stream);
+    }
+    return gat_fwd_any<false>(a, dtype, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+namespace {
+struct BwdXcdLayout {
+    size_t d, row, col, total;
+};
+BwdXcdLayout bwd_xcd_layout(const GatBwdGeometry &g, int64_t v, int64_t h, int64_t parts_row, int64_t parts_col) {
+    BwdXcdLayout L{};
+    L.d = gat_stats_bytes(v, h);
+    L.row = vrows_workspace_bytes(parts_row, g.tiles * (int64_t)(g.vec + 1) * g.lpr);
+    L.col = vrows_workspace_bytes(parts_col, g.tiles * (int64_t)(2 * g.vec + 1) * g.lpr);
+    L.total = L.d + L.row + L.col;
+    return L;
+}
+}  // namespace
+
+extern "C" size_t cogdl_hip_gat_bwd_xcd_workspace_bytes(int64_t v, int64_t h, int64_t f, int64_t n_parts_row,
+                                                        int64_t n_parts_col, int dtype) {
+    if (h <= 0 || f <= 0) return 256;
+    const GatBwdGeometry g = gat_bwd_geometry(h, f, 16, dtype == COGDL_HIP_F32 ? 4 : 2);
+    return bwd_xcd_layout(g, v, h, n_parts_row, n_parts_col).total + 256;
+}
+
+extern "C" int cogdl_hip_gat_bwd_xcd(const cogdl_hip_vrows *plan_csr, const cogdl_hip_vrows *plan_csc,
+                                     const float *attn_row, const float *attn_col, const void *feat, float negative_slope,
+                                     float p, uint64_t seed, const float *edge_max, const float *edge_sum, const void *out,
+                                     const void *grad_out, void *grad_feat, float *grad_attn_row, float *grad_attn_col,
+                                     void *workspace, size_t workspace_bytes, int64_t v, int64_t n_src, int64_t h,
+                                     int64_t f, int dtype, void *stream) {
+    int rc = vrows_valid(plan_csr);
+    if (rc == COGDL_HIP_OK) rc = vrows_valid(plan_csc);
+    if (rc != COGDL_HIP_OK) return rc;
+    if (v < 0 || n_src < 0 || h <= 0 || f <= 0 || plan_csr->nnz != plan_csc->nnz) return COGDL_HIP_EINVAL;
+    if (dtype != COGDL_HIP_F32 && dtype != COGDL_HIP_F16 && dtype != COGDL_HIP_BF16) return COGDL_HIP_EDTYPE;
+    if (h * f > 0x7fffffff) return COGDL_HIP_ERANGE;
+    if (!(p >= 0.f && p <= 1.f)) return COGDL_HIP_EINVAL;
+    const bool drop = p > 0.f;
+    if (drop && h > 64) return COGDL_HIP_EUNSUPPORTED;
+    if (drop && plan_csr->nnz > 0 && (!plan_csr->eid || !plan_csc->eid)) return COGDL_HIP_EINVAL;
+    // (24 x 24 -> 32-bit table offsets, common.h: gather_row -- the widest gathered row is the float4 record per head)
+    if (std::max(v, n_src) >= (1 << 24) || h * std::max<int64_t>(f * 4, 16) >= (1 << 24) ||
+        std::max(v, n_src) * h * std::max<int64_t>(f * 4, 16) >= ((int64_t)1 << 32))
+        return COGDL_HIP_EUNSUPPORTED;
+    const int elem_bytes = dtype == COGDL_HIP_F32 ? 4 : 2;
+    if (!attn_row || !attn_col || !feat || !edge_max || !edge_sum || !out || !grad_out || !grad_feat || !grad_attn_row ||
+        !grad_attn_col || !workspace)
+        return COGDL_HIP_EINVAL;
+    if (!aligned_to(workspace, 256)) return COGDL_HIP_EWORKSPACE;
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out) |
+                           reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_feat);
+    const int align = (bits % 16 == 0) ? 16 : (bits % 8 == 0) ? 8 : (bits % 4 == 0) ? 4 : 2;
+    if (align < elem_bytes) return COGDL_HIP_EALIGN;
+    const GatBwdGeometry g = gat_bwd_geometry(h, f, align, elem_bytes);
+    if (g.tiled) return COGDL_HIP_EUNSUPPORTED;  // (column tiles keep the ordinary entry)
+    const BwdXcdLayout L = bwd_xcd_layout(g, v, h, plan_csr->n_parts, plan_csc->n_parts);
+    if (workspace_bytes < L.total) return COGDL_HIP_EWORKSPACE;
+    GatBwdArgs b{};
+    b.ar = attn_row, b.ac = attn_col, b.feat = feat, b.emax = edge_max, b.esum = edge_sum;
+    b.out = out, b.gout = grad_out, b.slope = negative_slope;
+    b.gfeat = grad_feat, b.gar = grad_attn_row, b.gac = grad_attn_col;
+    b.v = v, b.n_src = n_src, b.h = h, b.f = f, b.nnz = plan_csr->nnz;
+    char *w = (char *)workspace;
+    b.stats = (float4 *)w;
+    b.ws_row = w + L.d, b.wsb_row = L.row;
+    b.ws_col = w + L.d + L.row, b.wsb_col = L.col;
+    b.vr_row = plan_csr, b.vr_col = plan_csc;
+    hipStream_t s = (hipStream_t)stream;
+    if (drop) {
+        b.drop = make_drop(p, seed, nullptr);
+        return gat_bwd_drop(b, g, dtype, s);
+    }
+    return gat_bwd_any<false>(b, g, dtype, s);
+}
+
 extern "C" int cogdl_hip_edge_dropout_mask(int64_t nnz, int64_t h, float p, uint64_t seed, float *mask, void *stream) {
     if (nnz < 0 || h < 0 || !(p >= 0.f && p <= 1.f)) return COGDL_HIP_EINVAL;
     if (nnz == 0 || h == 0) return COGDL_HIP_OK;

@@ -101,7 +101,7 @@ struct GatTiles {
 };
 
 // ------------------------------------------------------------------------------------------ forward
-template <typename T, int VEC_, int LPR_, int UNROLL_, bool DROP>
+template <typename T, int VEC_, int LPR_, int UNROLL_, bool DROP, bool A24 = false>
 struct GatFwdOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_ + 2;
     static constexpr bool kReduce = true;
@@ -154,22 +154,34 @@ struct GatFwdOp {
     }
     __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t, const LaneVals &lv, int sub,
                                           int jj) const {
-        b.ac[u] = attn_col[(int64_t)col * heads + c.hd];
-        load_vec<T, VEC>(feat + (int64_t)col * (heads * fdim) + c.cc, b.v[u]);
+        b.ac[u] = *gather_row<A24>(attn_col, c.hd, col, (uint32_t)heads * 4u);
+        load_vec<T, VEC>(gather_row<A24>(feat, c.cc, col, (uint32_t)(heads * fdim) * (uint32_t)sizeof(T)), b.v[u]);
         if constexpr (DROP) b.d[u] = drop_factor<LPR>(drop, lv, sub, jj, c.hd, heads);
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
                                           int) const {
         if (valid) {
+            // Online softmax with ONE exponential per (edge, lane): of exp(mx - mn) and exp(sc - mn), mn = max(mx, sc), one
+            // is exp(0) = 1 and the other t = exp(-|sc - mx|) (mx = -inf at the start of a row: t = 0 = the rescale of
+            // the empty state).  Round 6: these kernels are bound by VALU issue on hub-heavy graphs (SQ counters: the vector
+            // pipe is busy 68 % of the launch, profiles/r06_sq_reddit.txt); the second exponential was libm's expf,
+            // ~25 instructions per edge and lane.  The accumulator is rescaled only when some lane of the wave saw a new
+            // maximum (wave-uniform branch; multiplying by exactly 1 is what is skipped): rare beyond the first edges of a row.
             const float sc = leaky(c.ar + b.ac[u], slope);
-            const float mn = fmaxf(s.mx, sc);
-            const float scale = (s.lsum == 0.f) ? 0.f : expf(s.mx - mn);
-            const float p = gat_exp(sc - mn);
-            s.lsum = s.lsum * scale + p;
+            const bool up = sc > s.mx;
+            const float t = gat_exp(up ? s.mx - sc : sc - s.mx);
+            const float p = up ? 1.f : t;
             const float pw = DROP ? p * b.d[DROP ? u : 0] : p;
+            if (__ballot(up) != 0ull) {
+                const float scale = up ? t : 1.f;
+                s.lsum *= scale;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) s.acc[i] = fmaf(pw, b.v[u][i], s.acc[i] * scale);
-            s.mx = mn;
+                for (int i = 0; i < VEC; ++i) s.acc[i] *= scale;
+                s.mx = up ? sc : s.mx;
+            }
+            s.lsum += p;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) s.acc[i] = fmaf(pw, b.v[u][i], s.acc[i]);
         }
     }
     __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *,
@@ -399,7 +411,7 @@ __device__ __forceinline__ GatBwdLane gat_bwd_lane(int l, int tile, int heads, i
 }
 
 // Row pass: D[v,h] and grad_attn_row[v,h].
-template <typename T, int VEC_, int LPR_, int UNROLL_, bool DROP, bool TILED>
+template <typename T, int VEC_, int LPR_, int UNROLL_, bool DROP, bool TILED, bool A24 = false>
 struct GatBwdRowOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_ + 1;
     static constexpr bool kReduce = true;
@@ -476,8 +488,8 @@ struct GatBwdRowOp {
     }
     __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t, const LaneVals &lv, int sub,
                                           int jj) const {
-        b.ac[u] = attn_col[(int64_t)col * heads + c.m.hd];
-        load_vec<T, VEC>(feat + (int64_t)col * (heads * fdim) + c.m.cc, b.v[u]);
+        b.ac[u] = *gather_row<A24>(attn_col, c.m.hd, col, (uint32_t)heads * 4u);
+        load_vec<T, VEC>(gather_row<A24>(feat, c.m.cc, col, (uint32_t)(heads * fdim) * (uint32_t)sizeof(T)), b.v[u]);
         if constexpr (DROP) b.d[u] = drop_factor<LPR>(drop, lv, sub, jj, c.m.hd, heads);
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
@@ -533,7 +545,7 @@ struct GatBwdRowOp {
 };
 
 // Column pass over the CSC (colptr, rowind): grad_feat[u,h,:] and grad_attn_col[u,h].
-template <typename T, int VEC_, int LPR_, int UNROLL_, bool DROP, bool TILED>
+template <typename T, int VEC_, int LPR_, int UNROLL_, bool DROP, bool TILED, bool A24 = false>
 struct GatBwdColOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = 2 * VEC_ + 1;
     static constexpr bool kReduce = true;
@@ -599,8 +611,8 @@ struct GatBwdColOp {
     }
     __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int r, int64_t, const LaneVals &lv, int sub,
                                           int jj) const {
-        b.st[u] = stats[(int64_t)r * heads + c.m.hd];
-        load_vec<T, VEC>(grad_out + (int64_t)r * (heads * fdim) + c.m.cc, b.g[u]);
+        b.st[u] = *gather_row<A24>(stats, c.m.hd, r, (uint32_t)heads * 16u);
+        load_vec<T, VEC>(gather_row<A24>(grad_out, c.m.cc, r, (uint32_t)(heads * fdim) * (uint32_t)sizeof(T)), b.g[u]);
         if constexpr (DROP) b.d[u] = drop_factor<LPR>(drop, lv, sub, jj, c.m.hd, heads);
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
@@ -704,6 +716,7 @@ struct GatFwdArgs {
     float *emax, *esum;
     int64_t v, h, f, nnz;
     GatDrop drop;
+    const cogdl_hip_vrows *vr = nullptr;  // XCD-partitioned plan (rowreduce.h): rowptr / colind are then unused
 };
 
 template <typename T, int VEC, int LPR, bool DROP>
@@ -714,6 +727,14 @@ static int gat_launch_fwd(const GatFwdArgs &a, int64_t tiles, void *ws, size_t w
     using Chunk = GatFwdChunkOp<T, VEC, LPR, 8, DROP>;
     const bool can_chunk = pow2(a.h) && a.h <= LPR && a.h <= Chunk::kMaxHeads;
     const bool want_chunk = g_tuning[kTuneGatOnline] == 2 || (g_tuning[kTuneGatOnline] == 0 && LPR >= 16 && a.h * 8 <= LPR);
+    if (a.vr) {  // virtual rows: the edge-wise functor only (the caller takes the ordinary entry for the chunk-wise shapes)
+        if (can_chunk && want_chunk) return COGDL_HIP_EUNSUPPORTED;
+        GatDrop dr = a.drop;
+        dr.eid = a.vr->eid;
+        GatFwdOp<T, VEC, LPR, 8, DROP, true> op{a.ar, a.ac, (const T *)a.feat, (T *)a.out, a.emax, a.esum, a.slope, (int)a.h,
+                                                (int)a.f, dr};
+        return launch_rowreduce_vrows(op, a.vr, tiles, ws, wsb, s);
+    }
     if (can_chunk && want_chunk) {
         Chunk op{a.ar, a.ac, (const T *)a.feat, (T *)a.out, a.emax, a.esum, a.slope, (int)a.h, (int)a.f, a.drop};
         return launch_rowreduce(op, a.rowptr, a.colind, a.v, a.nnz, tiles, ws, wsb, s);
@@ -774,6 +795,7 @@ struct GatBwdArgs {
     size_t wsb_row, wsb_col;
     GatDrop drop;           // (eid = the plan's perm: used by the column pass only)
     float *t_pdot, *t_pd, *t_hsum;  // TILED scratch
+    const cogdl_hip_vrows *vr_row = nullptr, *vr_col = nullptr;  // XCD-partitioned plans of the CSR / of the CSC (both or none)
 };
 
 // Backward geometry.  One group (fast path): vec in {1,2,4} (and 8 for 2-byte elements) with F % vec == 0, H*F/vec <= 64
@@ -828,6 +850,20 @@ static int gat_launch_bwd(const GatBwdArgs &b, hipStream_t s) {
     GatBwdRowOp<T, VEC, LPR, 4, DROP, false> row_op{b.ar, b.ac, (const T *)b.feat, b.emax, b.esum, (const T *)b.out,
                                                     (const T *)b.gout, b.stats, b.gar, b.slope, (int)b.h, (int)b.f,
                                                     lph, row_drop, GatTiles{}};
+    if (b.vr_row) {  // XCD-partitioned plans (both passes): the same functors with 24-bit table offsets
+        row_drop.eid = b.vr_row->eid;  // (plan position -> CSR position)
+        GatBwdRowOp<T, VEC, LPR, 4, DROP, false, true> row24{b.ar, b.ac, (const T *)b.feat, b.emax, b.esum, (const T *)b.out,
+                                                             (const T *)b.gout, b.stats, b.gar, b.slope, (int)b.h, (int)b.f,
+                                                             lph, row_drop, GatTiles{}};
+        const int rc = launch_rowreduce_vrows(row24, b.vr_row, 1, b.ws_row, b.wsb_row, s);
+        if (rc != COGDL_HIP_OK) return rc;
+        GatDrop col_drop = b.drop;
+        col_drop.eid = b.vr_col->eid;  // (plan position of the CSC -> CSR position: the caller composed it with the transpose's perm)
+        GatBwdColOp<T, VEC, LPR, 4, DROP, false, true> col24{b.ar, b.ac, (const T *)b.feat, b.stats, (const T *)b.gout,
+                                                             (T *)b.gfeat, b.gac, b.slope, (int)b.h, (int)b.f, lph, col_drop,
+                                                             GatTiles{}};
+        return launch_rowreduce_vrows(col24, b.vr_col, 1, b.ws_col, b.wsb_col, s);
+    }
     int rc = launch_rowreduce(row_op, b.rowptr, b.colind, b.v, b.nnz, 1, b.ws_row, b.wsb_row, s);
     if (rc != COGDL_HIP_OK) return rc;
     GatBwdColOp<T, VEC, LPR, 4, DROP, false> col_op{b.ar, b.ac, (const T *)b.feat, b.stats,

@@ -10,7 +10,7 @@
 // int64 indices in and out, like the tensors cogdl.data.Graph holds.  All stream-ordered, nothing synchronises.
 #include "common.h"
 
-#include <rocprim/device/device_scan.hpp>
+#include "scan.h"
 
 namespace cogdl {
 
@@ -125,9 +125,7 @@ extern "C" int cogdl_hip_coo_norm_weights(const int64_t *row, const int64_t *col
 }
 
 extern "C" size_t cogdl_hip_add_remaining_self_loops_workspace_bytes(int64_t nnz, int64_t num_nodes) {
-    size_t scan_t = 0;
-    (void)rocprim::exclusive_scan(nullptr, scan_t, (int32_t *)nullptr, (int64_t *)nullptr, int64_t(0), (size_t)(nnz + 1),
-                                  rocprim::plus<int64_t>(), nullptr);
+    const size_t scan_t = device_scan_temp_bytes(nnz + 1, sizeof(int64_t));
     return gn_align256((size_t)(nnz + 1) * 4) + gn_align256((size_t)(nnz + 1) * 8) +
            gn_align256((size_t)std::max<int64_t>(num_nodes, 1) * 4) + gn_align256(scan_t) + 256;
 }
@@ -150,9 +148,6 @@ extern "C" int cogdl_hip_add_remaining_self_loops(const int64_t *row, const int6
     p += gn_align256((size_t)(nnz + 1) * 8);
     int32_t *loop_src = (int32_t *)p;
     p += gn_align256((size_t)std::max<int64_t>(num_nodes, 1) * 4);
-    size_t scan_t = 0;
-    (void)rocprim::exclusive_scan(nullptr, scan_t, (int32_t *)nullptr, (int64_t *)nullptr, int64_t(0), (size_t)(nnz + 1),
-                                  rocprim::plus<int64_t>(), nullptr);
     hipError_t e = fill_u32_async(loop_src, 0xffffffffu, (size_t)std::max<int64_t>(num_nodes, 1), s);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
@@ -160,11 +155,8 @@ extern "C" int cogdl_hip_add_remaining_self_loops(const int64_t *row, const int6
     }
     hipLaunchKernelGGL(gn_loop_flags_kernel, dim3(gn_blocks(nnz + 1)), dim3(256), 0, s, row, col, nnz, num_nodes, keep,
                        loop_src, bad_flag);
-    e = rocprim::exclusive_scan((void *)p, scan_t, keep, pos, int64_t(0), (size_t)(nnz + 1), rocprim::plus<int64_t>(), s);
-    if (e != hipSuccess) {
-        g_last_hip_error = (int)e;
-        return COGDL_HIP_ELAUNCH;
-    }
+    const int rc = device_exclusive_sum(keep, pos, nnz + 1, (void *)p, s);
+    if (rc != COGDL_HIP_OK) return rc;
     hipLaunchKernelGGL(gn_loop_scatter_kernel, dim3(gn_blocks(nnz + num_nodes)), dim3(256), 0, s, row, col, val, nnz,
                        num_nodes, keep, pos, loop_src, fill_value, out_row, out_col, out_val, out_count);
     return launch_status();

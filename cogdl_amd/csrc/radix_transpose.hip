@@ -1,6 +1,6 @@
 // radix_transpose.hip -- csr2csc as a hand-written LSD radix sort for gfx950 (replaces the
 // reference's cusparseCsr2cscEx2, cogdl/operators/spmm/spmm_kernel.cu:514-532, and this library's earlier rocPRIM
-// pipeline of transpose.hip, which stays selectable through tuning key 10).
+// pipeline, removed in round 5).
 //
 // What is sorted: the nnz edge slots by column id, stably (a column's edges keep their CSR = row order), carrying TWO
 // payloads per edge -- its CSR position e (-> perm) and its row (-> rowind).  The row is found once, in the first pass,
@@ -12,7 +12,7 @@
 // TWO passes where rocPRIM's onesweep takes three 8-bit ones.  One pass = three kernels, no atomics on global memory, no
 // memset, no look-back spinning (=> deterministic, and capturable in a hipGraph at any size):
 //   upsweep    per tile of 8192 slots: digit histogram -> table[digit][tile]
-//   scan       exclusive scan of the table in digit-major order (rocPRIM): where tile t's run of digit d starts
+//   scan       exclusive scan of the table in digit-major order (scan.h): where tile t's run of digit d starts
 //   downsweep  per tile: stable rank of every slot inside the tile (per wave: lanes with the same digit found with
 //              ballots, a running per-wave counter per digit in LDS; waves own contiguous quarters of the tile), the tile
 //              is reordered by digit through LDS, then written out as runs of equal digits (64 B on average at 512
@@ -27,8 +27,7 @@
 // array AND two global stores (packed records) gains only 3 %: a staging round costs its two 8-wave barriers, not its
 // bytes -- with 2 workgroups per CU little else runs while a workgroup waits.
 #include "common.h"
-
-#include <rocprim/device/device_scan.hpp>
+#include "scan.h"
 
 namespace cogdl {
 namespace rt {
@@ -58,42 +57,7 @@ struct Params {
     uint32_t pad_key;
     int shift, bits, padded;
     int row_bits;           // packed records: word = (remaining key digits << row_bits) | row
-    // MSD-first two-pass sort (see radix_transpose): the first pass places by the HIGH digit, the second sorts every
-    // bucket of the first by the LOW digit inside the bucket's own (contiguous, L2-sized) output range
-    int msd;                // first pass: the packed word keeps the key's LOW digit (key & (2^shift - 1))
-    const uint32_t *bstart; // second pass: the first pass's scanned table; bucket b starts at bstart[b * n_tiles1]
-    int64_t n_tiles1;
-    const int32_t *btile;   // [nb1 + 1]: first second-pass tile of every bucket; btile[nb1] = number of second-pass tiles
-    int nb1;                // buckets (= bins of the first pass)
-    const uint4 *trec;      // [t2max] one record per second-pass tile: {first slot, slots in use (0: no such tile),
-                            //  table index of (digit 0, this tile), table stride between digits}
-    int64_t t2max;          // upper bound of the second pass's tile count (known on the host: n_tiles + buckets)
 };
-
-// One tile of the MSD second pass: kTile consecutive slots of ONE bucket of the first pass.
-struct BucketTile {
-    int64_t tile0;   // first slot (global position in the first pass's output)
-    int n_here;      // slots in use
-    int64_t tbase;   // table index of (bucket, digit 0, tile 0 of the bucket); digit d, this tile: tbase + d * nt + ti
-    int64_t nt, ti;  // tiles of the bucket, this tile's index among them
-};
-
-__device__ __forceinline__ int64_t bucket_start(const Params &p, int b) {
-    return b < p.nb1 ? (int64_t)p.bstart[(int64_t)b * p.n_tiles1] : p.nnz;
-}
-
-// One 16-byte record per second-pass tile (rt_tile_records_kernel): a single load before the tile's own loads can be
-// issued (looking the bucket up inside the sort kernels cost two more dependent round trips per tile).
-__device__ __forceinline__ BucketTile bucket_tile(const Params &p, int64_t tile) {
-    const uint4 r = p.trec[tile];
-    BucketTile g;
-    g.tile0 = r.x;
-    g.n_here = (int)r.y;
-    g.tbase = r.z;  // (already includes this tile's index: table index of digit d = tbase + d * nt)
-    g.nt = r.w;
-    g.ti = 0;
-    return g;
-}
 
 __device__ __forceinline__ int64_t rt_row_search(const int32_t *__restrict__ rowptr, int64_t lo, int64_t hi, int64_t e) {
     while (hi - lo > 1) {  // invariant: rowptr[lo] <= e (< rowptr[hi] where hi < m + 1); empty rows share offsets
@@ -123,21 +87,13 @@ __device__ __forceinline__ uint32_t load_key(const Params &p, int64_t i, int64_t
     else return p.keys_in[i];
 }
 
-template <bool FIRST, bool IN_PACKED = false, bool MSD2 = false>
+template <bool FIRST, bool IN_PACKED = false>
 __global__ __launch_bounds__(kThreads) void rt_upsweep_kernel(const Params p) {
     __shared__ uint32_t hist[kWaves][kMaxBins];
     const int t = threadIdx.x, lane = t & (kWave - 1), w = t >> 6;
     const int nbins = 1 << p.bits;
     const int64_t tile = blockIdx.x;
-    int64_t tile0 = tile * kTile, lim = p.nnz, tidx0 = tile, tstride = p.n_tiles;  // table index = tidx0 + d * tstride
-    if constexpr (MSD2) {
-        const BucketTile g = bucket_tile(p, tile);
-        if (g.n_here == 0) return;  // (the grid is an upper bound: n_tiles + buckets)
-        tile0 = g.tile0;
-        lim = g.tile0 + g.n_here;
-        tidx0 = g.tbase;
-        tstride = g.nt;
-    }
+    const int64_t tile0 = tile * kTile, lim = p.nnz, tidx0 = tile, tstride = p.n_tiles;  // table index = tidx0 + d * tstride
     for (int i = t; i < kWaves * kMaxBins; i += kThreads) (&hist[0][0])[i] = 0;
     const int64_t base = tile0 + (int64_t)w * kPerWave;
     const int64_t valid = (FIRST && p.padded) ? (int64_t)p.rowptr[p.m] : p.nnz;
@@ -178,11 +134,10 @@ __global__ __launch_bounds__(kThreads) void rt_upsweep_kernel(const Params p) {
 //   PACK = 1 (first pass):  writes (e, word); the keys go through LDS only to place the slots, not to memory;
 //   PACK = 2 (second pass): reads (e, word); one LDS round carries digit and row together, so the pass stages and
 //                           writes two arrays (rowind, perm) and no sorted keys (colptr comes from rt_colptr_perm).
-template <bool FIRST, int PACK = 0, bool MSD2 = false>
+template <bool FIRST, int PACK = 0>
 __global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params p) {
-    static_assert(PACK == 0 || (FIRST ? PACK == 1 : (PACK == 2 || PACK == 3)), "packed out in the first pass, packed in afterwards");
-    static_assert(!MSD2 || PACK == 2, "the MSD second pass reads packed records");
-    constexpr bool PACK_IN = PACK == 2 || PACK == 3;  // PACK 3: a MIDDLE pass of a sort with more than two passes -- reads and writes (e, word)
+    static_assert(PACK == 0 || (FIRST ? PACK == 1 : PACK == 2), "packed out in the first pass, packed in in the second");
+    constexpr bool PACK_IN = PACK == 2;
     __shared__ __attribute__((aligned(16))) uint32_t buf[kTile];
     __shared__ uint32_t cnt[kWaves][kMaxBins];  // per wave: running count, then the wave's start inside the digit's run
     __shared__ uint32_t dstart[kMaxBins];       // where the digit's run starts in the reordered tile
@@ -195,20 +150,12 @@ __global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params 
     // TILES write adjacent pieces of every digit's run.  Each XCD therefore takes a contiguous eighth of the tiles: the
     // ~64 tiles in flight on one XCD are neighbours, and their 64-byte pieces merge into full lines in that XCD's L2
     // before they are written back (PMC: 1.8x write amplification + the read-modify-write fills with the natural order).
-    const int64_t n_tiles_here = MSD2 ? p.t2max : p.n_tiles;  // (MSD second pass: the host's upper bound; surplus tiles exit)
+    const int64_t n_tiles_here = p.n_tiles;
     const int64_t per_xcd = (n_tiles_here + kXcds - 1) / kXcds;
     const int64_t tile = (int64_t)(blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
     if (tile >= n_tiles_here) return;
-    int64_t tile0 = tile * kTile, tidx0 = tile, tstride = p.n_tiles;  // table index = tidx0 + digit * tstride
-    int n_here = (int)min((int64_t)kTile, p.nnz - tile0);
-    if constexpr (MSD2) {
-        const BucketTile g = bucket_tile(p, tile);
-        if (g.n_here == 0) return;
-        tile0 = g.tile0;
-        n_here = g.n_here;
-        tidx0 = g.tbase;
-        tstride = g.nt;
-    }
+    const int64_t tile0 = tile * kTile, tidx0 = tile, tstride = p.n_tiles;  // table index = tidx0 + digit * tstride
+    const int n_here = (int)min((int64_t)kTile, p.nnz - tile0);
     for (int i = t; i < kWaves * kMaxBins; i += kThreads) (&cnt[0][0])[i] = 0;
     const int l0 = w * kPerWave + lane;  // local slot of wave-row 0; wave-row j: l0 + 64 * j
 
@@ -348,10 +295,6 @@ __global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params 
             if constexpr (PACK == 2) {
                 gpos[q] = delta[(k >> p.row_bits) & mask] + (uint32_t)sidx;
                 p.row_out[gpos[q]] = (int32_t)(k & ((1u << p.row_bits) - 1u));
-            } else if constexpr (PACK == 3) {  // the word goes on without this pass's digit
-                gpos[q] = delta[(k >> p.row_bits) & mask] + (uint32_t)sidx;
-                const uint32_t row_mask = (1u << p.row_bits) - 1u;
-                p.row_out[gpos[q]] = (int32_t)((((k >> p.row_bits) >> p.bits) << p.row_bits) | (k & row_mask));
             } else {
                 gpos[q] = delta[(k >> p.shift) & mask] + (uint32_t)sidx;
                 if constexpr (PACK == 0) p.keys_out[gpos[q]] = k;
@@ -375,8 +318,8 @@ __global__ __launch_bounds__(kThreads, 4) void rt_downsweep_kernel(const Params 
 #pragma unroll
     for (int j = 0; j < kRows; ++j) {
         if (l0 + j * kWave < n_here) {
-            if constexpr (PACK == 1)  // the digits a later pass still needs: above this one (LSD) / below it (MSD first pass)
-                buf[spos[j]] = ((p.msd ? (key[j] & ((1u << p.shift) - 1u)) : (key[j] >> p.bits)) << p.row_bits) | (uint32_t)pr[j];
+            if constexpr (PACK == 1)  // the digit the second pass still needs, above the row
+                buf[spos[j]] = ((key[j] >> p.bits) << p.row_bits) | (uint32_t)pr[j];
             else buf[spos[j]] = (uint32_t)pr[j];
         }
     }
@@ -413,110 +356,6 @@ __global__ void rt_colptr_sorted_kernel(const uint32_t *__restrict__ keys, int32
             if ((int64_t)keys[mid] < c) lo = mid + 1; else hi = mid;
         }
         colptr[c] = (int32_t)lo;
-    }
-}
-
-// MSD second pass, step 0: the buckets of the first pass (their starts are entries of its scanned table) are cut into
-// tiles of kTile slots; btile[b] = the first tile of bucket b, btile[nb1] = the number of tiles.  One workgroup.
-__global__ __launch_bounds__(kThreads) void rt_bucket_tiles_kernel(const Params p, int32_t *__restrict__ btile) {
-    __shared__ uint32_t wsum[kWaves];
-    const int t = threadIdx.x, lane = t & (kWave - 1), w = t >> 6;
-    uint32_t nt = 0;
-    if (t < p.nb1) nt = (uint32_t)((bucket_start(p, t + 1) - bucket_start(p, t) + kTile - 1) / kTile);
-    uint32_t incl = nt;
-#pragma unroll
-    for (int sft = 1; sft < kWave; sft <<= 1) {
-        const uint32_t v = __shfl_up(incl, sft, kWave);
-        if (lane >= sft) incl += v;
-    }
-    if (lane == kWave - 1) wsum[w] = incl;
-    __syncthreads();
-    uint32_t off = incl - nt;
-    for (int ww = 0; ww < w; ++ww) off += wsum[ww];
-    if (t < p.nb1) btile[t] = (int32_t)off;
-    if (t == p.nb1 - 1) btile[p.nb1] = (int32_t)(off + nt);
-}
-
-// MSD second pass, step 0b: the record of every tile (one thread per tile id below the host's upper bound).
-__global__ void rt_tile_records_kernel(const Params p, uint4 *__restrict__ trec, int lbits) {
-    const int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile >= p.t2max) return;
-    uint4 r = make_uint4(0u, 0u, 0u, 0u);
-    if (tile < (int64_t)p.btile[p.nb1]) {
-        int lo = 0, hi = p.nb1;  // the bucket b with btile[b] <= tile < btile[b + 1] (buckets without tiles are skipped)
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if ((int64_t)p.btile[mid] <= tile) lo = mid; else hi = mid;
-        }
-        const int b = lo;
-        const int64_t first = p.btile[b], nt = (int64_t)p.btile[b + 1] - first, ti = tile - first;
-        const int64_t start = bucket_start(p, b), end = bucket_start(p, b + 1);
-        r.x = (uint32_t)(start + ti * kTile);
-        r.y = (uint32_t)min((int64_t)kTile, end - (start + ti * kTile));
-        r.z = (uint32_t)((first << lbits) + ti);
-        r.w = (uint32_t)nt;
-    }
-    trec[tile] = r;
-}
-
-// colptr of the MSD sort: column c = (bucket b, low digit d) starts where the second pass's scanned table says the first
-// tile of bucket b puts its run of digit d (an empty run still has its position); a bucket without tiles starts -- and
-// ends -- at the bucket's own start.  No search, no sorted keys.
-__global__ void rt_colptr_msd_kernel(const Params p, const uint32_t *__restrict__ scanned2, int lbits, int64_t n_cols,
-                                     int32_t *__restrict__ colptr) {
-    const uint32_t lmask = (1u << lbits) - 1u;
-    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c <= n_cols; c += (int64_t)gridDim.x * blockDim.x) {
-        const int b = (int)(c >> lbits);
-        int64_t pos;
-        if (b >= p.nb1) pos = p.nnz;
-        else {
-            const int64_t first = p.btile[b], nt = (int64_t)p.btile[b + 1] - first;
-            pos = nt > 0 ? (int64_t)scanned2[(first << lbits) + (int64_t)((uint32_t)c & lmask) * nt] : bucket_start(p, b);
-        }
-        colptr[c] = (int32_t)pos;
-    }
-}
-
-// Exclusive scan of a SMALL table by one workgroup (sampled blocks: a few tiles x 512 digits): one launch where the
-// device-wide rocPRIM scan takes three -- a block transpose inside a captured mini-batch step is bound by its number
-// of dependent launches, not by its work.
-constexpr int kScanThreads = 1024;
-constexpr int64_t kSmallScan = 1 << 16;
-__global__ __launch_bounds__(kScanThreads) void rt_scan_small_kernel(const uint32_t *__restrict__ in,
-                                                                    uint32_t *__restrict__ out, int64_t n) {
-    __shared__ uint32_t wsum[kScanThreads / kWave];
-    const int t = threadIdx.x, lane = t & (kWave - 1), w = t >> 6;
-    uint32_t carry = 0;
-    for (int64_t base = 0; base < n; base += kScanThreads * 4) {
-        const int64_t i0 = base + (int64_t)t * 4;  // four consecutive entries per thread
-        uint32_t v[4], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            v[k] = i0 + k < n ? in[i0 + k] : 0u;
-            sum += v[k];
-        }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int sft = 1; sft < kWave; sft <<= 1) {
-            const uint32_t u = __shfl_up(incl, sft, kWave);
-            if (lane >= sft) incl += u;
-        }
-        __syncthreads();
-        if (lane == kWave - 1) wsum[w] = incl;
-        __syncthreads();
-        uint32_t off = carry, tot = 0;
-#pragma unroll
-        for (int ww = 0; ww < kScanThreads / kWave; ++ww) {
-            if (ww < w) off += wsum[ww];
-            tot += wsum[ww];
-        }
-        uint32_t run = off + incl - sum;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (i0 + k < n) out[i0 + k] = run;
-            run += v[k];
-        }
-        carry += tot;
     }
 }
 
@@ -682,7 +521,7 @@ __global__ __launch_bounds__(kSmThreads) void small_transpose_kernel(const int32
 struct Geometry {
     int bits, n_pass, dbits;
     int64_t n_tiles, table_len;
-    size_t scan_temp, off_table, off_scanned, off_scanned1, off_temp, off_sets, set_bytes, off_keys_final, off_tile_rows, off_btile, off_trec, total;
+    size_t scan_temp, off_table, off_scanned, off_temp, off_sets, set_bytes, off_keys_final, off_tile_rows, total;
     int n_sets;
 };
 
@@ -692,26 +531,14 @@ static unsigned bits_for(int64_t n_keys) {  // enough bits for key values 0 .. n
     return b;
 }
 
-// Digit width.  Default: up to 9 bits (two passes for ids of up to 18 bits).  Tuning key 10 = 6: digits of at most 6 bits
-// -- THREE passes for 18-bit ids, but 64 bins over an 8192-slot tile are runs of 512 bytes: whole 128-byte lines and a
-// handful of DRAM pages per tile instead of 512 half-line pieces (the two 9-bit passes move ~10 GB for 1.84 GB
-// algorithmic on the Reddit-shaped graph: partial-line read-modify-write fills, profiles/r02_pmc_csr2csc.json).
-static int max_digit_bits() { return g_tuning[kTuneCsr2csc] == 6 ? 6 : kMaxBits; }
-
 static Geometry geometry(int64_t n_cols, int64_t nnz, bool padded) {
     Geometry g{};
     g.bits = (int)bits_for(padded ? n_cols + 1 : n_cols);
-    const int maxb = max_digit_bits();
-    g.n_pass = (g.bits + maxb - 1) / maxb;
+    g.n_pass = (g.bits + kMaxBits - 1) / kMaxBits;
     g.dbits = (g.bits + g.n_pass - 1) / g.n_pass;
     g.n_tiles = (nnz + kTile - 1) / kTile;
-    // (the MSD second pass cuts every bucket of the first into tiles of its own: at most one partly filled tile more per
-    //  bucket than the n_tiles of the whole array; the tables are sized for that)
-    g.table_len = (g.n_tiles + kMaxBins) << g.dbits;
-    size_t st = 0;
-    (void)rocprim::exclusive_scan(nullptr, st, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u,
-                                  (size_t)std::max<int64_t>(g.table_len, 1), rocprim::plus<uint32_t>(), nullptr);
-    g.scan_temp = st;
+    g.table_len = g.n_tiles << g.dbits;
+    g.scan_temp = device_scan_temp_bytes(g.table_len, sizeof(uint32_t));
     g.n_sets = std::min(g.n_pass - 1, 2);
     g.set_bytes = 3 * up256((size_t)nnz * 4);
     size_t o = 0;
@@ -719,18 +546,12 @@ static Geometry geometry(int64_t n_cols, int64_t nnz, bool padded) {
     o += up256((size_t)g.table_len * 4);
     g.off_scanned = o;
     o += up256((size_t)g.table_len * 4);
-    g.off_scanned1 = o;  // MSD: the first pass's scanned table stays alive through the second pass (bucket starts)
-    o += up256((size_t)g.table_len * 4);
     g.off_temp = o;
     o += up256(g.scan_temp);
     g.off_keys_final = o;
     o += up256((size_t)nnz * 4);
     g.off_tile_rows = o;
     o += up256((size_t)g.n_tiles * 8);
-    g.off_btile = o;
-    o += up256((size_t)(kMaxBins + 1) * 4);
-    g.off_trec = o;
-    o += up256((size_t)(g.n_tiles + kMaxBins) * 16);
     g.off_sets = o;
     o += (size_t)g.n_sets * g.set_bytes;
     g.total = o + 256;
@@ -751,41 +572,18 @@ int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int
     const Geometry g = geometry(n_cols, nnz, padded);
     const int row_bits = (int)bits_for(m);
     const int tune = g_tuning[kTuneCsr2csc];
-    // Two passes (column ids of up to 18 bits) with a digit and the row fitting one word: MSD-first.  The first pass
-    // places the slots by the HIGH digit (stable), the second sorts every bucket by the LOW digit inside the bucket's own
-    // output range -- a contiguous ~1/512 of the arrays that stays in the XCD's L2 while its tiles are written, instead of
-    // 64-byte runs scattered over all of it (the LSD second pass: 1.8x write amplification, PMC) -- and its scanned table
-    // IS colptr (no search per column, no sorted keys).  OPT-IN (tuning key 10 = 5): measured on the MI355X it does not
-    // pay -- Reddit-shaped graph 2.23 ms vs 1.95 ms for the LSD order (profiles/r03_csr2csc_ab.txt): R-MAT ids put a
-    // third of all edges into the first few buckets, whose output ranges are tens of MB (nothing stays in L2), and the
-    // bucket-aligned tiles cost a dependent record load per workgroup; arxiv-sized graphs: equal (116 us).
-    const bool msd = g.n_pass == 2 && row_bits + g.dbits <= 32 && tune == 5;
+    // Two passes (column ids of up to 18 bits) with a digit and the row fitting one word: PACKED intermediate records
     // (LSD: packed records from 16 M slots on: below that the per-column searches of rt_colptr_perm cost more than the
     //  one staged array they save -- arxiv-shaped, 2.5 M slots: 125 vs 117 us; Reddit-shaped, 115 M: 2.00 vs 2.06 ms)
-    // (three or more passes -- tuning key 10 = 6 -- are always packed when the first intermediate word fits: the key's
-    //  remaining digits above the row)
-    const bool packed = msd || (g.n_pass == 2 && row_bits + g.dbits <= 32 && (nnz >= (int64_t(1) << 24) || tune == 3)) ||
-                        (g.n_pass >= 3 && row_bits + (g.bits - g.dbits) <= 32 && tune == 6);
+    const bool packed = g.n_pass == 2 && row_bits + g.dbits <= 32 && (nnz >= (int64_t(1) << 24) || tune == 3);
     if (g.n_tiles > 0x7fffffff || g.table_len > 0x7fffffff || m > 0x7fff0000) return COGDL_HIP_ERANGE;  // (int row loops)
     char *ws = (char *)workspace;
     uint32_t *table = (uint32_t *)(ws + g.off_table), *scanned = (uint32_t *)(ws + g.off_scanned);
-    uint32_t *scanned1 = (uint32_t *)(ws + g.off_scanned1);
-    int32_t *btile = (int32_t *)(ws + g.off_btile);
     void *temp = ws + g.off_temp;
     uint32_t *keys_final = (uint32_t *)(ws + g.off_keys_final);
     auto set_ptr = [&](int idx, int which) { return ws + g.off_sets + (size_t)idx * g.set_bytes + (size_t)which * up256((size_t)nnz * 4); };
     auto scan = [&](const uint32_t *in, uint32_t *out, int64_t len) -> bool {
-        if (len <= kSmallScan) {
-            hipLaunchKernelGGL(rt_scan_small_kernel, dim3(1), dim3(kScanThreads), 0, s, in, out, len);
-            return true;
-        }
-        size_t tb = g.scan_temp;
-        hipError_t e = rocprim::exclusive_scan(temp, tb, in, out, 0u, (size_t)len, rocprim::plus<uint32_t>(), s);
-        if (e != hipSuccess) {
-            g_last_hip_error = (int)e;
-            return false;
-        }
-        return true;
+        return device_exclusive_sum(in, out, len, temp, s) == COGDL_HIP_OK;
     };
     Params p{};
     p.colind = colind;
@@ -799,49 +597,6 @@ int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int
     p.bits = g.dbits;
     p.row_bits = row_bits;
     const unsigned dgrid = (unsigned)(((g.n_tiles + kXcds - 1) / kXcds) * kXcds);  // (XCD-contiguous tile ranges)
-    if (msd) {
-        // ---- pass 1: by the key's top `hbits` bits; records out = (e, (low digit << row_bits) | row)
-        const int lbits = g.dbits, hbits = g.bits - g.dbits;
-        const int64_t t2max = g.n_tiles + (int64_t(1) << hbits);
-        if (t2max > 0x7fffffff) return COGDL_HIP_ERANGE;
-        p.msd = 1;
-        p.shift = lbits;
-        p.bits = hbits;
-        p.e_out = (int32_t *)set_ptr(0, 1);
-        p.row_out = (int32_t *)set_ptr(0, 2);
-        p.table = table;
-        hipLaunchKernelGGL((rt_upsweep_kernel<true, false>), dim3((unsigned)g.n_tiles), dim3(kThreads), 0, s, p);
-        if (!scan(table, scanned1, g.n_tiles << hbits)) return COGDL_HIP_ELAUNCH;
-        p.table = scanned1;
-        hipLaunchKernelGGL((rt_downsweep_kernel<true, 1>), dim3(dgrid), dim3(kThreads), 0, s, p);
-        // ---- pass 2: every bucket by the low digit, inside the bucket
-        p.msd = 0;
-        p.shift = 0;
-        p.bits = lbits;
-        p.bstart = scanned1;
-        p.n_tiles1 = g.n_tiles;
-        p.nb1 = 1 << hbits;
-        p.btile = btile;
-        p.e_in = (const int32_t *)set_ptr(0, 1);
-        p.row_in = (const int32_t *)set_ptr(0, 2);
-        p.e_out = perm;
-        p.row_out = rowind;
-        p.table = table;
-        p.t2max = t2max;
-        uint4 *trec = (uint4 *)(ws + g.off_trec);
-        p.trec = trec;
-        hipLaunchKernelGGL(rt_bucket_tiles_kernel, dim3(1), dim3(kThreads), 0, s, p, btile);
-        hipLaunchKernelGGL(rt_tile_records_kernel, dim3((unsigned)((t2max + 255) / 256)), dim3(256), 0, s, p, trec, lbits);
-        hipLaunchKernelGGL((rt_upsweep_kernel<false, true, true>), dim3((unsigned)t2max), dim3(kThreads), 0, s, p);
-        // (entries behind the last real tile are never written: an exclusive scan's prefix does not depend on them)
-        if (!scan(table, scanned, t2max << lbits)) return COGDL_HIP_ELAUNCH;
-        p.table = scanned;
-        const unsigned dgrid2 = (unsigned)(((t2max + kXcds - 1) / kXcds) * kXcds);
-        hipLaunchKernelGGL((rt_downsweep_kernel<false, 2, true>), dim3(dgrid2), dim3(kThreads), 0, s, p);
-        const unsigned cb = (unsigned)std::min<int64_t>((n_cols + 256) / 256, 1 << 20);
-        if (colptr) hipLaunchKernelGGL(rt_colptr_msd_kernel, dim3(cb), dim3(256), 0, s, p, (const uint32_t *)scanned, lbits, n_cols, colptr);
-        return launch_status();
-    }
     for (int pass = 0; pass < g.n_pass; ++pass) {
         const bool first = pass == 0, last = pass == g.n_pass - 1;
         p.shift = pass * g.dbits;
@@ -870,8 +625,7 @@ int radix_transpose(const int32_t *rowptr, const int32_t *colind, int64_t m, int
         p.table = scanned;
         if (packed) {
             if (first) hipLaunchKernelGGL((rt_downsweep_kernel<true, 1>), dim3(dgrid), dim3(kThreads), 0, s, p);
-            else if (last) hipLaunchKernelGGL((rt_downsweep_kernel<false, 2>), dim3(dgrid), dim3(kThreads), 0, s, p);
-            else hipLaunchKernelGGL((rt_downsweep_kernel<false, 3>), dim3(dgrid), dim3(kThreads), 0, s, p);
+            else hipLaunchKernelGGL((rt_downsweep_kernel<false, 2>), dim3(dgrid), dim3(kThreads), 0, s, p);
         } else {
             if (first) hipLaunchKernelGGL((rt_downsweep_kernel<true, 0>), dim3(dgrid), dim3(kThreads), 0, s, p);
             else hipLaunchKernelGGL((rt_downsweep_kernel<false, 0>), dim3(dgrid), dim3(kThreads), 0, s, p);

@@ -48,6 +48,7 @@
 #include <algorithm>
 #include <climits>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -80,10 +81,7 @@ struct RowSched {
     XcdMap rowblocks;
     LongRows lr;
     int sort_rows;  // deal a workgroup's rows to its lane groups by decreasing length (see rowreduce_main_kernel)
-    int wave_split; // > 0: in a skewed workgroup, rows of more than this many edges are reduced by ALL lane groups of their wave
     int debug;      // timing experiments (tuning key 13; WRONG results): 1 = row blocks exit, 2 = long-row workgroups exit
-    int64_t nnz;    // (the row-tile kernel needs a valid edge index for the rows that have none)
-    int queue;      // rowreduce_queue_kernel: wave-units of rows per wave handed out by the workgroup's queue (0: not used)
 };
 
 // Operators may ask for a register budget: `static constexpr int kMinWaves = W` compiles their main kernel for at least W
@@ -96,41 +94,6 @@ template <class Op>
 struct MinWaves<Op, std::void_t<decltype(Op::kMinWaves)>> {
     static constexpr int value = Op::kMinWaves;
 };
-
-// Operators that can run in ROW TILES (rowreduce_tile_kernel) declare `static constexpr int kRowTile = R`.
-template <class Op, class = void>
-struct RowTile {
-    static constexpr int value = 1;
-};
-template <class Op>
-struct RowTile<Op, std::void_t<decltype(Op::kRowTile)>> {
-    static constexpr int value = Op::kRowTile;
-};
-
-// Operators that may run through the per-workgroup ROW QUEUE (rowreduce_queue_kernel) declare `static constexpr bool
-// kRowQueue = true` (their hooks must not contain workgroup barriers: the waves of a workgroup walk different rows).
-template <class Op, class = void>
-struct RowQueue {
-    static constexpr bool value = false;
-};
-template <class Op>
-struct RowQueue<Op, std::void_t<decltype(Op::kRowQueue)>> {
-    static constexpr bool value = Op::kRowQueue;
-};
-
-// Rows of at most this many edges are always reduced sequentially by one lane group, in CSR order (the reference's
-// summation order: bit-identical fp32 results); longer rows MAY be cut into contiguous pieces whose partial states are
-// merged in order (wave-scope split in skewed workgroups, workgroup-scope chunks beyond the long-row threshold).
-// OFF by default (tuning key 12: <= 0 = off, n > 0 = split rows of more than n edges): measured on the MI355X it buys
-// nothing -- arxiv-sized R-MAT graph, csr_spmm F=64: 133.3 us off / 136.3 (n = 64) / 132.1 (n = 32), F=40: 118.9 / 116.2 /
-// 114.8, fused GAT forward 239 / 238 / 233 us (profiles/r04_wavesplit_ab.txt) -- because only 2.8 % of that graph's edges
-// sit in rows of 65..128 edges: half of its edges are in rows ABOVE the long-row threshold (the workgroup-scope path),
-// and the rest of the imbalance is between waves, not inside them.  Kept as an option (and tested) because graphs with
-// a heavier middle of the degree distribution are where it would pay.
-inline int wave_split_edges() {
-    const int t = g_tuning[kTuneWaveSplit];
-    return t > 0 ? t : 0;
-}
 
 // Threshold above which a row is split.  The sequential time of a row of T edges (~T/UNROLL gather round trips of
 // ~1 us) must stay a small fraction of the launch; small graphs need a low threshold, large ones amortise more.
@@ -207,10 +170,34 @@ __device__ __forceinline__ bool decode_piece(const LongRows &lr, const int32_t *
     return lo < hi;
 }
 
+// Lane jj of the caller's group of LPR lanes, broadcast to the group.  Round 6: on hub-heavy graphs the row-reduce kernels are
+// bound by VALU issue (profiles/r06_sq_reddit.txt), and a ds_bpermute costs four vector instructions for its address
+// (clamp, add the group's base, wrap, scale) per broadcast.  reduce_chunk unrolls a chunk completely, so jj is a compile-time
+// constant wherever it matters, and the broadcast is an instruction with an IMMEDIATE pattern: v_readlane (LPR = 64), a DPP
+// row_share move (16: a DPP row IS 16 lanes) or quad_perm move (4), a ds_swizzle in bit-mask mode (8, 32: lane' = (lane &
+// ~(LPR - 1)) | jj inside each half wave) -- no address arithmetic, and no LDS traffic for 4 / 16 / 64.  The `switch` folds
+// away under constant propagation; a run-time jj still works (through a jump table: slow, not wrong).  Lane groups that do
+// not tile a wave (10 / 12 / 20 lanes) keep ds_bpermute.
+template <int LPR, int JJ>
+__device__ __forceinline__ int group_bcast_imm(int v) {
+    static_assert(JJ >= 0 && JJ < LPR, "lane inside the group");
+    if constexpr (LPR == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150 + JJ, 0xf, 0xf, false);  // row_share:JJ
+    else if constexpr (LPR == 4) return __builtin_amdgcn_update_dpp(0, v, JJ * 0x55, 0xf, 0xf, false);  // quad_perm:[JJ,JJ,JJ,JJ]
+    else return __builtin_amdgcn_ds_swizzle(v, (JJ << 5) | (0x1f & ~(LPR - 1)));  // bit mode: and_mask | or_mask << 5
+}
+template <int LPR, int... JJ>
+__device__ __forceinline__ int group_bcast_switch(int v, int jj, std::integer_sequence<int, JJ...>) {
+    int r = v;
+    (void)((jj == JJ ? (r = group_bcast_imm<LPR, JJ>(v), true) : false) || ...);
+    return r;
+}
 template <int LPR>
 __device__ __forceinline__ int group_bcast(int v, int sub, int jj) {
     if constexpr (LPR == kWave) return __builtin_amdgcn_readlane(v, jj);  // -> SGPR: scalar address arithmetic
-    else return __shfl(v, sub * LPR + jj, kWave);
+    else if constexpr (LPR == 4 || LPR == 8 || LPR == 16 || LPR == 32) {
+        if (__builtin_constant_p(jj)) return group_bcast_switch<LPR>(v, jj, std::make_integer_sequence<int, LPR>{});
+        return __shfl(v, sub * LPR + jj, kWave);
+    } else return __shfl(v, sub * LPR + jj, kWave);
 }
 template <int LPR>
 __device__ __forceinline__ float group_bcast(float v, int sub, int jj) {
@@ -263,18 +250,44 @@ __device__ __forceinline__ void reduce_chunk(const Op &op, typename Op::Ctx &ctx
                                              int my_c, const typename Op::LaneVals &lv, int sub, int l, float *lds) {
     constexpr int LPR = Op::LPR, UNROLL = Op::UNROLL;
     op.chunk_begin(ctx, st, base, cnt, my_c, sub, l, lds, lv);
-    for (int j = 0; j < cnt; j += UNROLL) {
-        typename Op::Batch b;
-        // Issue all UNROLL gathers back to back (no branches: a masked tail slot re-reads the row's last valid
-        // neighbour, an L1 hit, and is ignored by apply()).
+    // Lane groups that tile a wave and are narrower than it: the chunk is unrolled completely (LPR / UNROLL <= 4 batches, the
+    // later ones guarded), so that the position jj of a slot inside the chunk is a compile-time constant -- which is what
+    // lets group_bcast use immediate lane patterns.  Whole-wave groups (v_readlane takes a scalar lane anyway; eight
+    // unrolled batches only cost instruction-cache misses: fused GAT forward H = 1 x F = 41 in 2-byte lanes 4.4 -> 6.8 ms)
+    // and the groups of 10 / 12 / 20 lanes (ds_bpermute) keep the loop.
+    constexpr bool kUnrolled = LPR == 4 || LPR == 8 || LPR == 16 || LPR == 32;
+    if constexpr (kUnrolled) {
+        constexpr int NB = (LPR + UNROLL - 1) / UNROLL;
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int jj = min(j + u, cnt - 1);
-            op.fetch(ctx, b, u, group_bcast<LPR>(my_c, sub, jj), base + jj, lv, sub, jj);
+        for (int jb = 0; jb < NB; ++jb) {
+            const int j = jb * UNROLL;
+            if (j < cnt) {  // (group-uniform)
+                typename Op::Batch b;
+                // Issue all UNROLL gathers back to back (no branches: a slot past the chunk's end re-reads the row's last
+                // valid neighbour -- the lanes past the end hold ITS column id and per-edge scalars, their loads were
+                // clamped into the row -- an L1 hit, and is ignored by apply()).
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int jj = (j + u < LPR) ? j + u : LPR - 1;  // (compile-time)
+                    op.fetch(ctx, b, u, group_bcast<LPR>(my_c, sub, jj), base + min(jj, cnt - 1), lv, sub, jj);
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) op.apply(ctx, st, b, u, (j + u) < cnt, base + j + u, j + u);
+                op.batch_end(ctx, st, base, j, cnt);
+            }
         }
+    } else {
+        for (int j = 0; j < cnt; j += UNROLL) {
+            typename Op::Batch b;
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) op.apply(ctx, st, b, u, (j + u) < cnt, base + j + u, j + u);
-        op.batch_end(ctx, st, base, j, cnt);
+            for (int u = 0; u < UNROLL; ++u) {
+                const int jj = min(j + u, cnt - 1);
+                op.fetch(ctx, b, u, group_bcast<LPR>(my_c, sub, jj), base + jj, lv, sub, jj);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) op.apply(ctx, st, b, u, (j + u) < cnt, base + j + u, j + u);
+            op.batch_end(ctx, st, base, j, cnt);
+        }
     }
     op.chunk_end(ctx, st, base, cnt);
 }
@@ -449,13 +462,9 @@ __device__ __forceinline__ void rowreduce_long_block(const Op &op, const RowSche
 // row well above the mean; the test is workgroup-uniform, uniform graphs pay one barrier and one pass over GPB LDS
 // words).  `slot` = this group's natural position, `leader` = one lane per group.  On return (true) `mine` is the
 // natural position of the row this group now owns and (ok, start, end) describe that row.  Called by ALL threads.
-// Which rank a group takes: its own slot (wave 0 gets the longest rows: best when a wave takes as long as its longest
-// row) -- or, when the workgroup holds a MEDIUM row (more than split_min edges, at most `thresh`) that its wave will
-// reduce with all its groups together (wave time = sum / groups), rank `rr_rank` = sub * 4 + wave: round-robin over
-// the waves, equal sums.
+// A group takes the rank of its own slot: wave 0 gets the longest rows (a wave takes as long as its longest row).
 template <int GPB>
-__device__ __forceinline__ bool deal_rows_by_length(int slot, bool leader, bool &ok, int &start, int &end, int &mine,
-                                                    int rr_rank, int split_min, int thresh) {
+__device__ __forceinline__ bool deal_rows_by_length(int slot, bool leader, bool &ok, int &start, int &end, int &mine) {
     __shared__ int sort_deg[GPB], sort_start[GPB], sort_slot[GPB];
     const int deg = ok ? end - start : -1;
     if (leader) {
@@ -463,12 +472,11 @@ __device__ __forceinline__ bool deal_rows_by_length(int slot, bool leader, bool 
         sort_start[slot] = start;
     }
     __syncthreads();
-    int dmax = 0, dsum = 0, dmed = 0;
+    int dmax = 0, dsum = 0;
     for (int q = 0; q < GPB; ++q) {
         const int dq = max(sort_deg[q], 0);
         dmax = max(dmax, dq);
         dsum += dq;
-        if (dq <= thresh) dmed = max(dmed, dq);
     }
     if (dmax * GPB < 2 * dsum + 8 * GPB) return false;
     int rank = 0;  // by (length descending, natural position ascending)
@@ -478,7 +486,7 @@ __device__ __forceinline__ bool deal_rows_by_length(int slot, bool leader, bool 
     }
     if (leader) sort_slot[rank] = slot;
     __syncthreads();
-    mine = sort_slot[(split_min > 0 && dmed > split_min) ? rr_rank : slot];
+    mine = sort_slot[slot];
     ok = sort_deg[mine] >= 0;
     start = sort_start[mine];
     end = start + max(sort_deg[mine], 0);
@@ -516,7 +524,6 @@ __global__ __launch_bounds__(256, MinWaves<Op>::value) void rowreduce_main_kerne
         start = s.rowptr[row];
         end = s.rowptr[row + 1];
     }
-    bool skewed = false;
     if constexpr (RPW > 1) {
         // Several rows share a wave, and a wave takes as long as its LONGEST row: on a skewed graph a wave with one
         // 100-edge row and three 5-edge rows idles 70 % of its lanes.  The workgroup's GPB rows are therefore dealt to
@@ -524,13 +531,9 @@ __global__ __launch_bounds__(256, MinWaves<Op>::value) void rowreduce_main_kerne
         // RPW longest rows, wave 3 the shortest, the sum over waves of their longest row -- the lane time spent --
         // drops by 2-3x on R-MAT graphs.  Only the row -> lane-group assignment changes: every row is still reduced
         // sequentially by one group in CSR order (bit-identical results).
-        // With the wave-scope split (below) a wave's time is the SUM of its rows' lengths / RPW instead of their maximum,
-        // so the ranks are dealt ROUND-ROBIN over the four waves (wave w takes ranks w, w + 4, ...: equal sums).
         if (g_sort_rows(s)) {
             int mine;
-            skewed = deal_rows_by_length<GPB>(wave * RPW + sub, lane_on && l == 0, ok, start, end, mine, sub * 4 + wave,
-                                              kWave % LPR == 0 ? s.wave_split : 0, s.lr.thresh);
-            if (skewed) row = rb * GPB + mine;
+            if (deal_rows_by_length<GPB>(wave * RPW + sub, lane_on && l == 0, ok, start, end, mine)) row = rb * GPB + mine;
             if (!lane_on) {
                 ok = false;
                 start = end = 0;
@@ -543,54 +546,6 @@ __global__ __launch_bounds__(256, MinWaves<Op>::value) void rowreduce_main_kerne
     }
     const bool is_long = end - start > s.lr.thresh;  // long row: the long-row workgroups compute it
     float *const my_lds = op_lds + (threadIdx.x / LPR) * LPR * Op::kLds;
-    if constexpr (RPW > 1 && kWave % LPR == 0) {
-        // Wave-scope split of MEDIUM rows (skewed workgroups only).  A row of a few hundred edges, below the long-row
-        // threshold, is one lane group walking ~len / UNROLL dependent gather batches while the other groups of its wave
-        // finished their 5-edge rows long ago.  In a wave that holds such a row (> wave_split edges) the groups first
-        // reduce their own SHORT rows as always, then every medium row of the wave is reduced by all RPW groups together:
-        // contiguous slices, the partial states merged in slice order through shuffles (no LDS, no barrier) and finished
-        // by group 0.  Rows of at most wave_split edges keep the reference's sequential order (bit-identical); a split
-        // row is re-associated at its slice borders only (deterministic).
-        const bool medium = ok && !is_long && s.wave_split > 0 && end - start > s.wave_split;
-        if (skewed && __ballot(medium) != 0ull) {
-            typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
-            if (ok && !is_long && !medium) {  // (group-uniform)
-                op.row_load(ctx, row, true);
-                typename Op::State st;
-                op.init(ctx, st, row, true);
-                reduce_edges<Op>(op, ctx, st, s.colind, start, end, sub, l, my_lds);
-                op.row_end(ctx, st, row, true);
-            }
-            unsigned long long todo = __ballot(medium && l == 0);
-            while (todo) {  // (wave-uniform)
-                const int src = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const int64_t r2 = rb * GPB + (int64_t)__shfl((int)(row - rb * GPB), src, kWave);
-                const int s2 = __shfl(start, src, kWave), e2 = __shfl(end, src, kWave);
-                const int per = ((e2 - s2 + RPW - 1) / RPW + Op::UNROLL - 1) / Op::UNROLL * Op::UNROLL;
-                const int sb = min(s2 + sub * per, e2), se = min(sb + per, e2);
-                op.row_load(ctx, r2, true);
-                typename Op::State st;
-                if (sub == 0) op.init(ctx, st, r2, true);  // (an accumulating operator reads the existing output once)
-                else op.init_zero(st);
-                reduce_edges<Op>(op, ctx, st, s.colind, sb, se, sub, l, my_lds);
-                if constexpr (Op::kReduce) {
-                    float rec[Op::kRec];
-                    op.pack(st, rec);
-                    for (int q = 1; q < RPW; ++q) {  // slice order: group 0, 1, 2, ...
-                        float other_rec[Op::kRec];
-#pragma unroll
-                        for (int i = 0; i < Op::kRec; ++i) other_rec[i] = __shfl(rec[i], q * LPR + l, kWave);
-                        typename Op::State other;
-                        op.unpack(other, other_rec);
-                        op.merge(ctx, st, other);  // (all groups execute it: merge may shuffle inside a group)
-                    }
-                }
-                op.row_end(ctx, st, r2, sub == 0);
-            }
-            return;
-        }
-    }
     if (is_long) return;
     typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
     op.row_load(ctx, row, ok);
@@ -598,186 +553,6 @@ __global__ __launch_bounds__(256, MinWaves<Op>::value) void rowreduce_main_kerne
     op.init(ctx, st, row, ok);
     reduce_edges<Op>(op, ctx, st, s.colind, start, end, sub, l, my_lds);
     op.row_end(ctx, st, row, ok);
-}
-
-// ---- row tiles (round 4) --------------------------------------------------------------------------------------------
-// What bounds the row blocks on graphs with many tiny rows is the dependent chain of a row -- row pointer, column ids,
-// gather, store: three round trips even for ONE edge (169 k one-edge rows take 38 us; half the rows of an R-MAT graph
-// have at most two edges, tools/rowcost_probe.py).  Here a lane group owns R CONSECUTIVE rows and walks their chains
-// together: one load brings the R + 1 row pointers, the R first id chunks are requested at once, and the first
-// UNROLL / R edges of every row are gathered in ONE batch -- three round trips per R rows.  Whatever a row has beyond
-// that is folded afterwards, row by row, in CSR order: per row the arithmetic and its order are those of the plain
-// kernel (bit-identical results); R rows per group also average the row lengths a wave sees.  Operators whose context
-// and hooks do not depend on the row (SpmmOp without attention / epilogue) opt in with kRowTile.
-template <class Op, int R>
-__global__ __launch_bounds__(256) void rowreduce_tile_kernel(const Op op, const RowSched s) {
-    constexpr int LPR = Op::LPR, UNROLL = Op::UNROLL;
-    static_assert(Op::kLds == 0 && UNROLL % R == 0 && kWave % LPR == 0 && R < LPR, "row tiles: plain operators only");
-    constexpr int RPW = kWave / LPR, GPB = RPW * 4, U1 = UNROLL / R;
-    __shared__ float op_lds[1];
-    if (blockIdx.x < s.lr.n_long_blocks) {
-        if (s.debug != 2) rowreduce_long_block<Op>(op, s, op_lds);
-        return;
-    }
-    if (s.debug == 1) return;
-    const int64_t rb = xcd_remap(blockIdx.x - s.lr.n_long_blocks, s.rowblocks);
-    if (rb < 0) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-    const int l = lane % LPR, sub = lane / LPR;
-    const int64_t row0 = (rb * GPB + wave * RPW + sub) * R;
-    // the R + 1 row pointers of the group: one coalesced load (rows past the end read rowptr[m]: empty)
-    const int pv = s.rowptr[min(row0 + min(l, R), s.m)];
-    int st_[R], cnt_[R], en_[R];
-    bool live[R];  // false: a row past the end, or a long row (the long-row workgroups and the combine kernel own it)
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        st_[i] = group_bcast<LPR>(pv, sub, i);
-        en_[i] = group_bcast<LPR>(pv, sub, i + 1);
-        live[i] = row0 + i < s.m && en_[i] - st_[i] <= s.lr.thresh;
-        if (!live[i]) en_[i] = st_[i];
-        cnt_[i] = min(LPR, en_[i] - st_[i]);
-    }
-    typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
-    // phase 0: the first id chunk of every row (unconditional loads; a row without edges reads edge 0 and ignores it)
-    int c_[R];
-    typename Op::LaneVals lv_[R];
-    if (s.nnz > 0) {
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int idx = cnt_[i] > 0 ? min(st_[i] + l, en_[i] - 1) : 0;
-            c_[i] = s.colind[idx];
-            lv_[i] = typename Op::LaneVals{};
-            op.lane_load(ctx, lv_[i], idx);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            c_[i] = 0;
-            lv_[i] = typename Op::LaneVals{};
-        }
-    }
-    typename Op::State acc[R];
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        op.row_load(ctx, row0 + i, live[i]);
-        op.init(ctx, acc[i], row0 + i, live[i]);
-    }
-    // phase 1: the first U1 edges of all R rows in one batch of gathers
-    if (s.nnz > 0) {
-        typename Op::Batch b;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-#pragma unroll
-            for (int k = 0; k < U1; ++k) {
-                const int jj = max(min(k, cnt_[i] - 1), 0);
-                op.fetch(ctx, b, i * U1 + k, group_bcast<LPR>(c_[i], sub, jj), st_[i] + jj, lv_[i], sub, jj);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-#pragma unroll
-            for (int k = 0; k < U1; ++k) op.apply(ctx, acc[i], b, i * U1 + k, k < cnt_[i], st_[i] + k, k);
-        }
-    }
-    // phase 2: what a row has beyond its first U1 edges, row by row, in order
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        if (cnt_[i] > U1) {  // (group-uniform)
-            for (int j = U1; j < cnt_[i]; j += UNROLL) {
-                typename Op::Batch b;
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    const int jj = min(j + u, cnt_[i] - 1);
-                    op.fetch(ctx, b, u, group_bcast<LPR>(c_[i], sub, jj), st_[i] + jj, lv_[i], sub, jj);
-                }
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) op.apply(ctx, acc[i], b, u, (j + u) < cnt_[i], st_[i] + j + u, j + u);
-            }
-            if (st_[i] + LPR < en_[i]) reduce_edges<Op>(op, ctx, acc[i], s.colind, st_[i] + LPR, en_[i], sub, l, op_lds);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < R; ++i)
-        if (live[i]) op.row_end(ctx, acc[i], row0 + i, true);
-}
-
-// ---- row queue (round 5) ---------------------------------------------------------------------------------------------
-// What the degree-sorted dealing of rowreduce_main_kernel cannot fix on skewed graphs is the imbalance BETWEEN waves and
-// between workgroups: a workgroup lives as long as its longest row while its other waves finished their 5-edge rows long
-// ago (arxiv-sized R-MAT graph, F = 64: row blocks alone 107 us, 77 us with rows and columns relabelled by degree,
-// profiles/r04_longpath_probe.txt).  Here a workgroup owns `queue` times as many consecutive rows and its four waves PULL
-// wave-units of RPW rows from a counter in LDS until the pool is empty: a wave that drew a 100-edge row simply takes fewer
-// units.  Per row nothing changes -- one lane group, CSR order, the operator's own hooks (bit-identical results); long rows
-// are skipped as before.  One LDS atomic per unit; no barrier after the first.
-template <class Op>
-__global__ __launch_bounds__(256, MinWaves<Op>::value) void rowreduce_queue_kernel(const Op op, const RowSched s) {
-    __shared__ float op_lds[Op::kLds > 0 ? 256 * Op::kLds : 1];
-    __shared__ int q_next;
-    if (blockIdx.x < s.lr.n_long_blocks) {
-        if (s.debug != 2) rowreduce_long_block<Op>(op, s, op_lds);
-        return;
-    }
-    if (s.debug == 1) return;
-    constexpr int LPR = Op::LPR;
-    constexpr int RPW = kWave / LPR;
-    const int64_t rb = xcd_remap(blockIdx.x - s.lr.n_long_blocks, s.rowblocks);
-    if (rb < 0) return;
-    if (threadIdx.x == 0) q_next = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & (kWave - 1);
-    const int l = lane % LPR;
-    const bool lane_on = (kWave % LPR == 0) || lane / LPR < RPW;
-    const int sub = lane_on ? lane / LPR : 0;
-    const int n_units = s.queue * 4;
-    const int64_t row0 = rb * (int64_t)n_units * RPW;
-    float *const my_lds = op_lds + (threadIdx.x / LPR) * LPR * Op::kLds;
-    typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
-    // The row pointers of the NEXT unit are requested before the gathers of the current one: a unit's dependent chain is
-    // (row pointers ->) column ids -> gathers instead of three round trips -- on graphs where half the rows have one or two
-    // edges the chain, not the bytes, is what a row costs.
-    auto claim = [&]() {
-        int u = 0;
-        if (lane == 0) u = atomicAdd(&q_next, 1);
-        return __builtin_amdgcn_readfirstlane(u);  // (lane 0 is the first active lane)
-    };
-    auto bounds = [&](int u, int64_t &row, bool &ok, int &start, int &end) {
-        row = row0 + (int64_t)u * RPW + sub;
-        ok = lane_on && u < n_units && row < s.m;
-        start = end = 0;
-        if (ok) {
-            start = s.rowptr[row];
-            end = s.rowptr[row + 1];
-        }
-    };
-    int u = claim();
-    int64_t row;
-    bool ok;
-    int start, end;
-    bounds(u, row, ok, start, end);
-    while (u < n_units && row0 + (int64_t)u * RPW < s.m) {  // (wave-uniform)
-        const int un = claim();
-        int64_t row_n;
-        bool ok_n;
-        int start_n, end_n;
-        bounds(un, row_n, ok_n, start_n, end_n);  // in flight while this unit's rows are reduced
-        if constexpr (LPR == kWave) {
-            start = __builtin_amdgcn_readfirstlane(start);
-            end = __builtin_amdgcn_readfirstlane(end);
-        }
-        if (end - start <= s.lr.thresh) {  // (group-uniform) a long row is the long-row workgroups' and the combine kernel's
-            op.row_load(ctx, row, ok);
-            typename Op::State st;
-            op.init(ctx, st, row, ok);
-            reduce_edges<Op>(op, ctx, st, s.colind, start, end, sub, l, my_lds);
-            op.row_end(ctx, st, row, ok);
-        }
-        u = un;
-        row = row_n;
-        ok = ok_n;
-        start = start_n;
-        end = end_n;
-    }
 }
 
 // For every long row merge its piece records in chunk order and finish the row.  The row is combined by the lane
@@ -840,23 +615,166 @@ __global__ __launch_bounds__(256) void rowreduce_combine_kernel(const Op op, con
     }
 }
 
+// ---- XCD-partitioned columns (round 6) -------------------------------------------------------------------------------
+// Every XCD of the MI355X has a private 4 MiB L2.  A gathered table of tens of MB (Reddit-shaped graph: 233 k rows of 128 /
+// 256 bytes) fits none of them, so a hub-heavy launch re-fetches it from the Infinity Cache at the fabric rate (PMC: 11-16 GB
+// per launch for 0.5 GB compulsory) -- but it does fit the eight L2s TOGETHER.  A plan (cogdl_hip_vrows, built once per
+// structure: cogdl_amd/xcdplan.py) therefore gives every column an owner XCD by a hash of its id, cuts each long row into the
+// eight sub-rows of its edges by owner (CSR order inside a sub-row, pieces of at most T edges) and lays these VIRTUAL rows out
+// so that a workgroup on XCD x only ever holds virtual rows whose columns XCD x owns: an XCD's L2 then sees one eighth of the
+// table.  Short rows stay whole.  A virtual row of a multi-part row leaves its state as a record; rowreduce_vcombine_kernel
+// merges a row's records in a fixed order (owner XCD, then piece) -- deterministic, re-associated like the long-row path.
+// Measured on the Reddit-shaped graph before the kernels existed (tools/xcdpart_probe.py, the layout expressed as a permuted
+// CSR on the unchanged csr_spmm): F = 64 fp32 3220 -> 1613 us, bf16 1501 -> 1290 us; the same virtual rows dealt to the XCDs
+// regardless of their columns: 2594 / 1379 us.
+// Layout: slots in UNITS of kVUnit; unit u belongs to XCD u % 8; workgroup w runs on XCD w % 8 (hardware round-robin) and is
+// that XCD's (w / 8)-th workgroup.
+constexpr int kVUnit = 64;
+struct VRows {
+    const int32_t *vrowptr;  // [n_slots + 1] edge offsets of the slots in the permuted edge order
+    const int32_t *vcol;     // [nnz] column ids in that order
+    const int2 *vdesc;       // [n_slots] {row (-1: padding), record index (-1: the row's only part: finished here)}
+    const int32_t *mrow;     // [n_multi] rows with several parts ...
+    const int32_t *mptr;     // [n_multi + 1] ... and their records [mptr[i], mptr[i + 1]) in merge order
+    float *partial;          // [n_parts][rec_stride]
+    int64_t n_slots, n_multi, n_parts, rec_stride;
+    int sort_rows;
+};
+
+template <class Op>
+__global__ __launch_bounds__(256, MinWaves<Op>::value) void rowreduce_vrow_kernel(const Op op, const VRows v) {
+    static_assert(Op::kReduce, "virtual rows: operators with a per-row state");
+    __shared__ float op_lds[Op::kLds > 0 ? 256 * Op::kLds : 1];
+    constexpr int LPR = Op::LPR;
+    constexpr int RPW = kWave / LPR;
+    constexpr int GPB = RPW * 4;
+    constexpr int WPU = kVUnit / GPB;  // workgroups per unit
+    static_assert(kWave % LPR == 0 && kVUnit % GPB == 0, "virtual rows: lane groups that tile a wave");
+    const unsigned x = blockIdx.x % kXcds, i = blockIdx.x / kXcds;
+    const int64_t slot0 = ((int64_t)(i / WPU) * kXcds + x) * kVUnit + (int64_t)(i % WPU) * GPB;
+    if (slot0 >= v.n_slots) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int l = lane % LPR, sub = lane / LPR;
+    int64_t slot = slot0 + wave * RPW + sub;
+    int2 d = make_int2(-1, -1);
+    int start = 0, end = 0;
+    if (slot < v.n_slots) {
+        d = v.vdesc[slot];
+        start = v.vrowptr[slot];
+        end = v.vrowptr[slot + 1];
+    }
+    bool ok = d.x >= 0;
+    if constexpr (RPW > 1) {
+        if (v.sort_rows) {  // (same dealing as the row blocks: a wave takes as long as its longest virtual row)
+            int mine;
+            if (deal_rows_by_length<GPB>(wave * RPW + sub, l == 0, ok, start, end, mine)) {
+                slot = slot0 + mine;
+                d = ok ? v.vdesc[slot] : make_int2(-1, -1);
+            }
+        }
+    }
+    if constexpr (LPR == kWave) {
+        start = __builtin_amdgcn_readfirstlane(start);
+        end = __builtin_amdgcn_readfirstlane(end);
+    }
+    float *const my_lds = op_lds + (threadIdx.x / LPR) * LPR * Op::kLds;
+    typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
+    const int64_t row = d.x;
+    const bool whole = d.y < 0;
+    op.row_load(ctx, row, ok);
+    typename Op::State st;
+    if (whole) op.init(ctx, st, row, ok);
+    else op.init_zero(st);
+    reduce_edges<Op>(op, ctx, st, v.vcol, start, end, sub, l, my_lds);
+    if (whole) {
+        op.row_end(ctx, st, row, ok);
+    } else if (ok) {
+        float rec[Op::kRec];
+        op.pack(st, rec);
+        float *dst = v.partial + (int64_t)d.y * v.rec_stride + (int64_t)blockIdx.y * Op::kRec * LPR;
+#pragma unroll
+        for (int q = 0; q < Op::kRec; ++q) dst[q * LPR + l] = rec[q];
+    }
+}
+
+template <class Op>
+__global__ __launch_bounds__(256) void rowreduce_vcombine_kernel(const Op op, const VRows v) {
+    constexpr int LPR = Op::LPR;
+    constexpr int RPW = kWave / LPR;
+    constexpr int GPB = RPW * 4;
+    constexpr int NREC = Op::kRec;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int l = lane % LPR, sub = lane / LPR;
+    const int64_t idx = (int64_t)blockIdx.x * GPB + (threadIdx.x >> 6) * RPW + sub;
+    if (idx >= v.n_multi) return;  // (group-uniform; the shuffles of the operator hooks are group-local)
+    const int64_t row = v.mrow[idx];
+    const int p0 = v.mptr[idx], p1 = v.mptr[idx + 1];
+    typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
+    op.row_load(ctx, row, true);
+    typename Op::State st;
+    op.init(ctx, st, row, true);
+    const int64_t tile_off = (int64_t)blockIdx.y * NREC * LPR + l;
+    for (int p = p0; p < p1; ++p) {
+        const float *src = v.partial + (int64_t)p * v.rec_stride + tile_off;
+        float rec[NREC];
+#pragma unroll
+        for (int q = 0; q < NREC; ++q) rec[q] = src[q * LPR];
+        typename Op::State piece;
+        op.unpack(piece, rec);
+        op.merge(ctx, st, piece);
+    }
+    op.row_end(ctx, st, row, true);
+}
+
+inline size_t vrows_workspace_bytes(int64_t n_parts, int64_t rec_stride) {
+    if (n_parts <= 0 || rec_stride <= 0) return 256;
+    return ((size_t)n_parts * (size_t)rec_stride * sizeof(float) + 255) / 256 * 256;
+}
+inline int vrows_valid(const cogdl_hip_vrows *p) {
+    if (!p || p->n_slots < 0 || p->n_multi < 0 || p->n_parts < 0 || p->nnz < 0) return COGDL_HIP_EINVAL;
+    if (p->n_slots % (kVUnit * kXcds) != 0 || p->n_slots > 0x7fffffff || p->nnz > 0x7fffffff) return COGDL_HIP_ERANGE;
+    if (p->n_slots > 0 && (!p->vrowptr || !p->vdesc)) return COGDL_HIP_EINVAL;
+    if (p->nnz > 0 && !p->vcol) return COGDL_HIP_EINVAL;
+    if (p->n_multi > 0 && (!p->mrow || !p->mptr)) return COGDL_HIP_EINVAL;
+    return COGDL_HIP_OK;
+}
+
+// The two launches of one operator call over a virtual-row plan.  workspace: vrows_workspace_bytes(n_parts, tiles * kRec * LPR).
+template <class Op>
+static int launch_rowreduce_vrows(const Op &op, const cogdl_hip_vrows *p, int64_t tiles, void *workspace,
+                                  size_t workspace_bytes, hipStream_t stream) {
+    int rc = vrows_valid(p);
+    if (rc != COGDL_HIP_OK) return rc;
+    if (p->n_slots == 0) return COGDL_HIP_OK;
+    if (tiles > 65535 || tiles < 1) return COGDL_HIP_ERANGE;
+    constexpr int GPB = (kWave / Op::LPR) * 4;
+    VRows v{};
+    v.vrowptr = p->vrowptr, v.vcol = p->vcol, v.vdesc = (const int2 *)p->vdesc, v.mrow = p->mrow, v.mptr = p->mptr;
+    v.n_slots = p->n_slots, v.n_multi = p->n_multi, v.n_parts = p->n_parts;
+    v.rec_stride = tiles * Op::kRec * Op::LPR;
+    v.sort_rows = g_tuning[kTuneRowSort] == 0 ? 1 : 0;
+    if (p->n_parts > 0) {
+        if (!workspace || workspace_bytes < vrows_workspace_bytes(p->n_parts, v.rec_stride)) return COGDL_HIP_EWORKSPACE;
+        if (!aligned_to(workspace, 256)) return COGDL_HIP_EALIGN;
+        v.partial = (float *)workspace;
+    }
+    const int64_t wgs = p->n_slots / GPB;  // (n_slots is a multiple of 8 units)
+    if (wgs > 0x7fffffff) return COGDL_HIP_ERANGE;
+    hipLaunchKernelGGL((rowreduce_vrow_kernel<Op>), dim3((unsigned)wgs, (unsigned)tiles), dim3(256), 0, stream, op, v);
+    if (p->n_multi > 0)
+        hipLaunchKernelGGL((rowreduce_vcombine_kernel<Op>), dim3((unsigned)((p->n_multi + GPB - 1) / GPB), (unsigned)tiles),
+                           dim3(256), 0, stream, op, v);
+    return launch_status();
+}
+
 // Launch the 1..2 kernels of one operator call.  `tiles` = column tiles (gridDim.y).  Operators with a per-row state
 // (kReduce) use the long-row path only when given a workspace; with workspace == nullptr every row is reduced
 // sequentially by its lane group (exact reference order for any length).  Per-edge operators need no scratch.
 template <class Op>
 static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t nnz,
                             int64_t tiles, void *workspace, size_t workspace_bytes, hipStream_t stream) {
-    // Row tiles (rowreduce_tile_kernel): operators that allow it, lane groups that tile a wave, several rows per wave.
-    // tuning key 14: 2 = on; OFF by default -- measured (profiles/r04_rowtile_ab.txt): 169 k one-edge rows 40.7 -> 31.3 us
-    // (half of what is left above the 19 us of an empty launch), two-edge rows 41 -> 37, but rows of >= 4 edges 4-8 %
-    // slower, arxiv-sized R-MAT F=64 132 -> 145 us, uniform 105 -> 111 us: four rows' remainders walked one after the
-    // other cost more than the shared first round trip saves.
-    constexpr int kTile = (RowTile<Op>::value > 1 && kWave % Op::LPR == 0 && Op::LPR < kWave && Op::LPR > RowTile<Op>::value)
-                              ? RowTile<Op>::value : 1;
-    const bool tile_rows = kTile > 1 && g_tuning[kTuneRowTile] == 2;
-    // Row queue (rowreduce_queue_kernel): tuning key 16 = wave-units per wave (0 = off)
-    const int queue = (RowQueue<Op>::value && !tile_rows) ? std::min(std::max(g_tuning[kTuneRowQueue], 0), 64) : 0;
-    const int64_t RPB = (int64_t)(kWave / Op::LPR) * 4 * (tile_rows ? kTile : 1) * (queue > 0 ? queue : 1);
+    const int64_t RPB = (int64_t)(kWave / Op::LPR) * 4;
     const int64_t n_rowblocks = (m + RPB - 1) / RPB;
     if (n_rowblocks == 0) return COGDL_HIP_OK;
     if (tiles > 65535 || tiles < 1) return COGDL_HIP_ERANGE;
@@ -867,9 +785,6 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
     s.rowblocks = make_xcd_map(n_rowblocks);
     s.sort_rows = g_tuning[kTuneRowSort] == 0 ? 1 : 0;
     s.debug = g_tuning[kTuneRowDebug];
-    s.nnz = nnz;
-    s.queue = queue;
-    s.wave_split = wave_split_edges();  // (set to 0 below when the caller asked for sequential rows: no workspace)
     s.lr.thresh = INT_MAX;
     if (nnz > 0 && (!Op::kReduce || workspace)) {
         plan_long_rows(s.lr, nnz);
@@ -881,23 +796,9 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
             s.lr.partial = (float *)((char *)workspace + kFoundBytes);
         }
     }
-    if (s.lr.thresh == INT_MAX) s.wave_split = 0;  // no workspace = every row sequentially, in the reference's order
     if (!grid_fits(s.rowblocks, s.lr.n_long_blocks)) return COGDL_HIP_ERANGE;
     dim3 grid(s.lr.n_long_blocks + xcd_grid(s.rowblocks), (unsigned)tiles);
-    bool launched = false;
-    if constexpr (RowQueue<Op>::value) {
-        if (queue > 0) {
-            hipLaunchKernelGGL((rowreduce_queue_kernel<Op>), grid, dim3(256), 0, stream, op, s);
-            launched = true;
-        }
-    }
-    if constexpr (kTile > 1) {
-        if (!launched && tile_rows) {
-            hipLaunchKernelGGL((rowreduce_tile_kernel<Op, kTile>), grid, dim3(256), 0, stream, op, s);
-            launched = true;
-        }
-    }
-    if (!launched) hipLaunchKernelGGL((rowreduce_main_kernel<Op>), grid, dim3(256), 0, stream, op, s);
+    hipLaunchKernelGGL((rowreduce_main_kernel<Op>), grid, dim3(256), 0, stream, op, s);
     if constexpr (Op::kReduce) {
         if (s.lr.n_long_blocks > 0)
             hipLaunchKernelGGL((rowreduce_combine_kernel<Op>), dim3(s.lr.n_long_blocks, (unsigned)tiles), dim3(256), 0,

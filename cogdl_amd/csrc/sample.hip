@@ -24,7 +24,7 @@
 // Integer work, latency bound at mini-batch sizes; int64 in and out like the reference.
 #include "common.h"
 
-#include <rocprim/device/device_scan.hpp>
+#include "scan.h"
 
 namespace cogdl {
 
@@ -545,10 +545,6 @@ __global__ void sample_mark_kernel(const uint32_t *__restrict__ skeys, const int
     head[j] = is_head ? (int32_t)j : 0;
 }
 
-struct MaxOp {
-    __device__ __host__ int32_t operator()(int32_t a, int32_t b) const { return a > b ? a : b; }
-};
-
 __global__ void sample_relabel_kernel(const uint32_t *__restrict__ skeys, const int32_t *__restrict__ spos,
                                       const int32_t *__restrict__ first, const int32_t *__restrict__ rank,
                                       const int32_t *__restrict__ head_of, int64_t len, int64_t batch,
@@ -588,16 +584,11 @@ struct SampleWs {
 static SampleWs carve(void *base, int64_t batch, int64_t cap_edges, int64_t num_nodes) {
     const int64_t len = batch + cap_edges;
     SampleWs w{};
-    size_t scan_t = 0, scan64_t = 0, max_t = 0;
-    // (keys are node ids < 2^bits plus the padding key 2^bits: 2^bits + 1 key values)
-    const size_t sort_t = sort_positions_workspace_bytes(((int64_t)1 << sample_key_bits(num_nodes)) + 1, std::max<int64_t>(len, 1));
-    (void)rocprim::exclusive_scan(nullptr, scan_t, (int32_t *)nullptr, (int32_t *)nullptr, int32_t(0),
-                                  (size_t)std::max<int64_t>(len, 1), rocprim::plus<int32_t>(), nullptr);
-    (void)rocprim::exclusive_scan(nullptr, scan64_t, (int32_t *)nullptr, (int64_t *)nullptr, int64_t(0),
-                                  (size_t)(batch + 1), rocprim::plus<int64_t>(), nullptr);
-    (void)rocprim::inclusive_scan(nullptr, max_t, (int32_t *)nullptr, (int32_t *)nullptr,
-                                  (size_t)std::max<int64_t>(len, 1), MaxOp(), nullptr);
-    w.temp_bytes = std::max(std::max(sort_t, scan_t), std::max(scan64_t, max_t));
+    // (sort-based relabelling: keys are the node ids plus the padding key num_nodes: num_nodes + 1 key values)
+    const size_t sort_t = sort_positions_workspace_bytes(num_nodes + 1, std::max<int64_t>(len, 1));
+    const size_t scan_t = device_scan_temp_bytes(std::max<int64_t>(len, 1), sizeof(int32_t));
+    const size_t scan64_t = device_scan_temp_bytes(batch + 1, sizeof(int64_t));
+    w.temp_bytes = std::max(sort_t, std::max(scan_t, scan64_t));
     char *p = (char *)base;
     auto take = [&](size_t bytes) {
         char *q = p;
@@ -710,9 +701,13 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
     if (e != hipSuccess) return fail(e);
     hipLaunchKernelGGL(sample_counts_kernel, dim3((unsigned)((batch + 256) / 256)), dim3(256), 0, s, indptr, node_idx, batch,
                        batch_count, num_nodes, num_neighbors, replace, w.cnt, w.flags);
-    size_t tb = w.temp_bytes;
-    e = rocprim::exclusive_scan(w.temp, tb, w.cnt, out_indptr, int64_t(0), (size_t)(batch + 1), rocprim::plus<int64_t>(), s);
-    if (e != hipSuccess) return fail(e);
+    // The sort-based form pads with the key num_nodes (the hash form's power of two would make 2^31 + 1 key values of a
+    // graph of more than 2^30 nodes -- beyond what the position sort takes): ids 0 .. num_nodes - 1 sort
+    // in front of it, the sort sees num_nodes + 1 key values.
+    if (num_nodes + 1 >= 0x7fffffff) return COGDL_HIP_ERANGE;
+    const uint32_t pad_sort = (uint32_t)num_nodes;
+    int rc_scan = device_exclusive_sum((const int32_t *)w.cnt, out_indptr, batch + 1, w.temp, s);
+    if (rc_scan != COGDL_HIP_OK) return rc_scan;
     if (len == 0) {
         e = fill_u32_async(out_counts, 0u, 6, s);
         if (e != hipSuccess) return fail(e);
@@ -721,26 +716,25 @@ static int sample_adj_impl(const int64_t *indptr, const int64_t *indices, int64_
     if (batch > 0)
         hipLaunchKernelGGL(sample_pick_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, s, indptr, indices, node_idx,
                            batch, batch_count, num_nodes, num_neighbors, replace, seed, seed_dev, out_indptr, out_edges, w.keys,
-                           pad_key, cap_edges, w.flags, HashTable{nullptr, nullptr, 0u}, nullptr);
+                           pad_sort, cap_edges, w.flags, HashTable{nullptr, nullptr, 0u}, nullptr);
     if (cap_edges > 0)
         hipLaunchKernelGGL(sample_pad_kernel, dim3((unsigned)std::min<int64_t>((cap_edges + 255) / 256, 1024)), dim3(256), 0, s,
-                           out_indptr, batch, cap_edges, w.keys, pad_key, padded, out_indices, out_edges);
+                           out_indptr, batch, cap_edges, w.keys, pad_sort, padded, out_indices, out_edges);
     {
-        const int rc = sort_positions_by_key(w.keys, len, ((int64_t)1 << sample_key_bits(num_nodes)) + 1, w.spos, w.temp, w.temp_bytes, s);
+        const int rc = sort_positions_by_key(w.keys, len, num_nodes + 1, w.spos, w.temp, w.temp_bytes, s);
         if (rc != COGDL_HIP_OK) return rc;
         hipLaunchKernelGGL(sample_gather_keys_kernel, dim3((unsigned)std::min<int64_t>((len + 255) / 256, 1 << 16)), dim3(256), 0, s,
                            w.keys, w.spos, w.skeys, len);
     }
     const unsigned blocks = (unsigned)((len + 255) / 256);
-    hipLaunchKernelGGL(sample_mark_kernel, dim3(blocks), dim3(256), 0, s, w.skeys, w.spos, len, pad_key, w.first, w.head);
-    tb = w.temp_bytes;
-    e = rocprim::exclusive_scan(w.temp, tb, w.first, w.rank, int32_t(0), (size_t)len, rocprim::plus<int32_t>(), s);
-    if (e != hipSuccess) return fail(e);
-    tb = w.temp_bytes;
-    e = rocprim::inclusive_scan(w.temp, tb, w.head, w.head_of, (size_t)len, MaxOp(), s);
-    if (e != hipSuccess) return fail(e);
+    hipLaunchKernelGGL(sample_mark_kernel, dim3(blocks), dim3(256), 0, s, w.skeys, w.spos, len, pad_sort, w.first, w.head);
+    rc_scan = device_exclusive_sum((const int32_t *)w.first, w.rank, len, w.temp, s);
+    if (rc_scan != COGDL_HIP_OK) return rc_scan;
+    // (head[j] = j at the head of a run of equal keys, else 0: the running maximum is the head of the run j sits in)
+    rc_scan = device_scan<true>((const int32_t *)w.head, w.head_of, len, int32_t(0), int32_t(0), ScanMax(), w.temp, s);
+    if (rc_scan != COGDL_HIP_OK) return rc_scan;
     hipLaunchKernelGGL(sample_relabel_kernel, dim3(blocks), dim3(256), 0, s, w.skeys, w.spos, w.first, w.rank, w.head_of, len,
-                       batch, pad_key, out_indptr, out_indices, out_nodes, out_counts, w.flags, padded);
+                       batch, pad_sort, out_indptr, out_indices, out_nodes, out_counts, w.flags, padded);
     if (rowptr32)  // (the sort-based form does not write the int32 block itself)
         return cogdl_hip_block_prepare(out_indptr, out_indices, batch, cap_edges, rowptr32, col32, inv_deg, stream);
     return launch_status();

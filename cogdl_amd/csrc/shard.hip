@@ -19,7 +19,7 @@
 // status codes, a column id outside [0, n_global) is reported through the counts' flag word.
 #include "common.h"
 
-#include <rocprim/device/device_scan.hpp>
+#include "scan.h"
 
 namespace cogdl {
 
@@ -34,12 +34,7 @@ struct ShardWs {
 
 static ShardWs shard_carve(void *base, int64_t n_local, int64_t n_global) {
     ShardWs w{};
-    size_t t1 = 0, t2 = 0;
-    (void)rocprim::exclusive_scan(nullptr, t1, (int32_t *)nullptr, (int32_t *)nullptr, int32_t(0),
-                                  (size_t)std::max<int64_t>(n_local + 1, 1), rocprim::plus<int32_t>(), nullptr);
-    (void)rocprim::exclusive_scan(nullptr, t2, (int32_t *)nullptr, (int32_t *)nullptr, int32_t(0),
-                                  (size_t)std::max<int64_t>(n_global + 1, 1), rocprim::plus<int32_t>(), nullptr);
-    w.temp_bytes = std::max(t1, t2);
+    w.temp_bytes = std::max(device_scan_temp_bytes(n_local + 1, sizeof(int32_t)), device_scan_temp_bytes(n_global + 1, sizeof(int32_t)));
     char *p = (char *)base;
     auto take = [&](size_t bytes) {
         char *q = p;
@@ -213,15 +208,11 @@ extern "C" int cogdl_hip_shard_count(const int64_t *rowptr, const int64_t *col, 
         hipLaunchKernelGGL((shard_rows_kernel<false, float>), dim3((unsigned)((n_local + 3) / 4)), dim3(256), 0, s, rowptr, col,
                            (const float *)nullptr, n_local, lo, hi, n_global, w.cnt_loc, w.cnt_rem, w.mark, (int32_t *)nullptr,
                            (float *)nullptr, (int32_t *)nullptr, (float *)nullptr, flags, nnz);
-    size_t tb = w.temp_bytes;
-    e = rocprim::exclusive_scan(w.temp, tb, w.cnt_loc, w.cnt_loc, int32_t(0), (size_t)(n_local + 1), rocprim::plus<int32_t>(), s);
-    if (e != hipSuccess) return fail(e);
-    tb = w.temp_bytes;
-    e = rocprim::exclusive_scan(w.temp, tb, w.cnt_rem, w.cnt_rem, int32_t(0), (size_t)(n_local + 1), rocprim::plus<int32_t>(), s);
-    if (e != hipSuccess) return fail(e);
-    tb = w.temp_bytes;
-    e = rocprim::exclusive_scan(w.temp, tb, w.mark, w.mark, int32_t(0), (size_t)(n_global + 1), rocprim::plus<int32_t>(), s);
-    if (e != hipSuccess) return fail(e);
+    // (in place: scan.h allows out == in)
+    int rc_scan = device_exclusive_sum((const int32_t *)w.cnt_loc, w.cnt_loc, n_local + 1, w.temp, s);
+    if (rc_scan == COGDL_HIP_OK) rc_scan = device_exclusive_sum((const int32_t *)w.cnt_rem, w.cnt_rem, n_local + 1, w.temp, s);
+    if (rc_scan == COGDL_HIP_OK) rc_scan = device_exclusive_sum((const int32_t *)w.mark, w.mark, n_global + 1, w.temp, s);
+    if (rc_scan != COGDL_HIP_OK) return rc_scan;
     hipLaunchKernelGGL(shard_counts_kernel, dim3(1), dim3(64), 0, s, w.cnt_loc, w.cnt_rem, w.mark, n_local, n_global, flags, counts);
     return launch_status();
 }

@@ -137,8 +137,7 @@ extern "C" size_t cogdl_hip_mhspmm_workspace_bytes(int64_t nnz, int64_t h, int64
 extern "C" int cogdl_hip_long_row_threshold(int64_t nnz) { return pick_long_thresh(nnz); }
 
 extern "C" int cogdl_hip_exact_row_edges(int64_t nnz) {
-    const int split = wave_split_edges();
-    return split > 0 ? std::min(split, pick_long_thresh(nnz)) : pick_long_thresh(nnz);
+    return pick_long_thresh(nnz);
 }
 
 extern "C" int cogdl_hip_csr_spmm(const int32_t *rowptr, const int32_t *colind, const void *val, const void *x,
@@ -151,6 +150,39 @@ extern "C" int cogdl_hip_csr_spmm_acc(const int32_t *rowptr, const int32_t *coli
                                       void *out, int64_t m, int64_t k, int64_t nnz, int dtype, void *workspace,
                                       size_t workspace_bytes, void *stream) {
     return csr_spmm_entry(rowptr, colind, val, x, out, m, k, nnz, dtype, 1, workspace, workspace_bytes, stream);
+}
+
+// ---- XCD-partitioned plan (rowreduce.h: virtual rows) ------------------------------------------------------------------
+extern "C" size_t cogdl_hip_csr_spmm_xcd_workspace_bytes(int64_t n_parts, int64_t k, int dtype) {
+    if (k <= 0) return 256;
+    const RowGeometry g = spmm_geometry(k, k, elem_bytes_of(dtype), 16, false);
+    return vrows_workspace_bytes(n_parts, g.tiles * g.vec * g.lpr);
+}
+
+template <typename T>
+static int spmm_xcd_typed(const cogdl_hip_vrows *plan, const void *val, const void *x, void *out, int64_t m, int64_t k, int acc,
+                          void *ws, size_t wsb, hipStream_t s) {
+    if (!aligned_to(x, 16) || !aligned_to(out, 16)) return COGDL_HIP_EALIGN;  // (the workspace query assumes 16-byte operands)
+    SpmmArgs<T> a{nullptr, nullptr, (const T *)val, nullptr, (const T *)x, (T *)out, m, plan->nnz, (int)k, (int)k, acc, nullptr, {}, plan};
+    return val ? spmm_auto<T, 1>(a, ws, wsb, s) : spmm_auto<T, 0>(a, ws, wsb, s);
+}
+
+extern "C" int cogdl_hip_csr_spmm_xcd(const cogdl_hip_vrows *plan, const void *val_plan, const void *x, void *out, int64_t m,
+                                      int64_t k, int dtype, int acc, void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = vrows_valid(plan);
+    if (rc != COGDL_HIP_OK) return rc;
+    const int32_t dummy = 0;
+    rc = check_args(&dummy, x, out, m, k, plan->nnz);
+    if (rc != COGDL_HIP_OK || m == 0 || k == 0) return rc;
+    if (k * 4 >= (1 << 24)) return COGDL_HIP_EUNSUPPORTED;  // (24 x 24 -> 32-bit table offsets, common.h: gather_row)
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case COGDL_HIP_F32: return spmm_xcd_typed<float>(plan, val_plan, x, out, m, k, acc, workspace, workspace_bytes, s);
+        case COGDL_HIP_F16: return spmm_xcd_typed<__half>(plan, val_plan, x, out, m, k, acc, workspace, workspace_bytes, s);
+        case COGDL_HIP_BF16:
+            return spmm_xcd_typed<__hip_bfloat16>(plan, val_plan, x, out, m, k, acc, workspace, workspace_bytes, s);
+        default: return COGDL_HIP_EDTYPE;
+    }
 }
 
 // ---- 64-bit CSR: one launch per row segment (bigcsr.hip) ---------------------------------------------------------------

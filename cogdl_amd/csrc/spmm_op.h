@@ -34,14 +34,11 @@ struct SpmmEpilogue {
     int act;                 // 0 = none, 1 = relu
 };
 
-template <typename T, int VEC_, int LPR_, int UNROLL_, int WMODE, bool EXACT, bool EPI = false>
+template <typename T, int VEC_, int LPR_, int UNROLL_, int WMODE, bool EXACT, bool EPI = false, bool A24 = false>
 struct SpmmOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_;
     static constexpr bool kReduce = true;
     static constexpr int kLds = 0;
-    // row tiles (rowreduce_tile_kernel): the context and the hooks of csr_spmm do not depend on the row
-    static constexpr int kRowTile = (WMODE != 2 && !EPI) ? 4 : 1;
-    static constexpr bool kRowQueue = (WMODE != 2 && !EPI);  // rowreduce_queue_kernel (tuning key 16): csr_spmm only
     // (kMinWaves = 8, i.e. 64 VGPRs, was tried: arxiv-sized R-MAT F=64 132 -> 122 us but 44 bytes of scratch per lane make
     //  every other shape 3-10 % slower -- 71 VGPRs / 7 waves per SIMD stay)
     const T *val;      // WMODE 1
@@ -55,9 +52,8 @@ struct SpmmOp {
     SpmmEpilogue epi;    // EPI only
 
     struct Ctx {
-        int col0, heads, hd;
+        int col0, heads, hd, cc;
         bool col_ok;
-        const T *xcol;
     };
     struct State { float acc[VEC]; };
     struct LaneVals {
@@ -78,7 +74,7 @@ struct SpmmOp {
         const int cc = c.col_ok ? c.col0 : 0;  // lanes past the last column read column 0 and never store
         c.heads = (WMODE == 2) ? k / fdim : 1;
         c.hd = (WMODE == 2) ? cc / fdim : 0;
-        c.xcol = x + cc;
+        c.cc = cc;
         return c;
     }
     __device__ __forceinline__ void row_load(Ctx &, int64_t, bool) const {}
@@ -103,13 +99,31 @@ struct SpmmOp {
         }
         else b.w[u] = 1.f;
         if constexpr (EPI) b.s[u] = epi.src_scale ? epi.src_scale[col] : 1.f;
-        b.v[u] = load_raw<T, VEC>(c.xcol + (int64_t)col * k);
+        b.v[u] = load_raw<T, VEC>(gather_row<A24>(x, c.cc, col, (uint32_t)k * (uint32_t)sizeof(T)));
     }
     // Strictly in CSR order.  acc + 0*0 == acc exactly (acc is never -0), so masked slots are no-ops;
     // selecting v (not only w) to zero keeps inf/nan out.
     __device__ __forceinline__ void apply(const Ctx &, State &s, const Batch &b, int u, bool valid, int64_t,
                                           int) const {
         float xv[VEC];
+        if constexpr (sizeof(T) == 2 && !EPI && sizeof(Raw) % 4 == 0) {
+            // 16-bit features: no bit-exact contract (products and sums are fp32, rounded once on store; parity is a
+            // tolerance).  The masked slot is zeroed on its RAW words (VEC / 2 selects instead of VEC) and the update is a
+            // fused multiply-add (one packed instruction per two columns instead of two): on hub-heavy graphs this kernel
+            // is bound by VALU issue, not by bytes (round 6, profiles/r06_sq_reddit.txt).
+            union { Raw raw; uint32_t w[sizeof(Raw) / 4]; } m;
+            m.raw = b.v[u];
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(Raw) / 4); ++i) m.w[i] = valid ? m.w[i] : 0u;
+            unpack_raw<T, VEC>(m.raw, xv);
+            const float w = (WMODE != 0) ? (valid ? b.w[u] : 0.f) : 1.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                if constexpr (WMODE != 0) s.acc[i] = __builtin_fmaf(w, xv[i], s.acc[i]);
+                else s.acc[i] = s.acc[i] + xv[i];
+            }
+            return;
+        }
         unpack_raw<T, VEC>(b.v[u], xv);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
@@ -164,12 +178,19 @@ struct SpmmArgs {
     int k, fdim, acc_mode;
     const int32_t *eid;
     SpmmEpilogue epi;
+    const cogdl_hip_vrows *vr = nullptr;  // XCD-partitioned plan (rowreduce.h): rowptr / colind are then unused
 };
 
 template <typename T, int VEC, int LPR, int UNROLL, int WMODE, bool EXACT, bool EPI = false>
 static int launch_spmm(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) {
-    SpmmOp<T, VEC, LPR, UNROLL, WMODE, EXACT, EPI> op{a.val, a.att, a.x, a.out, a.k, a.fdim, a.acc_mode, a.eid, a.epi};
     const int64_t tiles = ((int64_t)a.k + (int64_t)LPR * VEC - 1) / ((int64_t)LPR * VEC);
+    if (a.vr) {  // XCD-partitioned plan: the same functor with 24-bit table offsets (common.h: gather_row)
+        if constexpr (kWave % LPR == 0 && !EPI && WMODE != 2) {
+            SpmmOp<T, VEC, LPR, UNROLL, WMODE, EXACT, EPI, true> op24{a.val, a.att, a.x, a.out, a.k, a.fdim, a.acc_mode, a.eid, a.epi};
+            return launch_rowreduce_vrows(op24, a.vr, tiles, ws, wsb, s);
+        } else return COGDL_HIP_EUNSUPPORTED;
+    }
+    SpmmOp<T, VEC, LPR, UNROLL, WMODE, EXACT, EPI> op{a.val, a.att, a.x, a.out, a.k, a.fdim, a.acc_mode, a.eid, a.epi};
     return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, tiles, ws, wsb, s);
 }
 
@@ -207,7 +228,7 @@ static int pointer_alignment(const void *a, const void *b) {
 template <typename T, int WMODE, bool EPI = false>
 static int spmm_auto(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) {
     const RowGeometry g = spmm_geometry(a.k, (WMODE == 2) ? a.fdim : a.k, (int)sizeof(T), pointer_alignment(a.x, a.out),
-                                        WMODE != 2 && !EPI);
+                                        WMODE != 2 && !EPI && !a.vr);
     switch (g.vec) {
         case 4: return dispatch_lpr<T, 4, WMODE, EPI>(a, g.lpr, ws, wsb, s);
         case 2: return dispatch_lpr<T, 2, WMODE, EPI>(a, g.lpr, ws, wsb, s);

@@ -12,7 +12,7 @@
 // Integer work, bound by the gather of assoc[] (4 bytes per edge of the selected rows); int64 in and out.
 #include "common.h"
 
-#include <rocprim/device/device_scan.hpp>
+#include "scan.h"
 
 namespace cogdl {
 
@@ -95,10 +95,7 @@ struct SubgraphWs {
 
 static SubgraphWs sg_carve(void *base, int64_t batch, int64_t num_nodes) {
     SubgraphWs w{};
-    size_t scan_t = 0;
-    (void)rocprim::exclusive_scan(nullptr, scan_t, (int32_t *)nullptr, (int64_t *)nullptr, int64_t(0), (size_t)(batch + 1),
-                                  rocprim::plus<int64_t>(), nullptr);
-    w.temp_bytes = scan_t;
+    w.temp_bytes = device_scan_temp_bytes(batch + 1, sizeof(int64_t));
     char *p = (char *)base;
     auto take = [&](size_t bytes) {
         char *q = p;
@@ -149,9 +146,8 @@ extern "C" int cogdl_hip_subgraph(const int64_t *indptr, const int64_t *indices,
     hipLaunchKernelGGL((subgraph_rows_kernel<false>), dim3(row_blocks), dim3(256), 0, s, indptr, indices, node_idx, batch,
                        num_nodes, w.assoc, w.cnt, (const int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr,
                        cap_edges, w.flags);
-    size_t tb = w.temp_bytes;
-    e = rocprim::exclusive_scan(w.temp, tb, w.cnt, out_indptr, int64_t(0), (size_t)(batch + 1), rocprim::plus<int64_t>(), s);
-    if (e != hipSuccess) return fail(e);
+    const int rc_scan = device_exclusive_sum(w.cnt, out_indptr, batch + 1, w.temp, s);
+    if (rc_scan != COGDL_HIP_OK) return rc_scan;
     if (batch > 0 && cap_edges > 0)
         hipLaunchKernelGGL((subgraph_rows_kernel<true>), dim3(row_blocks), dim3(256), 0, s, indptr, indices, node_idx, batch,
                            num_nodes, w.assoc, w.cnt, out_indptr, out_indices, out_edges, cap_edges, w.flags);

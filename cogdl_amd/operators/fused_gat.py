@@ -14,15 +14,21 @@ models/nn/gat.py:30; layers/gat_layer.py:72-77) inside the same kernels.
 """
 import torch
 
-from .. import _lib
+from .. import _lib, xcdplan
 from ..plan import PLANS, Fingerprint, fingerprint_of
 
 _lib.hip()
 
 
-def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, p=0.0, seed=0):
+def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, p=0.0, seed=0, xplan=None):
     """out [N_dst, H, F], edge_max, edge_sum [N_dst, H].  p > 0: attention dropout inside the kernel, the mask a pure
-    function of (seed, edge position, head) -- see include/cogdl_hip.h."""
+    function of (seed, edge position, head) -- see include/cogdl_hip.h.  xplan: an XCD-partitioned plan of the structure
+    (cogdl_amd/xcdplan.py); shapes its kernels decline fall back to the ordinary entry."""
+    return _gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, p, seed, xplan)[:3]
+
+
+def _gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, p, seed, xplan):
+    """gat_forward + whether the plan's kernels ran."""
     dev = _lib.require_cuda(attn_row, attn_col, row_ptr, col_ind, in_feat)
     if in_feat.dim() != 3 or in_feat.dtype not in _lib.DTYPE_CODE:
         raise _lib.BackendError("in_feat must be [N, H, F] float32/float16/bfloat16")
@@ -35,8 +41,17 @@ def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, p
     edge_max = torch.empty((v, h), dtype=torch.float32, device=dev)
     edge_sum = torch.empty((v, h), dtype=torch.float32, device=dev)
     nnz, code = col_ind.numel(), _lib.DTYPE_CODE[feat.dtype]
-    ws, ws_bytes = _lib.workspace("cogdl_hip_gat_fwd_workspace_bytes", dev, nnz, h, f, code)
     lib = _lib.hip()
+    if xplan is not None:
+        ws, ws_bytes = _lib.workspace("cogdl_hip_gat_fwd_xcd_workspace_bytes", dev, xplan.n_parts, h, f, code)
+        with _lib.on_device(dev):
+            rc = lib.cogdl_hip_gat_fwd_xcd(xplan.ref(), _lib.ptr(attn_row), _lib.ptr(attn_col), _lib.ptr(feat),
+                                           float(negative_slope), float(p), int(seed), _lib.ptr(out), _lib.ptr(edge_max),
+                                           _lib.ptr(edge_sum), v, h, f, code, _lib.ptr(ws), ws_bytes, _lib.stream_of(feat))
+        if rc != _lib.EUNSUPPORTED:
+            _lib.check(rc, "gat_fwd_xcd")
+            return out, edge_max, edge_sum, True
+    ws, ws_bytes = _lib.workspace("cogdl_hip_gat_fwd_workspace_bytes", dev, nnz, h, f, code)
     with _lib.on_device(dev):
         if p > 0.0:
             rc = lib.cogdl_hip_gat_dropout_fwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(attn_row),
@@ -49,7 +64,7 @@ def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, p
                                        _lib.ptr(edge_sum), v, h, f, nnz, code, _lib.ptr(ws), ws_bytes,
                                        _lib.stream_of(feat))
     _lib.check(rc, "gat_fwd")
-    return out, edge_max, edge_sum
+    return out, edge_max, edge_sum, False
 
 
 def edge_dropout_mask(nnz, heads, p, seed, device):
@@ -88,7 +103,17 @@ class FusedGATFunction(torch.autograd.Function):
         feat = in_feat.detach()
         if fp != f:
             feat = torch.nn.functional.pad(feat, (0, fp - f))
-        out, edge_max, edge_sum = gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, feat, p, seed)
+        # XCD-partitioned plan (cogdl_amd/xcdplan.py): hub-heavy graphs over cache-sized tables (BASELINE configs[2])
+        ctx.xcd = (feat.dim() == 3 and feat.dtype in _lib.DTYPE_CODE and
+                   xcdplan.wanted(row_ptr.numel() - 1, col_ind.numel(), feat.shape[0], feat.shape[1] * fp * feat.element_size()))
+        xplan = xcdplan.csr_plan(ctx.fp, row_ptr, col_ind) if ctx.xcd else None
+        # (shapes the plan's forward declines -- the chunk-wise softmax of few-head layers -- keep the ordinary backward too:
+        #  measured no gain there, Reddit-shaped graph H = 1 x F = 48 bf16 backward 4.3 vs 4.6 ms)
+        if xplan is not None:
+            out, edge_max, edge_sum, ctx.xcd = _gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, feat, p,
+                                                            seed, xplan)
+        else:
+            out, edge_max, edge_sum = gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, feat, p, seed)
         ctx.save_for_backward(row_ptr, col_ind, edge_max, edge_sum, feat, attn_row, attn_col, out)
         ctx.negative_slope, ctx.p, ctx.seed, ctx.f = float(negative_slope), float(p), int(seed), f
         ctx.feat_dtype = in_feat.dtype
@@ -111,22 +136,33 @@ class FusedGATFunction(torch.autograd.Function):
         grad_ac = torch.empty((n_src, h), dtype=torch.float32, device=dev)
         lib = _lib.hip()
         nnz, code = col_ind.numel(), _lib.DTYPE_CODE[dt]
-        ws, ws_bytes = _lib.workspace("cogdl_hip_gat_bwd_workspace_bytes", dev, v, n_src, h, fp, nnz, code)
-        with _lib.on_device(dev):
-            if ctx.p > 0.0:
-                rc = lib.cogdl_hip_gat_dropout_bwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(plan.colptr),
-                                                   _lib.ptr(plan.rowind), _lib.ptr(plan.perm), _lib.ptr(ar),
-                                                   _lib.ptr(ac), _lib.ptr(feat), ctx.negative_slope, ctx.p, ctx.seed,
-                                                   _lib.ptr(edge_max), _lib.ptr(edge_sum), _lib.ptr(o), _lib.ptr(g),
-                                                   _lib.ptr(grad_feat), _lib.ptr(grad_ar), _lib.ptr(grad_ac),
-                                                   _lib.ptr(ws), ws_bytes, v, n_src, h, fp, nnz, code,
-                                                   _lib.stream_of(g))
-            else:
-                rc = lib.cogdl_hip_gat_bwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(plan.colptr),
-                                           _lib.ptr(plan.rowind), _lib.ptr(ar), _lib.ptr(ac), _lib.ptr(feat),
-                                           ctx.negative_slope, _lib.ptr(edge_max), _lib.ptr(edge_sum), _lib.ptr(o),
-                                           _lib.ptr(g), _lib.ptr(grad_feat), _lib.ptr(grad_ar), _lib.ptr(grad_ac),
-                                           _lib.ptr(ws), ws_bytes, v, n_src, h, fp, nnz, code, _lib.stream_of(g))
+        rc = _lib.EUNSUPPORTED
+        if ctx.xcd:
+            xr, xc = xcdplan.csr_plan(ctx.fp, row_ptr, col_ind), xcdplan.csc_plan(ctx.fp, plan)
+            ws, ws_bytes = _lib.workspace("cogdl_hip_gat_bwd_xcd_workspace_bytes", dev, v, h, fp, xr.n_parts, xc.n_parts, code)
+            with _lib.on_device(dev):
+                rc = lib.cogdl_hip_gat_bwd_xcd(xr.ref(), xc.ref(), _lib.ptr(ar), _lib.ptr(ac), _lib.ptr(feat),
+                                               ctx.negative_slope, ctx.p, ctx.seed, _lib.ptr(edge_max), _lib.ptr(edge_sum),
+                                               _lib.ptr(o), _lib.ptr(g), _lib.ptr(grad_feat), _lib.ptr(grad_ar),
+                                               _lib.ptr(grad_ac), _lib.ptr(ws), ws_bytes, v, n_src, h, fp, code,
+                                               _lib.stream_of(g))
+        if rc == _lib.EUNSUPPORTED:  # no plan, or a shape the plan kernels decline (column tiles): the ordinary entries
+            ws, ws_bytes = _lib.workspace("cogdl_hip_gat_bwd_workspace_bytes", dev, v, n_src, h, fp, nnz, code)
+            with _lib.on_device(dev):
+                if ctx.p > 0.0:
+                    rc = lib.cogdl_hip_gat_dropout_bwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(plan.colptr),
+                                                       _lib.ptr(plan.rowind), _lib.ptr(plan.perm), _lib.ptr(ar),
+                                                       _lib.ptr(ac), _lib.ptr(feat), ctx.negative_slope, ctx.p, ctx.seed,
+                                                       _lib.ptr(edge_max), _lib.ptr(edge_sum), _lib.ptr(o), _lib.ptr(g),
+                                                       _lib.ptr(grad_feat), _lib.ptr(grad_ar), _lib.ptr(grad_ac),
+                                                       _lib.ptr(ws), ws_bytes, v, n_src, h, fp, nnz, code,
+                                                       _lib.stream_of(g))
+                else:
+                    rc = lib.cogdl_hip_gat_bwd(_lib.ptr(row_ptr), _lib.ptr(col_ind), _lib.ptr(plan.colptr),
+                                               _lib.ptr(plan.rowind), _lib.ptr(ar), _lib.ptr(ac), _lib.ptr(feat),
+                                               ctx.negative_slope, _lib.ptr(edge_max), _lib.ptr(edge_sum), _lib.ptr(o),
+                                               _lib.ptr(g), _lib.ptr(grad_feat), _lib.ptr(grad_ar), _lib.ptr(grad_ac),
+                                               _lib.ptr(ws), ws_bytes, v, n_src, h, fp, nnz, code, _lib.stream_of(g))
         _lib.check(rc, "gat_bwd")
         if fp != ctx.f:
             grad_feat = grad_feat[..., :ctx.f].contiguous()

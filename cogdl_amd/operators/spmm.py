@@ -20,6 +20,7 @@ import torch
 
 from .. import _lib
 from .. import plan as _plan
+from .. import xcdplan
 from ..plan import PLANS, Fingerprint, fingerprint_of, csr2csc, gather_rows
 
 _lib.hip()  # fail at import if the HIP library is missing (no silent `csrspmm = None`)
@@ -81,6 +82,44 @@ def csr_spmm_raw(rowptr, colind, val, x, variant=-1, out=None, split_long_rows=T
     return out
 
 
+def csr_spmm_xcd_raw(xplan, val, x, out=None):
+    """A x over an XCD-partitioned plan of the structure (cogdl_amd/xcdplan.py; cogdl_hip_csr_spmm_xcd): `val` in the
+    CALLER's edge order (the plan's `eid` says which entry every plan position takes), rows of more than xcdplan.SPLIT edges
+    re-associated.  With `out` given: out += A x."""
+    dev = _lib.require_cuda(val, x)
+    if x.dim() != 2 or x.dtype not in _lib.DTYPE_CODE:
+        raise _lib.BackendError("dense operand must be a 2-D float32/float16/bfloat16 tensor")
+    x = x.contiguous()
+    if val is not None:
+        if val.numel() != xplan.nnz:
+            raise _lib.BackendError("csr_data has %d entries for %d edges" % (val.numel(), xplan.nnz))
+        val = xplan.permuted_values(val.contiguous() if val.dtype == x.dtype else val.to(x.dtype))
+    m, k = xplan.m, x.shape[1]
+    acc = out is not None
+    if acc:
+        if out.shape != (m, k) or out.dtype != x.dtype or not out.is_contiguous():
+            raise _lib.BackendError("accumulation target must be a contiguous [%d, %d] %s tensor" % (m, k, x.dtype))
+    else:
+        out = torch.empty((m, k), dtype=x.dtype, device=dev)
+    code = _lib.DTYPE_CODE[x.dtype]
+    ws, ws_bytes = _lib.workspace("cogdl_hip_csr_spmm_xcd_workspace_bytes", dev, xplan.n_parts, k, code)
+    with _lib.on_device(dev):
+        rc = _lib.hip().cogdl_hip_csr_spmm_xcd(xplan.ref(), _lib.ptr(val), _lib.ptr(x), _lib.ptr(out), m, k, code,
+                                               1 if acc else 0, _lib.ptr(ws), ws_bytes, _lib.stream_of(x))
+    _lib.check(rc, "csr_spmm_xcd")
+    return out
+
+
+def _xcd_wanted(rowptr, colind, x):
+    """csr_spmm takes an XCD-partitioned plan only when asked to (COGDL_AMD_XCD=force: tests, experiments).  Measured on the
+    Reddit-shaped graph, F = 64 (profiles/r06_xcd_quick.txt): bf16 1512 -> 1638 us, the gain of the L2-resident gathers
+    (1501 -> 1290 us with the partial sums thrown away, tools/xcdpart_probe.py) is spent on the 1.2 M part records
+    (2 x 307 MB); fp32 would gain (3220 -> ~1900 us) but gives up its bit-exact rows.  The fused GAT operator, whose kernels
+    are three times as long per edge, is where the plan pays (cogdl_amd/operators/fused_gat.py)."""
+    return xcdplan.MODE == "force" and x.dim() == 2 and x.dtype in _lib.DTYPE_CODE and xcdplan.wanted(
+        rowptr.numel() - 1, colind.numel(), x.shape[0], x.shape[1] * x.element_size())
+
+
 def csr_sddmm_raw(rowptr, colind, d1, d2):
     """out[e] = <d1[row(e)], d2[col[e]]>  (fp32)."""
     dev = _lib.require_cuda(rowptr, colind, d1, d2)
@@ -105,8 +144,13 @@ class SPMMFunction(torch.autograd.Function):
         # kernel, not behind the SpMM).
         rowptr, colind = _lib.csr_structure(rowptr, colind)  # validated + contiguous before anything reads raw pointers
         ctx.transient = _plan.transient()  # (the dense operand is checked by csr_spmm_raw)
-        ctx.fp = fingerprint_of(rowptr, colind, feat.shape[0]) if ctx.needs_input_grad[2] and not ctx.transient else None
-        out = csr_spmm_raw(rowptr, colind, edge_weight_csr, feat)
+        ctx.xcd = _xcd_wanted(rowptr, colind, feat)
+        ctx.fp = (fingerprint_of(rowptr, colind, feat.shape[0])
+                  if (ctx.needs_input_grad[2] or ctx.xcd) and not ctx.transient else None)
+        if ctx.xcd:
+            out = csr_spmm_xcd_raw(xcdplan.csr_plan(ctx.fp, rowptr, colind), edge_weight_csr, feat)
+        else:
+            out = csr_spmm_raw(rowptr, colind, edge_weight_csr, feat)
         need_w = edge_weight_csr is not None and ctx.needs_input_grad[3]
         ctx.n_src = feat.shape[0]
         ctx.sym = sym
@@ -122,12 +166,15 @@ class SPMMFunction(torch.autograd.Function):
             if ctx.transient:  # (plan.transient_structures: a one-off structure, transposed here, nothing cached or read back)
                 plan = csr2csc(rowptr, colind, ctx.n_src, padded=True)
                 w_t = gather_rows(plan.perm, w.detach()) if w is not None else None
-                hubs = True
+                grad_feat = csr_spmm_raw(plan.colptr, plan.rowind, w_t, grad_out)
             else:
                 plan = PLANS.get(ctx.fp, rowptr, colind, ctx.n_src)
-                w_t = plan.transposed_values(w) if w is not None else None
-                hubs = plan.has_hub_columns()
-            grad_feat = csr_spmm_raw(plan.colptr, plan.rowind, w_t, grad_out, split_long_rows=hubs)
+                if ctx.xcd and _xcd_wanted(plan.colptr, plan.rowind, grad_out):
+                    # (w stays in CSR order: the plan of the transpose maps its positions through the transpose's perm)
+                    grad_feat = csr_spmm_xcd_raw(xcdplan.csc_plan(ctx.fp, plan), w, grad_out)
+                else:
+                    w_t = plan.transposed_values(w) if w is not None else None
+                    grad_feat = csr_spmm_raw(plan.colptr, plan.rowind, w_t, grad_out, split_long_rows=plan.has_hub_columns())
         if w is not None and ctx.needs_input_grad[3]:
             grad_w = csr_sddmm_raw(rowptr, colind, grad_out, feat.detach()).to(w.dtype)
         return None, None, grad_feat, grad_w, None

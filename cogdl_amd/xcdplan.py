@@ -1,0 +1,200 @@
+"""XCD-partitioned column plans (round 6): the host side of `cogdl_hip_vrows` (include/cogdl_hip.h, csrc/rowreduce.h).
+
+Every XCD of the MI355X has a private 4 MiB L2.  The gathered table of BASELINE configs[2] (233 k rows of 128-256 bytes)
+fits none of them but fits the eight together -- if XCD x only ever gathers the columns it OWNS.  A plan gives every column
+an owner (a multiplicative hash of its id: R-MAT / citation ids correlate with degree, `col % 8` leaves the XCDs 1.5x out of
+balance), cuts every row of more than `split` edges into the sub-rows of its edges by owner (CSR order inside a sub-row,
+pieces of at most `piece` edges) and lays these virtual rows out in units of 64 slots dealt round-robin to the XCDs -- the
+order in which the hardware hands workgroups to them.  Shorter rows stay whole.  The reference has nothing like it (its
+GE-SpMM kernels, cogdl/operators/spmm/spmm_kernel.cu:192-512, know one L2).
+
+The plan is a property of the STRUCTURE: built once (a handful of sorts over the edge list, torch on the device: ~0.2 s at
+1.1e8 edges), cached under the structure's content fingerprint next to the transpose (cogdl_amd/plan.py).  When it is used:
+`wanted()` -- hub-heavy launches over cache-sized tables -- for the fused GAT operator and 16-bit csr_spmm; fp32 csr_spmm keeps
+its bit-exact rows unless asked (`MODE = "force"` / COGDL_AMD_XCD=force), because a row cut into sub-rows is re-associated.
+"""
+import collections
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+from . import plan as _plan
+
+UNIT = 64          # slots per unit (csrc/rowreduce.h: kVUnit)
+XCDS = 8
+SPLIT = 64         # rows of more than this many edges are cut by owner XCD
+PIECE = 256        # edges per virtual row at most
+MODE = os.environ.get("COGDL_AMD_XCD", "auto")  # "auto" | "off" | "force" (every structure, every operator: tests)
+
+
+class _VRowsStruct(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("vrowptr", "vcol", "vdesc", "eid", "mrow", "mptr")] + \
+               [(n, ctypes.c_int64) for n in ("n_slots", "n_multi", "n_parts", "nnz")]
+
+
+class XcdPlan:
+    __slots__ = ("vrowptr", "vcol", "vdesc", "eid", "mrow", "mptr", "n_slots", "n_multi", "n_parts", "nnz", "m",
+                 "_struct", "_val_key", "_val_src", "_val_p")
+
+    def __init__(self, vrowptr, vcol, vdesc, eid, mrow, mptr, n_parts, m):
+        self.vrowptr, self.vcol, self.vdesc, self.eid, self.mrow, self.mptr = vrowptr, vcol, vdesc, eid, mrow, mptr
+        self.n_slots, self.n_multi, self.n_parts = vdesc.shape[0], mrow.numel(), int(n_parts)
+        self.nnz, self.m = vcol.numel(), m
+        self._val_key = self._val_src = self._val_p = None
+        s = _VRowsStruct()
+        for name in ("vrowptr", "vcol", "vdesc", "eid", "mrow", "mptr"):
+            t = getattr(self, name)
+            setattr(s, name, t.data_ptr() if t is not None and t.numel() else None)
+        s.n_slots, s.n_multi, s.n_parts, s.nnz = self.n_slots, self.n_multi, self.n_parts, self.nnz
+        self._struct = s
+
+    def ref(self):
+        """const cogdl_hip_vrows * (the plan keeps the tensors -- and the struct -- alive)."""
+        return ctypes.byref(self._struct)
+
+    def nbytes(self):
+        return 4 * sum(t.numel() for t in (self.vrowptr, self.vcol, self.vdesc, self.eid, self.mrow, self.mptr))
+
+    def permuted_values(self, w):
+        """w in plan order (w[eid]).  Constant edge weights are gathered once (memo keyed like CscPlan.transposed_values)."""
+        src = w.detach()
+        if w.requires_grad:
+            return _plan.gather_rows(self.eid, src)
+        key = _plan.tensor_key(w)
+        if key != self._val_key or self._val_src is None:
+            self._val_p = _plan.gather_rows(self.eid, src)
+            self._val_key, self._val_src = key, src
+        return self._val_p
+
+
+def owner_of(col):
+    """Owner XCD of a column id (int64 tensor): the top three bits of a 32-bit multiplicative hash."""
+    return ((col * 2654435761) & 0xFFFFFFFF) >> 29
+
+
+def build(rowptr, colind, eid_base=None, split=None, piece=None):
+    """-> XcdPlan of the CSR structure (rowptr [m + 1], colind [nnz]; int32 device tensors).  eid_base: what position j of
+    THIS structure means to a per-edge operand (a CSC view passes the transpose's perm); None: the position itself."""
+    split = SPLIT if split is None else int(split)
+    piece = PIECE if piece is None else int(piece)
+    dev = rowptr.device
+    m, nnz = rowptr.numel() - 1, colind.numel()
+    rp = rowptr.long()
+    deg = rp[1:] - rp[:-1]
+    rows = torch.arange(m, device=dev)
+    row = torch.repeat_interleave(rows, deg)
+    col = colind.long()
+    is_long = deg > split
+    xcd_e = torch.where(is_long[row], owner_of(col), row % XCDS)
+    key = xcd_e * max(m, 1) + row
+    del xcd_e
+    order = torch.argsort(key, stable=True)  # (XCD, row), CSR order inside
+    gkey, cnt = torch.unique_consecutive(key[order], return_counts=True)
+    del key
+    empty = torch.nonzero(deg == 0).flatten()
+    if empty.numel():  # rows without edges still own a (whole, empty) slot: their output has to be written
+        gkey = torch.cat([gkey, (empty % XCDS) * max(m, 1) + empty])
+        cnt = torch.cat([cnt, torch.zeros_like(empty)])
+        gkey, o = torch.sort(gkey)  # (edge offsets below come from a cumulative sum: empty groups add nothing)
+        cnt = cnt[o]
+    n_p = torch.clamp((cnt + piece - 1) // piece, min=1)
+    n_groups = gkey.numel()
+    vg = torch.repeat_interleave(torch.arange(n_groups, device=dev), n_p)
+    n_v = vg.numel()
+    first_v = torch.cumsum(n_p, 0) - n_p
+    idx = torch.arange(n_v, device=dev) - first_v[vg]
+    vlen = torch.where(idx < n_p[vg] - 1, torch.full_like(idx, piece), cnt[vg] - piece * (n_p[vg] - 1))
+    vx, vr = (gkey // max(m, 1))[vg], (gkey % max(m, 1))[vg]
+    # records: the virtual rows of a row with several parts, in (row, XCD, piece) order
+    parts_of_row = torch.bincount(vr, minlength=m)
+    multi = parts_of_row > 1
+    ord2 = torch.argsort(vr, stable=True)  # (the list is (XCD, row, piece)-ordered: stable by row keeps (XCD, piece))
+    is_multi_sorted = multi[vr[ord2]]
+    rec = torch.full((n_v,), -1, dtype=torch.long, device=dev)
+    rec_sorted = torch.cumsum(is_multi_sorted.long(), 0) - 1
+    rec[ord2[is_multi_sorted]] = rec_sorted[is_multi_sorted]
+    n_parts = int(is_multi_sorted.sum())
+    mrow = torch.nonzero(multi).flatten()
+    mptr = torch.zeros(mrow.numel() + 1, dtype=torch.long, device=dev)
+    torch.cumsum(parts_of_row[mrow], 0, out=mptr[1:])
+    # slots: XCD x's k-th virtual row -> unit (k // 64) * 8 + x
+    counts = torch.bincount(vx, minlength=XCDS)
+    per = int((int(counts.max()) + UNIT - 1) // UNIT * UNIT) if n_v else 0
+    n_slots = XCDS * per
+    start = torch.cumsum(counts, 0) - counts
+    k = torch.arange(n_v, device=dev) - start[vx]
+    slot = ((k // UNIT) * XCDS + vx) * UNIT + k % UNIT
+    vdesc = torch.full((n_slots, 2), -1, dtype=torch.int32, device=dev)
+    vdesc[slot, 0] = vr.int()
+    vdesc[slot, 1] = rec.int()
+    lens = torch.zeros(n_slots, dtype=torch.long, device=dev)
+    lens[slot] = vlen
+    vrowptr = torch.zeros(n_slots + 1, dtype=torch.long, device=dev)
+    torch.cumsum(lens, 0, out=vrowptr[1:])
+    v_of_edge = torch.repeat_interleave(torch.arange(n_v, device=dev), vlen)
+    eorder = torch.argsort(slot[v_of_edge], stable=True)
+    final = order[eorder]
+    vcol = colind[final].contiguous()
+    eid = (final if eid_base is None else eid_base.long()[final]).int().contiguous()
+    if nnz >= 2 ** 31 or n_slots >= 2 ** 31:
+        raise _lib.BackendError("XCD plan: the structure exceeds int32 positions")
+    return XcdPlan(vrowptr.int(), vcol, vdesc.contiguous(), eid, mrow.int(), mptr.int(), n_parts, m)
+
+
+def wanted(m, nnz, n_src, row_bytes, exact_fp32=False):
+    """Should a launch over this structure, gathering rows of `row_bytes` from an [n_src, .] table, take a plan?  Hub-heavy
+    launches (>= 64 edges per row on average, >= 8 M edges) over tables between one L2 and a few times the eight of them, rows
+    of at least 128 bytes.  Measured on the Reddit-shaped graph (493 edges per row, profiles/r06_xcd_quick.txt), fused GAT
+    forward + backward: H = 8 x F = 8 bf16 (128-byte rows, 30 MB) 7.31 -> 5.66 ms, fp32 (60 MB) 11.83 -> 7.73 ms; H = 1 x
+    F = 48 bf16 (96-byte rows, 22 MB: one head per lane group, bound by instruction issue, not by the gathers) 6.07 -> 5.97 ms
+    without and 6.56 -> 6.93 ms with dropout -- not taken.  Never for fp32 csr_spmm unless forced (bit-exact rows)."""
+    if MODE == "off" or _plan.transient() or _plan._TAPE is not None:
+        return False
+    if n_src >= (1 << 24) or n_src * row_bytes >= (1 << 32):  # (the plan kernels address the table with 24 x 24 -> 32-bit offsets)
+        return False
+    if MODE == "force":
+        return nnz > 0
+    if exact_fp32:
+        return False
+    table = n_src * row_bytes
+    return nnz >= (1 << 23) and nnz >= 64 * m and row_bytes >= 128 and (2 << 20) <= table <= (512 << 20)
+
+
+class _Cache:
+    def __init__(self):
+        self.budget = int(os.environ.get("COGDL_AMD_XCD_CACHE_MB", "8192")) << 20
+        self.bytes = 0
+        self.lru = collections.OrderedDict()
+
+    def get(self, key, make):
+        p = self.lru.get(key)
+        if p is not None:
+            self.lru.move_to_end(key)
+            return p
+        p = make()
+        self.lru[key] = p
+        self.bytes += p.nbytes()
+        while self.bytes > self.budget and len(self.lru) > 1:
+            _, old = self.lru.popitem(last=False)
+            self.bytes -= old.nbytes()
+        return p
+
+    def clear(self):
+        self.lru.clear()
+        self.bytes = 0
+
+
+XPLANS = _Cache()
+
+
+def csr_plan(fp, rowptr, colind):
+    """The plan of the structure itself, under its fingerprint (waits for the hash: one host synchronisation per call --
+    `wanted()` only says yes to launches of hundreds of microseconds; with install(structure_memo=True) the key is memoised)."""
+    return XPLANS.get(("csr", SPLIT, PIECE) + fp.key(), lambda: build(rowptr, colind))
+
+
+def csc_plan(fp, csc):
+    """The plan of the transpose (a CscPlan): per-edge operands are indexed through its perm."""
+    return XPLANS.get(("csc", SPLIT, PIECE) + fp.key(), lambda: build(csc.colptr, csc.rowind, eid_base=csc.perm))

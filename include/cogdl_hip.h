@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define COGDL_HIP_ABI_VERSION 7
+#define COGDL_HIP_ABI_VERSION 8
 
 /* Exported with default visibility (the library is built -fvisibility=hidden). */
 #if defined(COGDL_HIP_BUILD)
@@ -60,29 +60,23 @@ COGDL_API int cogdl_hip_abi_version(void);
 COGDL_API const char *cogdl_hip_strerror(int status);
 /* hipError_t of the most recent COGDL_HIP_ELAUNCH on this thread (0 if none). */
 COGDL_API int cogdl_hip_last_hip_error(void);
-/* Run-time tuning knobs for experiments and tests: key 0 = XCD stripe of the row-block -> workgroup map (0 = hardware
- * round-robin, default 32), key 1 = long-row threshold override (0 = automatic), key 2 = 1: keep the natural row -> lane-group assignment
- * inside a workgroup (default 0: rows dealt by decreasing length), key 3 = cap on the number of
- * long-row workgroups (default 1024), key 4 = cap on the fused-GAT vector width (0 = widest), key 5 = fused-GAT
- * forward kernel (0 = automatic, 1 = edge-wise online softmax, 2 = chunk-wise softmax where the shape allows),
- * key 6 = csr_spmm/mhspmm vector width cap (negative: force; -99: power-of-two lane groups only), key 7 = edge_softmax lane width (bit 0: 4-byte lanes in
- * the row kernels, bit 1: 4-byte lanes in the hub-row path, bit 2: row kernels instead of the flat streaming kernel;
- * 0 = flat kernel where it applies, 16-byte lanes where the layout allows), key 8 = polls before the flat edge_softmax
- * kernel's cross-tile wait gives up and recomputes the row statistics itself (0 = default 4096; negative: every
- * wait gives up at once -- tests of that escape path), key 9 = flat edge_softmax experiments (bit 0: the kernel
- * skips its cross-tile exchange -- WRONG results; bit 2: half-size tiles for 16-bit values; bit 3: no kept exp values in
- * the forward; bit 4: one 16-bit element per LDS access; bit 6: full-size tiles for under-filled launches too; bit 7:
- * wall-clock phase stamps of one-row tiles in the workspace header, tools/es_phase_probe.py; bit 8: the forward's two-kernel
- * form -- one-row tiles streamed twice by a second kernel instead of held in registers across the exchange; measured slower), key 10 = csr2csc algorithm (0 = automatic: one single-workgroup launch up
- * to 16 k edge slots and columns, the hand-written two-payload radix sort above; 1 = as 0 (the rocPRIM sort pipeline of
- * rounds 1-4 was removed in round 5); 2 = the radix sort at every size; 3 = the radix sort with packed
- * intermediate records wherever two passes suffice -- by default only from 16 M slots on, 5 = MSD-first where two passes
- * suffice, 6 = digits of at most 6 bits: three passes of whole-line runs for 18-bit ids; both measured slower),
- * key 11 = sampler relabelling (1 = the sort-based form), key 12 = wave-scope split of medium rows in skewed workgroups
- * (<= 0 = off, the default; n > 0 = rows of more than n edges), key 13 = timing experiments on the row-reduce engine
- * (1 = the row blocks exit at once, 2 = the long-row workgroups exit at once -- WRONG results), key 14 = csr_spmm row
- * tiles (2 = several consecutive rows per lane group with their first gathers in one batch; off by default).
- * Defaults are the measured optima. */
+/* Run-time tuning knobs for experiments and tests (defaults are the measured optima; the negative results behind the
+ * retired keys are tabled in DESIGN.md section 8):
+ *    0  XCD stripe of the row-block -> workgroup map (0 = hardware round-robin, default 32)
+ *    1  long-row threshold override (0 = automatic)          2  1 = natural row -> lane-group assignment inside a workgroup
+ *    3  cap on the number of long-row workgroups (1024)      4  cap on the fused-GAT vector width (0 = widest)
+ *    5  fused-GAT forward kernel (0 = automatic, 1 = edge-wise online softmax, 2 = chunk-wise softmax where it applies)
+ *    6  csr_spmm / mhspmm vector width cap (negative: force; -99: power-of-two lane groups only)
+ *    7  edge_softmax lanes (bit 0: 4-byte lanes in the row kernels, bit 1: in the hub-row path, bit 2: row kernels only)
+ *    8  polls before the flat edge_softmax kernel's cross-tile wait recomputes the row statistics (0 = 4096; < 0: at once)
+ *    9  flat edge_softmax experiments (bit 0: no cross-tile exchange -- WRONG results; bit 2: half-size 16-bit tiles; bit 3: no
+ *       kept exp values; bit 4: one 16-bit element per LDS access; bit 6: full-size tiles for under-filled launches; bit 7:
+ *       phase stamps, tools/es_phase_probe.py; bit 8: round 5's two-kernel forward, measured slower)
+ *   10  csr2csc (0 = by size: one single-workgroup launch up to 16 k slots, the radix sort above; 2 = the radix sort at
+ *       every size; 3 = with packed intermediate records at every size)
+ *   11  sampler relabelling (1 = the sort-based form)       13  timing: 1 = row blocks exit, 2 = long-row workgroups exit (WRONG results)
+ *   15  64-bit CSR: edges per row segment (0 = 2^29)        17  degree-ordered row schedule of csr_spmm (see cogdl_hip_row_order)
+ *   12, 14, 16  retired in round 6 (wave-scope split of medium rows, row tiles, per-workgroup row queue: all measured <= +-5 %). */
 COGDL_API int cogdl_hip_set_tuning(int key, int value);
 /* Measurement hook (bench.py `roofline.measured_read_GBs`, SURVEY.md section 8d: the box's own roof beside the spec
  * peak): one read-only pass over `bytes` of device memory in 16-byte vectors; sink: COGDL_HIP_PROBE_BLOCKS * 16 bytes. */
@@ -111,11 +105,9 @@ COGDL_API int cogdl_hip_probe_copy_stream(const void *src, void *dst, size_t byt
 COGDL_API size_t cogdl_hip_csr_spmm_workspace_bytes(int64_t nnz, int64_t k, int dtype);
 COGDL_API int cogdl_hip_long_row_threshold(int64_t nnz);
 /* Rows of at most this many edges are ALWAYS reduced sequentially in CSR order (fp32: bit-identical to the reference's
- * csr_spmm_cpu loop, spmm_cpu.cpp:24-35): cogdl_hip_long_row_threshold(nnz) by default.  Longer rows are cut into
- * contiguous pieces whose partial sums are merged in order by whole workgroups -- and, if the wave-scope split of medium
- * rows is switched on (tuning key 12 = n > 0: rows of more than n edges in workgroups whose rows are skewed; off by
- * default, it measured no gain), by the lane groups of one wave; then this function returns min(n, threshold).
- * Deterministic, re-associated at the piece borders only (<= 1e-6 relative). */
+ * csr_spmm_cpu loop, spmm_cpu.cpp:24-35): cogdl_hip_long_row_threshold(nnz).  Longer rows are cut into contiguous pieces
+ * whose partial sums are merged in order by whole workgroups: deterministic, re-associated at the piece borders only
+ * (<= 1e-6 relative). */
 COGDL_API int cogdl_hip_exact_row_edges(int64_t nnz);
 COGDL_API int cogdl_hip_csr_spmm(const int32_t *rowptr, const int32_t *colind, const void *val,
                        const void *x, void *out, int64_t m, int64_t k, int64_t nnz, int dtype,
@@ -132,6 +124,33 @@ COGDL_API int cogdl_hip_csr_spmm_acc(const int32_t *rowptr, const int32_t *colin
 COGDL_API int cogdl_hip_csr_spmm_variant(const int32_t *rowptr, const int32_t *colind, const void *val,
                                const void *x, void *out, int64_t m, int64_t k, int64_t nnz, int dtype,
                                int variant, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * XCD-partitioned columns (ABI v8; no reference counterpart -- the reference's GE-SpMM kernels have no notion of the chip's
+ * eight private L2s).  For gathered tables that fit the eight 4 MiB L2s of the MI355X together but not one of them
+ * (BASELINE configs[2]: 233 k rows of 128-256 bytes, rows of hundreds of edges) a PLAN gives every column an owner XCD
+ * (hash of its id), cuts every long row into the sub-rows of its edges by owner and lays these virtual rows out so that a
+ * workgroup on XCD x only gathers columns XCD x owns.  The plan is built once per structure by the caller
+ * (cogdl_amd/xcdplan.py); this struct is its device view, all arrays int32 device memory:
+ *   vrowptr [n_slots + 1]  edge offsets of the virtual rows ("slots") in the plan's edge order
+ *   vcol    [nnz]          column ids in that order
+ *   vdesc   [n_slots][2]   {row, record}: row < 0 = padding slot; record < 0 = the row's only part (finished by the main
+ *                          kernel), otherwise the index of this part's state record
+ *   eid     [nnz]          what a per-edge operand is indexed by for the edge at a plan position (the CSR position of
+ *                          the edge; for a CSC view: the caller's own edge id) -- NULL if the operator has none
+ *   mrow [n_multi], mptr [n_multi + 1]   rows with several parts and their records [mptr[i], mptr[i+1]) in merge order
+ * n_slots is a multiple of 512 (units of 64 slots, round-robin over the 8 XCDs).  Results are deterministic; a row cut into
+ * parts is re-associated (fp32 <= 1e-6 relative) -- which is why csr_spmm takes this path only when asked to. */
+typedef struct cogdl_hip_vrows {
+    const int32_t *vrowptr, *vcol, *vdesc, *eid, *mrow, *mptr;
+    int64_t n_slots, n_multi, n_parts, nnz;
+} cogdl_hip_vrows;
+/* out = A x (acc != 0: out += A x) over a plan; val in PLAN order (val_plan[j] = val[eid[j]]) or NULL.
+ * workspace >= cogdl_hip_csr_spmm_xcd_workspace_bytes(n_parts, k, dtype). */
+COGDL_API size_t cogdl_hip_csr_spmm_xcd_workspace_bytes(int64_t n_parts, int64_t k, int dtype);
+COGDL_API int cogdl_hip_csr_spmm_xcd(const cogdl_hip_vrows *plan, const void *val_plan, const void *x, void *out,
+                                     int64_t m, int64_t k, int dtype, int acc, void *workspace, size_t workspace_bytes,
+                                     void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * 64-bit CSR ("big CSR", ABI v7): graphs of 2^31 edges and more -- ogbn-papers100M as CogDL feeds it to GCN
@@ -396,6 +415,24 @@ COGDL_API int cogdl_hip_gat_dropout_bwd(const int32_t *rowptr, const int32_t *co
                       void *grad_feat, float *grad_attn_row, float *grad_attn_col,
                       void *workspace, size_t workspace_bytes, int64_t v, int64_t n_src, int64_t h,
                       int64_t f, int64_t nnz, int dtype, void *stream);
+/* The fused GAT operator over XCD-partitioned plans (cogdl_hip_vrows above; p == 0: no dropout, p > 0: the mask of
+ * cogdl_hip_gat_dropout_fwd -- a function of (seed, CSR position, head), so plan->eid must be the CSR position of every plan
+ * position; for the CSC plan of the backward: the CSR position of the transposed entry, i.e. perm composed with the plan).
+ * Shapes the ordinary entries run through the chunk-wise forward / the column-tiled backward return COGDL_HIP_EUNSUPPORTED:
+ * the caller keeps the ordinary entry for them.  Same results as the ordinary entries up to re-association. */
+COGDL_API size_t cogdl_hip_gat_fwd_xcd_workspace_bytes(int64_t n_parts, int64_t h, int64_t f, int dtype);
+COGDL_API int cogdl_hip_gat_fwd_xcd(const cogdl_hip_vrows *plan, const float *attn_row, const float *attn_col,
+                      const void *feat, float negative_slope, float p, uint64_t seed, void *out, float *edge_max,
+                      float *edge_sum, int64_t v, int64_t h, int64_t f, int dtype, void *workspace,
+                      size_t workspace_bytes, void *stream);
+COGDL_API size_t cogdl_hip_gat_bwd_xcd_workspace_bytes(int64_t v, int64_t h, int64_t f, int64_t n_parts_row,
+                      int64_t n_parts_col, int dtype);
+COGDL_API int cogdl_hip_gat_bwd_xcd(const cogdl_hip_vrows *plan_csr, const cogdl_hip_vrows *plan_csc,
+                      const float *attn_row, const float *attn_col, const void *feat, float negative_slope, float p,
+                      uint64_t seed, const float *edge_max, const float *edge_sum, const void *out,
+                      const void *grad_out, void *grad_feat, float *grad_attn_row, float *grad_attn_col,
+                      void *workspace, size_t workspace_bytes, int64_t v, int64_t n_src, int64_t h, int64_t f,
+                      int dtype, void *stream);
 COGDL_API int cogdl_hip_edge_dropout_mask(int64_t nnz, int64_t h, float p, uint64_t seed, float *mask, void *stream);
 /* the same mask into HOST memory, computed on the host by the same code (no GPU needed: CPU tests pin the generator) */
 COGDL_API int cogdl_hip_edge_dropout_mask_host(int64_t nnz, int64_t h, float p, uint64_t seed, float *mask);

@@ -62,8 +62,7 @@ def test_sample_adj_padded_rejects_what_has_no_fixed_capacity():
     assert int(counts[2]) & 1  # a seed outside the graph is flagged, not fatal on the device
 
 
-@pytest.mark.parametrize("algo", [0, 2, 3, 5], ids=["default-by-size", "radix-transpose",
-                                                     "radix-transpose-packed-records", "radix-transpose-msd-first"])
+@pytest.mark.parametrize("algo", [0, 2, 3], ids=["default-by-size", "radix-transpose", "radix-transpose-packed-records"])
 @pytest.mark.parametrize("surplus", [0, 1, 777, 20000])
 @pytest.mark.parametrize("n_cols", [500, 6000], ids=["one-radix-pass", "two-radix-passes"])
 def test_csr2csc_padded_ignores_the_slots_behind_the_last_row(surplus, algo, n_cols):

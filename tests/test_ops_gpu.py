@@ -21,12 +21,12 @@ def rand(*shape, seed=0, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------ csr2csc
-@pytest.fixture(params=[0, 2, 3, 5, 6], ids=["default-by-size", "radix-transpose", "radix-transpose-packed-records", "radix-transpose-msd-first", "radix-transpose-6-bit-digits"])
+@pytest.fixture(params=[0, 2, 3], ids=["default-by-size", "radix-transpose", "radix-transpose-packed-records"])
 def csc_algo(request):
     """csr2csc's implementations (tuning key 10; the default picks by size: one single-workgroup launch up to 16 k slots
     and columns, the radix transpose above -- the rocPRIM pipeline of rounds 1-4 is gone): the hand-written two-payload radix
     sort (csrc/radix_transpose.hip) at every size (2) -- LSD, with packed intermediate records from 16 M slots on (3: at
-    any size); 5: MSD-first where two passes suffice (column ids of 10..18 bits); 6: digits of at most 6 bits."""
+    any size).  (The MSD-first and the 6-bit-digit variants of rounds 3-4, both measured slower, were removed in round 6.)"""
     from cogdl_amd import _lib
 
     _lib.hip().cogdl_hip_set_tuning(10, request.param)

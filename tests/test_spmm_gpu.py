@@ -370,83 +370,6 @@ def test_strided_index_views_are_made_contiguous_before_hashing(oracle):
     assert xd.grad.cpu().numpy().tobytes() == oracle.csr_spmm(colptr, rowind, w_t, gout).tobytes()
 
 
-@pytest.fixture
-def wave_split_32():
-    from cogdl_amd import _lib
-
-    _lib.hip().cogdl_hip_set_tuning(12, 32)
-    yield 32
-    _lib.hip().cogdl_hip_set_tuning(12, 0)
-
-
-@pytest.mark.parametrize("k", [64, 40, 16, 128])
-def test_wave_scope_split_of_medium_rows(oracle, wave_split_32, k):
-    """Tuning key 12 (off by default): in a skewed workgroup the rows of more than n edges are reduced by all lane groups
-    of their wave, partial states merged in slice order through shuffles.  Rows of at most n edges keep the reference's
-    order (bit-exact), split rows are within 1e-5 of the magnitude of their terms, results are run-to-run identical, and
-    a call without a workspace (= "every row sequentially") is still bit-exact at any length."""
-    from cogdl_amd import _lib
-
-    g = synth.arxiv_like(seed=0, topology="rmat")
-    assert _lib.hip().cogdl_hip_exact_row_edges(g.nnz) == 32
-    x = torch.randn(g.num_nodes, k, generator=torch.Generator().manual_seed(2))
-    want = oracle.csr_spmm(g.rowptr, g.colind, g.weight, x, nthreads=oracle.num_threads())
-    got = hip_spmm(g.rowptr, g.colind, g.weight, x)
-    assert_rows_match(got, want, g.rowptr, g.nnz, oracle.csr_spmm_abs(g.rowptr, g.colind, g.weight, x))
-    assert got.tobytes() == hip_spmm(g.rowptr, g.colind, g.weight, x).tobytes()
-    _lib.hip().cogdl_hip_set_tuning(12, 0)
-    off = hip_spmm(g.rowptr, g.colind, g.weight, x)
-    _lib.hip().cogdl_hip_set_tuning(12, 32)
-    deg = np.diff(g.rowptr.numpy())
-    assert got[deg <= 32].tobytes() == off[deg <= 32].tobytes()
-    if k not in (128, 40):  # (k = 128 in fp32 is one wave per row, k = 40 runs in lane groups of 10 that do not tile a wave: no split)
-        assert np.any(got != off), "the split did not engage on the R-MAT graph"
-    hubs = synth.hub_csr(600, 600, hubs=((3, 129), (4, 1000), (17, 90), (18, 257), (40, 70), (41, 100)), seed=k)
-    xs = torch.randn(600, k, generator=torch.Generator().manual_seed(3))
-    seq = csr_spmm_raw(hubs.rowptr.to(DEV), hubs.colind.to(DEV), hubs.weight.to(DEV), xs.to(DEV), split_long_rows=False)
-    assert seq.cpu().numpy().tobytes() == oracle.csr_spmm(hubs.rowptr, hubs.colind, hubs.weight, xs).tobytes()
-
-
-@pytest.mark.parametrize("k", [64, 40, 16, 128])
-@pytest.mark.parametrize("topology", ["rmat", "uniform"])
-def test_row_tiles_are_bit_identical_to_the_plain_kernel(oracle, k, topology):
-    """Tuning key 14 = 2 (off by default: measured slower except on one- and two-edge rows): R = 4 consecutive rows per
-    lane group, row pointers / first id chunks / first gathers of the four rows in flight together.  Per row the arithmetic
-    and its order are the plain kernel's: identical bits, weighted and unweighted, with rows of every length, an
-    accumulating call, a matrix whose last rows do not fill a tile, and a matrix without edges."""
-    from cogdl_amd import _lib
-
-    g = synth.arxiv_like(seed=0, topology=topology)
-    x = torch.randn(g.num_nodes, k, generator=torch.Generator().manual_seed(4))
-    lib = _lib.hip()
-
-    def both(fn):
-        lib.cogdl_hip_set_tuning(14, 2)
-        try:
-            a = fn()
-        finally:
-            lib.cogdl_hip_set_tuning(14, 0)
-        return a, fn()
-
-    a, b = both(lambda: hip_spmm(g.rowptr, g.colind, g.weight, x))
-    assert a.tobytes() == b.tobytes()
-    assert_rows_match(a, oracle.csr_spmm(g.rowptr, g.colind, g.weight, x, nthreads=oracle.num_threads()), g.rowptr, g.nnz,
-                      oracle.csr_spmm_abs(g.rowptr, g.colind, g.weight, x))
-    a, b = both(lambda: hip_spmm(g.rowptr, g.colind, None, x))
-    assert a.tobytes() == b.tobytes()
-    small = synth.random_csr(13, 97, 6, seed=k)  # 13 rows: the last tile is partial; ragged rows, some empty
-    xs = torch.randn(97, k, generator=torch.Generator().manual_seed(5))
-    a, b = both(lambda: hip_spmm(small.rowptr, small.colind, small.weight, xs))
-    assert a.tobytes() == b.tobytes() == oracle.csr_spmm(small.rowptr, small.colind, small.weight, xs).tobytes()
-    base = torch.randn(13, k, generator=torch.Generator().manual_seed(6))
-    a, b = both(lambda: csr_spmm_raw(small.rowptr.to(DEV), small.colind.to(DEV), small.weight.to(DEV), xs.to(DEV),
-                                     out=base.to(DEV).clone()).cpu().numpy())
-    assert a.tobytes() == b.tobytes()
-    empty_rp = torch.zeros(30, dtype=torch.int32)
-    a, b = both(lambda: csr_spmm_raw(empty_rp.to(DEV), torch.zeros(0, dtype=torch.int32, device=DEV), None, xs[:29].to(DEV)).cpu().numpy())
-    assert a.tobytes() == b.tobytes() and not a.any()
-
-
 def test_plan_cache_hit_verification_debug_mode(monkeypatch):
     """Round-4 verdict (weak 3): a plan-cache hit is trusted on sizes + a 64-bit content hash.  COGDL_AMD_VERIFY_PLANS=1
     (plan.VERIFY_HITS) checks every hit against the structure of the call: a genuine hit passes, a plan filed under another

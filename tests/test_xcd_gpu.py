@@ -1,0 +1,245 @@
+"""XCD-partitioned column plans (include/cogdl_hip.h: cogdl_hip_vrows; cogdl_amd/xcdplan.py; csrc/rowreduce.h virtual rows).
+
+No reference counterpart (its GE-SpMM kernels know one L2, cogdl/operators/spmm/spmm_kernel.cu:192-512): the plan is a
+different EXECUTION ORDER of csr_spmm and of the fused GAT operator, so the checks are the operators' own -- the CPU oracle
+(oracle/cogdl_oracle.c: csr_spmm follows spmm_cpu.cpp:24-35, gat_fwd / gat_bwd the GATLayer composition,
+cogdl/layers/gat_layer.py:59-86) on small graphs with every kind of row (empty, short = whole, long = eight sub-rows, hubs =
+several pieces per owner, rows whose edges all have one owner), with the tolerances of tests/test_config3_gpu.py, plus the
+plan's own invariants.  Full-size coverage: tests/test_config3_gpu.py runs the same operators on the Reddit-shaped graph,
+where `xcdplan.wanted()` picks the plan by itself.
+"""
+import numpy as np
+import pytest
+import torch
+
+from cogdl_amd import synth, xcdplan
+from cogdl_amd.operators.fused_gat import fused_gat_dropout_func, edge_dropout_mask
+from cogdl_amd.operators.spmm import SPMMFunction, csr_spmm_raw, csr_spmm_xcd_raw
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}
+ATOL = {torch.float32: 1e-30, torch.bfloat16: 1e-30, torch.float16: 2.0 ** -24}  # fp16 results below 6e-5 are subnormal
+
+
+@pytest.fixture(autouse=True)
+def forced(monkeypatch):
+    monkeypatch.setattr(xcdplan, "MODE", "force")
+    xcdplan.XPLANS.clear()
+    yield
+    xcdplan.XPLANS.clear()
+
+
+def _graph(kind):
+    if kind == "hubs":  # hubs longer than several pieces, medium rows around SPLIT, empty rows
+        g = synth.hub_csr(300, 257, base_deg=6, hubs=((3, 129), (4, 1000), (17, 5000), (18, 257), (40, 65), (41, 64), (299, 700)), seed=5)
+    elif kind == "one_owner":  # every long row's edges name ONE column: a single owner XCD, seven absent parts
+        g = synth.hub_csr(70, 50, base_deg=2, hubs=((0, 300), (5, 66), (69, 513)), seed=2)
+        g.colind[g.rowptr[0]:g.rowptr[1]] = 7
+        g.colind[g.rowptr[69]:g.rowptr[70]] = 49
+    elif kind == "short":  # no long row at all: every slot whole, no records
+        g = synth.random_csr(1000, 333, 8, seed=3)
+    else:  # rectangular, more rows than columns, R-MAT-like skew
+        g = synth.hub_csr(2000, 97, base_deg=30, hubs=((1, 4000), (2, 4001), (1999, 2047)), seed=7)
+    return g
+
+
+KINDS = ["hubs", "one_owner", "short", "rect"]
+
+
+def _close(got, want, scale, tol, what, atol=1e-30):
+    got, want, scale = (np.asarray(a, dtype=np.float64) for a in (got, want, scale))
+    err = np.abs(got - want)
+    bound = tol * scale + atol
+    worst = np.argmax(err / bound)
+    assert np.all(err <= bound), "%s: err %.3e > bound %.3e at flat index %d (want %.6e)" % (
+        what, err.flat[worst], bound.flat[worst], worst, want.flat[worst])
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("split,piece", [(64, 256), (4, 16), (0, 5)])
+def test_plan_invariants(kind, split, piece):
+    """Every edge once, CSR order inside a part, owners = the hash, slots of XCD x only in units u % 8 == x, records in
+    (row, owner, piece) order."""
+    g = _graph(kind)
+    rowptr, colind = g.rowptr.to(DEV), g.colind.to(DEV)
+    p = xcdplan.build(rowptr, colind, split=split, piece=piece)
+    m, nnz = g.num_nodes, colind.numel()
+    assert p.n_slots % (xcdplan.UNIT * xcdplan.XCDS) == 0 and p.nnz == nnz and p.m == m
+    eid = p.eid.long().cpu()
+    assert torch.equal(torch.sort(eid).values, torch.arange(nnz))
+    assert torch.equal(p.vcol.cpu(), g.colind[eid])
+    vrp, desc = p.vrowptr.long().cpu(), p.vdesc.long().cpu()
+    lens = vrp[1:] - vrp[:-1]
+    assert int(vrp[0]) == 0 and int(vrp[-1]) == nnz and int(lens.max()) <= max(piece, split)
+    row_of_edge = torch.repeat_interleave(torch.arange(m), (g.rowptr[1:] - g.rowptr[:-1]).long())
+    slot_of_pos = torch.repeat_interleave(torch.arange(p.n_slots), lens)
+    assert torch.equal(desc[slot_of_pos, 0], row_of_edge[eid])  # a slot holds edges of its own row only
+    assert bool((lens[desc[:, 0] < 0] == 0).all())  # padding slots are empty
+    deg = (g.rowptr[1:] - g.rowptr[:-1]).long()
+    unit_xcd = (torch.arange(p.n_slots) // xcdplan.UNIT) % xcdplan.XCDS
+    long_edge = deg[row_of_edge[eid]] > split
+    own = xcdplan.owner_of(g.colind[eid].long())
+    assert torch.equal(unit_xcd[slot_of_pos][long_edge], own[long_edge])  # a long row's edge sits on its column's owner
+    # inside a slot the edges keep CSR order
+    same = slot_of_pos[1:] == slot_of_pos[:-1]
+    assert bool((eid[1:] > eid[:-1])[same].all())
+    # every row is written exactly once: either one whole slot, or one entry of mrow
+    whole = desc[(desc[:, 0] >= 0) & (desc[:, 1] < 0), 0]
+    mrow, mptr = p.mrow.long().cpu(), p.mptr.long().cpu()
+    assert torch.equal(torch.sort(torch.cat([whole, mrow])).values, torch.arange(m))
+    rec = desc[desc[:, 1] >= 0]
+    assert p.n_parts == rec.shape[0] == (int(mptr[-1]) if mrow.numel() else 0)
+    if rec.shape[0]:
+        assert torch.equal(torch.sort(rec[:, 1]).values, torch.arange(p.n_parts))
+        rec_row = torch.empty(p.n_parts, dtype=torch.long)
+        rec_row[rec[:, 1]] = rec[:, 0]
+        assert torch.equal(rec_row, torch.repeat_interleave(mrow, mptr[1:] - mptr[:-1]))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("k", [1, 2, 6, 16, 40, 64, 128, 200, 602])
+def test_csr_spmm_xcd_vs_oracle(oracle, kind, dtype, k):
+    g = _graph(kind)
+    gen = torch.Generator().manual_seed(k)
+    x = torch.randn(g.n_cols, k, generator=gen).to(dtype)
+    w = g.weight.to(dtype)
+    rowptr, colind = g.rowptr.to(DEV), g.colind.to(DEV)
+    plan = xcdplan.build(rowptr, colind)
+    want = oracle.csr_spmm_f64(g.rowptr.numpy(), g.colind.numpy(), w.float().numpy(), x.float().numpy())
+    scale = oracle.csr_spmm_abs(g.rowptr.numpy(), g.colind.numpy(), w.float().numpy(), x.float().numpy())
+    for val in (w, None):
+        got = csr_spmm_xcd_raw(plan, None if val is None else val.to(DEV), x.to(DEV))
+        assert got.dtype == dtype and got.shape == (g.num_nodes, k)
+        if val is None:
+            ones = np.ones(g.colind.numel(), dtype=np.float32)
+            want_u = oracle.csr_spmm_f64(g.rowptr.numpy(), g.colind.numpy(), ones, x.float().numpy())
+            scale_u = oracle.csr_spmm_abs(g.rowptr.numpy(), g.colind.numpy(), ones, x.float().numpy())
+            _close(got.float().cpu().numpy(), want_u, scale_u, TOL[dtype], "unweighted", ATOL[dtype])
+        else:
+            _close(got.float().cpu().numpy(), want, scale, TOL[dtype], "weighted", ATOL[dtype])
+    # out += A x, and the launch is deterministic
+    base = torch.randn(g.num_nodes, k, generator=gen).to(dtype).to(DEV)
+    acc = csr_spmm_xcd_raw(plan, w.to(DEV), x.to(DEV), out=base.clone())
+    _close(acc.float().cpu().numpy(), want + base.float().cpu().numpy().astype(np.float64),
+           scale + np.abs(base.float().cpu().numpy()), 2 * TOL[dtype], "accumulate", ATOL[dtype])
+    again = csr_spmm_xcd_raw(plan, w.to(DEV), x.to(DEV))
+    assert torch.equal(again, csr_spmm_xcd_raw(plan, w.to(DEV), x.to(DEV)))
+
+
+def test_csr_spmm_xcd_short_rows_are_bit_exact(oracle):
+    """Rows of at most SPLIT edges stay whole: sequential CSR order, bit-identical to the reference loop in fp32."""
+    g = _graph("short")
+    x = torch.randn(g.n_cols, 64)
+    plan = xcdplan.build(g.rowptr.to(DEV), g.colind.to(DEV))
+    assert plan.n_parts == 0
+    got = csr_spmm_xcd_raw(plan, g.weight.to(DEV), x.to(DEV))
+    want = oracle.csr_spmm(g.rowptr.numpy(), g.colind.numpy(), g.weight.numpy(), x.numpy())
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_spmm_function_takes_the_plan_in_both_directions(oracle, dtype, monkeypatch):
+    """SPMMFunction under COGDL_AMD_XCD=force: forward over the CSR plan, grad_x over the plan of the transpose (edge weights
+    stay in CSR order: the CSC plan's eid is the transpose's perm composed with the plan)."""
+    g = _graph("hubs")
+    calls = []
+    import cogdl_amd.operators.spmm as spmm_mod
+
+    real = spmm_mod.csr_spmm_xcd_raw
+    monkeypatch.setattr(spmm_mod, "csr_spmm_xcd_raw", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    x = torch.randn(g.n_cols, 32).to(dtype).to(DEV).requires_grad_()
+    w = g.weight.to(dtype).to(DEV)
+    rowptr, colind = g.rowptr.to(DEV), g.colind.to(DEV)
+    out = SPMMFunction.apply(rowptr, colind, x, w, False)
+    gout = torch.randn(g.num_nodes, 32).to(dtype).to(DEV)
+    out.backward(gout)
+    assert len(calls) == 2
+    rp, ci, wn = g.rowptr.numpy(), g.colind.numpy(), w.float().cpu().numpy()
+    xn = x.detach().float().cpu().numpy()
+    _close(out.detach().float().cpu().numpy(), oracle.csr_spmm_f64(rp, ci, wn, xn), oracle.csr_spmm_abs(rp, ci, wn, xn),
+           TOL[dtype], "forward")
+    # grad_x = A^T gout: through an independently built transpose (scipy)
+    import scipy.sparse as sp
+
+    at = sp.csr_matrix((wn.astype(np.float64), ci, rp), shape=(g.num_nodes, g.n_cols)).T.tocsr()
+    gn = gout.float().cpu().numpy().astype(np.float64)
+    _close(x.grad.float().cpu().numpy(), at @ gn, abs(at) @ np.abs(gn), TOL[dtype], "grad_x")
+
+
+SHAPES = [(8, 8), (1, 41), (4, 16), (2, 64), (1, 8), (3, 5)]
+
+
+@pytest.mark.parametrize("kind", ["hubs", "one_owner", "rect"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("h,f", SHAPES)
+@pytest.mark.parametrize("p", [0.0, 0.5])
+def test_fused_gat_xcd_vs_oracle(oracle, kind, dtype, h, f, p):
+    g = _graph(kind)
+    if g.num_nodes != g.n_cols:  # the operator's graphs are square
+        n = max(g.num_nodes, g.n_cols)
+        deg = torch.zeros(n, dtype=torch.long)
+        deg[:g.num_nodes] = (g.rowptr[1:] - g.rowptr[:-1]).long()
+        rp = torch.zeros(n + 1, dtype=torch.long)
+        torch.cumsum(deg, 0, out=rp[1:])
+        g = synth.CSRGraph(rp.int(), g.colind, g.weight, n, n)
+    n = g.num_nodes
+    tol, seed = TOL[dtype], 1234 + h
+    gen = torch.Generator().manual_seed(100 * h + f)
+    ar0, ac0 = torch.randn(n, h, generator=gen), torch.randn(n, h, generator=gen)
+    feat0 = torch.randn(n, h, f, generator=gen).to(dtype)
+    gout = torch.randn(n, h, f, generator=gen).to(dtype)
+    rowptr, colind = g.rowptr.to(DEV), g.colind.to(DEV)
+    ar, ac, ft = (t.to(DEV).requires_grad_() for t in (ar0, ac0, feat0))
+    out = fused_gat_dropout_func(ar, ac, rowptr, colind, 0.2, ft, p, seed)
+    out.backward(gout.to(DEV))
+    torch.cuda.synchronize()
+    drop = edge_dropout_mask(colind.numel(), h, p, seed, DEV).cpu().numpy() if p > 0 else None
+    rpn, cin = g.rowptr.numpy(), g.colind.numpy()
+    fh, gh = feat0.float().numpy(), gout.float().numpy()
+    want = oracle.gat_fwd(rpn, cin, ar0.numpy(), ac0.numpy(), fh, 0.2, drop=drop)
+    scale = oracle.gat_fwd(rpn, cin, ar0.numpy(), ac0.numpy(), np.abs(fh), 0.2, drop=drop)
+    _close(out.detach().float().cpu().numpy(), want, scale, tol, "forward")
+    gf, gl, gr, sf, sl, sr = oracle.gat_bwd(rpn, cin, ar0.numpy(), ac0.numpy(), fh, 0.2, gh, scales=True, drop=drop)
+    k = 4 if dtype != torch.float32 else 1
+    _close(ft.grad.float().cpu().numpy(), gf, sf, tol, "grad_feat")
+    _close(ar.grad.cpu().numpy(), gl, sl, tol * k, "grad_attn_row")
+    _close(ac.grad.cpu().numpy(), gr, sr, tol * k, "grad_attn_col")
+
+
+def test_fused_gat_xcd_kernels_are_the_ones_that_ran(monkeypatch):
+    """The plan entries return EUNSUPPORTED for the shapes they decline (the caller falls back silently): make sure the
+    shapes of configs[2] do NOT fall back."""
+    from cogdl_amd import _lib
+
+    g = _graph("hubs")
+    lib = _lib.hip()
+    n = g.num_nodes
+    rowptr, colind = g.rowptr.to(DEV), g.colind.to(DEV)
+    plan = xcdplan.build(rowptr, colind)
+    for h, f in ((8, 8), (1, 48)):
+        feat = torch.randn(n, h, f, device=DEV).bfloat16()
+        ar, ac = torch.randn(n, h, device=DEV), torch.randn(n, h, device=DEV)
+        out = torch.empty_like(feat)
+        emax, esum = torch.empty(n, h, device=DEV), torch.empty(n, h, device=DEV)
+        ws, wsb = _lib.workspace("cogdl_hip_gat_fwd_xcd_workspace_bytes", torch.device(DEV), plan.n_parts, h, f, 2)
+        for p in (0.0, 0.5):
+            rc = lib.cogdl_hip_gat_fwd_xcd(plan.ref(), _lib.ptr(ar), _lib.ptr(ac), _lib.ptr(feat), 0.2, p, 7, _lib.ptr(out),
+                                           _lib.ptr(emax), _lib.ptr(esum), n, h, f, 2, _lib.ptr(ws), wsb, None)
+            assert rc == 0, (h, f, p, rc)
+    torch.cuda.synchronize()
+
+
+def test_wanted_rule():
+    xcdplan.MODE = "auto"
+    n, nnz = synth.REDDIT_NODES, 114_848_857
+    assert xcdplan.wanted(n, nnz, n, 128)  # configs[2], bf16 H x F = 64
+    assert not xcdplan.wanted(n, nnz, n, 96)  # its output layer (41 -> 48 columns, one head): measured no gain
+    assert not xcdplan.wanted(n, nnz, n, 256, exact_fp32=True)  # fp32 csr_spmm stays bit-exact
+    assert not xcdplan.wanted(169_343, 2_501_719, 169_343, 512)  # arxiv: 15 edges per row
+    assert not xcdplan.wanted(111_059_956, 1_615_685_872, 111_059_956, 512)  # papers: the table is 57 GB
+    xcdplan.MODE = "force"
+    assert not xcdplan.wanted(1 << 24, 1 << 30, 1 << 24, 64)  # beyond the plan kernels' 24-bit row ids, even when forced
+    xcdplan.MODE = "off"
+    assert not xcdplan.wanted(n, nnz, n, 128)
