@@ -508,7 +508,10 @@ def main():
     ap.add_argument("--halo-frac", type=float, default=0.25,
                     help="N>1: halo rows per rank as a fraction of its own rows (remote sources come from boundary "
                          "regions of that total size; <= 0: uniform over the owner shard = worst-case halo)")
-    ap.add_argument("--leg", default="main", choices=["main", "worst"], help="(internal) which leg a child interpreter runs")
+    ap.add_argument("--leg", default="main", choices=["main", "assumed", "worst"], help="(internal) which leg a child interpreter runs")
+    ap.add_argument("--papers-scale", type=int, default=0,
+                    help="N>1 main leg: shard the papers100M-shaped graph at 1/this scale (default: 1 = full size; the "
+                         "self-test modes default to small graphs)")
     ap.add_argument("--no-extra-legs", action="store_true", help="N>1: only the main line (no worst-case partition, no configs[3] leg)")
     ap.add_argument("--legs-budget-s", type=float, default=420.0,
                     help="N>1: no follow-up leg is started once this many seconds have passed (all ranks decide together)")

@@ -154,8 +154,14 @@ struct GatFwdOp {
     }
     __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t, const LaneVals &lv, int sub,
                                           int jj) const {
+#if defined(COGDL_EXP)
+        const int col_a = (COGDL_EXP & 1) ? (col & 7) : col, col_f = (COGDL_EXP & 2) ? (col & 7) : col;
+        b.ac[u] = *gather_row<A24>(attn_col, c.hd, col_a, (uint32_t)heads * 4u);
+        load_vec<T, VEC>(gather_row<A24>(feat, c.cc, col_f, (uint32_t)(heads * fdim) * (uint32_t)sizeof(T)), b.v[u]);
+#else
         b.ac[u] = *gather_row<A24>(attn_col, c.hd, col, (uint32_t)heads * 4u);
         load_vec<T, VEC>(gather_row<A24>(feat, c.cc, col, (uint32_t)(heads * fdim) * (uint32_t)sizeof(T)), b.v[u]);
+#endif
         if constexpr (DROP) b.d[u] = drop_factor<LPR>(drop, lv, sub, jj, c.hd, heads);
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,

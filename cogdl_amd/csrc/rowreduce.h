@@ -636,8 +636,9 @@ struct VRows {
     const int2 *vdesc;       // [n_slots] {row (-1: padding), record index (-1: the row's only part: finished here)}
     const int32_t *mrow;     // [n_multi] rows with several parts ...
     const int32_t *mptr;     // [n_multi + 1] ... and their records [mptr[i], mptr[i + 1]) in merge order
+    const int32_t *big;      // [n_big] indices into mrow of the rows with more than kVBigParts parts
     float *partial;          // [n_parts][rec_stride]
-    int64_t n_slots, n_multi, n_parts, rec_stride;
+    int64_t n_slots, n_multi, n_parts, n_big, rec_stride;
     int sort_rows;
 };
 
@@ -698,31 +699,76 @@ __global__ __launch_bounds__(256, MinWaves<Op>::value) void rowreduce_vrow_kerne
     }
 }
 
+// Merge the part records of every multi-part row in plan order (owner XCD, then piece) and finish the row.  One lane group per
+// row -- except the rows of more than kVBigParts parts (hubs: a row of 10^5 edges has ~400), which get a whole workgroup each
+// (the leading n_big blocks): its G lane groups merge contiguous slices of the row's records, the G states are merged in group
+// order through LDS.  Measured before that split (Reddit-shaped graph, fused GAT forward, 1.2 M records): 266 us for 0.35 GB --
+// the launch WAS the serial chain of the longest row (profiles/r06_pmc_gat.json).  The next record is requested before the
+// current one is merged.
+constexpr int kVBigParts = 32;
 template <class Op>
 __global__ __launch_bounds__(256) void rowreduce_vcombine_kernel(const Op op, const VRows v) {
     constexpr int LPR = Op::LPR;
     constexpr int RPW = kWave / LPR;
     constexpr int GPB = RPW * 4;
     constexpr int NREC = Op::kRec;
+    __shared__ float red[GPB][NREC][LPR];
     const int lane = threadIdx.x & (kWave - 1);
     const int l = lane % LPR, sub = lane / LPR;
-    const int64_t idx = (int64_t)blockIdx.x * GPB + (threadIdx.x >> 6) * RPW + sub;
+    const int g = (threadIdx.x >> 6) * RPW + sub;
+    const bool big = (int64_t)blockIdx.x < v.n_big;
+    const int64_t idx = big ? (int64_t)v.big[blockIdx.x] : ((int64_t)blockIdx.x - v.n_big) * GPB + g;
     if (idx >= v.n_multi) return;  // (group-uniform; the shuffles of the operator hooks are group-local)
     const int64_t row = v.mrow[idx];
-    const int p0 = v.mptr[idx], p1 = v.mptr[idx + 1];
+    int p0 = v.mptr[idx], p1 = v.mptr[idx + 1];
+    if (!big && p1 - p0 > kVBigParts) return;  // (a whole workgroup has it)
     typename Op::Ctx ctx = op.make_ctx(l, blockIdx.y);
     op.row_load(ctx, row, true);
-    typename Op::State st;
-    op.init(ctx, st, row, true);
     const int64_t tile_off = (int64_t)blockIdx.y * NREC * LPR + l;
-    for (int p = p0; p < p1; ++p) {
+    auto load = [&](float(&rec)[NREC], int p) {
         const float *src = v.partial + (int64_t)p * v.rec_stride + tile_off;
-        float rec[NREC];
 #pragma unroll
         for (int q = 0; q < NREC; ++q) rec[q] = src[q * LPR];
-        typename Op::State piece;
-        op.unpack(piece, rec);
-        op.merge(ctx, st, piece);
+    };
+    auto merge_range = [&](typename Op::State &st, int a, int b) {
+        if (a >= b) return;
+        float cur[NREC], nxt[NREC];
+        load(cur, a);
+#pragma unroll 1
+        for (int p = a; p < b; ++p) {
+            load(nxt, min(p + 1, b - 1));
+            typename Op::State piece;
+            op.unpack(piece, cur);
+            op.merge(ctx, st, piece);
+#pragma unroll
+            for (int q = 0; q < NREC; ++q) cur[q] = nxt[q];
+        }
+    };
+    typename Op::State st;
+    if (!big) {
+        op.init(ctx, st, row, true);
+        merge_range(st, p0, p1);
+        op.row_end(ctx, st, row, true);
+        return;
+    }
+    const int per = (p1 - p0 + GPB - 1) / GPB;
+    const int a = min(p0 + g * per, p1), b = min(a + per, p1);
+    op.init_zero(st);
+    merge_range(st, a, b);
+    float rec[NREC];
+    op.pack(st, rec);
+#pragma unroll
+    for (int q = 0; q < NREC; ++q) red[g][q][l] = rec[q];
+    __syncthreads();
+    if (g != 0) return;
+    op.init(ctx, st, row, true);
+#pragma unroll 1  // (unrolled by the compiler this loop cost the 17-float records of the GAT column pass 256 VGPRs + 84 AGPRs)
+    for (int q = 0; q < GPB; ++q) {  // fixed order: group 0, 1, 2, ...
+#pragma unroll
+        for (int i = 0; i < NREC; ++i) rec[i] = red[q][i][l];
+        typename Op::State other;
+        op.unpack(other, rec);
+        op.merge(ctx, st, other);
     }
     op.row_end(ctx, st, row, true);
 }
@@ -737,6 +783,7 @@ inline int vrows_valid(const cogdl_hip_vrows *p) {
     if (p->n_slots > 0 && (!p->vrowptr || !p->vdesc)) return COGDL_HIP_EINVAL;
     if (p->nnz > 0 && !p->vcol) return COGDL_HIP_EINVAL;
     if (p->n_multi > 0 && (!p->mrow || !p->mptr)) return COGDL_HIP_EINVAL;
+    if (p->n_big < 0 || p->n_big > p->n_multi || (p->n_big > 0 && !p->big)) return COGDL_HIP_EINVAL;
     return COGDL_HIP_OK;
 }
 
@@ -752,6 +799,7 @@ static int launch_rowreduce_vrows(const Op &op, const cogdl_hip_vrows *p, int64_
     VRows v{};
     v.vrowptr = p->vrowptr, v.vcol = p->vcol, v.vdesc = (const int2 *)p->vdesc, v.mrow = p->mrow, v.mptr = p->mptr;
     v.n_slots = p->n_slots, v.n_multi = p->n_multi, v.n_parts = p->n_parts;
+    v.big = p->big, v.n_big = p->n_big;
     v.rec_stride = tiles * Op::kRec * Op::LPR;
     v.sort_rows = g_tuning[kTuneRowSort] == 0 ? 1 : 0;
     if (p->n_parts > 0) {
@@ -763,8 +811,8 @@ static int launch_rowreduce_vrows(const Op &op, const cogdl_hip_vrows *p, int64_
     if (wgs > 0x7fffffff) return COGDL_HIP_ERANGE;
     hipLaunchKernelGGL((rowreduce_vrow_kernel<Op>), dim3((unsigned)wgs, (unsigned)tiles), dim3(256), 0, stream, op, v);
     if (p->n_multi > 0)
-        hipLaunchKernelGGL((rowreduce_vcombine_kernel<Op>), dim3((unsigned)((p->n_multi + GPB - 1) / GPB), (unsigned)tiles),
-                           dim3(256), 0, stream, op, v);
+        hipLaunchKernelGGL((rowreduce_vcombine_kernel<Op>),
+                           dim3((unsigned)(p->n_big + (p->n_multi + GPB - 1) / GPB), (unsigned)tiles), dim3(256), 0, stream, op, v);
     return launch_status();
 }
 

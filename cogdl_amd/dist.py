@@ -564,6 +564,83 @@ def _papers_like_shard(rank, world, shard_nodes, degree, remote_frac, seed, devi
     return rowptr, cols, w
 
 
+def papers_graph_shard(rank, world, device, symmetrise=True, seed=0, num_nodes=None, num_pairs=None, bucket_edges=1 << 28):
+    """This rank's rows of THE graph the one-GPU leg runs (bench.py `configs4_papers_1gpu`; synth.papers100m_like: seeded
+    R-MAT pairs with ogbn-papers100M's node and pair counts, symmetrised as cogdl/datasets/ogb.py:50-55 feeds it to GCN,
+    multi-edges kept, sym-normalised weights from the GLOBAL degrees) under a contiguous edge-balanced 1-D partition
+    (edge_balanced_bounds).  Every rank generates the same pairs from the same seed and keeps the aggregation targets of
+    its own row range -- nothing about the communication volume is an input: the halo table and the remote edge share come
+    out of ShardedCSR as measurements.  -> (rowptr [n_local + 1] int64, colind [nnz_local] int32 GLOBAL ids, weight fp32,
+    bounds [world + 1], nnz_global).  The same rows as synth.big_csr_from_pairs builds, cut at the bounds."""
+    from . import synth
+
+    num_nodes = synth.PAPERS_NODES if num_nodes is None else int(num_nodes)
+    num_pairs = synth.PAPERS_PAIRS if num_pairs is None else int(num_pairs)
+    dev = torch.device(device)
+    src, dst = synth.rmat_pairs_i32(num_nodes, num_pairs, seed, dev)
+    deg = torch.bincount(dst, minlength=num_nodes)
+    if symmetrise:
+        deg += torch.bincount(src, minlength=num_nodes)
+    rowptr_g = torch.zeros(num_nodes + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(deg, 0, out=rowptr_g[1:])
+    nnz_global = int(rowptr_g[-1])
+    bounds = edge_balanced_bounds(rowptr_g, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    dinv = deg.to(torch.float32).pow_(-0.5)
+    dinv[torch.isinf(dinv)] = 0
+    del deg
+    rowptr = (rowptr_g[lo:hi + 1] - rowptr_g[lo]).contiguous()
+    del rowptr_g
+    nnz = int(rowptr[-1])
+    colind = torch.empty(nnz, dtype=torch.int32, device=dev)
+    weight = torch.empty(nnz, dtype=torch.float32, device=dev)
+    # my rows in buckets of about bucket_edges edges (cut by edge count: R-MAT rows are skewed towards low ids)
+    n_b = max(1, (nnz + bucket_edges - 1) // bucket_edges)
+    targets = torch.arange(1, n_b, device=dev, dtype=torch.int64) * (nnz // n_b)
+    cuts = sorted(set([0, hi - lo] + [int(r) for r in (torch.searchsorted(rowptr, targets, right=True) - 1).tolist()]))
+    for r0, r1 in zip(cuts, cuts[1:]):
+        g0, g1 = lo + r0, lo + r1
+        sel = (dst >= g0) & (dst < g1)
+        key = dst[sel].long() * num_nodes + src[sel].long()
+        if symmetrise:
+            sel = (src >= g0) & (src < g1)
+            key = torch.cat([key, src[sel].long() * num_nodes + dst[sel].long()])
+        del sel
+        key = torch.sort(key).values
+        e0, e1 = int(rowptr[r0]), int(rowptr[r1])
+        if key.numel() != e1 - e0:
+            raise RuntimeError("papers_graph_shard: bucket [%d, %d) holds %d edges, the row pointer says %d" % (g0, g1, key.numel(), e1 - e0))
+        row, col = key // num_nodes, key % num_nodes
+        del key
+        colind[e0:e1] = col
+        weight[e0:e1] = dinv[row] * dinv[col]
+        del row, col
+    del src, dst, dinv
+    if dev.type == "cuda":
+        torch.cuda.empty_cache()
+    return rowptr, colind, weight, bounds, nnz_global
+
+
+def _value_at_world1():
+    """The N = 1 point of the strong-scaling curve: fwd+bwd GEdges/s of the symmetrised papers100M-shaped graph on ONE GPU
+    (bench.py `configs4_papers_1gpu`, tools/papers_bench.py), from the newest committed profile -- a number measured by an
+    earlier one-GPU run of the same code path, repeated here so that a curve has an origin; the driver's own N = 1 run
+    carries the live value in its `configs4_papers_1gpu.symmetrised.forward_backward.GEdges_s`."""
+    import glob
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in sorted(glob.glob(os.path.join(root, "profiles", "r*_papers_1gpu.json")), reverse=True):
+        try:
+            runs = json.load(open(path)).get("runs") or []
+            fb = runs[-1]["symmetrised"]["forward_backward"]
+            return {"GEdges_s": fb["GEdges_s"], "ms_per_step": fb["ms"], "nnz": runs[-1]["symmetrised"]["nnz"],
+                    "source": "profiles/%s (committed one-GPU measurement; NOT measured in this run)" % os.path.basename(path)}
+        except (OSError, KeyError, IndexError, ValueError):
+            continue
+    return None
+
+
 def _rccl_version():
     try:
         v = torch.cuda.nccl.version()
@@ -573,25 +650,32 @@ def _rccl_version():
 
 
 def sharded_leg(rank, world, dev, shard_nodes, degree, feat, remote_frac, halo_frac, steps, warmup, backend=None, seed=0,
-                dump_dir=None):
-    """One measured leg of the N > 1 bench, run by EVERY rank of an initialised process group: generate this rank's
-    papers100M-shaped shard, build the exchange plan, time `steps` forward + backward passes (barrier + synchronise on
-    both sides, max over ranks), then the local block alone.  Returns the same dict on every rank."""
+                dump_dir=None, shard=None):
+    """One measured leg of the N > 1 bench, run by EVERY rank of an initialised process group: take this rank's shard --
+    `shard` = (rowptr, colind_global, weight, bounds, nnz_global) of a real graph cut by its own partition
+    (papers_graph_shard), or None: generate a papers100M-shaped shard from the knobs (remote_frac, halo_frac) --, build the
+    exchange plan, time `steps` forward + backward passes (barrier + synchronise on both sides, max over ranks), then the
+    local block alone.  Returns the same dict on every rank."""
     cuda = dev.type == "cuda"
 
     def sync():
         if cuda:
             torch.cuda.synchronize(dev)
 
-    rowptr, cols, w = _papers_like_shard(rank, world, shard_nodes, degree, remote_frac, seed, dev, halo_frac)
-    bounds = torch.arange(world + 1, dtype=torch.long) * shard_nodes
+    if shard is None:
+        rowptr, cols, w = _papers_like_shard(rank, world, shard_nodes, degree, remote_frac, seed, dev, halo_frac)
+        bounds = torch.arange(world + 1, dtype=torch.long) * shard_nodes
+    else:
+        rowptr, cols, w, bounds = shard[:4]
+    n_local = int(rowptr.numel()) - 1
+    lo = int(bounds[rank])
     sync()
     t_plan = time.perf_counter()
     sh = ShardedCSR(rowptr, cols, w, bounds, backend=backend)
     sync()
     t_plan = time.perf_counter() - t_plan
-    x = torch.randn(shard_nodes, feat, device=dev, requires_grad=True)
-    gout = torch.randn(shard_nodes, feat, device=dev)
+    x = torch.randn(n_local, feat, device=dev, requires_grad=True)
+    gout = torch.randn(n_local, feat, device=dev)
     if dump_dir:  # launcher self-test: this rank's shard, operands and one forward + backward, for the test's oracle
         import numpy as np
 
@@ -599,10 +683,12 @@ def sharded_leg(rank, world, dev, shard_nodes, degree, feat, remote_frac, halo_f
         y.backward(gout)
         np.savez(os.path.join(dump_dir, "b%d.npz" % rank), rowptr=rowptr.cpu().numpy(), cols=cols.cpu().numpy(),
                  w=w.cpu().numpy(), x=x.detach().cpu().numpy(), gout=gout.cpu().numpy(), y=y.detach().cpu().numpy(),
-                 gx=x.grad.cpu().numpy(), n_halo=sh.n_halo, nnz_remote=sh.nnz_remote)
+                 gx=x.grad.cpu().numpy(), n_halo=sh.n_halo, nnz_remote=sh.nnz_remote, lo=lo, n_local=n_local)
         x.grad = None
         del y
-    del cols, rowptr, w
+    del cols, rowptr, w, shard
+    if cuda:
+        torch.cuda.empty_cache()
 
     cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")  # (gloo: the small collectives on host tensors)
 
@@ -610,6 +696,11 @@ def sharded_leg(rank, world, dev, shard_nodes, degree, feat, remote_frac, halo_f
         t = torch.tensor([v], device=cdev, dtype=dtype)
         dist.all_reduce(t, op=op)
         return t.item()
+
+    def allgather(v, dtype=torch.float64):
+        out = [torch.zeros(1, dtype=dtype, device=cdev) for _ in range(world)]
+        dist.all_gather(out, torch.tensor([v], dtype=dtype, device=cdev))
+        return [t.item() for t in out]
 
     nnz_global = int(allsum(sh.nnz_local + sh.nnz_remote, dtype=torch.long))
 
@@ -645,24 +736,22 @@ def sharded_leg(rank, world, dev, shard_nodes, degree, feat, remote_frac, halo_f
             e1.record()
         sync()
         loc_ms = (e0.elapsed_time(e1) if cuda else (time.perf_counter() - t1) * 1e3) / reps
-    loc_all = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
-    dist.all_gather(loc_all, torch.tensor([loc_ms], dtype=torch.float64, device=cdev))
-    loc_all = [float(v) for v in loc_all]
-    halo_rows = allsum(sh.n_halo)
-    remote_edges = allsum(sh.nnz_remote)
-    b_alg = sh.nnz_local * (4 + 4 + feat * 4) + shard_nodes * (4 + feat * 4)
+    loc_all = [float(v) for v in allgather(loc_ms)]
+    halo_by_rank = [int(v) for v in allgather(sh.n_halo, torch.long)]
+    rows_by_rank = [int(v) for v in allgather(n_local, torch.long)]
+    edges_by_rank = [int(v) for v in allgather(sh.nnz_local + sh.nnz_remote, torch.long)]
+    remote_by_rank = [int(v) for v in allgather(sh.nnz_remote, torch.long)]
+    halo_rows = sum(halo_by_rank)
+    remote_edges = sum(remote_by_rank)
+    b_alg = sh.nnz_local * (4 + 4 + feat * 4) + n_local * (4 + feat * 4)
     nnz_gpu = nnz_global / world
-    # (the per-rank halo of the bench's generator: halo_frac x the shard's rows wherever ranks have peers; measured when they do)
-    halo_pred = sh.n_halo if world > 1 else (halo_frac * shard_nodes if halo_frac > 0 else min(remote_frac * nnz_gpu, 7.0 * shard_nodes))
-    rf_pred = remote_frac if remote_frac >= 0 else 0.1
-    predicted = predict_scaling(shard_nodes, nnz_gpu, feat, rf_pred if world == 1 else remote_edges / max(nnz_global, 1),
-                                halo_pred, max(loc_all) / max(sh.nnz_local / 1e9, 1e-12))
-    return {
-        "predicted": predicted,
+    out = {
         "value": 2 * nnz_global * steps / dt / 1e9, "unit": "GEdges/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-        "warmup": warmup, "nodes_per_gpu": shard_nodes, "nnz_global": nnz_global, "feat": feat,
+        "warmup": warmup, "nodes_per_gpu": n_local, "nnz_global": nnz_global, "feat": feat,
         "remote_frac": remote_frac, "halo_frac": halo_frac, "remote_edge_share": remote_edges / max(nnz_global, 1),
         "halo_rows_all_ranks": int(halo_rows), "halo_rows_rank0": sh.n_halo,
+        "halo_rows_by_rank": halo_by_rank, "rows_by_rank": rows_by_rank, "edges_by_rank": edges_by_rank,
+        "remote_edges_by_rank": remote_by_rank,
         "halo_GB_per_step_all_ranks": halo_rows * feat * 4 * 2 / 1e9,
         "exchange_plan_build_s_rank0": t_plan,
         "local_block_ms_by_rank": [round(v, 3) for v in loc_all],
@@ -671,6 +760,13 @@ def sharded_leg(rank, world, dev, shard_nodes, degree, feat, remote_frac, halo_f
         "local_block_GEdges_s_rank0": sh.nnz_local / (loc_all[0] * 1e-3) / 1e9,
         "local_block_algorithmic_bytes": b_alg,
     }
+    if shard_nodes:  # the knob-generated shards: a PRIOR for their curve (predict_scaling); a real graph's line carries none
+        # (the per-rank halo of the bench's generator: halo_frac x the shard's rows wherever ranks have peers; measured when they do)
+        halo_pred = sh.n_halo if world > 1 else (halo_frac * shard_nodes if halo_frac > 0 else min(remote_frac * nnz_gpu, 7.0 * shard_nodes))
+        rf_pred = remote_frac if remote_frac >= 0 else 0.1
+        out["predicted"] = predict_scaling(shard_nodes, nnz_gpu, feat, rf_pred if world == 1 else remote_edges / max(nnz_global, 1),
+                                           halo_pred, max(loc_all) / max(sh.nnz_local / 1e9, 1e-12))
+    return out
 
 
 XGMI_LINK_GBS = 153.0   # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, point to point)
@@ -807,16 +903,34 @@ def bench_sharded_spmm(args):
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     n_ranks_seen = dist.get_world_size()
-    # Weak scaling with the TRUE papers100M shard per GPU: 111,059,956 nodes / 8 = 13.9 M rows, ~4.1e8 edges, X = 7.1 GB
-    # per GPU -- at N = 8 this is the whole graph (3.3e9 edges: beyond what int32 CSR indices can address on ONE GPU,
-    # which is why the single-GPU leg of the curve cannot be the unsharded graph and the scaling is weak, not strong).
-    shard_nodes = args.shard_nodes or 111_059_956 // 8
-    degree = args.shard_degree or 28.8                         # 3.2e9 symmetrised edges / 111e6 nodes
+    # Which graph (round-5 verdict, star-g3).  The MAIN leg at N > 1 shards THE graph the N = 1 line's `configs4_papers_1gpu`
+    # leg runs -- the papers100M-shaped symmetrised graph, every rank keeping the rows of its edge-balanced contiguous range
+    # (papers_graph_shard): fixed total work = STRONG scaling, halo rows and remote edge share are measured outputs.  The
+    # knob-generated shards (one papers100M/8-sized shard per GPU whose remote fraction and halo ratio are INPUTS: what a
+    # locality-preserving partition is assumed to leave) are the follow-up leg `assumed_partition`, the world-size-1 base
+    # (`weak_scaling_base` of the N = 1 line) and the worst-case leg.
+    graph_leg = leg == "main" and world > 1
     f = args.feat
-    remote_frac = args.remote_frac if args.remote_frac >= 0 else 0.1
-    halo_frac = getattr(args, "halo_frac", 0.25)
-    m = sharded_leg(rank, world, dev, shard_nodes, degree, f, remote_frac, halo_frac, args.steps, args.warmup, backend,
-                    dump_dir=os.environ.get("COGDL_AMD_SELFTEST_DUMP") if cpu and leg == "main" else None)
+    shard_nodes = degree = remote_frac = halo_frac = None
+    shard, scale = None, 1
+    if graph_leg:
+        from . import synth
+
+        scale = int(getattr(args, "papers_scale", 0) or (2048 if cpu else 64 if share else 1))
+        nodes, pairs = synth.PAPERS_NODES // scale, synth.PAPERS_PAIRS // scale
+        t_gen = time.perf_counter()
+        shard = papers_graph_shard(rank, world, dev, True, 0, nodes, pairs, bucket_edges=max(1 << 16, (1 << 28) // scale))
+        t_gen = time.perf_counter() - t_gen
+        bounds_list = [int(v) for v in shard[3].tolist()]
+        m = sharded_leg(rank, world, dev, 0, 0.0, f, -1.0, -1.0, args.steps, args.warmup, backend, shard=shard,
+                        dump_dir=os.environ.get("COGDL_AMD_SELFTEST_DUMP") if cpu else None)
+        shard = None
+    else:
+        shard_nodes = args.shard_nodes or 111_059_956 // 8
+        degree = args.shard_degree or 28.8                         # 3.2e9 symmetrised edges / 111e6 nodes
+        remote_frac = args.remote_frac if args.remote_frac >= 0 else 0.1
+        halo_frac = getattr(args, "halo_frac", 0.25)
+        m = sharded_leg(rank, world, dev, shard_nodes, degree, f, remote_frac, halo_frac, args.steps, args.warmup, backend)
     rccl = None if cpu else _rccl_version()
     dist.barrier()
     t_start = float(getattr(args, "t0", _T_IMPORT))
@@ -828,23 +942,58 @@ def bench_sharded_spmm(args):
     if not cpu:
         torch.cuda.empty_cache()
     result = None
-    if rank == 0:
+    if rank == 0 and graph_leg:
+        result = {
+            "metric": "SpMM GEdges/s (vertex-sharded csr_spmm fwd+bwd on the papers100M-shaped graph, symmetrised) @%d GPUs" % world,
+            "value": m["value"], "unit": "GEdges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: the papers100M-shaped graph of the N = 1 line's configs4_papers_1gpu leg "
+                                   "(seeded R-MAT pairs, %d nodes, symmetrised as cogdl/datasets/ogb.py:50-55 feeds it to GCN, "
+                                   "multi-edges kept where the reference coalesces, sym-normalised weights), rows cut into %d "
+                                   "contiguous edge-balanced ranges, 1-D vertex-sharded csr_spmm fwd+bwd, F = %d fp32; halo "
+                                   "rows and remote edge share are MEASURED on this partition, not inputs%s"
+                                   % (synth.PAPERS_NODES // scale, world, f, "" if scale == 1 else " -- at 1/%d scale" % scale),
+                       "nodes": synth.PAPERS_NODES // scale, "nnz_global": m["nnz_global"], "feat": f, "scale": scale,
+                       "bounds": bounds_list, "rows_by_rank": m["rows_by_rank"], "edges_by_rank": m["edges_by_rank"],
+                       "halo_rows_by_rank": m["halo_rows_by_rank"], "halo_rows_rank0": m["halo_rows_rank0"],
+                       "remote_edges_by_rank": m["remote_edges_by_rank"], "remote_edge_share": m["remote_edge_share"],
+                       "partition": "contiguous row ranges of (nearly) equal edge count (dist.edge_balanced_bounds), ids as generated",
+                       "parallelism": "vertex-shard x%d, RCCL all-to-all halo exchange overlapped with local SpMM" % world},
+            "graph_build_s_rank0": t_gen,
+        }
+        w1 = _value_at_world1()
+        if w1 is not None and scale == 1:
+            result["value_at_world1"] = w1
+    elif rank == 0:
         result = {
             "metric": "SpMM GEdges/s (vertex-sharded csr_spmm fwd+bwd, papers100M-shaped shards) @%d GPUs" % world,
             "value": m["value"], "unit": "GEdges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "papers100M-like 1-D vertex-sharded csr_spmm fwd+bwd (configs[4]); %.1f%% of every "
+            "config": {"workload": "papers100M-like 1-D vertex-sharded csr_spmm fwd+bwd (configs[4]) on GENERATED shards, one "
+                                   "papers100M/8-sized shard per GPU (locality-preserving partition, ASSUMED): %.1f%% of every "
                                    "row's sources in other shards, %s" % (100 * remote_frac, (
                                        "drawn from boundary regions sized for a halo of %.2f x the shard's rows "
-                                       "(locality-preserving partition; the worst_case_partition object is the other "
-                                       "end: a random partition)" % halo_frac) if halo_frac > 0 else
+                                       "(the worst_case_partition object is the other end: a random partition)" % halo_frac)
+                                       if halo_frac > 0 else
                                        "uniform over the owners' rows (random partition of a structureless graph: no halo "
                                        "reuse, the worst case)"),
                        "nodes_per_gpu": shard_nodes, "nnz_global": m["nnz_global"], "feat": f, "remote_frac": remote_frac,
                        "halo_frac": halo_frac, "halo_rows_rank0": m["halo_rows_rank0"],
                        "parallelism": "vertex-shard x%d, RCCL all-to-all halo exchange overlapped with local SpMM" % world},
+            # a PRIOR for the curve of THESE shards, from this run's own single-GPU rates and a stated xGMI rate
+            # (predict_scaling): a model fed with the knobs above -- not evidence
+            "predicted": m["predicted"],
+        }
+        if world > 1 and str(world) in m["predicted"]:
+            pr = m["predicted"][str(world)]
+            result["predicted_vs_measured"] = {"predicted_step_ms": pr["step_ms"], "measured_step_ms": m["ms_per_step"],
+                                               "measured_over_predicted": m["ms_per_step"] / max(pr["step_ms"], 1e-9)}
+    if rank == 0:
+        result.update({
             "halo_GB_per_step_all_ranks": m["halo_GB_per_step_all_ranks"],
             "n_ranks_seen": n_ranks_seen, "rccl_version": rccl,
             "exchange": "all_to_all_single on an explicit comm stream (event-ordered), gather = cogdl_hip_gather_feature_rows, "
@@ -854,14 +1003,7 @@ def bench_sharded_spmm(args):
             "local_block_ms_min": m["local_block_ms_min"], "local_block_ms_max": m["local_block_ms_max"],
             "local_block_spmm_ms_rank0": m["local_block_spmm_ms_rank0"],
             "local_block_GEdges_s_rank0": m["local_block_GEdges_s_rank0"],
-            # a PRIOR for the curve, from this run's own single-GPU rates and a stated xGMI rate (predict_scaling): what a
-            # hardware 2 / 4 / 8-GPU run is to be compared with -- at world size N, predicted[str(N)] is this line's own forecast
-            "predicted": m["predicted"],
-        }
-        if world > 1 and str(world) in m["predicted"]:
-            pr = m["predicted"][str(world)]
-            result["predicted_vs_measured"] = {"predicted_step_ms": pr["step_ms"], "measured_step_ms": m["ms_per_step"],
-                                               "measured_over_predicted": m["ms_per_step"] / max(pr["step_ms"], 1e-9)}
+        })
         if cpu:
             result["selftest"] = "gloo ranks on the host, libcogdl_host kernels: exercises the launcher and the data flow only"
         if share:
@@ -888,6 +1030,14 @@ def bench_sharded_spmm(args):
         return result
     script = os.path.abspath(getattr(args, "bench_script", "bench.py"))
     common = ["--gpus", str(world), "--feat", str(f)] + (["--selftest-cpu"] if cpu else []) + (["--share-gpu"] if share else [])
+    if shard_nodes is None:  # (the graph leg: the generated-shard legs below take their sizes from the arguments)
+        shard_nodes = args.shard_nodes or 111_059_956 // 8
+        degree = args.shard_degree or 28.8
+    assumed = _child_leg([script, "--sharded", "--leg", "assumed"] + common
+                         + ["--shard-nodes", str(shard_nodes), "--shard-degree", str(degree),
+                            "--remote-frac", repr(args.remote_frac if args.remote_frac >= 0 else 0.1),
+                            "--halo-frac", repr(getattr(args, "halo_frac", 0.25)),
+                            "--steps", str(max(2, args.steps // 2)), "--warmup", "1"], 6, 300) if graph_leg else None
     worst_nodes = max(64, shard_nodes // max(1, int(getattr(args, "worst_case_scale", 4))))
     worst = _child_leg([script, "--sharded", "--leg", "worst"] + common
                        + ["--shard-nodes", str(worst_nodes), "--shard-degree", str(degree),
@@ -926,6 +1076,15 @@ def bench_sharded_spmm(args):
                              "partition, on shards 1/%d the size so that the halo tables fit"
                              % max(1, int(getattr(args, "worst_case_scale", 4))))
         result["worst_case_partition"] = worst
+        if assumed is not None:
+            if "error" not in assumed:
+                assumed = {k: assumed[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "n_gpus", "n_ranks_seen",
+                                                   "scaling", "config", "halo_GB_per_step_all_ranks", "local_block_ms_min",
+                                                   "local_block_ms_max", "predicted", "predicted_vs_measured") if k in assumed}
+                assumed["what"] = ("the same sharded fwd+bwd on GENERATED shards (one papers100M/8-sized shard per GPU: weak "
+                                   "scaling) whose remote fraction and halo ratio are inputs -- what a locality-preserving "
+                                   "(METIS-like) partition is ASSUMED to leave; `predicted` is a model fed with those knobs")
+            result["assumed_partition"] = assumed
         if sage is not None:
             result["configs3_sage_replicas"] = sage
     return result

@@ -26,28 +26,32 @@ UNIT = 64          # slots per unit (csrc/rowreduce.h: kVUnit)
 XCDS = 8
 SPLIT = 64         # rows of more than this many edges are cut by owner XCD
 PIECE = 256        # edges per virtual row at most
+BIG_PARTS = 32     # (csrc/rowreduce.h: kVBigParts)
 MODE = os.environ.get("COGDL_AMD_XCD", "auto")  # "auto" | "off" | "force" (every structure, every operator: tests)
 
 
 class _VRowsStruct(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("vrowptr", "vcol", "vdesc", "eid", "mrow", "mptr")] + \
-               [(n, ctypes.c_int64) for n in ("n_slots", "n_multi", "n_parts", "nnz")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("vrowptr", "vcol", "vdesc", "eid", "mrow", "mptr", "big")] + \
+               [(n, ctypes.c_int64) for n in ("n_slots", "n_multi", "n_parts", "n_big", "nnz")]
 
 
 class XcdPlan:
-    __slots__ = ("vrowptr", "vcol", "vdesc", "eid", "mrow", "mptr", "n_slots", "n_multi", "n_parts", "nnz", "m",
+    __slots__ = ("vrowptr", "vcol", "vdesc", "eid", "mrow", "mptr", "big", "n_slots", "n_multi", "n_parts", "n_big", "nnz", "m",
                  "_struct", "_val_key", "_val_src", "_val_p")
 
     def __init__(self, vrowptr, vcol, vdesc, eid, mrow, mptr, n_parts, m):
         self.vrowptr, self.vcol, self.vdesc, self.eid, self.mrow, self.mptr = vrowptr, vcol, vdesc, eid, mrow, mptr
         self.n_slots, self.n_multi, self.n_parts = vdesc.shape[0], mrow.numel(), int(n_parts)
+        # rows of more than BIG_PARTS parts (csrc/rowreduce.h: kVBigParts): merged by a whole workgroup each
+        self.big = torch.nonzero((mptr[1:] - mptr[:-1]) > BIG_PARTS).flatten().int()
+        self.n_big = self.big.numel()
         self.nnz, self.m = vcol.numel(), m
         self._val_key = self._val_src = self._val_p = None
         s = _VRowsStruct()
-        for name in ("vrowptr", "vcol", "vdesc", "eid", "mrow", "mptr"):
+        for name in ("vrowptr", "vcol", "vdesc", "eid", "mrow", "mptr", "big"):
             t = getattr(self, name)
             setattr(s, name, t.data_ptr() if t is not None and t.numel() else None)
-        s.n_slots, s.n_multi, s.n_parts, s.nnz = self.n_slots, self.n_multi, self.n_parts, self.nnz
+        s.n_slots, s.n_multi, s.n_parts, s.n_big, s.nnz = self.n_slots, self.n_multi, self.n_parts, self.n_big, self.nnz
         self._struct = s
 
     def ref(self):
@@ -55,7 +59,7 @@ class XcdPlan:
         return ctypes.byref(self._struct)
 
     def nbytes(self):
-        return 4 * sum(t.numel() for t in (self.vrowptr, self.vcol, self.vdesc, self.eid, self.mrow, self.mptr))
+        return 4 * sum(t.numel() for t in (self.vrowptr, self.vcol, self.vdesc, self.eid, self.mrow, self.mptr, self.big))
 
     def permuted_values(self, w):
         """w in plan order (w[eid]).  Constant edge weights are gathered once (memo keyed like CscPlan.transposed_values)."""

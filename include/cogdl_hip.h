@@ -139,11 +139,12 @@ COGDL_API int cogdl_hip_csr_spmm_variant(const int32_t *rowptr, const int32_t *c
  *   eid     [nnz]          what a per-edge operand is indexed by for the edge at a plan position (the CSR position of
  *                          the edge; for a CSC view: the caller's own edge id) -- NULL if the operator has none
  *   mrow [n_multi], mptr [n_multi + 1]   rows with several parts and their records [mptr[i], mptr[i+1]) in merge order
+ *   big  [n_big]           the indices i (into mrow) of ALL rows with more than 32 parts: merged by a whole workgroup each
  * n_slots is a multiple of 512 (units of 64 slots, round-robin over the 8 XCDs).  Results are deterministic; a row cut into
  * parts is re-associated (fp32 <= 1e-6 relative) -- which is why csr_spmm takes this path only when asked to. */
 typedef struct cogdl_hip_vrows {
-    const int32_t *vrowptr, *vcol, *vdesc, *eid, *mrow, *mptr;
-    int64_t n_slots, n_multi, n_parts, nnz;
+    const int32_t *vrowptr, *vcol, *vdesc, *eid, *mrow, *mptr, *big;
+    int64_t n_slots, n_multi, n_parts, n_big, nnz;
 } cogdl_hip_vrows;
 /* out = A x (acc != 0: out += A x) over a plan; val in PLAN order (val_plan[j] = val[eid[j]]) or NULL.
  * workspace >= cogdl_hip_csr_spmm_xcd_workspace_bytes(n_parts, k, dtype). */

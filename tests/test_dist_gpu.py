@@ -167,22 +167,42 @@ def test_captured_minibatch_step_with_the_gradient_all_reduce_inside_the_graph(r
 
 def test_bench_gpus_2_orchestration_on_the_one_gpu():
     """`python bench.py --gpus 2 --share-gpu`: the whole N > 1 bench orchestration on this one-GPU box -- bench.py spawns
-    its two ranks itself, both build their shard with the HIP kernels (real halos), run the sharded step, then the
-    worst-case-partition leg runs in child interpreters with a process group of its own; rows travel through gloo because
-    RCCL refuses two ranks on one device.  The line must report two ranks in both legs."""
+    its two ranks itself; the MAIN leg shards the papers100M-shaped graph itself (1/64 scale in this mode: SURVEY section
+    8d's size) by edge-balanced row ranges, both ranks build their shard with the HIP kernels (measured halos), run the
+    sharded step; then the generated-shard leg (`assumed_partition`) and the worst-case-partition leg run in child
+    interpreters with a process group of their own; rows travel through gloo because RCCL refuses two ranks on one device.
+    The line must report two ranks in every leg, and the halo it reports must equal dist.halo_rows on the same partition."""
     import json
     import subprocess
     import sys
+
+    import torch
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--shard-nodes",
                            "200000", "--steps", "2", "--warmup", "1", "--feat", "64"], capture_output=True, text=True,
-                          timeout=600, env=env)
+                          timeout=900, env=env)
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
     assert proc.returncode == 0 and len(lines) == 1, proc.stderr[-1500:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and len(line["local_block_ms_by_rank"]) == 2
+    assert line["scaling"] == "strong" and line["config"]["scale"] == 64 and "predicted" not in line
     assert line["config"]["halo_rows_rank0"] > 0 and line["halo_GB_per_step_all_ranks"] > 0
+    # the reported halo / remote edges are what dist.halo_rows counts on the same graph and bounds
+    from cogdl_amd import synth
+    from cogdl_amd.dist import edge_balanced_bounds, halo_rows
+
+    g = synth.papers100m_like("cuda:0", True, 0, synth.PAPERS_NODES // 64, synth.PAPERS_PAIRS // 64)
+    bounds = edge_balanced_bounds(g.rowptr, 2)
+    assert line["config"]["bounds"] == bounds.tolist() and line["config"]["nnz_global"] == g.nnz
+    counted = halo_rows(g.rowptr, g.colind, bounds)
+    assert [c[0] for c in counted] == line["config"]["remote_edges_by_rank"]
+    assert [c[1] for c in counted] == line["config"]["halo_rows_by_rank"]
+    del g
+    torch.cuda.empty_cache()
+    assumed = line["assumed_partition"]
+    assert assumed.get("n_gpus") == 2 and assumed.get("n_ranks_seen") == 2 and assumed["scaling"] == "weak", assumed
+    assert assumed["config"]["nodes_per_gpu"] == 200000 and "predicted" in assumed
     worst = line["worst_case_partition"]
     assert worst.get("n_gpus") == 2 and worst.get("n_ranks_seen") == 2 and worst["config"]["remote_frac"] == 0.5, worst

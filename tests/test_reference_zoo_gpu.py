@@ -57,6 +57,37 @@ for _name in list(_lib.HIP_SIGNATURES):
         continue
     setattr(lib, _name, _counting(_name, getattr(lib, _name)))
 
+# ---- identical dropout masks in both legs (round-5 verdict, item 7).  torch's fused dropout kernel maps its random numbers to
+# MEMORY positions: the contiguous [E, H] attention of the HIP operators and the transposed view the fallback stacks
+# (cogdl/utils/spmm_utils.py:186-189; dropped at cogdl/layers/gat_layer.py:75) drew different masks from the same generator
+# state.  Both legs now hand dropout the tensor in its LOGICAL (contiguous) layout, so element (e, h) of call k sees the
+# same random number in both -- the default-argument attention models compare at the tolerance of every other model.
+_torch_dropout = torch.nn.functional.dropout
+def _dropout_logical_layout(input, p=0.5, training=True, inplace=False):
+    if not input.is_contiguous():
+        input, inplace = input.contiguous(), False
+    return _torch_dropout(input, p, training, inplace)
+torch.nn.functional.dropout = _dropout_logical_layout
+
+# ---- and the same SOFTMAX in both legs.  With identical masks the default-argument gat / revgat legs still differed by 20 %
+# (round 6, tools/exp/zoo_debug2.py): the fallback's edge_softmax_val (cogdl/utils/spmm_utils.py:149-152) HALVES every score
+# while the largest exceeds 10 -- in place, which is not a shift: the result is the softmax of score / 2^k -- and a training
+# forward (features scaled by 1 / (1 - 0.6) by the input dropout) produces such scores; evaluation and the *_nodrop legs do
+# not, which is why those always agreed.  The operator the HIP kernel replaces, the reference's CUDA edge_softmax
+# (cogdl/operators/edge_softmax/edge_softmax.cu:7-60), subtracts the row maximum: the true softmax.  The fallback leg
+# therefore runs the reference's own lines WITHOUT that loop (everything else verbatim in meaning: exp, row sums through
+# spmm, division); scores stay far below exp's fp32 range here (asserted).
+def _edge_softmax_val_without_the_halving_loop(graph, edge_val):
+    assert float(edge_val.max()) < 60.0
+    with graph.local_graph():
+        edge_val = torch.exp(edge_val)
+        graph.edge_weight = edge_val
+        x = torch.ones(graph.num_nodes, 1).to(edge_val.device)
+        node_sum = spmm_utils.spmm(graph, x).squeeze()
+        row = graph.edge_index[0]
+        return edge_val / node_sum[row]
+spmm_utils.edge_softmax_val = _edge_softmax_val_without_the_halving_loop
+
 def use_fallback(on, fused_gat=True):
     """on: the dispatcher resolves nothing (flags set, callables None) -> spmm_scatter / edge_softmax_val / per-head spmm,
     the reference's own torch code on the same GPU.  off: resolve again -> the HIP operators (fused_gat=False: all but
@@ -121,12 +152,11 @@ SPARSE_ENTRIES = ("cogdl_hip_csr_spmm", "cogdl_hip_csr_spmm_variant", "cogdl_hip
 # Models that aggregate once, on the CPU, before training (pre-computed propagation) or not at all: no HIP call is expected
 # on the training path -- they are in the sweep to show that install() does not break them.
 NO_SPARSE_ON_GPU = {"correct_smooth_mlp", "sign"}  # (an MLP on features; SIGN propagates once, on the CPU, before training)
-# Default-argument GAT models apply nn.Dropout to the attention: the two legs draw different masks (see FP16 above), so
-# their losses agree only as far as two dropout draws do.  The *_nodrop legs are the exact comparison of the same operators.
-LOOSE = {"gat": 0.5, "drgat": 0.5, "revgat": 0.5,
-         # 14 GENConv layers with a learned softmax temperature: the sum order of edge_softmax / scatter_add is amplified
-         # layer by layer (1.1e-3 on the first loss; deepergcn, 3 such layers, is bit-equal)
-         "revgen": 5e-3}
+# (Rounds 4-5 compared gat / drgat / revgat at 50 % and revgen at 5e-3: "different dropout draws" and "sum order amplified by 14
+#  GENConv layers".  Neither was the cause -- see COMMON: torch's layout-dependent dropout mask and, mostly, the halving loop of
+#  the fallback's edge_softmax_val.  With both legs on the same mask and the same softmax every model compares at 1e-4; measured
+#  in round 6: gat bit-equal, revgat / revgen / drgat 1e-7.)
+LOOSE = {}
 
 
 def _run(script, *args, timeout=2400):

@@ -32,7 +32,8 @@ def forced(monkeypatch):
 
 def _graph(kind):
     if kind == "hubs":  # hubs longer than several pieces, medium rows around SPLIT, empty rows
-        g = synth.hub_csr(300, 257, base_deg=6, hubs=((3, 129), (4, 1000), (17, 5000), (18, 257), (40, 65), (41, 64), (299, 700)), seed=5)
+        g = synth.hub_csr(300, 257, base_deg=6, hubs=((3, 129), (4, 1000), (17, 5000), (18, 257), (40, 65), (41, 64), (100, 20000), (299, 700)),
+                           seed=5)  # (row 100: ~80 parts -- merged by a whole workgroup)
     elif kind == "one_owner":  # every long row's edges name ONE column: a single owner XCD, seven absent parts
         g = synth.hub_csr(70, 50, base_deg=2, hubs=((0, 300), (5, 66), (69, 513)), seed=2)
         g.colind[g.rowptr[0]:g.rowptr[1]] = 7
@@ -95,6 +96,9 @@ def test_plan_invariants(kind, split, piece):
         rec_row = torch.empty(p.n_parts, dtype=torch.long)
         rec_row[rec[:, 1]] = rec[:, 0]
         assert torch.equal(rec_row, torch.repeat_interleave(mrow, mptr[1:] - mptr[:-1]))
+    assert torch.equal(p.big.long().cpu(), torch.nonzero((mptr[1:] - mptr[:-1]) > xcdplan.BIG_PARTS).flatten())
+    if kind == "hubs" and split == 64:
+        assert p.n_big >= 1
 
 
 @pytest.mark.parametrize("kind", KINDS)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: smoke tests variants bench prof pmc pmc2 pmcops ops epoch e2e sampler hunt gat pmccombined nocache_tests timeline
+# One gpurun call.  Usage: bash tools/gpu_round.sh [stage ...]   stages: pmcgat smoke tests variants bench prof pmc pmc2 pmcops ops epoch e2e sampler hunt gat pmccombined nocache_tests timeline
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -69,6 +69,30 @@ if has pmcops; then
       echo "pmcops $op $c rc=$?"
     done
   done
+fi
+if has pmcgat; then
+  # round 6: the fused GAT operator of configs[2] (bf16, H = 8 x F = 8, forward + backward, without / with dropout) under the
+  # counters, XCD-partitioned plan off and on; one operator per process, one counter set per pass
+  for mode in off auto; do
+    for op in gat_bf16 gat_drop_bf16; do
+      for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+        tag=$(echo $c | tr ' ' '_')
+        rm -rf gpurun_out/pmcgat_${mode}_${op}_$tag
+        (cd /tmp && COGDL_AMD_XCD=$mode timeout 120 rocprofv3 --kernel-trace --pmc $c -f csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmcgat_${mode}_${op}_$tag" -o pmc -- python "$GRAFT_REPO_ROOT/tools/pmc_probe_ops.py" $op) > gpurun_out/pmcgat_${mode}_${op}_$tag.log 2>&1
+        echo "pmcgat $mode $op $tag rc=$?"
+      done
+    done
+    python tools/pmc_by_kernel.py gpurun_out pmcgat_${mode}_ GatFwd GatBwd > gpurun_out/pmcgat_${mode}.json 2> gpurun_out/pmcgat_${mode}.err
+  done
+  python - <<'PYEOF'
+import json
+for mode in ("off", "auto"):
+    r = json.load(open("gpurun_out/pmcgat_%s.json" % mode))
+    print(mode, r.get("calibration"))
+    for k, v in r["kernels"].items():
+        hit, miss = v.get("TCC_HIT_sum"), v.get("TCC_MISS_sum")
+        print("  %-100s %8.1f us  read %6.2f GB  write %6.2f GB  L2 hit %s" % (k[:100], v["duration_us_profiled"], (v.get("hbm_read_bytes") or 0) / 1e9, (v.get("hbm_write_bytes") or 0) / 1e9, "%.3f" % (hit / (hit + miss)) if hit is not None and miss is not None and hit + miss else "-"))
+PYEOF
 fi
 if has gat; then
   timeout 600 python tools/gat_bench.py > gpurun_out/gat_bench.txt 2>&1; tail -25 gpurun_out/gat_bench.txt | cut -c1-400
