@@ -133,7 +133,7 @@ def load_pmc_traffic(phase="arxiv_uniform_F128"):
         return None, None
 
 
-def gcn_epoch_ms(gd, rowptr64, colind64, x, reps=20, warmup=5, mfma_linear=True, captured=False):
+def gcn_epoch_ms(gd, rowptr64, colind64, x, reps=20, warmup=5, mfma_linear=True, captured=False, return_step=False):
     """The 'GNN epoch time' half of BASELINE.json's metric: one full-graph training step (= one epoch) of CogDL's
     default `gcn` model (cogdl/models/nn/gcn.py:26-29: 2 GCNLayers, hidden 64, relu, dropout 0.5; GCNLayer.forward
     = spmm(graph, linear(x)), cogdl/layers/gcn_layer.py:51-53) on the arxiv-shaped graph, 40 classes, Adam(lr 0.01,
@@ -176,6 +176,8 @@ def gcn_epoch_ms(gd, rowptr64, colind64, x, reps=20, warmup=5, mfma_linear=True,
         step = graphs.capture(step, warmup=3)
     for _ in range(warmup):
         step()
+    if return_step:  # (tools/epoch_account.py replays the step under rocprofv3 --kernel-trace; the MFMA linear hook stays installed)
+        return step
     ts = []
     for _ in range(reps):
         torch.cuda.synchronize()
@@ -321,6 +323,12 @@ def bench_single(args):
     except Exception as e:  # a capture failure must not take the bench line down
         result["gnn_epoch"]["ms_hipgraph"] = None
         result["gnn_epoch"]["hipgraph_error"] = repr(e)[:300]
+    if not args.no_pmc:
+        # where the captured epoch goes: the library's kernels / torch's kernels (three largest named) / launch gaps, from one
+        # rocprofv3 --kernel-trace of the hipGraph replay in a child interpreter (tools/epoch_account.py)
+        from tools import epoch_account
+
+        result["gnn_epoch"]["accounting"] = epoch_account.collect()
     if not args.no_trainer:
         tr = trainer_epoch()
         if tr is not None:
@@ -356,11 +364,11 @@ def bench_single(args):
     except Exception as e:
         result["roofline"]["measured_error"] = repr(e)[:300]
     if not args.no_papers:
-        result["configs4_papers_1gpu"] = papers_leg()
+        result["configs4_papers_1gpu"] = papers_leg(pmc=not args.no_pmc)
     return result
 
 
-def papers_leg(budget_s=300):
+def papers_leg(budget_s=300, pmc=True):
     """`configs4_papers_1gpu`: BASELINE.json configs[4] at FULL size on this one GPU (tools/papers_bench.py, child
     interpreter): the papers100M-shaped graph -- 111,059,956 nodes, 1.6e9 directed / 3.2e9 symmetrised R-MAT edges generated
     on the device, F = 128 fp32 -- through csrspmm with 64-bit row pointers: forward, backward and forward + backward,
@@ -371,9 +379,31 @@ def papers_leg(budget_s=300):
     r = _child_leg([os.path.join(ROOT, "tools", "papers_bench.py"), "--steps", "3"], 6, budget_s)
     if "error" in r:
         r["error"] = r["error"][-400:]
-    try:  # HBM-side traffic of this leg's kernel: collected once per round under rocprofv3 --pmc (tools/gpu_pmc_papers.sh), not in this run
+    # HBM-side traffic of this leg's kernel, measured IN THIS RUN (north_star: "rocprof-reported achieved HBM GB/s ... in the
+    # same run"): one rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass pair over a full forward pass of each graph (tools/
+    # pmc_live.py collect_papers: the same seeded graph and 64-bit plan, counters summed over the pass's segment launches, ~20 s
+    # per graph), calibrated on a 1 GiB copy inside the same pass.  `frac_of_measured_copy` of the traffic = counted bytes / kernel time against this
+    # box's own copy roof.  The committed profile of an earlier round stays as the fallback, labelled.
+    if pmc:
+        from tools import pmc_live
+
+        roofs = r.get("roofs") or {}
+        for name in ("directed", "symmetrised"):
+            if not isinstance(r.get(name), dict) or "error" in r[name]:
+                continue
+            t = pmc_live.collect_papers(name)
+            if "error" not in t:
+                t["frac_of_spec"] = t["hbm_GBs"] / 8000.0
+                if roofs.get("measured_copy_GBs"):
+                    t["frac_of_measured_copy"] = t["hbm_GBs"] / roofs["measured_copy_GBs"]
+            r[name]["traffic"] = t
+    measured = all(isinstance(r.get(k), dict) and "error" not in (r[k].get("traffic") or {"error": 1}) for k in ("directed", "symmetrised"))
+    r["traffic_source"] = ("measured in this run (rocprofv3 --pmc over one full forward pass per graph, counters summed over its segment launches): <graph>.traffic" if measured
+                           else "committed profile only (traffic_committed_profile): the in-run passes were skipped or failed")
+    try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_papers.json")))
-        r["traffic_committed_profile"] = {"source": "profiles/r05_pmc_papers.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the directed leg; NOT measured in this run)",
+        r["traffic_committed_profile"] = {"source": "profiles/r05_pmc_papers.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the directed leg, "
+                                                    "whole graph, round 5; NOT measured in this run -- fallback)",
                                           "hbm_side_bytes_per_pass": prof["reading"]["hbm_side_bytes_per_pass_GB"] * 1e9,
                                           "algorithmic_bytes_per_pass": prof["reading"]["algorithmic_bytes_per_pass_GB"] * 1e9}
     except Exception:

@@ -154,14 +154,8 @@ struct GatFwdOp {
     }
     __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t, const LaneVals &lv, int sub,
                                           int jj) const {
-#if defined(COGDL_EXP)
-        const int col_a = (COGDL_EXP & 1) ? (col & 7) : col, col_f = (COGDL_EXP & 2) ? (col & 7) : col;
-        b.ac[u] = *gather_row<A24>(attn_col, c.hd, col_a, (uint32_t)heads * 4u);
-        load_vec<T, VEC>(gather_row<A24>(feat, c.cc, col_f, (uint32_t)(heads * fdim) * (uint32_t)sizeof(T)), b.v[u]);
-#else
         b.ac[u] = *gather_row<A24>(attn_col, c.hd, col, (uint32_t)heads * 4u);
         load_vec<T, VEC>(gather_row<A24>(feat, c.cc, col, (uint32_t)(heads * fdim) * (uint32_t)sizeof(T)), b.v[u]);
-#endif
         if constexpr (DROP) b.d[u] = drop_factor<LPR>(drop, lv, sub, jj, c.hd, heads);
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
@@ -703,6 +697,11 @@ inline RowGeometry gat_fwd_geometry(int64_t h, int64_t f, int elem_bytes, int al
     //  halving the vector once: H=1 x F=48 bf16 2.89 -> 2.39 ms.  With the next chunk's ids prefetched in reduce_edges the
     //  8 fat lanes win again: 2.35 vs 2.49 ms, with dropout 2.66 vs 2.85 ms, H=2 x F=32 2.33 vs 2.70 ms
     //  (tools/gat_h1_probe.py) -- the rule is gone.)
+    // (Round 6: one head of 16-bit features in FOUR lanes of 16 elements -- two 16-byte loads per lane, a third fewer
+    //  lane-instructions per edge, 16 rows per wave -- measured slower: Reddit-shaped graph, H = 1 x F = 48 bf16 forward 1920 ->
+    //  2226 us, F = 64 1587 -> 1995 us (profiles/r06_gat_h1.txt); removed again.  What the same run showed instead: F = 64 is
+    //  FASTER than F = 48 -- 128-byte rows are one L2 line each, 96-byte rows straddle -- see _padded_width in
+    //  cogdl_amd/operators/fused_gat.py.)
     const int64_t need = (h * f + vec - 1) / vec;
     int lpr = 8;
     while (lpr < kWave && lpr < need) lpr <<= 1;

@@ -82,15 +82,25 @@ def edge_dropout_mask(nnz, heads, p, seed, device):
 PAD_FEATURES = True  # tests switch it off to drive the kernels at the caller's own (odd, unaligned) widths
 
 
-def _padded_width(f, elem_bytes):
+def _padded_width(f, elem_bytes, heads=1):
     """Feature width the kernels run at.  A row of F elements whose byte length is not a multiple of 16 forces narrow,
     unaligned loads on EVERY gathered row (F = 41 in bf16: 82-byte rows, one 2-byte load per lane: the second layer of
-    the gat model ran at 32 % of the roofline); padding feat once per call to the next multiple of 16 bytes costs a pass
-    over [N, H, F] -- nothing next to the per-edge gathers -- and the padded columns are exact zeros throughout."""
+    the gat model ran at 32 % of the roofline); padding feat once per call costs a pass over [N, H, F] -- nothing next to the
+    per-edge gathers -- and the padded columns are exact zeros throughout.
+    Round 6: rows (H x F elements) between 64 and 256 bytes are padded on to 128 / 256 bytes -- ONE (two) L2 lines per gathered
+    row instead of a row that straddles line borders: Reddit-shaped graph, H = 1 bf16, F = 48 (96-byte rows) forward 1920 us /
+    backward 4193 us, F = 64 (128-byte rows) 1587 / 3397 us (profiles/r06_gat_h1.txt) -- the gathers are L2 line requests, and
+    the lanes the wider row occupies were idle anyway (lane groups are powers of two)."""
     if not PAD_FEATURES:
         return f
     q = 16 // elem_bytes
-    return (f + q - 1) // q * q
+    fp = (f + q - 1) // q * q
+    row = heads * fp * elem_bytes
+    if 64 < row <= 256 and row & (row - 1):
+        target = 128 if row < 128 else 256
+        if target % (heads * elem_bytes) == 0 and (target // (heads * elem_bytes)) % q == 0:
+            fp = target // (heads * elem_bytes)
+    return fp
 
 
 class FusedGATFunction(torch.autograd.Function):
@@ -99,7 +109,8 @@ class FusedGATFunction(torch.autograd.Function):
         row_ptr, col_ind = _lib.csr_structure(row_ptr, col_ind)
         ctx.fp = fingerprint_of(row_ptr, col_ind, in_feat.shape[0])  # before the kernel: lands early for backward
         f = in_feat.shape[-1]
-        fp = _padded_width(f, in_feat.element_size()) if in_feat.dim() == 3 and in_feat.dtype in _lib.DTYPE_CODE else f
+        fp = (_padded_width(f, in_feat.element_size(), in_feat.shape[1])
+              if in_feat.dim() == 3 and in_feat.dtype in _lib.DTYPE_CODE else f)
         feat = in_feat.detach()
         if fp != f:
             feat = torch.nn.functional.pad(feat, (0, fp - f))

@@ -149,7 +149,9 @@ def main():
     src, dst = synth.rmat_pairs_i32(nodes, pairs, 0, dev)
     torch.cuda.synchronize()
     result = {"what": "csr_spmm on the papers100M-shaped graph at full size on ONE GPU (BASELINE configs[4], the N = 1 end of the "
-                      "scaling curve), fp32, R-MAT pairs generated on the device, multi-edges kept, sym-normalised weights",
+                      "scaling curve), fp32, R-MAT pairs generated on the device, multi-edges KEPT (the reference coalesces them, "
+                      "cogdl/datasets/ogb.py:50-55 -- R-MAT draws duplicates, the dataset has none: the edge count is the pair count; harmless for "
+                      "bandwidth), sym-normalised weights",
               "roofs": roofs, "pairs_s": time.perf_counter() - t0, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     for name, sym in (("directed", False), ("symmetrised", True)):
         if args.only and args.only != name:
