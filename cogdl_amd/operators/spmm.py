@@ -110,14 +110,25 @@ def csr_spmm_xcd_raw(xplan, val, x, out=None):
     return out
 
 
-def _xcd_wanted(rowptr, colind, x):
-    """csr_spmm takes an XCD-partitioned plan only when asked to (COGDL_AMD_XCD=force: tests, experiments).  Measured on the
-    Reddit-shaped graph, F = 64 (profiles/r06_xcd_quick.txt): bf16 1512 -> 1638 us, the gain of the L2-resident gathers
-    (1501 -> 1290 us with the partial sums thrown away, tools/xcdpart_probe.py) is spent on the 1.2 M part records
-    (2 x 307 MB); fp32 would gain (3220 -> ~1900 us) but gives up its bit-exact rows.  The fused GAT operator, whose kernels
-    are three times as long per edge, is where the plan pays (cogdl_amd/operators/fused_gat.py)."""
-    return xcdplan.MODE == "force" and x.dim() == 2 and x.dtype in _lib.DTYPE_CODE and xcdplan.wanted(
-        rowptr.numel() - 1, colind.numel(), x.shape[0], x.shape[1] * x.element_size())
+def _xcd_split(rowptr, colind, x):
+    """Does this csr_spmm launch take an XCD-partitioned plan (cogdl_amd/xcdplan.py), and cut at which row length?
+    -> None (no plan) or the split.
+      fp32    hub-heavy structures over cache-sized tables (xcdplan.wanted): yes, with split = the exact-row bound of the
+              ordinary path (cogdl_hip_exact_row_edges(nnz)) -- rows up to that length stay whole and bit-identical to the
+              reference loop, as before; only the rows the ordinary path already re-associates (its long-row pieces) are cut by
+              owner XCD instead of into contiguous chunks.  Measured on the Reddit-shaped graph, F = 64: see
+              profiles/r06_xcd_spmm_fp32.txt.
+      16-bit  only when asked to (COGDL_AMD_XCD=force: tests, experiments).  Measured (profiles/r06_xcd_quick.txt): bf16 F = 64
+              1512 -> 1638 us -- the gain of the L2-resident gathers (1501 -> 1290 us with the partial sums thrown away,
+              tools/xcdpart_probe.py) is spent on the part records."""
+    if x.dim() != 2 or x.dtype not in _lib.DTYPE_CODE:
+        return None
+    m, nnz = rowptr.numel() - 1, colind.numel()
+    if xcdplan.MODE == "force":
+        return xcdplan.SPLIT if xcdplan.wanted(m, nnz, x.shape[0], x.shape[1] * x.element_size()) else None
+    if x.dtype == torch.float32 and xcdplan.wanted(m, nnz, x.shape[0], x.shape[1] * x.element_size()):
+        return int(_lib.hip().cogdl_hip_exact_row_edges(nnz))
+    return None
 
 
 def csr_sddmm_raw(rowptr, colind, d1, d2):
@@ -144,11 +155,11 @@ class SPMMFunction(torch.autograd.Function):
         # kernel, not behind the SpMM).
         rowptr, colind = _lib.csr_structure(rowptr, colind)  # validated + contiguous before anything reads raw pointers
         ctx.transient = _plan.transient()  # (the dense operand is checked by csr_spmm_raw)
-        ctx.xcd = _xcd_wanted(rowptr, colind, feat)
+        ctx.xcd = _xcd_split(rowptr, colind, feat)
         ctx.fp = (fingerprint_of(rowptr, colind, feat.shape[0])
-                  if (ctx.needs_input_grad[2] or ctx.xcd) and not ctx.transient else None)
-        if ctx.xcd:
-            out = csr_spmm_xcd_raw(xcdplan.csr_plan(ctx.fp, rowptr, colind), edge_weight_csr, feat)
+                  if (ctx.needs_input_grad[2] or ctx.xcd is not None) and not ctx.transient else None)
+        if ctx.xcd is not None:
+            out = csr_spmm_xcd_raw(xcdplan.csr_plan(ctx.fp, rowptr, colind, ctx.xcd), edge_weight_csr, feat)
         else:
             out = csr_spmm_raw(rowptr, colind, edge_weight_csr, feat)
         need_w = edge_weight_csr is not None and ctx.needs_input_grad[3]
@@ -169,9 +180,10 @@ class SPMMFunction(torch.autograd.Function):
                 grad_feat = csr_spmm_raw(plan.colptr, plan.rowind, w_t, grad_out)
             else:
                 plan = PLANS.get(ctx.fp, rowptr, colind, ctx.n_src)
-                if ctx.xcd and _xcd_wanted(plan.colptr, plan.rowind, grad_out):
+                split_t = _xcd_split(plan.colptr, plan.rowind, grad_out) if ctx.xcd is not None else None
+                if split_t is not None:
                     # (w stays in CSR order: the plan of the transpose maps its positions through the transpose's perm)
-                    grad_feat = csr_spmm_xcd_raw(xcdplan.csc_plan(ctx.fp, plan), w, grad_out)
+                    grad_feat = csr_spmm_xcd_raw(xcdplan.csc_plan(ctx.fp, plan, split_t), w, grad_out)
                 else:
                     w_t = plan.transposed_values(w) if w is not None else None
                     grad_feat = csr_spmm_raw(plan.colptr, plan.rowind, w_t, grad_out, split_long_rows=plan.has_hub_columns())

@@ -103,13 +103,15 @@ def build(rowptr, colind, eid_base=None, split=None, piece=None):
         cnt = torch.cat([cnt, torch.zeros_like(empty)])
         gkey, o = torch.sort(gkey)  # (edge offsets below come from a cumulative sum: empty groups add nothing)
         cnt = cnt[o]
-    n_p = torch.clamp((cnt + piece - 1) // piece, min=1)
+    # pieces of at most `piece` edges -- for the sub-rows of LONG rows only: a row of at most `split` edges stays ONE virtual
+    # row whatever its length (sequential CSR order: fp32 csr_spmm's bit-exact rows, split = its exact-row bound > piece)
+    n_p = torch.where(is_long[gkey % max(m, 1)], torch.clamp((cnt + piece - 1) // piece, min=1), torch.ones_like(cnt))
     n_groups = gkey.numel()
     vg = torch.repeat_interleave(torch.arange(n_groups, device=dev), n_p)
     n_v = vg.numel()
     first_v = torch.cumsum(n_p, 0) - n_p
     idx = torch.arange(n_v, device=dev) - first_v[vg]
-    vlen = torch.where(idx < n_p[vg] - 1, torch.full_like(idx, piece), cnt[vg] - piece * (n_p[vg] - 1))
+    vlen = torch.where(n_p[vg] == 1, cnt[vg], torch.where(idx < n_p[vg] - 1, torch.full_like(idx, piece), cnt[vg] - piece * (n_p[vg] - 1)))
     vx, vr = (gkey // max(m, 1))[vg], (gkey % max(m, 1))[vg]
     # records: the virtual rows of a row with several parts, in (row, XCD, piece) order
     parts_of_row = torch.bincount(vr, minlength=m)
@@ -147,21 +149,20 @@ def build(rowptr, colind, eid_base=None, split=None, piece=None):
     return XcdPlan(vrowptr.int(), vcol, vdesc.contiguous(), eid, mrow.int(), mptr.int(), n_parts, m)
 
 
-def wanted(m, nnz, n_src, row_bytes, exact_fp32=False):
+def wanted(m, nnz, n_src, row_bytes):
     """Should a launch over this structure, gathering rows of `row_bytes` from an [n_src, .] table, take a plan?  Hub-heavy
     launches (>= 64 edges per row on average, >= 8 M edges) over tables between one L2 and a few times the eight of them, rows
     of at least 128 bytes.  Measured on the Reddit-shaped graph (493 edges per row, profiles/r06_xcd_quick.txt), fused GAT
     forward + backward: H = 8 x F = 8 bf16 (128-byte rows, 30 MB) 7.31 -> 5.66 ms, fp32 (60 MB) 11.83 -> 7.73 ms; H = 1 x
     F = 48 bf16 (96-byte rows, 22 MB: one head per lane group, bound by instruction issue, not by the gathers) 6.07 -> 5.97 ms
-    without and 6.56 -> 6.93 ms with dropout -- not taken.  Never for fp32 csr_spmm unless forced (bit-exact rows)."""
+    without and 6.56 -> 6.93 ms with dropout -- not taken (the operator pads such rows to 128 bytes: fused_gat._padded_width).
+    Which operators ask: the fused GAT operator, and csr_spmm in fp32 (cut at its exact-row bound: operators/spmm.py)."""
     if MODE == "off" or _plan.transient() or _plan._TAPE is not None:
         return False
     if n_src >= (1 << 24) or n_src * row_bytes >= (1 << 32):  # (the plan kernels address the table with 24 x 24 -> 32-bit offsets)
         return False
     if MODE == "force":
         return nnz > 0
-    if exact_fp32:
-        return False
     table = n_src * row_bytes
     return nnz >= (1 << 23) and nnz >= 64 * m and row_bytes >= 128 and (2 << 20) <= table <= (512 << 20)
 
@@ -193,12 +194,15 @@ class _Cache:
 XPLANS = _Cache()
 
 
-def csr_plan(fp, rowptr, colind):
+def csr_plan(fp, rowptr, colind, split=None):
     """The plan of the structure itself, under its fingerprint (waits for the hash: one host synchronisation per call --
-    `wanted()` only says yes to launches of hundreds of microseconds; with install(structure_memo=True) the key is memoised)."""
-    return XPLANS.get(("csr", SPLIT, PIECE) + fp.key(), lambda: build(rowptr, colind))
+    `wanted()` only says yes to launches of hundreds of microseconds; with install(structure_memo=True) the key is memoised).
+    split: rows of more than this many edges are cut by owner (default SPLIT; fp32 csr_spmm passes its exact-row bound)."""
+    split = SPLIT if split is None else int(split)
+    return XPLANS.get(("csr", split, PIECE) + fp.key(), lambda: build(rowptr, colind, split=split))
 
 
-def csc_plan(fp, csc):
+def csc_plan(fp, csc, split=None):
     """The plan of the transpose (a CscPlan): per-edge operands are indexed through its perm."""
-    return XPLANS.get(("csc", SPLIT, PIECE) + fp.key(), lambda: build(csc.colptr, csc.rowind, eid_base=csc.perm))
+    split = SPLIT if split is None else int(split)
+    return XPLANS.get(("csc", split, PIECE) + fp.key(), lambda: build(csc.colptr, csc.rowind, eid_base=csc.perm, split=split))

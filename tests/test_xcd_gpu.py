@@ -58,7 +58,7 @@ def _close(got, want, scale, tol, what, atol=1e-30):
 
 
 @pytest.mark.parametrize("kind", KINDS)
-@pytest.mark.parametrize("split,piece", [(64, 256), (4, 16), (0, 5)])
+@pytest.mark.parametrize("split,piece", [(64, 256), (4, 16), (0, 5), (1024, 256)])
 def test_plan_invariants(kind, split, piece):
     """Every edge once, CSR order inside a part, owners = the hash, slots of XCD x only in units u % 8 == x, records in
     (row, owner, piece) order."""
@@ -85,6 +85,12 @@ def test_plan_invariants(kind, split, piece):
     # inside a slot the edges keep CSR order
     same = slot_of_pos[1:] == slot_of_pos[:-1]
     assert bool((eid[1:] > eid[:-1])[same].all())
+    # a row of at most `split` edges is ONE virtual row, however long (bit-exact rows of fp32 csr_spmm)
+    # (a longer row whose edges all have one owner and fit one piece is a single part too)
+    is_whole = (desc[:, 0] >= 0) & (desc[:, 1] < 0)
+    whole_rows = desc[is_whole, 0]
+    assert torch.equal(lens[is_whole], deg[whole_rows])
+    assert bool(torch.isin(torch.nonzero(deg <= split).flatten(), whole_rows).all())
     # every row is written exactly once: either one whole slot, or one entry of mrow
     whole = desc[(desc[:, 0] >= 0) & (desc[:, 1] < 0), 0]
     mrow, mptr = p.mrow.long().cpu(), p.mptr.long().cpu()
@@ -235,12 +241,50 @@ def test_fused_gat_xcd_kernels_are_the_ones_that_ran(monkeypatch):
     torch.cuda.synchronize()
 
 
+def test_csrspmm_fp32_on_the_reddit_shaped_graph_takes_the_plan_and_keeps_its_exact_rows(oracle, monkeypatch):
+    """fp32 csr_spmm over a hub-heavy structure and a cache-sized table (auto mode): the plan is cut at the exact-row bound of
+    the ordinary path, so every row of at most cogdl_hip_exact_row_edges(nnz) edges is still BIT-identical to the reference loop
+    (spmm_cpu.cpp:24-35, the oracle) and the longer ones are within the fp32 tolerance; grad_x over the plan of the transpose
+    equals the ordinary path's within the same tolerance."""
+    from cogdl_amd import _lib
+    import cogdl_amd.operators.spmm as spmm_mod
+
+    monkeypatch.setattr(xcdplan, "MODE", "auto")
+    g = synth.reddit_like(seed=0, device=DEV, norm="sym")
+    n, k = g.num_nodes, 32
+    calls = []
+    real = spmm_mod.csr_spmm_xcd_raw
+    monkeypatch.setattr(spmm_mod, "csr_spmm_xcd_raw", lambda *a, **kw: (calls.append(a[0]), real(*a, **kw))[1])
+    x = torch.randn(n, k, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)).requires_grad_()
+    gout = torch.randn(n, k, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    out = SPMMFunction.apply(g.rowptr, g.colind, x, g.weight, False)
+    out.backward(gout)
+    bound = int(_lib.hip().cogdl_hip_exact_row_edges(g.nnz))
+    assert len(calls) == 2 and bound >= 128
+    deg = g.degrees().cpu().numpy()
+    rp, ci, w = g.rowptr.cpu().numpy(), g.colind.cpu().numpy(), g.weight.cpu().numpy()
+    xh = x.detach().cpu().numpy()
+    want = oracle.csr_spmm(rp, ci, w, xh, nthreads=16)
+    got = out.detach().cpu().numpy()
+    short = deg <= bound
+    assert short.sum() > 100_000 and (~short).sum() > 1000
+    assert np.array_equal(got[short], want[short])
+    scale = oracle.csr_spmm_abs(rp, ci, w, xh)
+    _close(got, oracle.csr_spmm_f64(rp, ci, w, xh), scale, TOL[torch.float32], "forward (long rows re-associated)")
+    gx_plan = x.grad.clone()
+    x.grad = None
+    monkeypatch.setattr(xcdplan, "MODE", "off")
+    SPMMFunction.apply(g.rowptr, g.colind, x, g.weight, False).backward(gout)
+    assert len(calls) == 2
+    tol = 2e-5 * float(gout.abs().max()) * float(g.weight.abs().max()) * float(deg.max())
+    assert float((gx_plan - x.grad).abs().max()) <= tol
+
+
 def test_wanted_rule():
     xcdplan.MODE = "auto"
     n, nnz = synth.REDDIT_NODES, 114_848_857
     assert xcdplan.wanted(n, nnz, n, 128)  # configs[2], bf16 H x F = 64
     assert not xcdplan.wanted(n, nnz, n, 96)  # its output layer (41 -> 48 columns, one head): measured no gain
-    assert not xcdplan.wanted(n, nnz, n, 256, exact_fp32=True)  # fp32 csr_spmm stays bit-exact
     assert not xcdplan.wanted(169_343, 2_501_719, 169_343, 512)  # arxiv: 15 edges per row
     assert not xcdplan.wanted(111_059_956, 1_615_685_872, 111_059_956, 512)  # papers: the table is 57 GB
     xcdplan.MODE = "force"
