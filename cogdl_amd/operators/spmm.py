@@ -110,6 +110,9 @@ def csr_spmm_xcd_raw(xplan, val, x, out=None):
     return out
 
 
+SPLIT_16 = 256  # (= xcdplan.SPLIT: 16-bit csr_spmm and the fused GAT operator share one plan per structure)
+
+
 def _xcd_split(rowptr, colind, x):
     """Does this csr_spmm launch take an XCD-partitioned plan (cogdl_amd/xcdplan.py), and cut at which row length?
     -> None (no plan) or the split.
@@ -118,16 +121,17 @@ def _xcd_split(rowptr, colind, x):
               reference loop, as before; only the rows the ordinary path already re-associates (its long-row pieces) are cut by
               owner XCD instead of into contiguous chunks.  Measured on the Reddit-shaped graph, F = 64: see
               profiles/r06_xcd_spmm_fp32.txt.
-      16-bit  only when asked to (COGDL_AMD_XCD=force: tests, experiments).  Measured (profiles/r06_xcd_quick.txt): bf16 F = 64
-              1512 -> 1638 us -- the gain of the L2-resident gathers (1501 -> 1290 us with the partial sums thrown away,
-              tools/xcdpart_probe.py) is spent on the part records."""
+      16-bit  the same structures and tables, cut at SPLIT_16 = 256 edges (no bit-exact contract to keep).  Measured on the
+              Reddit-shaped graph (profiles/r06_xcd_spmm_split.txt): bf16 F = 64 1524 -> 1316 us, F = 128 3241 -> 2291 us; at
+              split 64 / 1024: 1386 / 1345 us.  (Before the hub rows' part records were merged by whole workgroups -- rowreduce.h:
+              rowreduce_vcombine_kernel -- the same plan LOST: 1512 -> 1638 us, profiles/r06_xcd_quick.txt.)"""
     if x.dim() != 2 or x.dtype not in _lib.DTYPE_CODE:
         return None
     m, nnz = rowptr.numel() - 1, colind.numel()
     if xcdplan.MODE == "force":
         return xcdplan.SPLIT if xcdplan.wanted(m, nnz, x.shape[0], x.shape[1] * x.element_size()) else None
-    if x.dtype == torch.float32 and xcdplan.wanted(m, nnz, x.shape[0], x.shape[1] * x.element_size()):
-        return int(_lib.hip().cogdl_hip_exact_row_edges(nnz))
+    if xcdplan.wanted(m, nnz, x.shape[0], x.shape[1] * x.element_size()):
+        return int(_lib.hip().cogdl_hip_exact_row_edges(nnz)) if x.dtype == torch.float32 else SPLIT_16
     return None
 
 

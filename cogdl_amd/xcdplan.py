@@ -24,7 +24,8 @@ from . import plan as _plan
 
 UNIT = 64          # slots per unit (csrc/rowreduce.h: kVUnit)
 XCDS = 8
-SPLIT = 64         # rows of more than this many edges are cut by owner XCD
+SPLIT = 256        # rows of more than this many edges are cut by owner XCD (Reddit-shaped graph, fused GAT bf16 H8xF8 with dropout,
+                   # fwd+bwd by split / piece: 64/256 6.21 ms, 128/256 6.02, 256/256 5.82, 256/512 6.15, 512/512 6.11: profiles/r06_gat_split.txt)
 PIECE = 256        # edges per virtual row at most
 BIG_PARTS = 32     # (csrc/rowreduce.h: kVBigParts)
 MODE = os.environ.get("COGDL_AMD_XCD", "auto")  # "auto" | "off" | "force" (every structure, every operator: tests)
