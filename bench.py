@@ -7,13 +7,17 @@ N = 1 : BASELINE.json configs[1] -- "GCN on ogbn-arxiv (170k nodes, 1.2M edges, 
         (uniform-random topology = worst-case locality; no dataset is available offline), inputs resident in HBM.
         value = GEdges/s = 2 * nnz * steps / time.
 N > 1 : configs[4] -- vertex-sharded csr_spmm (1-D row partition, halo rows exchanged with an RCCL all-to-all
-        overlapped with the local-column SpMM), weak scaling: a fixed papers100M-like shard per GPU (10 % of a row's
-        sources in other shards, taken from boundary regions that give a halo of 0.25 x the shard's rows = a
-        locality-preserving partition; --remote-frac / --halo-frac set them, the halo volume is reported).
+        overlapped with the local-column SpMM) over THE graph the N = 1 line's configs4_papers_1gpu leg runs: the
+        papers100M-shaped symmetrised graph (3.2e9 edges), every rank keeping the rows of its edge-balanced contiguous
+        range (cogdl_amd/dist.py: papers_graph_shard) -- strong scaling; halo rows and remote edge share are MEASURED on
+        that partition and reported, value_at_world1 repeats the one-GPU figure of the same metric.
         value = global nnz * 2 * steps / time (max over ranks).  Started without a launcher, `bench.py --gpus N` spawns
-        its N ranks itself (torch.distributed.run on 127.0.0.1); a rank count that differs from --gpus is refused.  Two
-        follow-up legs run in child process groups with hard timeouts and land in the same line: worst_case_partition
-        (random partition: (N-1)/N of the sources remote) and configs3_sage_replicas (tools/sage_bench.py --captured).
+        its N ranks itself (torch.distributed.run on 127.0.0.1); a rank count that differs from --gpus is refused.
+        Follow-up legs run in child process groups with hard timeouts and land in the same line: assumed_partition (the
+        generated shards of rounds 2-5: one papers100M/8-sized shard per GPU, weak scaling, --remote-frac / --halo-frac
+        as INPUTS = what a locality-preserving partition is assumed to leave, with its `predicted` model),
+        worst_case_partition (random partition: (N-1)/N of the sources remote) and configs3_sage_replicas
+        (tools/sage_bench.py --captured).
 
 One JSON line on stdout (rank 0).  Extra objects: roofline (dominant kernel, HIP-event timed inside the timed region;
 `traffic` = PMC bytes measured by rocprofv3 passes inside this run; `rmat` and `hbm_resident` = the same kernel on the
@@ -25,7 +29,10 @@ the fused attention-dropout operator, beside the unchanged layer's time and the 
 configs4_papers_1gpu (round 5): BASELINE configs[4] at FULL size on this one GPU -- the papers100M-shaped graph, 1.6e9 directed
 and 3.2e9 symmetrised edges, F = 128 fp32, through csrspmm with 64-bit row pointers (tools/papers_bench.py): the N = 1 end of
 the 1 -> 8 curve; and roofline.measured_copy_GBs / measured_read_GBs: the box's own roofs, measured in the same run
-(fractions of the 8 TB/s spec number are not comparable across boxes).
+(fractions of the 8 TB/s spec number are not comparable across boxes).  Round 6: configs4_papers_1gpu.<graph>.traffic = the HBM-side
+bytes of a full forward pass per graph (rocprofv3 --pmc inside this run), gnn_epoch.accounting = library / torch kernel time and
+launch gaps of the captured GCN epoch (rocprofv3 --kernel-trace inside this run), configs2_gat.roofline.*.l2_frac = the fused GAT
+kernels against the aggregate L2 bandwidth (their tables are cache-resident).
 """
 import argparse
 import json

@@ -163,8 +163,9 @@ struct GatFwdOp {
         if (valid) {
             // Online softmax with ONE exponential per (edge, lane): of exp(mx - mn) and exp(sc - mn), mn = max(mx, sc), one
             // is exp(0) = 1 and the other t = exp(-|sc - mx|) (mx = -inf at the start of a row: t = 0 = the rescale of
-            // the empty state).  Round 6: these kernels are bound by VALU issue on hub-heavy graphs (SQ counters: the vector
-            // pipe is busy 68 % of the launch, profiles/r06_sq_reddit.txt); the second exponential was libm's expf,
+            // the empty state).  Round 6: these kernels are bound by instruction issue on hub-heavy graphs (SQ counters,
+            // profiles/r06_sq_reddit.txt; with both gathers folded to L2 hits the launch only drops from 1888 to 1474 us: DESIGN
+            // section 5); the second exponential was libm's expf,
             // ~25 instructions per edge and lane.  The accumulator is rescaled only when some lane of the wave saw a new
             // maximum (wave-uniform branch; multiplying by exactly 1 is what is skipped): rare beyond the first edges of a row.
             const float sc = leaky(c.ar + b.ac[u], slope);
