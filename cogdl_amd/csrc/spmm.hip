@@ -65,7 +65,11 @@ RowGeometry spmm_geometry(int64_t k, int64_t unit, int elem_bytes, int align, bo
     // degrees); uniform degrees: +-0 .. -4 % (those are bound by the per-row latency chain, not by lanes -- F=20 takes
     // 68 us where F=40 takes 99 us).  Groups of 5 / 6 lanes (F=20 / 24) gained nothing.  csr_spmm only; tuning key
     // 6 == -99 switches it off for A-B runs.
-    if (narrow_groups && g_tuning[kTuneSpmmVec] != -99 && (need == 10 || need == 12 || need == 20)) lpr = (int)need;
+    // Round 6: groups of 10 and 12 lanes no longer pay -- the power-of-two groups got immediate-pattern broadcasts and fully
+    // unrolled chunks (rowreduce.h: group_bcast), the odd ones keep ds_bpermute: fp32 F = 40 R-MAT 105.9 (10 lanes) vs 102.0 us
+    // (16), uniform 88.3 vs 85.8, F = 48 102.6 vs 99.1, bf16 F = 40 R-MAT 100.1 vs 91.6 -- but 20 lanes still beat 32 (F = 80
+    // R-MAT 129 vs 137 us, bf16 119 vs 132) (tools/exp/f40_ab.py, profiles/r06_narrow_groups.txt).
+    if (narrow_groups && g_tuning[kTuneSpmmVec] != -99 && need == 20) lpr = (int)need;
     RowGeometry g;
     g.vec = vec;
     g.lpr = lpr;

@@ -200,8 +200,6 @@ template <typename T, int VEC, int WMODE, bool EPI, int UNROLL>
 static int dispatch_lpr_u(const SpmmArgs<T> &a, int lpr, void *ws, size_t wsb, hipStream_t s) {
     if constexpr (WMODE != 2 && !EPI) {  // lane groups that do not divide the wave (spmm_geometry: narrow_groups)
         switch (lpr) {
-            case 10: return launch_spmm<T, VEC, 10, UNROLL, WMODE, true, EPI>(a, ws, wsb, s);
-            case 12: return launch_spmm<T, VEC, 12, UNROLL, WMODE, true, EPI>(a, ws, wsb, s);
             case 20: return launch_spmm<T, VEC, 20, UNROLL, WMODE, true, EPI>(a, ws, wsb, s);
             default: break;
         }
