@@ -32,18 +32,41 @@ def _colind32(graph):
     return hit[2]
 
 
+def _weights_as(graph, dtype):
+    """graph.raw_edge_weight in the dtype of x, memoised like the column ids: the reference casts per call
+    (`csr_data.half()`, utils/spmm_utils.py:103-104) -- 6.4 GB per call at 3.2e9 edges, and a NEW tensor identity per call,
+    which would defeat every per-weights cache behind it (transposed values, the symmetry test of bigcsr.py)."""
+    w = graph.raw_edge_weight
+    if w is None or w.dtype == dtype:
+        return w
+    adj = graph._adj
+    memo = adj.__dict__.setdefault(_ATTR + "w", {})
+    key = (tensor_key(w), dtype)
+    hit = memo.get("hit")
+    if hit is None or hit[0] != key or hit[1] is not w:
+        hit = (key, w, w.to(dtype))
+        memo["hit"] = hit
+    return hit[2]
+
+
+def _edge_count(graph):
+    """The edge count from a tensor SHAPE: `Adjacency.num_edges` is `row_ptr[-1]` -- a device read, i.e. a synchronisation per
+    call and a capture error inside a hipGraph -- once the COO rows are dropped (cogdl/data/data.py:327-333).  `col` holds one
+    entry per edge in both forms."""
+    col = getattr(getattr(graph, "_adj", None), "col", None)
+    return int(col.shape[0]) if torch.is_tensor(col) else 0
+
+
 def make_spmm(reference_spmm):
     def spmm(graph, x, actnn=False, fast_spmm=None, fast_spmm_cpu=None):
         big = (torch.is_tensor(x) and x.is_cuda and not actnn and getattr(graph, "grb_adj", None) is None
-               and int(graph.num_edges) >= BIG_EDGES)
+               and _edge_count(graph) >= BIG_EDGES)
         if not big:
             return reference_spmm(graph, x, actnn=actnn, fast_spmm=fast_spmm, fast_spmm_cpu=fast_spmm_cpu)
         # the dispatcher's GPU branch, utils/spmm_utils.py:98-109, with the row pointer left as it is
         if graph.out_norm is not None:
             x = graph.out_norm * x
-        csr_data = graph.raw_edge_weight
-        if x.dtype == torch.half:
-            csr_data = csr_data.half()
+        csr_data = _weights_as(graph, torch.half) if x.dtype == torch.half else graph.raw_edge_weight
         x = csrspmm(graph.row_indptr, _colind32(graph), x, csr_data, graph.is_symmetric())
         if graph.in_norm is not None:
             x = graph.in_norm * x

@@ -45,6 +45,7 @@ class BigCsr:
         self._seg_addr = ctypes.addressof(self.seg)
         self._transposed = None
         self._val_key = self._val_src = self._val_t = None
+        self._sym_checked = {}
 
     @property
     def n_segments(self):
@@ -121,6 +122,37 @@ class BigCsr:
         del ws
         return BigCsr(colptr, rowind, n_cols=self.m), perm, val_t
 
+    # ---- the caller's `sym` flag ---------------------------------------------------------------------------------------
+    def symmetric_verified(self, w, probes=4, tol=1e-5):
+        """True when A (with the values `w`) passes a randomised symmetry test: for seeded random X, Y in R^{n x probes},
+        <Y, A X> = <X, A Y> column by column iff (A - A^T) is orthogonal to X Y^T - Y X^T -- an asymmetric A fails with a
+        difference of the order ||A - A^T||_F, a symmetric one passes up to fp32 rounding (~1e-7 ||A||_F).  The threshold is
+        `tol` * ||A||_F.  Two forward passes at width `probes`, once per (structure, weight tensor); the answer is cached.
+
+        Why: the reference's SPMMFunction trusts `sym` blindly and multiplies by A again in backward
+        (cogdl/operators/spmm.py:63-66) -- wrong for row-normalised weights on a symmetric STRUCTURE.  Here the flag only
+        saves the transpose (26 GB of indices and values at papers100M size) after the matrix has passed this test."""
+        if self.m != self.n_cols:
+            return False
+        key = None if w is None else tensor_key(w)
+        hit = self._sym_checked.get(key)
+        if hit is not None and (w is None or hit[1] is w):
+            return hit[0]
+        dev = self.rowptr32.device
+        g = torch.Generator(device=dev)
+        g.manual_seed(0x5EED)
+        x = torch.randn(self.m, probes, device=dev, generator=g)
+        y = torch.randn(self.m, probes, device=dev, generator=g)
+        wv = None if w is None else w.detach().float()
+        s1 = (y.double() * self.spmm(wv, x).double()).sum(0)
+        s2 = (x.double() * self.spmm(wv, y).double()).sum(0)
+        fro = float(self.nnz) ** 0.5 if wv is None else float(torch.linalg.vector_norm(wv))
+        ok = bool(((s1 - s2).abs().max() <= tol * max(fro, 1e-30)).item())
+        if len(self._sym_checked) >= 4:
+            self._sym_checked.pop(next(iter(self._sym_checked)))
+        self._sym_checked[key] = (ok, w)
+        return ok
+
     # ---- cached transpose for autograd -------------------------------------------------------------------------------
     def transposed(self, w):
         """(BigCsr of A^T, w[perm] | None) for the backward pass; both cached (constant weights are moved once, keyed on
@@ -192,10 +224,11 @@ class BigSPMMFunction(torch.autograd.Function):
     the same on the cached 64-bit transpose (grad_x) and the segmented sddmm (grad of the edge weights)."""
 
     @staticmethod
-    def forward(ctx, rowptr, colind, feat, edge_weight_csr=None):
+    def forward(ctx, rowptr, colind, feat, edge_weight_csr=None, sym=False):
         plan = plan_of(rowptr, colind, feat.shape[0])
         out = plan.spmm(edge_weight_csr, feat)
         ctx.plan = plan
+        ctx.sym = bool(sym)
         need_w = edge_weight_csr is not None and ctx.needs_input_grad[3]
         ctx.save_for_backward(edge_weight_csr, feat if need_w else None)
         return out
@@ -206,8 +239,13 @@ class BigSPMMFunction(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         grad_feat = grad_w = None
         if ctx.needs_input_grad[2]:
-            t, w_t = ctx.plan.transposed(w)
+            # `sym` (Graph.is_symmetric(), passed on by the dispatcher): A^T = A, the forward plan serves the backward --
+            # but only after the matrix has passed the symmetry test (the reference's blind trust is its `sym` bug)
+            if ctx.sym and ctx.plan.symmetric_verified(w):
+                t, w_t = ctx.plan, (None if w is None else w.detach())
+            else:
+                t, w_t = ctx.plan.transposed(w)
             grad_feat = t.spmm(w_t, grad_out)
         if w is not None and ctx.needs_input_grad[3]:
             grad_w = ctx.plan.sddmm(grad_out, feat.detach()).to(w.dtype)
-        return None, None, grad_feat, grad_w
+        return None, None, grad_feat, grad_w, None

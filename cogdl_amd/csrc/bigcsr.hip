@@ -44,6 +44,16 @@ __global__ void segment_cuts_kernel(const int64_t *__restrict__ rowptr, int64_t 
     edges[j] = rowptr[r];
 }
 
+// A row pointer that decreases anywhere (or does not start at 0: segment_cuts_kernel stores rowptr[0] in edges[0]) makes
+// the rebased 32-bit pointers negative or wrapped and the 32-bit kernels would index out of bounds: edges[0] = -1 marks it
+// (plan time, one pass over rowptr; the host rejects edges[0] != 0).
+__global__ void rowptr_monotone_kernel(const int64_t *__restrict__ rowptr, int64_t m, int64_t *__restrict__ edges) {
+    bool bad = false;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (int64_t)gridDim.x * blockDim.x)
+        bad |= rowptr[r + 1] < rowptr[r];
+    if (bad) edges[0] = -1;
+}
+
 struct SegTable {
     int n;
     int64_t row[COGDL_HIP_MAX_SEGMENTS + 1];
@@ -62,10 +72,14 @@ __global__ void rebase_rowptr_kernel(const int64_t *__restrict__ rowptr, const S
 }
 
 // ---- transpose ------------------------------------------------------------------------------------------------------
-// cnt[c] += colptr_s[c + 1] - colptr_s[c]
-__global__ void add_counts_kernel(const int32_t *__restrict__ colptr_s, int64_t n_cols, int64_t *__restrict__ cnt) {
-    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cols; c += (int64_t)gridDim.x * blockDim.x)
-        cnt[c] += (int64_t)(colptr_s[c + 1] - colptr_s[c]);
+// cnt[colind[e]] += 1 over ALL edges (64-bit atomics resolved in L2; ids outside [0, n_cols) are left to the segment
+// transposes of pass 2, which reject them)
+__global__ void count_columns_kernel(const int32_t *__restrict__ colind, int64_t nnz, int64_t n_cols,
+                                     int64_t *__restrict__ cnt) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = colind[e];
+        if (c >= 0 && c < n_cols) atomicAdd((unsigned long long *)(cnt + c), 1ull);
+    }
 }
 
 // Exclusive scan of int64 in three launches (block sums, their scan by one workgroup, the blocks again): plan-time code,
@@ -228,6 +242,8 @@ extern "C" int cogdl_hip_csr_segments(const int64_t *rowptr, int64_t m, int64_t 
     hipStream_t s = (hipStream_t)stream;
     int64_t *rows_d = (int64_t *)scratch, *edges_d = rows_d + COGDL_HIP_MAX_SEGMENTS + 1;
     hipLaunchKernelGGL(segment_cuts_kernel, dim3(1), dim3(128), 0, s, rowptr, m, max_edges, (int)n_cuts, rows_d, edges_d);
+    hipLaunchKernelGGL(rowptr_monotone_kernel, dim3((unsigned)std::min<int64_t>((m + 255) / 256, 1 << 14)), dim3(256), 0, s,
+                       rowptr, m, edges_d);
     int64_t host[2 * (COGDL_HIP_MAX_SEGMENTS + 1)];
     hipError_t e = hipMemcpyAsync(host, scratch, sizeof(host), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -237,6 +253,7 @@ extern "C" int cogdl_hip_csr_segments(const int64_t *rowptr, int64_t m, int64_t 
     }
     const int64_t *rows = host, *edges = host + COGDL_HIP_MAX_SEGMENTS + 1;
     if (edges[n_cuts] != nnz) return COGDL_HIP_EINVAL;  // rowptr[m] != nnz
+    if (edges[0] != 0) return COGDL_HIP_EINVAL;         // rowptr[0] != 0, or rowptr decreases somewhere
     int n = 0;
     for (int64_t j = 1; j <= n_cuts; ++j) {  // (a row longer than max_edges owns several targets: equal cuts collapse)
         if (rows[j] == out->row[n]) continue;
@@ -323,17 +340,14 @@ extern "C" int cogdl_hip_csr2csc_i64(const int32_t *rowptr32, const cogdl_hip_se
     int32_t *colptr_s = (int32_t *)(ws + L.off_colptr_s), *rowind_s = (int32_t *)(ws + L.off_rowind_s);
     int32_t *perm_s = (int32_t *)(ws + L.off_perm_s);
     void *inner = ws + L.off_inner;
-    const unsigned cblocks = (unsigned)std::min<int64_t>((n_cols + 255) / 256, 1 << 16);
     auto transpose_segment = [&](int sgm) {
         const int64_t m_s = seg->row[sgm + 1] - seg->row[sgm], nz = seg->edge[sgm + 1] - seg->edge[sgm];
         return cogdl_hip_csr2csc(rowptr32 + seg->row[sgm] + sgm, colind + seg->edge[sgm], m_s, n_cols, nz, colptr_s, rowind_s,
                                  perm_s, inner, L.inner_bytes, stream);
     };
-    // pass 1: column counts (accumulated in the output colptr), scanned in place
-    for (int sgm = 0; sgm < seg->n; ++sgm) {
-        if ((rc = transpose_segment(sgm)) != COGDL_HIP_OK) return rc;
-        hipLaunchKernelGGL(add_counts_kernel, dim3(cblocks), dim3(256), 0, s, colptr_s, n_cols, colptr);
-    }
+    // pass 1: column counts (a histogram over colind, accumulated in the output colptr), scanned in place
+    hipLaunchKernelGGL(count_columns_kernel, dim3((unsigned)std::min<int64_t>((nnz + 255) / 256, 1 << 16)), dim3(256), 0, s,
+                       colind, nnz, n_cols, colptr);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)L.n_scan_blocks), dim3(kScanBlock), 0, s, colptr, n_cols, sums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kScanBlock), 0, s, sums, L.n_scan_blocks);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)L.n_scan_blocks), dim3(kScanBlock), 0, s, colptr, n_cols, sums, colptr);

@@ -311,7 +311,7 @@ def csrspmm(rowptr, colind, x, csr_data, sym=False, actnn=False):
         # graph of 2^31 edges or more (the reference's cast wraps, cogdl/utils/spmm_utils.py:106)
         from ..bigcsr import BigSPMMFunction
 
-        return BigSPMMFunction.apply(rowptr, colind, x, csr_data)
+        return BigSPMMFunction.apply(rowptr, colind, x, csr_data, sym)
     return SPMMFunction.apply(rowptr, colind, x, csr_data, sym)
 
 

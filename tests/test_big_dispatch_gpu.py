@@ -73,6 +73,8 @@ c1 = big_dispatch._colind32(g); assert big_dispatch._colind32(g) is c1          
 with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
     oh = layer(g, T(z["x"]).to(DEV))
 assert oh.dtype == torch.float16
+wh = big_dispatch._weights_as(g, torch.half); assert wh.dtype == torch.half and big_dispatch._weights_as(g, torch.half) is wh
+assert big_dispatch._edge_count(g) == g.col_indices.numel()    # from a tensor shape: no device read (num_edges is row_ptr[-1])
 np.testing.assert_allclose(oh.float().cpu().numpy(), z["out_train"], rtol=5e-2, atol=5e-2)
 # the reference Trainer end to end on the 64-bit path
 before = calls["big"]

@@ -149,6 +149,56 @@ def test_autograd_through_csrspmm_int64(oracle):
         clear_plans()
 
 
+def test_sym_flag_saves_the_transpose_only_for_matrices_that_pass_the_symmetry_test(oracle):
+    """`sym` (Graph.is_symmetric(), which the reference trusts blindly: cogdl/operators/spmm.py:63-66) -- the 64-bit path
+    verifies it once per (structure, weights): sym-normalised weights on a symmetrised graph reuse the forward plan (no
+    transpose is built), row-normalised weights on the SAME structure and a directed graph fall back to the true transpose.
+    grad_x is that of the oracle's transpose in all three cases."""
+    _lib.hip().cogdl_hip_set_tuning(15, 3000)
+    try:
+        for name, g, expect in (
+            ("sym", synth.scaled(4000, 9, seed=2, topology="rmat", norm="sym"), True),
+            ("none", synth.scaled(4000, 9, seed=2, topology="rmat", norm=None), True),
+            ("row", synth.scaled(4000, 9, seed=2, topology="rmat", norm="row"), False),
+            ("directed", synth.finalize(*synth.uniform_pairs(4000, 20000, 5), 4000, symmetrise=False, norm="sym"), False),
+        ):
+            clear_plans()
+            from cogdl_amd.bigcsr import plan_of
+
+            x, gout = rand(g.n_cols, 24, seed=4), rand(g.num_nodes, 24, seed=5)
+            rowptr64, colind = g.rowptr.long().to(DEV), g.colind.to(DEV)
+            w = None if g.weight is None else g.weight.to(DEV)
+            xd = x.to(DEV).requires_grad_()
+            for _ in range(2):
+                xd.grad = None
+                csrspmm(rowptr64, colind, xd, w, True).backward(gout.to(DEV))
+            plan = plan_of(rowptr64, colind, g.n_cols)
+            assert plan.n_segments > 3
+            assert plan.symmetric_verified(w) is expect, name
+            assert (plan._transposed is None) is expect, name
+            assert len(plan._sym_checked) == 1
+            colptr, rowind, w_t, _ = oracle.csr2csc(g.rowptr, g.colind, g.weight)
+            want = oracle.csr_spmm(colptr, rowind, w_t, gout)
+            check_rows(xd.grad.cpu().numpy(), want, np.diff(colptr), 128, oracle.csr_spmm_abs(colptr, rowind, w_t, gout))
+            # without the flag: always the transpose
+            clear_plans()
+            xd.grad = None
+            csrspmm(rowptr64, colind, xd, w, False).backward(gout.to(DEV))
+            assert plan_of(rowptr64, colind, g.n_cols)._transposed is not None
+    finally:
+        _lib.hip().cogdl_hip_set_tuning(15, 0)
+        clear_plans()
+
+
+def test_malformed_row_pointers_are_rejected_at_plan_time():
+    """rowptr[0] != 0 or a decreasing rowptr would rebase to negative / wrapped 32-bit pointers."""
+    col = torch.zeros(6, dtype=torch.int32, device=DEV)
+    for bad in ([1, 2, 4, 6], [0, 4, 2, 6], [0, 7, 6, 6]):
+        with pytest.raises(_lib.BackendError):
+            BigCsr(torch.tensor(bad, dtype=torch.int64, device=DEV), col, n_cols=3)
+    assert BigCsr(torch.tensor([0, 2, 2, 6], dtype=torch.int64, device=DEV), col, n_cols=3).n_segments == 1
+
+
 def test_empty_and_degenerate_structures():
     z = torch.zeros(1, dtype=torch.int64, device=DEV)
     e = torch.zeros(0, dtype=torch.int32, device=DEV)
