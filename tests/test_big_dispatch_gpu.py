@@ -64,8 +64,12 @@ big_dispatch.BIG_EDGES = 1
 _lib.hip().cogdl_hip_set_tuning(15, 200)
 big = run()
 assert calls["big"] >= 2 and calls["segments"] >= 2, calls     # forward and backward went through the segmented kernels
+np.testing.assert_allclose(big[0], plain[0], rtol=1e-6, atol=1e-6, err_msg="out")
+# backward: the graph is symmetric and says so, the 64-bit path verifies it and multiplies by A again (the reference's own
+# `sym` branch, operators/spmm.py:63-66) where the 32-bit path walks the true transpose -- the same sums in another order
 for a, b, name in zip(big, plain, ("out", "grad_x", "grad_W", "grad_b")):
-    np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6, err_msg=name)
+    np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-5, err_msg=name)
+assert all(p._transposed is None for p, _, _ in bigcsr._BIG_PLANS.values())   # ... and no transpose was built
 np.testing.assert_allclose(big[0], z["out_train"], rtol=1e-4, atol=1e-5)      # the reference's own CPU output
 np.testing.assert_allclose(big[1], z["grad_x"], rtol=1e-4, atol=1e-5)
 c1 = big_dispatch._colind32(g); assert big_dispatch._colind32(g) is c1          # one int32 copy per structure

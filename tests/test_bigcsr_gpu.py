@@ -178,8 +178,16 @@ def test_sym_flag_saves_the_transpose_only_for_matrices_that_pass_the_symmetry_t
             assert (plan._transposed is None) is expect, name
             assert len(plan._sym_checked) == 1
             colptr, rowind, w_t, _ = oracle.csr2csc(g.rowptr, g.colind, g.weight)
-            want = oracle.csr_spmm(colptr, rowind, w_t, gout)
-            check_rows(xd.grad.cpu().numpy(), want, np.diff(colptr), 128, oracle.csr_spmm_abs(colptr, rowind, w_t, gout))
+            want_t = oracle.csr_spmm(colptr, rowind, w_t, gout)
+            got = xd.grad.cpu().numpy()
+            if expect:
+                # the reference's own `sym` branch: A again, in A's edge order (cogdl/operators/spmm.py:63-66) -- equal to the
+                # transpose's product up to the summation order inside a row (self loops sit at the END of a CSR row here)
+                want = oracle.csr_spmm(g.rowptr, g.colind, g.weight, gout)
+                check_rows(got, want, g.degrees().numpy(), 128, oracle.csr_spmm_abs(g.rowptr, g.colind, g.weight, gout))
+                np.testing.assert_allclose(got, want_t, rtol=1e-5, atol=1e-5)
+            else:
+                check_rows(got, want_t, np.diff(colptr), 128, oracle.csr_spmm_abs(colptr, rowind, w_t, gout))
             # without the flag: always the transpose
             clear_plans()
             xd.grad = None
