@@ -35,6 +35,30 @@ namespace cogdl {
 // error |x| * 2^-24 (< 2e-6 wherever the weight is not negligible); the rare state merges keep libm's expf.
 __device__ __forceinline__ float gat_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+// (Round 6, tried: max(v, slope * v) for slopes in [0, 1] -- two instructions on paper; the uniform test on the slope stays
+//  inside the batch loop as two scalar branches per edge and fmaxf brings a canonicalising v_max of its own: no gain.)
+// Backward: a[e,h] = exp(s - max) / sum as ONE fused multiply-add and ONE v_exp: exp2(s * log2(e) + nml) with
+// nml = -(max * log2(e) + log2(sum)) per (row, head) -- where subtract / scale / v_exp / multiply by 1 / sum were four.  The
+// argument carries one rounding instead of two plus the reciprocal's (a moves by ~1e-7 relative; parity of the backward is a
+// tolerance).  A row that has edges has sum >= 1 (its maximum contributes exp(0)); sum == 0 gives nml = -inf, a = 0.
+constexpr float kLog2e = 1.4426950408889634f;
+__device__ __forceinline__ float gat_neg_max_log(float mx, float ls) {
+    return ls > 0.f ? -(mx * kLog2e + __log2f(ls)) : -INFINITY;
+}
+__device__ __forceinline__ float gat_softmax_weight(float s, float nml) {
+    return __builtin_amdgcn_exp2f(__builtin_fmaf(s, kLog2e, nml));
+}
+// A kernel argument that the compiler must keep in a vector register (v_cndmask with VCC takes no scalar second source,
+// and the compiler would rather re-materialise the v_mov per edge than spend the register).
+__device__ __forceinline__ float pinned_vgpr(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+// LeakyReLU and its derivative from ONE compare: f = 1 or slope, value = v * f (v * 1 is exact).
+__device__ __forceinline__ float leaky_with_grad(float v, float slope, float &grad) {
+    grad = v > 0.f ? 1.f : slope;
+    return v * grad;
+}
 static inline bool pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // Attention dropout of the DROP functors.
@@ -69,7 +93,9 @@ __device__ __forceinline__ float drop_factor(const GatDrop &dr, const DropLane<t
         const uint32_t w2 = (uint32_t)group_bcast<LPR>((int)lv.khi, sub, jj);
         if (hd >= 32) w = w2;
     }
-    return ((w >> (hd & 31)) & 1u) ? dr.scale : 0.f;
+    // bit hd as a mask of 32 copies (ONE signed bit-field extract), and-ed on to the scale's bits: two instructions where
+    // shift / and / compare / select were four plus the condition register's wait states
+    return __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)w, (uint32_t)(hd & 31), 1u) & __float_as_uint(dr.scale));
 }
 
 // Sum over the `lph` lanes (power of two, aligned) that hold one head.
@@ -100,12 +126,69 @@ struct GatTiles {
     int64_t rows;
 };
 
+// Per-SOURCE scalars of a chunk through LDS (ACH / ACS template arguments of the functors below; round 6, second half).
+// The fused kernels over an XCD-partitioned plan are bound by the CU's memory pipeline as much as by the vector ALUs: one
+// wave64 memory instruction per ~16 cycles whatever it loads (Reddit-shaped graph, bf16 H = 8 x F = 8 forward: 4.2e7 vector
+// memory instructions in 1449 us = one per 19.7 cycles and CU, profiles/r06_mem_pipeline.txt), and every edge costs two:
+// its 128-byte feature row and the 4 bytes per lane of attn_col (or the 16-byte stats record of the column pass) -- the
+// second one moves a sixteenth of the bytes for the same slot.  With 8-lane groups a chunk is 8 edges and lane l already
+// holds the column id of edge l: it loads the WHOLE scalar row of ITS edge once per chunk (H = 8: two 16-byte loads, H = 1:
+// one dword / one 16-byte record), parks it in the group's LDS scratch when the first slot is folded (the loads were issued
+// BEFORE the chunk's gathers, so waiting for them does not wait for the gathers), and every slot reads its value back:
+// 10 (9) memory instructions per chunk instead of 16, the rest is LDS traffic (which has its own pipeline).  Rows are
+// rotated by the group's index inside the wave so that the eight groups of a wave hit different banks.
+template <int N>
+struct ChunkScalars {
+    float v[N > 0 ? N : 1];
+    float *lds;
+    int rot;
+};
+template <int N, bool A24>
+__device__ __forceinline__ void chunk_scalars_load(ChunkScalars<N> &cs, const float *table, int my_c, int sub, float *lds) {
+    if constexpr (N > 0) {
+        const float *src = gather_row<A24>(table, 0, my_c, (uint32_t)N * 4u);
+        if constexpr (N % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < N / 4; ++q) {
+                const float4 t = reinterpret_cast<const float4 *>(src)[q];
+                cs.v[4 * q] = t.x, cs.v[4 * q + 1] = t.y, cs.v[4 * q + 2] = t.z, cs.v[4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < N; ++q) cs.v[q] = src[q];
+        }
+        cs.lds = lds;
+        cs.rot = sub;
+    }
+}
+// called by every lane of the group when the chunk's first slot is folded
+template <int N, int LPR>
+__device__ __forceinline__ void chunk_scalars_park(const ChunkScalars<N> &cs, int l) {
+    if constexpr (N > 0) {
+        float *dst = cs.lds + ((l + cs.rot) & (LPR - 1)) * N;
+        if constexpr (N % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < N / 4; ++q)
+                reinterpret_cast<float4 *>(dst)[q] = make_float4(cs.v[4 * q], cs.v[4 * q + 1], cs.v[4 * q + 2], cs.v[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < N; ++q) dst[q] = cs.v[q];
+        }
+    }
+}
+template <int N, int LPR>
+__device__ __forceinline__ const float *chunk_scalars_row(const ChunkScalars<N> &cs, int jpos) {
+    return cs.lds + ((jpos + cs.rot) & (LPR - 1)) * N;
+}
+
 // ------------------------------------------------------------------------------------------ forward
-template <typename T, int VEC_, int LPR_, int UNROLL_, bool DROP, bool A24 = false>
+// ACH: 0 = attn_col[col, head] gathered per slot; H (8 or 1, groups of 8 lanes, heads == ACH) = through ChunkScalars.
+template <typename T, int VEC_, int LPR_, int UNROLL_, bool DROP, bool A24 = false, int ACH = 0>
 struct GatFwdOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_ + 2;
     static constexpr bool kReduce = true;
-    static constexpr int kLds = 0;
+    static constexpr int kLds = ACH;
+    static_assert(ACH == 0 || LPR_ == 8, "ChunkScalars: groups of 8 lanes");
     static constexpr bool kExpensiveLaneLoad = DROP;  // (the keep bits of an edge: one Philox call)
     const float *attn_row, *attn_col;
     const T *feat;
@@ -115,9 +198,10 @@ struct GatFwdOp {
     int heads, fdim;
     GatDrop drop;
     struct Ctx {
-        int col0, cc, hd;
+        int col0, cc, hd, l;
         bool col_ok;
         float ar;
+        ChunkScalars<ACH> cs;
     };
     struct State {
         float acc[VEC];
@@ -136,6 +220,7 @@ struct GatFwdOp {
         c.col_ok = c.col0 < heads * fdim;
         c.cc = c.col_ok ? c.col0 : 0;
         c.hd = c.cc / fdim;
+        c.l = l;
         c.ar = 0.f;
         return c;
     }
@@ -154,13 +239,19 @@ struct GatFwdOp {
     }
     __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t, const LaneVals &lv, int sub,
                                           int jj) const {
-        b.ac[u] = *gather_row<A24>(attn_col, c.hd, col, (uint32_t)heads * 4u);
+        if constexpr (ACH == 0) b.ac[u] = *gather_row<A24>(attn_col, c.hd, col, (uint32_t)heads * 4u);
         load_vec<T, VEC>(gather_row<A24>(feat, c.cc, col, (uint32_t)(heads * fdim) * (uint32_t)sizeof(T)), b.v[u]);
         if constexpr (DROP) b.d[u] = drop_factor<LPR>(drop, lv, sub, jj, c.hd, heads);
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
-                                          int) const {
+                                          int jpos) const {
+        if constexpr (ACH > 0) {
+            if (jpos == 0) chunk_scalars_park<ACH, LPR>(c.cs, c.l);
+        }
         if (valid) {
+            float ac_u;
+            if constexpr (ACH > 0) ac_u = chunk_scalars_row<ACH, LPR>(c.cs, jpos)[ACH == 1 ? 0 : c.hd];
+            else ac_u = b.ac[u];
             // Online softmax with ONE exponential per (edge, lane): of exp(mx - mn) and exp(sc - mn), mn = max(mx, sc), one
             // is exp(0) = 1 and the other t = exp(-|sc - mx|) (mx = -inf at the start of a row: t = 0 = the rescale of
             // the empty state).  Round 6: these kernels are bound by instruction issue on hub-heavy graphs (SQ counters,
@@ -168,9 +259,10 @@ struct GatFwdOp {
             // section 5); the second exponential was libm's expf,
             // ~25 instructions per edge and lane.  The accumulator is rescaled only when some lane of the wave saw a new
             // maximum (wave-uniform branch; multiplying by exactly 1 is what is skipped): rare beyond the first edges of a row.
-            const float sc = leaky(c.ar + b.ac[u], slope);
-            const bool up = sc > s.mx;
-            const float t = gat_exp(up ? s.mx - sc : sc - s.mx);
+            const float sc = leaky(c.ar + ac_u, slope);
+            const float dlt = sc - s.mx;
+            const bool up = dlt > 0.f;
+            const float t = gat_exp(-fabsf(dlt));  // (|.| and the sign are operand modifiers of the multiply in front of v_exp)
             const float p = up ? 1.f : t;
             const float pw = DROP ? p * b.d[DROP ? u : 0] : p;
             if (__ballot(up) != 0ull) {
@@ -185,8 +277,10 @@ struct GatFwdOp {
             for (int i = 0; i < VEC; ++i) s.acc[i] = fmaf(pw, b.v[u][i], s.acc[i]);
         }
     }
-    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *,
-                                                const LaneVals &) const {}
+    __device__ __forceinline__ void chunk_begin(Ctx &c, State &, int, int, int my_c, int sub, int, float *lds,
+                                                const LaneVals &) const {
+        chunk_scalars_load<ACH, A24>(c.cs, attn_col, my_c, sub, lds);
+    }
     __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
@@ -412,18 +506,19 @@ __device__ __forceinline__ GatBwdLane gat_bwd_lane(int l, int tile, int heads, i
 }
 
 // Row pass: D[v,h] and grad_attn_row[v,h].
-template <typename T, int VEC_, int LPR_, int UNROLL_, bool DROP, bool TILED, bool A24 = false>
+template <typename T, int VEC_, int LPR_, int UNROLL_, bool DROP, bool TILED, bool A24 = false, int ACH = 0>
 struct GatBwdRowOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = VEC_ + 1;
     static constexpr bool kReduce = true;
-    static constexpr int kLds = 0;
+    static constexpr int kLds = ACH;  // (ChunkScalars: attn_col of a chunk's edges, see the forward functor)
+    static_assert(ACH == 0 || (LPR_ == 8 && !TILED), "ChunkScalars: groups of 8 lanes");
     static constexpr int kMinWaves = (VEC_ == 8) ? 5 : 1;  // 8-element lanes: 90-105 VGPRs, five waves per SIMD fit in 102
     static constexpr bool kExpensiveLaneLoad = DROP;  // (the keep bits of an edge: one Philox call)
     const float *attn_row, *attn_col;
     const T *feat;  // feat / out / grad_out in the layer's dtype (f32, f16, bf16): read natively, fp32 arithmetic
     const float *edge_max, *edge_sum;
     const T *out, *grad_out;
-    float4 *stats;  // [V, H] {attn_row, edge_max, 1 / edge_sum, D}: everything the column pass needs per (row, head), as
+    float4 *stats;  // [V, H] {attn_row, nml (gat_neg_max_log), D, 1 / edge_sum}: everything the column pass needs per (row, head), as
                     // ONE 16-byte gather per edge and lane instead of four 4-byte gathers from four arrays (each of
                     // which drags its own 64-byte sector in: the four scalars cost as much traffic as the feature row)
     float *grad_attn_row;
@@ -435,7 +530,9 @@ struct GatBwdRowOp {
     struct Ctx {
         GatBwdLane m;
         float g[VEC];
-        float d, ar, mx, inv;
+        float d, ar, nml, inv, slope_v;
+        int l;
+        ChunkScalars<ACH> cs;
     };
     // grad_attn_row[v,h] = sum_e c_e (d_e <g, feat[col_e]> - D) with c_e = a_e * LeakyReLU'(.)
     //                    = < g, sum_e c_e d_e feat[col_e] >  -  D * sum_e c_e :
@@ -455,6 +552,8 @@ struct GatBwdRowOp {
     __device__ __forceinline__ Ctx make_ctx(int l, int tile) const {
         Ctx c;
         c.m = gat_bwd_lane<VEC, LPR, TILED>(l, tile, heads, fdim);
+        c.slope_v = pinned_vgpr(slope);
+        c.l = l;
         return c;
     }
     __device__ __forceinline__ int lane_of(const Ctx &) const { return (int)(threadIdx.x & (kWave - 1)) % LPR; }
@@ -463,7 +562,8 @@ struct GatBwdRowOp {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) c.g[i] = 0.f;
         float d = 0.f;
-        c.ar = c.mx = c.inv = 0.f;
+        c.ar = c.inv = 0.f;
+        c.nml = -INFINITY;
         if (ok && c.m.col_ok) {
             load_vec<T, VEC>(grad_out + row * (int64_t)k + c.m.cc, c.g);
             float o[VEC];
@@ -471,8 +571,8 @@ struct GatBwdRowOp {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) d = fmaf(c.g[i], o[i], d);
             c.ar = attn_row[row * heads + c.m.hd];
-            c.mx = edge_max[row * heads + c.m.hd];
             const float ls = edge_sum[row * heads + c.m.hd];
+            c.nml = gat_neg_max_log(edge_max[row * heads + c.m.hd], ls);
             c.inv = ls > 0.f ? 1.f / ls : 0.f;
         }
         if constexpr (TILED) c.d = seg_sum<LPR>(d, lane_of(c), c.m.seg_last);
@@ -489,23 +589,33 @@ struct GatBwdRowOp {
     }
     __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int col, int64_t, const LaneVals &lv, int sub,
                                           int jj) const {
-        b.ac[u] = *gather_row<A24>(attn_col, c.m.hd, col, (uint32_t)heads * 4u);
+        if constexpr (ACH == 0) b.ac[u] = *gather_row<A24>(attn_col, c.m.hd, col, (uint32_t)heads * 4u);
         load_vec<T, VEC>(gather_row<A24>(feat, c.m.cc, col, (uint32_t)(heads * fdim) * (uint32_t)sizeof(T)), b.v[u]);
         if constexpr (DROP) b.d[u] = drop_factor<LPR>(drop, lv, sub, jj, c.m.hd, heads);
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
-                                          int) const {
+                                          int jpos) const {
+        if constexpr (ACH > 0) {
+            if (jpos == 0) chunk_scalars_park<ACH, LPR>(c.cs, c.l);
+        }
         if (valid) {
-            const float pre = c.ar + b.ac[u];
-            const float ce = gat_exp(leaky(pre, slope) - c.mx) * c.inv * (pre > 0.f ? 1.f : slope);
+            float ac_u;
+            if constexpr (ACH > 0) ac_u = chunk_scalars_row<ACH, LPR>(c.cs, jpos)[ACH == 1 ? 0 : c.m.hd];
+            else ac_u = b.ac[u];
+            const float pre = c.ar + ac_u;
+            float lg;
+            const float lk = leaky_with_grad(pre, c.slope_v, lg);
+            const float ce = gat_softmax_weight(lk, c.nml) * lg;
             const float cw = DROP ? ce * b.d[DROP ? u : 0] : ce;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) s.s[i] = fmaf(cw, b.v[u][i], s.s[i]);
             s.csum += ce;
         }
     }
-    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *,
-                                                const LaneVals &) const {}
+    __device__ __forceinline__ void chunk_begin(Ctx &c, State &, int, int, int my_c, int sub, int, float *lds,
+                                                const LaneVals &) const {
+        chunk_scalars_load<ACH, A24>(c.cs, attn_col, my_c, sub, lds);
+    }
     __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t row, bool ok) const {
@@ -523,7 +633,7 @@ struct GatBwdRowOp {
         } else {
             dot = head_sum<LPR>(dot, lph);
             if (ok && c.m.head_lane) {
-                stats[row * heads + c.m.hd] = make_float4(c.ar, c.mx, c.inv, c.d);
+                stats[row * heads + c.m.hd] = make_float4(c.ar, c.nml, c.d, c.inv);
                 grad_attn_row[row * heads + c.m.hd] = dot - c.d * s.csum;
             }
         }
@@ -546,17 +656,19 @@ struct GatBwdRowOp {
 };
 
 // Column pass over the CSC (colptr, rowind): grad_feat[u,h,:] and grad_attn_col[u,h].
-template <typename T, int VEC_, int LPR_, int UNROLL_, bool DROP, bool TILED, bool A24 = false>
+// ACS: 4 = one head: the 16-byte stats record of a chunk's edges through ChunkScalars (every lane of a group reads the same).
+template <typename T, int VEC_, int LPR_, int UNROLL_, bool DROP, bool TILED, bool A24 = false, int ACS = 0>
 struct GatBwdColOp {
     static constexpr int VEC = VEC_, LPR = LPR_, UNROLL = UNROLL_, kRec = 2 * VEC_ + 1;
     static constexpr bool kReduce = true;
-    static constexpr int kLds = 0;
+    static constexpr int kLds = ACS;
+    static_assert(ACS == 0 || (ACS == 4 && LPR_ == 8 && !TILED), "ChunkScalars: groups of 8 lanes, one head");
     // 8-element lanes sit at 133-138 VGPRs: just past the 128 of four waves per SIMD
     static constexpr int kMinWaves = (VEC_ == 8) ? 4 : 1;
     static constexpr bool kExpensiveLaneLoad = DROP;  // (the keep bits of an edge: one Philox call)
     const float *attn_row, *attn_col;
     const T *feat;
-    const float4 *stats;  // [V, H] {attn_row, edge_max, 1 / edge_sum, D} (written by the row pass)
+    const float4 *stats;  // [V, H] {attn_row, nml, D, 1 / edge_sum} (written by the row pass; the first three are ONE 12-byte gather)
     const T *grad_out;
     T *grad_feat;  // rounded once on store (fp32 accumulation)
     float *grad_attn_col;
@@ -568,7 +680,9 @@ struct GatBwdColOp {
     struct Ctx {
         GatBwdLane m;
         float f[VEC];
-        float ac;
+        float ac, slope_v;
+        int l;
+        ChunkScalars<ACS> cs;
     };
     // grad_attn_col[u,h] = sum_e c_e (d_e <feat[u], g[row_e]> - D[row_e])
     //                    = <feat[u], sum_e c_e d_e g[row_e]> - sum_e c_e D[row_e]:
@@ -589,6 +703,8 @@ struct GatBwdColOp {
     __device__ __forceinline__ Ctx make_ctx(int l, int tile) const {
         Ctx c;
         c.m = gat_bwd_lane<VEC, LPR, TILED>(l, tile, heads, fdim);
+        c.slope_v = pinned_vgpr(slope);
+        c.l = l;
         return c;
     }
     __device__ __forceinline__ int lane_of(const Ctx &) const { return (int)(threadIdx.x & (kWave - 1)) % LPR; }
@@ -612,16 +728,24 @@ struct GatBwdColOp {
     }
     __device__ __forceinline__ void fetch(const Ctx &c, Batch &b, int u, int r, int64_t, const LaneVals &lv, int sub,
                                           int jj) const {
-        b.st[u] = *gather_row<A24>(stats, c.m.hd, r, (uint32_t)heads * 16u);
+        if constexpr (ACS == 0) b.st[u] = *gather_row<A24>(stats, c.m.hd, r, (uint32_t)heads * 16u);
         load_vec<T, VEC>(gather_row<A24>(grad_out, c.m.cc, r, (uint32_t)(heads * fdim) * (uint32_t)sizeof(T)), b.g[u]);
         if constexpr (DROP) b.d[u] = drop_factor<LPR>(drop, lv, sub, jj, c.m.hd, heads);
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
-                                          int) const {
+                                          int jpos) const {
+        if constexpr (ACS > 0) {
+            if (jpos == 0) chunk_scalars_park<ACS, LPR>(c.cs, c.l);
+        }
         if (valid) {
-            const float pre = b.st[u].x + c.ac;
-            const float a = gat_exp(leaky(pre, slope) - b.st[u].y) * b.st[u].z;
-            const float ce = a * (pre > 0.f ? 1.f : slope);
+            float4 st_u;
+            if constexpr (ACS > 0) st_u = *reinterpret_cast<const float4 *>(chunk_scalars_row<ACS, LPR>(c.cs, jpos));
+            else st_u = b.st[u];
+            const float pre = st_u.x + c.ac;
+            float lg;
+            const float lk = leaky_with_grad(pre, c.slope_v, lg);
+            const float a = gat_softmax_weight(lk, st_u.y);
+            const float ce = a * lg;
             const float aw = DROP ? a * b.d[DROP ? u : 0] : a;
             const float cw = DROP ? ce * b.d[DROP ? u : 0] : ce;
 #pragma unroll
@@ -629,11 +753,13 @@ struct GatBwdColOp {
                 s.acc[i] = fmaf(aw, b.g[u][i], s.acc[i]);
                 s.t[i] = fmaf(cw, b.g[u][i], s.t[i]);
             }
-            s.cd = fmaf(ce, b.st[u].w, s.cd);
+            s.cd = fmaf(ce, st_u.z, s.cd);
         }
     }
-    __device__ __forceinline__ void chunk_begin(Ctx &, State &, int, int, int, int, int, float *,
-                                                const LaneVals &) const {}
+    __device__ __forceinline__ void chunk_begin(Ctx &c, State &, int, int, int my_c, int sub, int, float *lds,
+                                                const LaneVals &) const {
+        chunk_scalars_load<ACS, A24>(c.cs, reinterpret_cast<const float *>(stats), my_c, sub, lds);
+    }
     __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
     __device__ __forceinline__ void row_end(const Ctx &c, const State &s, int64_t u_node, bool ok) const {
@@ -737,6 +863,18 @@ static int gat_launch_fwd(const GatFwdArgs &a, int64_t tiles, void *ws, size_t w
         if (can_chunk && want_chunk) return COGDL_HIP_EUNSUPPORTED;
         GatDrop dr = a.drop;
         dr.eid = a.vr->eid;
+        if constexpr (LPR == 8) {  // ChunkScalars (attn_col through LDS): 8 heads / one head in groups of 8 lanes
+            if (tiles == 1 && a.h == 8 && g_tuning[kTuneGatOnline] != 3) {
+                GatFwdOp<T, VEC, LPR, 8, DROP, true, 8> op{a.ar, a.ac, (const T *)a.feat, (T *)a.out, a.emax, a.esum, a.slope,
+                                                           (int)a.h, (int)a.f, dr};
+                return launch_rowreduce_vrows(op, a.vr, tiles, ws, wsb, s);
+            }
+            if (tiles == 1 && a.h == 1 && g_tuning[kTuneGatOnline] != 3) {
+                GatFwdOp<T, VEC, LPR, 8, DROP, true, 1> op{a.ar, a.ac, (const T *)a.feat, (T *)a.out, a.emax, a.esum, a.slope,
+                                                           (int)a.h, (int)a.f, dr};
+                return launch_rowreduce_vrows(op, a.vr, tiles, ws, wsb, s);
+            }
+        }
         GatFwdOp<T, VEC, LPR, 8, DROP, true> op{a.ar, a.ac, (const T *)a.feat, (T *)a.out, a.emax, a.esum, a.slope, (int)a.h,
                                                 (int)a.f, dr};
         return launch_rowreduce_vrows(op, a.vr, tiles, ws, wsb, s);
@@ -858,13 +996,38 @@ static int gat_launch_bwd(const GatBwdArgs &b, hipStream_t s) {
                                                     lph, row_drop, GatTiles{}};
     if (b.vr_row) {  // XCD-partitioned plans (both passes): the same functors with 24-bit table offsets
         row_drop.eid = b.vr_row->eid;  // (plan position -> CSR position)
-        GatBwdRowOp<T, VEC, LPR, 4, DROP, false, true> row24{b.ar, b.ac, (const T *)b.feat, b.emax, b.esum, (const T *)b.out,
-                                                             (const T *)b.gout, b.stats, b.gar, b.slope, (int)b.h, (int)b.f,
-                                                             lph, row_drop, GatTiles{}};
-        const int rc = launch_rowreduce_vrows(row24, b.vr_row, 1, b.ws_row, b.wsb_row, s);
-        if (rc != COGDL_HIP_OK) return rc;
         GatDrop col_drop = b.drop;
         col_drop.eid = b.vr_col->eid;  // (plan position of the CSC -> CSR position: the caller composed it with the transpose's perm)
+        int rc = COGDL_HIP_EUNSUPPORTED;
+        const bool scalars = LPR == 8 && g_tuning[kTuneGatOnline] != 3;  // ChunkScalars (see GatFwdOp)
+        if constexpr (LPR == 8) {
+            if (scalars && b.h == 8) {
+                GatBwdRowOp<T, VEC, LPR, 4, DROP, false, true, 8> row24{b.ar, b.ac, (const T *)b.feat, b.emax, b.esum,
+                                                                        (const T *)b.out, (const T *)b.gout, b.stats, b.gar, b.slope,
+                                                                        (int)b.h, (int)b.f, lph, row_drop, GatTiles{}};
+                rc = launch_rowreduce_vrows(row24, b.vr_row, 1, b.ws_row, b.wsb_row, s);
+            } else if (scalars && b.h == 1) {
+                GatBwdRowOp<T, VEC, LPR, 4, DROP, false, true, 1> row24{b.ar, b.ac, (const T *)b.feat, b.emax, b.esum,
+                                                                        (const T *)b.out, (const T *)b.gout, b.stats, b.gar, b.slope,
+                                                                        (int)b.h, (int)b.f, lph, row_drop, GatTiles{}};
+                rc = launch_rowreduce_vrows(row24, b.vr_row, 1, b.ws_row, b.wsb_row, s);
+            }
+        }
+        if (rc == COGDL_HIP_EUNSUPPORTED) {
+            GatBwdRowOp<T, VEC, LPR, 4, DROP, false, true> row24{b.ar, b.ac, (const T *)b.feat, b.emax, b.esum, (const T *)b.out,
+                                                                 (const T *)b.gout, b.stats, b.gar, b.slope, (int)b.h, (int)b.f,
+                                                                 lph, row_drop, GatTiles{}};
+            rc = launch_rowreduce_vrows(row24, b.vr_row, 1, b.ws_row, b.wsb_row, s);
+        }
+        if (rc != COGDL_HIP_OK) return rc;
+        if constexpr (LPR == 8) {
+            if (scalars && b.h == 1) {
+                GatBwdColOp<T, VEC, LPR, 4, DROP, false, true, 4> col24{b.ar, b.ac, (const T *)b.feat, b.stats, (const T *)b.gout,
+                                                                        (T *)b.gfeat, b.gac, b.slope, (int)b.h, (int)b.f, lph,
+                                                                        col_drop, GatTiles{}};
+                return launch_rowreduce_vrows(col24, b.vr_col, 1, b.ws_col, b.wsb_col, s);
+            }
+        }
         GatBwdColOp<T, VEC, LPR, 4, DROP, false, true> col24{b.ar, b.ac, (const T *)b.feat, b.stats, (const T *)b.gout,
                                                              (T *)b.gfeat, b.gac, b.slope, (int)b.h, (int)b.f, lph, col_drop,
                                                              GatTiles{}};

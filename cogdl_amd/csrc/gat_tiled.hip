@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void gat_finish_kernel(const float *__restrict
     }
     if constexpr (ROW) {
         const float ls = edge_sum[i];
-        stats[i] = make_float4(attn_row[i], edge_max[i], ls > 0.f ? 1.f / ls : 0.f, d);  // (the column pass's per-edge record)
+        stats[i] = make_float4(attn_row[i], gat_neg_max_log(edge_max[i], ls), d, ls > 0.f ? 1.f / ls : 0.f);  // (the column pass's per-edge record)
         out[i] = dot - d * hsum[i];
     } else {
         out[i] = dot - hsum[i];

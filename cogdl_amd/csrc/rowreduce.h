@@ -72,7 +72,7 @@ struct RowGeometry {
     int vec, lpr;
     int64_t tiles;
 };
-RowGeometry spmm_geometry(int64_t k, int64_t unit, int elem_bytes, int align, bool narrow_groups = false);
+RowGeometry spmm_geometry(int64_t k, int64_t unit, int elem_bytes, int align, bool narrow_groups = false, bool wide16 = false);
 
 struct RowSched {
     const int32_t *rowptr;
@@ -181,8 +181,11 @@ __device__ __forceinline__ bool decode_piece(const LongRows &lr, const int32_t *
 template <int LPR, int JJ>
 __device__ __forceinline__ int group_bcast_imm(int v) {
     static_assert(JJ >= 0 && JJ < LPR, "lane inside the group");
-    if constexpr (LPR == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150 + JJ, 0xf, 0xf, false);  // row_share:JJ
-    else if constexpr (LPR == 4) return __builtin_amdgcn_update_dpp(0, v, JJ * 0x55, 0xf, 0xf, false);  // quad_perm:[JJ,JJ,JJ,JJ]
+    // (bound_ctrl: the source lane of a row_share / quad_perm is always a lane of the caller's own group, i.e. active whenever
+    //  the destination is -- the DPP move needs no "old" value, and with bound_ctrl the compiler does not materialise one: a
+    //  v_mov 0 in front of EVERY broadcast otherwise, two per edge in csr_spmm's batches.)
+    if constexpr (LPR == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150 + JJ, 0xf, 0xf, true);  // row_share:JJ
+    else if constexpr (LPR == 4) return __builtin_amdgcn_update_dpp(0, v, JJ * 0x55, 0xf, 0xf, true);  // quad_perm:[JJ,JJ,JJ,JJ]
     else return __builtin_amdgcn_ds_swizzle(v, (JJ << 5) | (0x1f & ~(LPR - 1)));  // bit mode: and_mask | or_mask << 5
 }
 template <int LPR, int... JJ>

@@ -34,11 +34,27 @@ namespace cogdl {
 //   * rows of >= 512 B (fp32 F >= 128) use 8-byte lanes so that a whole wave (or two) shares a row: scalar column
 //     broadcast, no intra-wave length divergence (fp32 F=256: 390 -> 359 us with two column tiles per row).
 // `align` = guaranteed alignment in bytes of x and out (the workspace query assumes 16: allocator memory).
-RowGeometry spmm_geometry(int64_t k, int64_t unit, int elem_bytes, int align, bool narrow_groups) {
-    const int maxv = std::min(4, 16 / elem_bytes);
+//   * wide16 (round 6; the XCD-partitioned plans of 16-bit csr_spmm): 16-byte lanes whatever the row width.  On the graphs a
+//     plan is built for -- hub-heavy, every gather an L2 hit -- the launch is bound by the CU's memory pipeline, which takes
+//     one wave64 memory instruction per 16 cycles whether its lanes load 8 or 16 bytes (Reddit-shaped graph, bf16 F = 64 in
+//     8-byte lanes: 4.3e7 vector memory instructions in 1331 us = one per 17.2 cycles and CU, profiles/r06_mem_pipeline.txt):
+//     16-byte lanes gather twice the rows per instruction, and halve the per-edge lane arithmetic with it: bf16 F = 64
+//     1327 -> 1107 us, F = 128 2295 -> 1836 us, F = 256 3825 -> 3265 us, F = 40 1403 -> 1342 us (fp16 alike;
+//     tools/exp/wide16_ab.py, profiles/r06_wide16_ab.txt).  Tuning key 6 != 0 switches it off.
+RowGeometry spmm_geometry(int64_t k, int64_t unit, int elem_bytes, int align, bool narrow_groups, bool wide16) {
+    const bool wide = wide16 && elem_bytes == 2 && g_tuning[kTuneSpmmVec] == 0;
+    const int maxv = wide ? 8 : std::min(4, 16 / elem_bytes);
     auto legal = [&](int v) { return v <= maxv && unit % v == 0 && align % (v * elem_bytes) == 0; };
     int vec = 1;
     while (vec * 2 <= maxv && legal(vec * 2)) vec *= 2;  // widest legal
+    if (wide && vec == 8 && k > 32) {  // (rows of at most 64 bytes -- four 16-byte lanes, 16 rows per wave -- measured slower: F = 32 886 -> 1202 us)
+        RowGeometry g;
+        g.vec = 8;
+        g.lpr = 4;
+        while (g.lpr < kWave && (int64_t)g.lpr * 8 < k) g.lpr <<= 1;
+        g.tiles = (k + (int64_t)g.lpr * 8 - 1) / ((int64_t)g.lpr * 8);
+        return g;
+    }
     auto lanes = [&](int v) {  // LPR for vector width v
         int l = 4;
         while (l < kWave && (int64_t)l * v < k) l <<= 1;
@@ -159,8 +175,8 @@ extern "C" int cogdl_hip_csr_spmm_acc(const int32_t *rowptr, const int32_t *coli
 // ---- XCD-partitioned plan (rowreduce.h: virtual rows) ------------------------------------------------------------------
 extern "C" size_t cogdl_hip_csr_spmm_xcd_workspace_bytes(int64_t n_parts, int64_t k, int dtype) {
     if (k <= 0) return 256;
-    const RowGeometry g = spmm_geometry(k, k, elem_bytes_of(dtype), 16, false);
-    return vrows_workspace_bytes(n_parts, g.tiles * g.vec * g.lpr);
+    const RowGeometry g = spmm_geometry(k, k, elem_bytes_of(dtype), 16, false), gw = spmm_geometry(k, k, elem_bytes_of(dtype), 16, false, true);
+    return std::max(vrows_workspace_bytes(n_parts, g.tiles * g.vec * g.lpr), vrows_workspace_bytes(n_parts, gw.tiles * gw.vec * gw.lpr));
 }
 
 template <typename T>

@@ -184,14 +184,22 @@ struct SpmmArgs {
 template <typename T, int VEC, int LPR, int UNROLL, int WMODE, bool EXACT, bool EPI = false>
 static int launch_spmm(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) {
     const int64_t tiles = ((int64_t)a.k + (int64_t)LPR * VEC - 1) / ((int64_t)LPR * VEC);
-    if (a.vr) {  // XCD-partitioned plan: the same functor with 24-bit table offsets (common.h: gather_row)
-        if constexpr (kWave % LPR == 0 && !EPI && WMODE != 2) {
+    if constexpr (VEC == 8) {  // 16-byte lanes of 16-bit elements: XCD-partitioned plans only (spmm_geometry: wide16)
+        if (!a.vr) return COGDL_HIP_EUNSUPPORTED;
+        if constexpr (kWave % LPR == 0 && !EPI && WMODE != 2 && sizeof(T) == 2) {
             SpmmOp<T, VEC, LPR, UNROLL, WMODE, EXACT, EPI, true> op24{a.val, a.att, a.x, a.out, a.k, a.fdim, a.acc_mode, a.eid, a.epi};
             return launch_rowreduce_vrows(op24, a.vr, tiles, ws, wsb, s);
         } else return COGDL_HIP_EUNSUPPORTED;
+    } else {
+        if (a.vr) {  // XCD-partitioned plan: the same functor with 24-bit table offsets (common.h: gather_row)
+            if constexpr (kWave % LPR == 0 && !EPI && WMODE != 2) {
+                SpmmOp<T, VEC, LPR, UNROLL, WMODE, EXACT, EPI, true> op24{a.val, a.att, a.x, a.out, a.k, a.fdim, a.acc_mode, a.eid, a.epi};
+                return launch_rowreduce_vrows(op24, a.vr, tiles, ws, wsb, s);
+            } else return COGDL_HIP_EUNSUPPORTED;
+        }
+        SpmmOp<T, VEC, LPR, UNROLL, WMODE, EXACT, EPI> op{a.val, a.att, a.x, a.out, a.k, a.fdim, a.acc_mode, a.eid, a.epi};
+        return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, tiles, ws, wsb, s);
     }
-    SpmmOp<T, VEC, LPR, UNROLL, WMODE, EXACT, EPI> op{a.val, a.att, a.x, a.out, a.k, a.fdim, a.acc_mode, a.eid, a.epi};
-    return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, tiles, ws, wsb, s);
 }
 
 // (VEC, LPR) choice: as many lanes per row as the row has VEC-wide columns (whole-wave rows are the
@@ -226,8 +234,11 @@ static int pointer_alignment(const void *a, const void *b) {
 template <typename T, int WMODE, bool EPI = false>
 static int spmm_auto(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s) {
     const RowGeometry g = spmm_geometry(a.k, (WMODE == 2) ? a.fdim : a.k, (int)sizeof(T), pointer_alignment(a.x, a.out),
-                                        WMODE != 2 && !EPI && !a.vr);
+                                        WMODE != 2 && !EPI && !a.vr, WMODE != 2 && !EPI && a.vr != nullptr);
     switch (g.vec) {
+        case 8:
+            if constexpr (sizeof(T) == 2 && WMODE != 2 && !EPI) return dispatch_lpr<T, 8, WMODE, EPI>(a, g.lpr, ws, wsb, s);
+            else return COGDL_HIP_EUNSUPPORTED;
         case 4: return dispatch_lpr<T, 4, WMODE, EPI>(a, g.lpr, ws, wsb, s);
         case 2: return dispatch_lpr<T, 2, WMODE, EPI>(a, g.lpr, ws, wsb, s);
         default: return dispatch_lpr<T, 1, WMODE, EPI>(a, g.lpr, ws, wsb, s);

@@ -28,6 +28,7 @@ SPLIT = 256        # rows of more than this many edges are cut by owner XCD (Red
                    # fwd+bwd by split / piece: 64/256 6.21 ms, 128/256 6.02, 256/256 5.82, 256/512 6.15, 512/512 6.11: profiles/r06_gat_split.txt)
 PIECE = 256        # edges per virtual row at most
 BIG_PARTS = 32     # (csrc/rowreduce.h: kVBigParts)
+SORT_BY_LENGTH = os.environ.get("COGDL_AMD_XCD_SORT", "1") != "0"  # (A/B switch: the slot order inside an XCD's stream)
 MODE = os.environ.get("COGDL_AMD_XCD", "auto")  # "auto" | "off" | "force" (every structure, every operator: tests)
 
 
@@ -131,7 +132,19 @@ def build(rowptr, colind, eid_base=None, split=None, piece=None):
     per = int((int(counts.max()) + UNIT - 1) // UNIT * UNIT) if n_v else 0
     n_slots = XCDS * per
     start = torch.cumsum(counts, 0) - counts
-    k = torch.arange(n_v, device=dev) - start[vx]
+    if SORT_BY_LENGTH and n_v:
+        # An XCD's virtual rows in order of DECREASING length: the lane groups of a wave (and the waves of a workgroup) then
+        # walk rows of the same length -- a wave lasts as long as its longest row, and in (row, piece) order neighbours
+        # differ by an order of magnitude on a skewed graph (Reddit-shaped graph, fused GAT forward: 5.2 vector instructions per
+        # edge executed where the loop body has 3.5: a third of all lane-slots masked off, profiles/r06_mem_pipeline.txt).
+        # Longest first is also the better schedule for the launch's tail.  Which slot walks a virtual row changes nothing
+        # in what it computes, and the records are merged by (row, XCD, piece) as before: results are bit-identical.
+        by_len = torch.argsort(vx * (int(vlen.max()) + 1) + (int(vlen.max()) - vlen), stable=True)
+        k = torch.empty(n_v, dtype=torch.long, device=dev)
+        k[by_len] = torch.arange(n_v, device=dev) - start[vx[by_len]]
+        del by_len
+    else:
+        k = torch.arange(n_v, device=dev) - start[vx]
     slot = ((k // UNIT) * XCDS + vx) * UNIT + k % UNIT
     vdesc = torch.full((n_slots, 2), -1, dtype=torch.int32, device=dev)
     vdesc[slot, 0] = vr.int()

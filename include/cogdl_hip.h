@@ -65,8 +65,10 @@ COGDL_API int cogdl_hip_last_hip_error(void);
  *    0  XCD stripe of the row-block -> workgroup map (0 = hardware round-robin, default 32)
  *    1  long-row threshold override (0 = automatic)          2  1 = natural row -> lane-group assignment inside a workgroup
  *    3  cap on the number of long-row workgroups (1024)      4  cap on the fused-GAT vector width (0 = widest)
- *    5  fused-GAT forward kernel (0 = automatic, 1 = edge-wise online softmax, 2 = chunk-wise softmax where it applies)
- *    6  csr_spmm / mhspmm vector width cap (negative: force; -99: power-of-two lane groups only)
+ *    5  fused-GAT forward kernel (0 = automatic, 1 = edge-wise online softmax, 2 = chunk-wise softmax where it applies,
+ *       3 = plan kernels without the per-chunk scalars through LDS: attn_col / stats gathered per edge as before)
+ *    6  csr_spmm / mhspmm vector width cap (negative: force; -99: power-of-two lane groups only; any value but 0 also keeps the
+ *       16-bit plan kernels at 8-byte lanes)
  *    7  edge_softmax lanes (bit 0: 4-byte lanes in the row kernels, bit 1: in the hub-row path, bit 2: row kernels only)
  *    8  polls before the flat edge_softmax kernel's cross-tile wait recomputes the row statistics (0 = 4096; < 0: at once)
  *    9  flat edge_softmax experiments (bit 0: no cross-tile exchange -- WRONG results; bit 2: half-size 16-bit tiles; bit 3: no
@@ -75,7 +77,7 @@ COGDL_API int cogdl_hip_last_hip_error(void);
  *   10  csr2csc (0 = by size: one single-workgroup launch up to 16 k slots, the radix sort above; 2 = the radix sort at
  *       every size; 3 = with packed intermediate records at every size)
  *   11  sampler relabelling (1 = the sort-based form)       13  timing: 1 = row blocks exit, 2 = long-row workgroups exit (WRONG results)
- *   15  64-bit CSR: edges per row segment (0 = 2^29)        17  degree-ordered row schedule of csr_spmm (see cogdl_hip_row_order)
+ *   15  64-bit CSR: edges per row segment (0 = 2^29)
  *   12, 14, 16  retired in round 6 (wave-scope split of medium rows, row tiles, per-workgroup row queue: all measured <= +-5 %). */
 COGDL_API int cogdl_hip_set_tuning(int key, int value);
 /* Measurement hook (bench.py `roofline.measured_read_GBs`, SURVEY.md section 8d: the box's own roof beside the spec
