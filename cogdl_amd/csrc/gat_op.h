@@ -132,8 +132,8 @@ struct GatTiles {
 // memory instructions in 1449 us = one per 19.7 cycles and CU, profiles/r06_mem_pipeline.txt), and every edge costs two:
 // its 128-byte feature row and the 4 bytes per lane of attn_col (or the 16-byte stats record of the column pass) -- the
 // second one moves a sixteenth of the bytes for the same slot.  With 8-lane groups a chunk is 8 edges and lane l already
-// holds the column id of edge l: it loads the WHOLE scalar row of ITS edge once per chunk (H = 8: two 16-byte loads, H = 1:
-// one dword / one 16-byte record), parks it in the group's LDS scratch when the first slot is folded (the loads were issued
+// holds the column id of edge l: it loads the WHOLE scalar row of ITS edge once per chunk (H = 1: one dword / one 16-byte
+// record; H = 8 -- two 16-byte loads -- is implemented by the same code and measured slower, see gat_launch_fwd), parks it in the group's LDS scratch when the first slot is folded (the loads were issued
 // BEFORE the chunk's gathers, so waiting for them does not wait for the gathers), and every slot reads its value back:
 // 10 (9) memory instructions per chunk instead of 16, the rest is LDS traffic (which has its own pipeline).  Rows are
 // rotated by the group's index inside the wave so that the eight groups of a wave hit different banks.
@@ -859,16 +859,14 @@ static int gat_launch_fwd(const GatFwdArgs &a, int64_t tiles, void *ws, size_t w
     using Chunk = GatFwdChunkOp<T, VEC, LPR, 8, DROP>;
     const bool can_chunk = pow2(a.h) && a.h <= LPR && a.h <= Chunk::kMaxHeads;
     const bool want_chunk = g_tuning[kTuneGatOnline] == 2 || (g_tuning[kTuneGatOnline] == 0 && LPR >= 16 && a.h * 8 <= LPR);
-    if (a.vr) {  // virtual rows: the edge-wise functor only (the caller takes the ordinary entry for the chunk-wise shapes)
-        if (can_chunk && want_chunk) return COGDL_HIP_EUNSUPPORTED;
+    if (a.vr) {  // virtual rows: the edge-wise functor, also for the shapes the ordinary entry runs chunk-wise -- with an XCD's
+        // virtual rows in order of length the plan wins there too (Reddit-shaped graph, fp32 H = 1 x F = 41 layer of the gat
+        // model: training step 20.7 -> 16.9 ms, profiles/r06_gat_bench.txt)
         GatDrop dr = a.drop;
         dr.eid = a.vr->eid;
-        if constexpr (LPR == 8) {  // ChunkScalars (attn_col through LDS): 8 heads / one head in groups of 8 lanes
-            if (tiles == 1 && a.h == 8 && g_tuning[kTuneGatOnline] != 3) {
-                GatFwdOp<T, VEC, LPR, 8, DROP, true, 8> op{a.ar, a.ac, (const T *)a.feat, (T *)a.out, a.emax, a.esum, a.slope,
-                                                           (int)a.h, (int)a.f, dr};
-                return launch_rowreduce_vrows(op, a.vr, tiles, ws, wsb, s);
-            }
+        if constexpr (LPR == 8) {  // ChunkScalars (attn_col through LDS): one head in groups of 8 lanes
+            // (8 heads -- two 16-byte loads per lane and chunk instead of eight dword loads per lane group -- measured SLOWER:
+            //  bf16 H = 8 x F = 8 forward 1456 -> 1526 us, backward 2909 -> 2993 us: the instantiation is gone)
             if (tiles == 1 && a.h == 1 && g_tuning[kTuneGatOnline] != 3) {
                 GatFwdOp<T, VEC, LPR, 8, DROP, true, 1> op{a.ar, a.ac, (const T *)a.feat, (T *)a.out, a.emax, a.esum, a.slope,
                                                            (int)a.h, (int)a.f, dr};
@@ -1001,12 +999,7 @@ static int gat_launch_bwd(const GatBwdArgs &b, hipStream_t s) {
         int rc = COGDL_HIP_EUNSUPPORTED;
         const bool scalars = LPR == 8 && g_tuning[kTuneGatOnline] != 3;  // ChunkScalars (see GatFwdOp)
         if constexpr (LPR == 8) {
-            if (scalars && b.h == 8) {
-                GatBwdRowOp<T, VEC, LPR, 4, DROP, false, true, 8> row24{b.ar, b.ac, (const T *)b.feat, b.emax, b.esum,
-                                                                        (const T *)b.out, (const T *)b.gout, b.stats, b.gar, b.slope,
-                                                                        (int)b.h, (int)b.f, lph, row_drop, GatTiles{}};
-                rc = launch_rowreduce_vrows(row24, b.vr_row, 1, b.ws_row, b.wsb_row, s);
-            } else if (scalars && b.h == 1) {
+            if (scalars && b.h == 1) {
                 GatBwdRowOp<T, VEC, LPR, 4, DROP, false, true, 1> row24{b.ar, b.ac, (const T *)b.feat, b.emax, b.esum,
                                                                         (const T *)b.out, (const T *)b.gout, b.stats, b.gar, b.slope,
                                                                         (int)b.h, (int)b.f, lph, row_drop, GatTiles{}};

@@ -26,7 +26,8 @@ UNIT = 64          # slots per unit (csrc/rowreduce.h: kVUnit)
 XCDS = 8
 SPLIT = 256        # rows of more than this many edges are cut by owner XCD (Reddit-shaped graph, fused GAT bf16 H8xF8 with dropout,
                    # fwd+bwd by split / piece: 64/256 6.21 ms, 128/256 6.02, 256/256 5.82, 256/512 6.15, 512/512 6.11: profiles/r06_gat_split.txt)
-PIECE = 256        # edges per virtual row at most
+PIECE = 512        # edges per virtual row at most (with the virtual rows in order of length, same probe: 256/256 5.20 ms, 256/512 5.02,
+                   # 512/512 5.24, 128/256 5.19, 256/128 5.47: profiles/r06_gat_split2.txt)
 BIG_PARTS = 32     # (csrc/rowreduce.h: kVBigParts)
 SORT_BY_LENGTH = os.environ.get("COGDL_AMD_XCD_SORT", "1") != "0"  # (A/B switch: the slot order inside an XCD's stream)
 MODE = os.environ.get("COGDL_AMD_XCD", "auto")  # "auto" | "off" | "force" (every structure, every operator: tests)

@@ -11,7 +11,7 @@ for h, f, dt in ((8, 8, torch.bfloat16), (1, 41, torch.bfloat16), (8, 8, torch.f
     ft = torch.randn(n, h, f, device=dev).to(dt).requires_grad_(); grad = torch.randn(n, h, f, device=dev).to(dt)
     for p in (0.0, 0.5):
         out = []
-        for split, piece in ((64, 256), (128, 256), (256, 256), (256, 512), (512, 512)):
+        for split, piece in ((64, 128), (128, 128), (256, 128), (64, 256), (128, 256), (256, 256), (256, 512), (512, 512)):
             xcdplan.SPLIT, xcdplan.PIECE = split, piece
             fw = lambda: fused_gat_dropout_func(ar.detach(), ac.detach(), g.rowptr, g.colind, 0.2, ft.detach(), p, seed=3)
             def step():
