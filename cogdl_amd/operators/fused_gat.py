@@ -115,8 +115,13 @@ class FusedGATFunction(torch.autograd.Function):
         if fp != f:
             feat = torch.nn.functional.pad(feat, (0, fp - f))
         # XCD-partitioned plan (cogdl_amd/xcdplan.py): hub-heavy graphs over cache-sized tables (BASELINE configs[2])
-        ctx.xcd = (feat.dim() == 3 and feat.dtype in _lib.DTYPE_CODE and
-                   xcdplan.wanted(row_ptr.numel() - 1, col_ind.numel(), feat.shape[0], feat.shape[1] * fp * feat.element_size()))
+        ok = feat.dim() == 3 and feat.dtype in _lib.DTYPE_CODE
+        row_bytes = feat.shape[1] * fp * feat.element_size() if ok else 0
+        ctx.xcd = ok and xcdplan.wanted(row_ptr.numel() - 1, col_ind.numel(), feat.shape[0], row_bytes)
+        if ok and not ctx.xcd and getattr(row_ptr, "_cogdl_amd_struct", None) is not None and ctx.fp.event is not None:
+            # a memoised fingerprint (install(structure_memo=True)): skewed structures of any size (xcdplan.ordered_wanted)
+            ctx.fp.key()
+            ctx.xcd = xcdplan.ordered_wanted(ctx.fp, row_ptr, row_ptr.numel() - 1, col_ind.numel(), feat.shape[0], row_bytes)
         xplan = xcdplan.csr_plan(ctx.fp, row_ptr, col_ind) if ctx.xcd else None
         # (a shape the plan's forward declines -- column tiles -- keeps the ordinary backward too)
         if xplan is not None:
@@ -147,7 +152,9 @@ class FusedGATFunction(torch.autograd.Function):
         lib = _lib.hip()
         nnz, code = col_ind.numel(), _lib.DTYPE_CODE[dt]
         rc = _lib.EUNSUPPORTED
-        if ctx.xcd:
+        # (the structure's key is known by now -- PLANS.get has waited for the hash: a skewed structure takes the plans in
+        #  backward whether or not its forward call could)
+        if ctx.xcd or xcdplan.ordered_wanted(ctx.fp, row_ptr, v, col_ind.numel(), n_src, h * fp * feat.element_size()):
             xr, xc = xcdplan.csr_plan(ctx.fp, row_ptr, col_ind), xcdplan.csc_plan(ctx.fp, plan)
             ws, ws_bytes = _lib.workspace("cogdl_hip_gat_bwd_xcd_workspace_bytes", dev, v, h, fp, xr.n_parts, xc.n_parts, code)
             with _lib.on_device(dev):

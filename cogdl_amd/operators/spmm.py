@@ -113,7 +113,7 @@ def csr_spmm_xcd_raw(xplan, val, x, out=None):
 SPLIT_16 = 256  # (= xcdplan.SPLIT: 16-bit csr_spmm and the fused GAT operator share one plan per structure)
 
 
-def _xcd_split(rowptr, colind, x):
+def _xcd_split(rowptr, colind, x, fp=None):
     """Does this csr_spmm launch take an XCD-partitioned plan (cogdl_amd/xcdplan.py), and cut at which row length?
     -> None (no plan) or the split.
       fp32    hub-heavy structures over cache-sized tables (xcdplan.wanted): yes, with split = the exact-row bound of the
@@ -132,6 +132,10 @@ def _xcd_split(rowptr, colind, x):
         return xcdplan.SPLIT if xcdplan.wanted(m, nnz, x.shape[0], x.shape[1] * x.element_size()) else None
     if xcdplan.wanted(m, nnz, x.shape[0], x.shape[1] * x.element_size()):
         return int(_lib.hip().cogdl_hip_exact_row_edges(nnz)) if x.dtype == torch.float32 else SPLIT_16
+    # skewed structures of any size, when the structure's fingerprint is on the host already (xcdplan.ordered_wanted): cut at the
+    # exact-row bound whatever the dtype (rows up to it stay whole and sequential, as in the ordinary launch)
+    if xcdplan.ordered_wanted(fp, rowptr, m, nnz, x.shape[0], x.shape[1] * x.element_size()):
+        return int(_lib.hip().cogdl_hip_exact_row_edges(nnz))
     return None
 
 
@@ -161,7 +165,14 @@ class SPMMFunction(torch.autograd.Function):
         ctx.transient = _plan.transient()  # (the dense operand is checked by csr_spmm_raw)
         ctx.xcd = _xcd_split(rowptr, colind, feat)
         ctx.fp = (fingerprint_of(rowptr, colind, feat.shape[0])
-                  if (ctx.needs_input_grad[2] or ctx.xcd is not None) and not ctx.transient else None)
+                  if (ctx.needs_input_grad[2] or ctx.xcd is not None or getattr(rowptr, "_cogdl_amd_struct", None) is not None)
+                  and not ctx.transient else None)
+        if ctx.xcd is None and ctx.fp is not None and getattr(rowptr, "_cogdl_amd_struct", None) is not None:
+            # a memoised fingerprint (install(structure_memo=True)): its key costs ONE wait per structure, after which skewed
+            # structures of any size take a plan -- deterministically, from the first call on
+            if ctx.fp.event is not None:
+                ctx.fp.key()
+            ctx.xcd = _xcd_split(rowptr, colind, feat, ctx.fp)
         if ctx.xcd is not None:
             out = csr_spmm_xcd_raw(xcdplan.csr_plan(ctx.fp, rowptr, colind, ctx.xcd), edge_weight_csr, feat)
         else:
@@ -184,7 +195,9 @@ class SPMMFunction(torch.autograd.Function):
                 grad_feat = csr_spmm_raw(plan.colptr, plan.rowind, w_t, grad_out)
             else:
                 plan = PLANS.get(ctx.fp, rowptr, colind, ctx.n_src)
-                split_t = _xcd_split(plan.colptr, plan.rowind, grad_out) if ctx.xcd is not None else None
+                # (the key is known here -- PLANS.get has waited for the hash: the transpose of a skewed structure takes a plan
+                #  whether or not the forward call could)
+                split_t = _xcd_split(plan.colptr, plan.rowind, grad_out, ctx.fp)
                 if split_t is not None:
                     # (w stays in CSR order: the plan of the transpose maps its positions through the transpose's perm)
                     grad_feat = csr_spmm_xcd_raw(xcdplan.csc_plan(ctx.fp, plan, split_t), w, grad_out)

@@ -280,6 +280,53 @@ def test_csrspmm_fp32_on_the_reddit_shaped_graph_takes_the_plan_and_keeps_its_ex
     assert float((gx_plan - x.grad).abs().max()) <= tol
 
 
+def test_skewed_structures_of_any_size_take_a_plan_once_their_fingerprint_is_known(oracle, monkeypatch):
+    """xcdplan.ordered_wanted: the arxiv-sized R-MAT graph is far below `wanted()`'s size, but skewed -- the BACKWARD pass (which
+    has the structure's key anyway) walks the transpose's plan; the forward pass does too once the fingerprint is memoised with
+    the structure (install(structure_memo=True): here the memo record is attached by hand).  Rows up to the exact-row bound are
+    bit-identical to the ordinary launch; the uniform graph of the same size keeps the ordinary launch throughout."""
+    import cogdl_amd.operators.spmm as spmm_mod
+    from cogdl_amd import _lib
+    from cogdl_amd.structure_memo import StructureMemo
+
+    monkeypatch.setattr(xcdplan, "MODE", "auto")
+    xcdplan._SKEW.clear()
+    calls = []
+    real = spmm_mod.csr_spmm_xcd_raw
+    monkeypatch.setattr(spmm_mod, "csr_spmm_xcd_raw", lambda *a, **k: (calls.append(a[0]), real(*a, **k))[1])
+    for topo, expect in (("rmat", True), ("uniform", False)):
+        g = synth.arxiv_like(seed=0, topology=topo)
+        rowptr, colind, w = g.rowptr.to(DEV), g.colind.to(DEV), g.weight.to(DEV)
+        x = torch.randn(g.num_nodes, 40, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)).requires_grad_()
+        gout = torch.randn(g.num_nodes, 40, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+        plain = csr_spmm_raw(rowptr, colind, w, x.detach())
+        del calls[:]
+        out = SPMMFunction.apply(rowptr, colind, x, w, False)  # fresh tensors: the hash is in flight, the forward stays ordinary
+        assert not calls and torch.equal(out, plain)
+        out.backward(gout)
+        assert len(calls) == (1 if expect else 0), topo
+        gx_first = x.grad.clone()
+        # ... memoised structure: both directions
+        memo = StructureMemo()
+        memo.rowptr32, memo.colind32 = rowptr, colind
+        rowptr._cogdl_amd_struct = memo
+        del calls[:]
+        x.grad = None
+        out = SPMMFunction.apply(rowptr, colind, x, w, False)
+        out.backward(gout)
+        assert len(calls) == (2 if expect else 0), topo
+        if expect:
+            assert calls[0].n_parts > 0 and calls[0].m == g.num_nodes
+            exact = int(_lib.hip().cogdl_hip_exact_row_edges(g.nnz))
+            short = (g.degrees() <= exact).to(DEV)
+            assert torch.equal(out[short], plain[short])  # whole virtual rows: the reference's sequential order
+            scale = csr_spmm_raw(rowptr, colind, w.abs(), x.detach().abs())
+            assert bool(((out - plain).abs() <= 2e-5 * scale + 1e-30).all())
+            assert torch.equal(x.grad, gx_first)  # the same plan of the transpose as the un-memoised backward
+        del rowptr._cogdl_amd_struct
+    xcdplan._SKEW.clear()
+
+
 def test_wanted_rule():
     xcdplan.MODE = "auto"
     n, nnz = synth.REDDIT_NODES, 114_848_857
