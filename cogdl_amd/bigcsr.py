@@ -12,6 +12,7 @@ launch of the ordinary 32-bit kernels on rebased int32 row pointers (csrc/bigcsr
 per (rowptr, colind) tensor identity: a caller of this path keeps its index tensors, it does not re-cast them per call.
 """
 import ctypes
+import os
 
 import torch
 
@@ -19,8 +20,19 @@ from . import _lib
 from .plan import tensor_key
 
 
+# Row schedule of the segment launches (cogdl_hip_csr_spmm_i64_ordered): rows by decreasing degree inside windows of ROW_WINDOW
+# rows.  The lane groups of a wave (two rows per wave at F = 128 fp32) and the waves of a workgroup then carry rows of one
+# length -- on a power-law graph neighbouring ids differ by orders of magnitude, and a wave with an idle group keeps half its
+# gathers in flight.  Windows keep the row pointer / output traffic of concurrently running workgroups together.  Measured on
+# one eighth of the papers100M-shaped symmetrised graph (X = 7.1 GB; rows physically re-ordered, tools/exp/papers_order_ab.py,
+# profiles/r06_papers_order_ab.txt): F = 128 fp32 42.8 -> 38.5 ms (0.635 -> 0.705 of 8 TB/s), whole-graph degree order 39.4 ms.
+# Results are bit-identical (a row is still one lane group's sequential sum).  COGDL_AMD_ROW_ORDER=0 switches it off.
+ORDER_ROWS = os.environ.get("COGDL_AMD_ROW_ORDER", "1") != "0"
+ROW_WINDOW = 1 << 16
+
+
 class BigCsr:
-    """Plan of one 64-bit CSR structure: segment cuts + rebased int32 row pointers (device)."""
+    """Plan of one 64-bit CSR structure: segment cuts + rebased int32 row pointers + the row schedule (device)."""
 
     def __init__(self, rowptr, colind, n_cols=None, max_edges=0):
         dev = _lib.require_cuda(rowptr, colind)
@@ -43,9 +55,26 @@ class BigCsr:
                                                  _lib.stream_of(self.rowptr))
             _lib.check(rc, "csr_rebase_rowptr")
         self._seg_addr = ctypes.addressof(self.seg)
+        self.row_order = self._row_schedule() if ORDER_ROWS and self.m > 0 and self.seg.n > 0 else None
         self._transposed = None
         self._val_key = self._val_src = self._val_t = None
         self._sym_checked = {}
+
+    def _row_schedule(self):
+        """[m] int32: per segment a permutation of its LOCAL row ids -- decreasing degree inside windows of ROW_WINDOW rows."""
+        dev = self.rowptr.device
+        order = torch.empty(self.m, dtype=torch.int32, device=dev)
+        rows = self.segment_rows()
+        for s in range(self.seg.n):
+            r0, r1 = rows[s], rows[s + 1]
+            if r1 <= r0:
+                continue
+            deg = self.rowptr[r0 + 1:r1 + 1] - self.rowptr[r0:r1]
+            top = int(deg.max()) + 1
+            key = (torch.arange(r1 - r0, device=dev) // ROW_WINDOW) * top + (top - 1 - deg)
+            order[r0:r1] = torch.argsort(key, stable=True).int()
+            del deg, key
+        return order
 
     @property
     def n_segments(self):
@@ -58,7 +87,7 @@ class BigCsr:
         return [int(self.seg.edge[i]) for i in range(self.seg.n + 1)]
 
     def nbytes(self):
-        return 4 * self.rowptr32.numel()
+        return 4 * self.rowptr32.numel() + (4 * self.row_order.numel() if self.row_order is not None else 0)
 
     # ---- operators ---------------------------------------------------------------------------------------------------
     def spmm(self, val, x, split_long_rows=True):
@@ -81,8 +110,9 @@ class BigCsr:
             ws_bytes = lib.cogdl_hip_csr_spmm_i64_workspace_bytes(self._seg_addr, k, code)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
         with _lib.on_device(dev):
-            rc = lib.cogdl_hip_csr_spmm_i64(_lib.ptr(self.rowptr32), self._seg_addr, _lib.ptr(self.colind), _lib.ptr(val),
-                                            _lib.ptr(x), _lib.ptr(out), k, code, _lib.ptr(ws), ws_bytes, _lib.stream_of(x))
+            rc = lib.cogdl_hip_csr_spmm_i64_ordered(_lib.ptr(self.rowptr32), self._seg_addr, _lib.ptr(self.colind), _lib.ptr(val),
+                                                    _lib.ptr(x), _lib.ptr(out), k, code, _lib.ptr(self.row_order), _lib.ptr(ws),
+                                                    ws_bytes, _lib.stream_of(x))
         _lib.check(rc, "csr_spmm_i64")
         return out
 

@@ -82,6 +82,9 @@ struct RowSched {
     LongRows lr;
     int sort_rows;  // deal a workgroup's rows to its lane groups by decreasing length (see rowreduce_main_kernel)
     int debug;      // timing experiments (tuning key 13; WRONG results): 1 = row blocks exit, 2 = long-row workgroups exit
+    const int32_t *order;  // NULL, or a permutation of the rows: row block b walks rows order[b * GPB ..] (a plan-time schedule,
+                           // e.g. rows by degree inside windows: the lane groups of a wave then carry rows of one length; every
+                           // row is still reduced by one group in CSR order and written to its own place -- same results)
 };
 
 // Operators may ask for a register budget: `static constexpr int kMinWaves = W` compiles their main kernel for at least W
@@ -524,6 +527,7 @@ __global__ __launch_bounds__(256, MinWaves<Op>::value) void rowreduce_main_kerne
     bool ok = lane_on && row < s.m;
     int start = 0, end = 0;
     if (ok) {
+        if (s.order) row = s.order[row];
         start = s.rowptr[row];
         end = s.rowptr[row + 1];
     }
@@ -536,7 +540,10 @@ __global__ __launch_bounds__(256, MinWaves<Op>::value) void rowreduce_main_kerne
         // sequentially by one group in CSR order (bit-identical results).
         if (g_sort_rows(s)) {
             int mine;
-            if (deal_rows_by_length<GPB>(wave * RPW + sub, lane_on && l == 0, ok, start, end, mine)) row = rb * GPB + mine;
+            if (deal_rows_by_length<GPB>(wave * RPW + sub, lane_on && l == 0, ok, start, end, mine)) {
+                row = rb * GPB + mine;
+                if (s.order && ok) row = s.order[row];
+            }
             if (!lane_on) {
                 ok = false;
                 start = end = 0;
@@ -824,7 +831,8 @@ static int launch_rowreduce_vrows(const Op &op, const cogdl_hip_vrows *p, int64_
 // sequentially by its lane group (exact reference order for any length).  Per-edge operators need no scratch.
 template <class Op>
 static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *colind, int64_t m, int64_t nnz,
-                            int64_t tiles, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+                            int64_t tiles, void *workspace, size_t workspace_bytes, hipStream_t stream,
+                            const int32_t *row_order = nullptr) {
     const int64_t RPB = (int64_t)(kWave / Op::LPR) * 4;
     const int64_t n_rowblocks = (m + RPB - 1) / RPB;
     if (n_rowblocks == 0) return COGDL_HIP_OK;
@@ -836,6 +844,7 @@ static int launch_rowreduce(const Op &op, const int32_t *rowptr, const int32_t *
     s.rowblocks = make_xcd_map(n_rowblocks);
     s.sort_rows = g_tuning[kTuneRowSort] == 0 ? 1 : 0;
     s.debug = g_tuning[kTuneRowDebug];
+    s.order = row_order;
     s.lr.thresh = INT_MAX;
     if (nnz > 0 && (!Op::kReduce || workspace)) {
         plan_long_rows(s.lr, nnz);

@@ -95,9 +95,11 @@ RowGeometry spmm_geometry(int64_t k, int64_t unit, int elem_bytes, int align, bo
 
 template <typename T>
 static int spmm_typed(const int32_t *rowptr, const int32_t *colind, const void *val, const void *x, void *out,
-                      int64_t m, int64_t k, int64_t nnz, int acc_mode, void *ws, size_t wsb, hipStream_t s) {
+                      int64_t m, int64_t k, int64_t nnz, int acc_mode, void *ws, size_t wsb, hipStream_t s,
+                      const int32_t *row_order = nullptr) {
     if (!aligned_to(x, sizeof(T)) || !aligned_to(out, sizeof(T))) return COGDL_HIP_EALIGN;
     SpmmArgs<T> a{rowptr, colind, (const T *)val, nullptr, (const T *)x, (T *)out, m, nnz, (int)k, (int)k, acc_mode, nullptr, {}};
+    a.row_order = row_order;
     return val ? spmm_auto<T, 1>(a, ws, wsb, s) : spmm_auto<T, 0>(a, ws, wsb, s);
 }
 
@@ -112,15 +114,15 @@ static int check_args(const int32_t *rowptr, const void *x, const void *out, int
 
 static int csr_spmm_entry(const int32_t *rowptr, const int32_t *colind, const void *val, const void *x, void *out,
                           int64_t m, int64_t k, int64_t nnz, int dtype, int acc_mode, void *ws, size_t wsb,
-                          void *stream) {
+                          void *stream, const int32_t *row_order = nullptr) {
     int rc = check_args(rowptr, x, out, m, k, nnz);
     if (rc != COGDL_HIP_OK || m == 0 || k == 0) return rc;
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
-        case COGDL_HIP_F32: return spmm_typed<float>(rowptr, colind, val, x, out, m, k, nnz, acc_mode, ws, wsb, s);
-        case COGDL_HIP_F16: return spmm_typed<__half>(rowptr, colind, val, x, out, m, k, nnz, acc_mode, ws, wsb, s);
+        case COGDL_HIP_F32: return spmm_typed<float>(rowptr, colind, val, x, out, m, k, nnz, acc_mode, ws, wsb, s, row_order);
+        case COGDL_HIP_F16: return spmm_typed<__half>(rowptr, colind, val, x, out, m, k, nnz, acc_mode, ws, wsb, s, row_order);
         case COGDL_HIP_BF16:
-            return spmm_typed<__hip_bfloat16>(rowptr, colind, val, x, out, m, k, nnz, acc_mode, ws, wsb, s);
+            return spmm_typed<__hip_bfloat16>(rowptr, colind, val, x, out, m, k, nnz, acc_mode, ws, wsb, s, row_order);
         default: return COGDL_HIP_EDTYPE;
     }
 }
@@ -217,6 +219,18 @@ extern "C" size_t cogdl_hip_csr_spmm_i64_workspace_bytes(const cogdl_hip_segment
 extern "C" int cogdl_hip_csr_spmm_i64(const int32_t *rowptr32, const cogdl_hip_segments *seg, const int32_t *colind,
                                       const void *val, const void *x, void *out, int64_t k, int dtype, void *workspace,
                                       size_t workspace_bytes, void *stream) {
+    return cogdl_hip_csr_spmm_i64_ordered(rowptr32, seg, colind, val, x, out, k, dtype, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cogdl_hip_csr_spmm_ordered(const int32_t *rowptr, const int32_t *colind, const void *val, const void *x,
+                                          void *out, int64_t m, int64_t k, int64_t nnz, int dtype, const int32_t *row_order,
+                                          void *workspace, size_t workspace_bytes, void *stream) {
+    return csr_spmm_entry(rowptr, colind, val, x, out, m, k, nnz, dtype, 0, workspace, workspace_bytes, stream, row_order);
+}
+
+extern "C" int cogdl_hip_csr_spmm_i64_ordered(const int32_t *rowptr32, const cogdl_hip_segments *seg, const int32_t *colind,
+                                              const void *val, const void *x, void *out, int64_t k, int dtype,
+                                              const int32_t *row_order, void *workspace, size_t workspace_bytes, void *stream) {
     int rc = segments_valid(seg);
     if (rc != COGDL_HIP_OK) return rc;
     if (k < 0) return COGDL_HIP_EINVAL;
@@ -226,7 +240,7 @@ extern "C" int cogdl_hip_csr_spmm_i64(const int32_t *rowptr32, const cogdl_hip_s
         const int64_t r0 = seg->row[s], e0 = seg->edge[s];
         rc = csr_spmm_entry(rowptr32 + r0 + s, colind ? colind + e0 : nullptr, val ? (const char *)val + (size_t)e0 * es : nullptr, x,
                             out ? (char *)out + (size_t)r0 * (size_t)k * es : nullptr, seg->row[s + 1] - r0, k,
-                            seg->edge[s + 1] - e0, dtype, 0, workspace, workspace_bytes, stream);
+                            seg->edge[s + 1] - e0, dtype, 0, workspace, workspace_bytes, stream, row_order ? row_order + r0 : nullptr);
         if (rc != COGDL_HIP_OK) return rc;
     }
     return COGDL_HIP_OK;

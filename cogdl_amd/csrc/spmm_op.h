@@ -179,6 +179,7 @@ struct SpmmArgs {
     const int32_t *eid;
     SpmmEpilogue epi;
     const cogdl_hip_vrows *vr = nullptr;  // XCD-partitioned plan (rowreduce.h): rowptr / colind are then unused
+    const int32_t *row_order = nullptr;   // ordinary launch: the row blocks' schedule (rowreduce.h: RowSched::order)
 };
 
 template <typename T, int VEC, int LPR, int UNROLL, int WMODE, bool EXACT, bool EPI = false>
@@ -198,7 +199,7 @@ static int launch_spmm(const SpmmArgs<T> &a, void *ws, size_t wsb, hipStream_t s
             } else return COGDL_HIP_EUNSUPPORTED;
         }
         SpmmOp<T, VEC, LPR, UNROLL, WMODE, EXACT, EPI> op{a.val, a.att, a.x, a.out, a.k, a.fdim, a.acc_mode, a.eid, a.epi};
-        return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, tiles, ws, wsb, s);
+        return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, tiles, ws, wsb, s, a.row_order);
     }
 }
 

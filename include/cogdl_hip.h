@@ -189,6 +189,19 @@ COGDL_API size_t cogdl_hip_csr_spmm_i64_workspace_bytes(const cogdl_hip_segments
 COGDL_API int cogdl_hip_csr_spmm_i64(const int32_t *rowptr32, const cogdl_hip_segments *seg, const int32_t *colind,
                                      const void *val, const void *x, void *out, int64_t k, int dtype, void *workspace,
                                      size_t workspace_bytes, void *stream);
+/* The same with a plan-time ROW SCHEDULE (round 6; no reference counterpart: spmm_kernel.cu walks rows in id order).
+ * row_order: [m] int32, a permutation of 0 .. m-1 (for the segmented form: per segment a permutation of the segment's LOCAL
+ * row ids 0 .. rows-1, stored at row_order[row[s] ..]); row block b of the launch walks rows row_order[b * G ..] instead of
+ * b * G .. -- e.g. rows by decreasing degree inside windows, so that the lane groups of a wave carry rows of one length.
+ * Every row is still reduced by one lane group in CSR order and written to its own place: results are those of the
+ * unordered call bit for bit.  NULL = id order.  The entries are not validated (a plan-time artefact of the caller, like
+ * colind: an id outside [0, m) reads out of bounds). */
+COGDL_API int cogdl_hip_csr_spmm_ordered(const int32_t *rowptr, const int32_t *colind, const void *val, const void *x,
+                                         void *out, int64_t m, int64_t k, int64_t nnz, int dtype, const int32_t *row_order,
+                                         void *workspace, size_t workspace_bytes, void *stream);
+COGDL_API int cogdl_hip_csr_spmm_i64_ordered(const int32_t *rowptr32, const cogdl_hip_segments *seg, const int32_t *colind,
+                                             const void *val, const void *x, void *out, int64_t k, int dtype,
+                                             const int32_t *row_order, void *workspace, size_t workspace_bytes, void *stream);
 /* csr_sddmm over all segments (d1: [row[n], k], d2: [n_src, k], out: [edge[n]] fp32). */
 COGDL_API int cogdl_hip_csr_sddmm_i64(const int32_t *rowptr32, const cogdl_hip_segments *seg, const int32_t *colind,
                                       const float *d1, const float *d2, float *out, int64_t k, void *stream);

@@ -198,6 +198,44 @@ def test_sym_flag_saves_the_transpose_only_for_matrices_that_pass_the_symmetry_t
         clear_plans()
 
 
+def test_row_schedule_is_a_permutation_per_segment_and_changes_no_bit(monkeypatch):
+    """cogdl_hip_csr_spmm_i64_ordered / cogdl_hip_csr_spmm_ordered: the plan's row schedule (decreasing degree inside windows)
+    is per segment a permutation of the segment's local row ids; results equal the unordered launch bit for bit -- also for an
+    arbitrary permutation through the 32-bit entry."""
+    import cogdl_amd.bigcsr as bc
+
+    g = synth.hub_csr(3000, 2500, base_deg=6, seed=3)
+    x = rand(g.n_cols, 40, seed=1).to(DEV)
+    w = g.weight.to(DEV)
+    monkeypatch.setattr(bc, "ROW_WINDOW", 256)
+    plan = big(g, 700)
+    assert plan.n_segments > 5 and plan.row_order is not None
+    rows = plan.segment_rows()
+    order = plan.row_order.cpu().numpy()
+    deg = g.degrees().numpy()
+    for s in range(plan.n_segments):
+        loc = order[rows[s]:rows[s + 1]]
+        assert np.array_equal(np.sort(loc), np.arange(rows[s + 1] - rows[s]))
+        d = deg[rows[s]:rows[s + 1]][loc]
+        for w0 in range(0, len(d), 256):  # decreasing inside every window, windows in place
+            assert np.all(np.diff(d[w0:w0 + 256]) <= 0) and np.all(loc[w0:w0 + 256] // 256 == w0 // 256)
+    out = plan.spmm(w, x)
+    monkeypatch.setattr(bc, "ORDER_ROWS", False)
+    plain = big(g, 700)
+    assert plain.row_order is None and torch.equal(plain.spmm(w, x), out)
+    # 32-bit entry, an arbitrary permutation
+    lib = _lib.hip()
+    rowptr, colind = g.rowptr.to(DEV), g.colind.to(DEV)
+    perm = torch.randperm(g.num_nodes, generator=torch.Generator().manual_seed(4)).int().to(DEV)
+    ws_bytes = lib.cogdl_hip_csr_spmm_workspace_bytes(g.nnz, 40, 0)
+    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=DEV)
+    got = torch.empty(g.num_nodes, 40, device=DEV)
+    rc = lib.cogdl_hip_csr_spmm_ordered(rowptr.data_ptr(), colind.data_ptr(), w.data_ptr(), x.data_ptr(), got.data_ptr(), g.num_nodes,
+                                        40, g.nnz, 0, perm.data_ptr(), ws.data_ptr(), ws_bytes, None)
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(got, csr_spmm_raw(rowptr, colind, w, x))
+
+
 def test_malformed_row_pointers_are_rejected_at_plan_time():
     """rowptr[0] != 0 or a decreasing rowptr would rebase to negative / wrapped 32-bit pointers."""
     col = torch.zeros(6, dtype=torch.int32, device=DEV)

@@ -64,11 +64,21 @@ def arxiv():
     for topo in ("uniform", "rmat"):
         g = synth.arxiv_like(seed=0, topology=topo).to(DEV)
         n, nnz = g.num_nodes, g.nnz
+        from cogdl_amd import _lib, xcdplan
+        from cogdl_amd.operators.spmm import csr_spmm_xcd_raw
+        # the launch a SKEWED structure takes once its fingerprint is known (xcdplan.ordered_wanted): virtual rows by length
+        xplan = xcdplan.build(g.rowptr, g.colind, split=int(_lib.hip().cogdl_hip_exact_row_edges(nnz))) if topo == "rmat" else None
         for f in (40, 64, 128, 256):
             x = torch.randn(n, f, device=DEV)
             cfg = "arxiv-%s F=%d f32" % (topo, f)
             report("csr_spmm", cfg, timeit(lambda: csr_spmm_raw(g.rowptr, g.colind, g.weight, x)),
                    nnz * (8 + f * 4) + n * (4 + f * 4), nnz)
+            if xplan is not None:
+                report("csr_spmm (plan: rows by length)", cfg, timeit(lambda: csr_spmm_xcd_raw(xplan, g.weight, x)),
+                       nnz * (8 + f * 4) + n * (4 + f * 4), nnz)
+                xb16, wb16 = x.bfloat16(), g.weight.bfloat16()
+                report("csr_spmm (plan: rows by length)", "arxiv-%s F=%d bf16" % (topo, f),
+                       timeit(lambda: csr_spmm_xcd_raw(xplan, wb16, xb16)), nnz * (6 + f * 2) + n * (4 + f * 2), nnz)
             if f in (64, 128):
                 from cogdl_amd.operators.spmm import csr_spmm_epilogue_raw
                 on, inn = torch.rand(n, 1, device=DEV) + 0.5, torch.rand(n, 1, device=DEV) + 0.5
