@@ -100,7 +100,7 @@ HIP_SIGNATURES = {
     "cogdl_hip_csr_rebase_rowptr": ([_vp, _vp, _vp, _vp], _i32),
     "cogdl_hip_csr_spmm_i64_workspace_bytes": ([_vp, _i64, _i32], _sz),
     "cogdl_hip_csr_spmm_i64": ([_vp] * 6 + [_i64, _i32, _vp, _sz, _vp], _i32),
-    "cogdl_hip_csr_spmm_ordered": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _vp, _vp, _sz, _vp], _i32),
+    "cogdl_hip_csr_spmm_ordered": ([_vp] * 5 + [_i64, _i64, _i64, _i32, _i32, _vp, _vp, _sz, _vp], _i32),
     "cogdl_hip_csr_spmm_i64_ordered": ([_vp] * 6 + [_i64, _i32, _vp, _vp, _sz, _vp], _i32),
     "cogdl_hip_csr_sddmm_i64": ([_vp] * 6 + [_i64, _vp], _i32),
     "cogdl_hip_csr2csc_i64_workspace_bytes": ([_vp, _i64], _sz),

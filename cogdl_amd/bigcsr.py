@@ -31,6 +31,17 @@ ORDER_ROWS = os.environ.get("COGDL_AMD_ROW_ORDER", "1") != "0"
 ROW_WINDOW = 1 << 16
 
 
+def window_degree_order(rowptr, window=None):
+    """int32 permutation of the rows of `rowptr` (any integer dtype, device tensor): decreasing degree inside windows of
+    `window` rows (default ROW_WINDOW), windows in place."""
+    window = ROW_WINDOW if window is None else int(window)
+    m = rowptr.numel() - 1
+    deg = (rowptr[1:] - rowptr[:-1]).long()
+    top = int(deg.max()) + 1 if m else 1
+    key = (torch.arange(m, device=rowptr.device) // window) * top + (top - 1 - deg)
+    return torch.argsort(key, stable=True).int()
+
+
 class BigCsr:
     """Plan of one 64-bit CSR structure: segment cuts + rebased int32 row pointers + the row schedule (device)."""
 
@@ -69,11 +80,7 @@ class BigCsr:
             r0, r1 = rows[s], rows[s + 1]
             if r1 <= r0:
                 continue
-            deg = self.rowptr[r0 + 1:r1 + 1] - self.rowptr[r0:r1]
-            top = int(deg.max()) + 1
-            key = (torch.arange(r1 - r0, device=dev) // ROW_WINDOW) * top + (top - 1 - deg)
-            order[r0:r1] = torch.argsort(key, stable=True).int()
-            del deg, key
+            order[r0:r1] = window_degree_order(self.rowptr[r0:r1 + 1])
         return order
 
     @property

@@ -223,9 +223,9 @@ extern "C" int cogdl_hip_csr_spmm_i64(const int32_t *rowptr32, const cogdl_hip_s
 }
 
 extern "C" int cogdl_hip_csr_spmm_ordered(const int32_t *rowptr, const int32_t *colind, const void *val, const void *x,
-                                          void *out, int64_t m, int64_t k, int64_t nnz, int dtype, const int32_t *row_order,
-                                          void *workspace, size_t workspace_bytes, void *stream) {
-    return csr_spmm_entry(rowptr, colind, val, x, out, m, k, nnz, dtype, 0, workspace, workspace_bytes, stream, row_order);
+                                          void *out, int64_t m, int64_t k, int64_t nnz, int dtype, int acc,
+                                          const int32_t *row_order, void *workspace, size_t workspace_bytes, void *stream) {
+    return csr_spmm_entry(rowptr, colind, val, x, out, m, k, nnz, dtype, acc ? 1 : 0, workspace, workspace_bytes, stream, row_order);
 }
 
 extern "C" int cogdl_hip_csr_spmm_i64_ordered(const int32_t *rowptr32, const cogdl_hip_segments *seg, const int32_t *colind,

@@ -39,9 +39,10 @@ def _check_csr(rowptr, colind, x):
         raise _lib.BackendError("unsupported dtype %s" % x.dtype)
 
 
-def csr_spmm_raw(rowptr, colind, val, x, variant=-1, out=None, split_long_rows=True):
+def csr_spmm_raw(rowptr, colind, val, x, variant=-1, out=None, split_long_rows=True, row_order=None):
     """One cogdl_hip_csr_spmm launch on the current stream (no autograd).  With `out` given the result is
-    accumulated into it (out += A x, cogdl_hip_csr_spmm_acc)."""
+    accumulated into it (out += A x, cogdl_hip_csr_spmm_acc).  row_order: an int32 permutation of the rows, the row blocks'
+    schedule (cogdl_hip_csr_spmm_ordered; same results bit for bit)."""
     dev = _lib.require_cuda(rowptr, colind, val, x)
     _check_csr(rowptr, colind, x)
     x = x.contiguous()
@@ -67,7 +68,13 @@ def csr_spmm_raw(rowptr, colind, val, x, variant=-1, out=None, split_long_rows=T
         if KERNEL_EVENTS is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        if acc:
+        if row_order is not None:
+            if row_order.dtype != torch.int32 or row_order.numel() != m or not row_order.is_contiguous():
+                raise _lib.BackendError("row_order must be a contiguous int32 permutation of the %d rows" % m)
+            rc = lib.cogdl_hip_csr_spmm_ordered(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(val), _lib.ptr(x), _lib.ptr(out), m, k,
+                                                nnz, code, 1 if acc else 0, _lib.ptr(row_order), _lib.ptr(ws), ws_bytes,
+                                                _lib.stream_of(x))
+        elif acc:
             rc = lib.cogdl_hip_csr_spmm_acc(_lib.ptr(rowptr), _lib.ptr(colind), _lib.ptr(val), _lib.ptr(x),
                                             _lib.ptr(out), m, k, nnz, code, _lib.ptr(ws), ws_bytes,
                                             _lib.stream_of(x))

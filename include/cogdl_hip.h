@@ -197,8 +197,8 @@ COGDL_API int cogdl_hip_csr_spmm_i64(const int32_t *rowptr32, const cogdl_hip_se
  * unordered call bit for bit.  NULL = id order.  The entries are not validated (a plan-time artefact of the caller, like
  * colind: an id outside [0, m) reads out of bounds). */
 COGDL_API int cogdl_hip_csr_spmm_ordered(const int32_t *rowptr, const int32_t *colind, const void *val, const void *x,
-                                         void *out, int64_t m, int64_t k, int64_t nnz, int dtype, const int32_t *row_order,
-                                         void *workspace, size_t workspace_bytes, void *stream);
+                                         void *out, int64_t m, int64_t k, int64_t nnz, int dtype, int acc /* != 0: out += A x */,
+                                         const int32_t *row_order, void *workspace, size_t workspace_bytes, void *stream);
 COGDL_API int cogdl_hip_csr_spmm_i64_ordered(const int32_t *rowptr32, const cogdl_hip_segments *seg, const int32_t *colind,
                                              const void *val, const void *x, void *out, int64_t k, int dtype,
                                              const int32_t *row_order, void *workspace, size_t workspace_bytes, void *stream);

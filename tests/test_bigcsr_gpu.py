@@ -231,7 +231,7 @@ def test_row_schedule_is_a_permutation_per_segment_and_changes_no_bit(monkeypatc
     ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=DEV)
     got = torch.empty(g.num_nodes, 40, device=DEV)
     rc = lib.cogdl_hip_csr_spmm_ordered(rowptr.data_ptr(), colind.data_ptr(), w.data_ptr(), x.data_ptr(), got.data_ptr(), g.num_nodes,
-                                        40, g.nnz, 0, perm.data_ptr(), ws.data_ptr(), ws_bytes, None)
+                                        40, g.nnz, 0, 0, perm.data_ptr(), ws.data_ptr(), ws_bytes, None)
     torch.cuda.synchronize()
     assert rc == 0 and torch.equal(got, csr_spmm_raw(rowptr, colind, w, x))
 
