@@ -118,10 +118,13 @@ class FusedGATFunction(torch.autograd.Function):
         ok = feat.dim() == 3 and feat.dtype in _lib.DTYPE_CODE
         row_bytes = feat.shape[1] * fp * feat.element_size() if ok else 0
         ctx.xcd = ok and xcdplan.wanted(row_ptr.numel() - 1, col_ind.numel(), feat.shape[0], row_bytes)
-        if ok and not ctx.xcd and getattr(row_ptr, "_cogdl_amd_struct", None) is not None and ctx.fp.event is not None:
-            # a memoised fingerprint (install(structure_memo=True)): skewed structures of any size (xcdplan.ordered_wanted)
-            ctx.fp.key()
-            ctx.xcd = xcdplan.ordered_wanted(ctx.fp, row_ptr, row_ptr.numel() - 1, col_ind.numel(), feat.shape[0], row_bytes)
+        if ok and not ctx.xcd:
+            # a memoised fingerprint (install(structure_memo=True), or the identity memo of plan.fingerprint_of once a backward
+            # pass has asked for its key): skewed structures of any size (xcdplan.ordered_wanted)
+            if getattr(row_ptr, "_cogdl_amd_struct", None) is not None and ctx.fp.event is not None:
+                ctx.fp.key()
+            if ctx.fp._key is not None:
+                ctx.xcd = xcdplan.ordered_wanted(ctx.fp, row_ptr, row_ptr.numel() - 1, col_ind.numel(), feat.shape[0], row_bytes)
         xplan = xcdplan.csr_plan(ctx.fp, row_ptr, col_ind) if ctx.xcd else None
         # (a shape the plan's forward declines -- column tiles -- keeps the ordinary backward too)
         if xplan is not None:

@@ -171,15 +171,21 @@ class SPMMFunction(torch.autograd.Function):
         rowptr, colind = _lib.csr_structure(rowptr, colind)  # validated + contiguous before anything reads raw pointers
         ctx.transient = _plan.transient()  # (the dense operand is checked by csr_spmm_raw)
         ctx.xcd = _xcd_split(rowptr, colind, feat)
-        ctx.fp = (fingerprint_of(rowptr, colind, feat.shape[0])
-                  if (ctx.needs_input_grad[2] or ctx.xcd is not None or getattr(rowptr, "_cogdl_amd_struct", None) is not None)
-                  and not ctx.transient else None)
-        if ctx.xcd is None and ctx.fp is not None and getattr(rowptr, "_cogdl_amd_struct", None) is not None:
+        memo = getattr(rowptr, "_cogdl_amd_struct", None) is not None
+        if ctx.transient:
+            ctx.fp = None
+        elif ctx.needs_input_grad[2] or ctx.xcd is not None or memo:
+            ctx.fp = fingerprint_of(rowptr, colind, feat.shape[0])
+        else:
+            ctx.fp = _plan.known_fingerprint(rowptr, colind, feat.shape[0])  # (never hashes: inference calls stay as they were)
+        if ctx.xcd is None and ctx.fp is not None:
             # a memoised fingerprint (install(structure_memo=True)): its key costs ONE wait per structure, after which skewed
-            # structures of any size take a plan -- deterministically, from the first call on
-            if ctx.fp.event is not None:
+            # structures of any size take a plan -- deterministically, from the first call on.  The identity memo (the same
+            # index tensor objects as an earlier call, plan.fingerprint_of) has its key once a backward pass has asked for it.
+            if memo and ctx.fp.event is not None:
                 ctx.fp.key()
-            ctx.xcd = _xcd_split(rowptr, colind, feat, ctx.fp)
+            if ctx.fp._key is not None:
+                ctx.xcd = _xcd_split(rowptr, colind, feat, ctx.fp)
         if ctx.xcd is not None:
             out = csr_spmm_xcd_raw(xcdplan.csr_plan(ctx.fp, rowptr, colind, ctx.xcd), edge_weight_csr, feat)
         else:

@@ -327,6 +327,31 @@ def test_skewed_structures_of_any_size_take_a_plan_once_their_fingerprint_is_kno
     xcdplan._SKEW.clear()
 
 
+def test_identity_memo_of_fingerprints():
+    """plan.fingerprint_of: the very same index tensor OBJECTS are hashed once; an in-place edit, a clone or other objects with
+    the same contents are hashed again (and agree on the key); known_fingerprint never hashes."""
+    from cogdl_amd import plan as _plan
+
+    _plan.clear_identity_memo()
+    g = synth.random_csr(500, 400, 6, seed=1)
+    rowptr, colind = g.rowptr.to(DEV), g.colind.to(DEV)
+    assert _plan.known_fingerprint(rowptr, colind, 400) is None
+    fp = _plan.fingerprint_of(rowptr, colind, 400)
+    assert _plan.fingerprint_of(rowptr, colind, 400) is fp and _plan.known_fingerprint(rowptr, colind, 400) is fp
+    assert _plan.fingerprint_of(rowptr, colind, 401) is not fp  # another column count: another key
+    other = _plan.fingerprint_of(rowptr.clone(), colind.clone(), 400)
+    assert other is not fp and other.key() == fp.key()
+    colind[0] = (int(colind[0]) + 1) % 400  # in place: the version counter moves, the memo misses, the key changes
+    fp2 = _plan.fingerprint_of(rowptr, colind, 400)
+    assert fp2 is not fp and fp2.key() != fp.key()
+    del rowptr, colind
+    import gc
+
+    gc.collect()
+    assert all(h[0]() is None or h[1]() is not None for h in _plan._IDENT.values())  # weak references: nothing kept alive
+    _plan.clear_identity_memo()
+
+
 def test_wanted_rule():
     xcdplan.MODE = "auto"
     n, nnz = synth.REDDIT_NODES, 114_848_857
