@@ -26,9 +26,12 @@ from .plan import tensor_key
 # gathers in flight.  Windows keep the row pointer / output traffic of concurrently running workgroups together.  Measured on
 # one eighth of the papers100M-shaped symmetrised graph (X = 7.1 GB; rows physically re-ordered, tools/exp/papers_order_ab.py,
 # profiles/r06_papers_order_ab.txt): F = 128 fp32 42.8 -> 38.5 ms (0.635 -> 0.705 of 8 TB/s), whole-graph degree order 39.4 ms.
+# At full size (3.2e9 edges, profiles/r06_papers_row_order.txt, r06_papers_sweep.txt): symmetrised forward 352 -> 292 ms; by window
+# size 4096: 347 ms, 16384: 322, 65536: 292, 262144: 291, 2^20: 308, whole segment: 300; the long-row threshold (512) re-swept
+# under the schedule: 256: 316 ms, 1024 / 2048: 293.
 # Results are bit-identical (a row is still one lane group's sequential sum).  COGDL_AMD_ROW_ORDER=0 switches it off.
 ORDER_ROWS = os.environ.get("COGDL_AMD_ROW_ORDER", "1") != "0"
-ROW_WINDOW = 1 << 16
+ROW_WINDOW = int(os.environ.get("COGDL_AMD_ROW_WINDOW", 1 << 16))
 
 
 def window_degree_order(rowptr, window=None):
