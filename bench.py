@@ -256,8 +256,8 @@ def rmat_roofline(dev, feats=(128, 64, 40)):
     g = synth.arxiv_like(seed=0, topology="rmat")
     gd = g.to(dev)
     out = {"topology": "arxiv-sized R-MAT (a=.57,b=.19,c=.19), nnz=%d, max degree %d" % (g.nnz, int(g.degrees().max())),
-           "what": "kernel_ms / frac: the launch a skewed structure takes once its fingerprint is on the host (every backward "
-                   "pass; forward calls under install(structure_memo=True)) -- cogdl_hip_csr_spmm_xcd over a plan cut at the "
+           "what": "kernel_ms / frac: the launch a skewed structure takes once its fingerprint is on the host (backward "
+                   "passes from the second sighting on; forward calls under install(structure_memo=True) or with the same index tensors) -- cogdl_hip_csr_spmm_xcd over a plan cut at the "
                    "exact-row bound, virtual rows in order of length (cogdl_amd/xcdplan.py: ordered_wanted); "
                    "ordinary_kernel_ms / frac_ordinary: cogdl_hip_csr_spmm (a forward call whose structure hash is still in "
                    "flight).  Rows up to the exact-row bound are bit-identical in both.  Fractions above 1: the 27-87 MB "

@@ -26,7 +26,7 @@ from . import _lib
 
 class CscPlan:
     __slots__ = ("colptr", "rowind", "perm", "m", "n_cols", "nnz", "_val_key", "_val_src", "_val_t",
-                 "_max_col_degree", "ready", "_ws")
+                 "_max_col_degree", "ready", "_ws", "sightings")
 
     def __init__(self, colptr, rowind, perm, m, n_cols, nnz):
         self.colptr, self.rowind, self.perm = colptr, rowind, perm
@@ -34,6 +34,7 @@ class CscPlan:
         self._val_key, self._val_src, self._val_t = None, None, None
         self._max_col_degree = None
         self.ready, self._ws = None, None  # (csr2csc(stream=...): the event to wait for, the workspace kept until then)
+        self.sightings = 1  # cache look-ups that found this structure (PlanCache._lookup): > 1 = a structure that comes back
 
     def has_hub_columns(self):
         """Does A^T have rows beyond the long-row threshold?  (One reduction + sync, once per plan.)  When it does not,
@@ -385,6 +386,7 @@ class PlanCache:
         if plan is not None:
             self.lru.move_to_end(key)
             self.hits += 1
+            plan.sightings += 1
             if VERIFY_HITS:
                 verify_plan(plan, rowptr, colind)
             return plan

@@ -189,7 +189,8 @@ _SKEW = {}
 
 def ordered_wanted(fp, rowptr, m, nnz, n_src, row_bytes):
     """The second way into a plan (round 6): a SKEWED structure of any size whose fingerprint is ALREADY KNOWN on the host --
-    memoised with the Graph (install(structure_memo=True)), or a backward pass, which has waited for the hash anyway.  What a
+    memoised with the Graph (install(structure_memo=True)) or by tensor identity (plan.fingerprint_of), or a backward pass, which
+    has waited for the hash anyway (the operators take it from the structure's second sighting on: plan.CscPlan.sightings).  What a
     plan buys there is its slot order: an XCD's virtual rows by decreasing length, so that the lane groups of a wave walk rows
     of one length, and hub rows as pieces merged by rowreduce_vcombine_kernel.  Measured on the arxiv-sized R-MAT graph (max
     degree 10^4; tools/exp/small_plan_ab.py, profiles/r06_small_plan_ab.txt), ordinary launch -> plan cut at the exact-row

@@ -301,11 +301,19 @@ def test_skewed_structures_of_any_size_take_a_plan_once_their_fingerprint_is_kno
         gout = torch.randn(g.num_nodes, 40, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
         plain = csr_spmm_raw(rowptr, colind, w, x.detach())
         del calls[:]
-        out = SPMMFunction.apply(rowptr, colind, x, w, False)  # fresh tensors: the hash is in flight, the forward stays ordinary
+        out = SPMMFunction.apply(rowptr.clone(), colind.clone(), x, w, False)  # fresh tensors: the hash is in flight, the forward stays ordinary
         assert not calls and torch.equal(out, plain)
         out.backward(gout)
-        assert len(calls) == (1 if expect else 0), topo
+        assert not calls  # first sighting of the structure: a one-off structure must not pay a plan build
+        gx_plain = x.grad.clone()
+        x.grad = None
+        out = SPMMFunction.apply(rowptr.clone(), colind.clone(), x, w, False)  # (new objects again: no identity memo)
+        assert not calls and torch.equal(out, plain)
+        out.backward(gout)
+        assert len(calls) == (1 if expect else 0), topo  # second sighting: the transpose's plan
         gx_first = x.grad.clone()
+        scale_t = gx_plain.abs().max()
+        assert bool(((gx_first - gx_plain).abs() <= 2e-5 * scale_t).all())
         # ... memoised structure: both directions
         memo = StructureMemo()
         memo.rowptr32, memo.colind32 = rowptr, colind
