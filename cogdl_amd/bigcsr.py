@@ -42,7 +42,19 @@ def window_degree_order(rowptr, window=None):
     deg = (rowptr[1:] - rowptr[:-1]).long()
     top = int(deg.max()) + 1 if m else 1
     key = (torch.arange(m, device=rowptr.device) // window) * top + (top - 1 - deg)
-    return torch.argsort(key, stable=True).int()
+    order = torch.argsort(key, stable=True)
+    mode = os.environ.get("COGDL_AMD_ROW_SCHED", "desc")  # experiments: "asc", "mix" (tools/exp/papers_sweep2.sh)
+    if mode == "asc":
+        key = (torch.arange(m, device=rowptr.device) // window) * top + deg
+        order = torch.argsort(key, stable=True)
+    elif mode == "mix" and m >= 2 * window:
+        # inside every full window: blocks of 8 rows taken alternately from the long and from the short half
+        full = (m // window) * window
+        o = order[:full].view(-1, window // 8, 8)
+        half = o.shape[1] // 2
+        mixed = torch.stack([o[:, :half], o[:, half:2 * half]], dim=2).reshape(o.shape[0], -1, 8)
+        order = torch.cat([mixed.reshape(-1), order[full:]])
+    return order.int()
 
 
 class BigCsr:
