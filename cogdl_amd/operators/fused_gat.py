@@ -158,7 +158,7 @@ class FusedGATFunction(torch.autograd.Function):
         # (the structure's key is known by now -- PLANS.get has waited for the hash: a skewed structure takes the plans in
         #  backward whether or not its forward call could)
         #  -- from the structure's second sighting on: a one-off structure must not pay the plan builds)
-        if ctx.xcd or (plan.sightings > 1 and
+        if ctx.xcd or (getattr(plan, "sightings", 1) > 1 and
                        xcdplan.ordered_wanted(ctx.fp, row_ptr, v, col_ind.numel(), n_src, h * fp * feat.element_size())):
             xr, xc = xcdplan.csr_plan(ctx.fp, row_ptr, col_ind), xcdplan.csc_plan(ctx.fp, plan)
             ws, ws_bytes = _lib.workspace("cogdl_hip_gat_bwd_xcd_workspace_bytes", dev, v, h, fp, xr.n_parts, xc.n_parts, code)

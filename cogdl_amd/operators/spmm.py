@@ -211,7 +211,7 @@ class SPMMFunction(torch.autograd.Function):
                 # (the key is known here -- PLANS.get has waited for the hash: the transpose of a skewed structure takes a plan
                 #  whether or not the forward call could -- from its SECOND sighting on: a structure that never comes back, a
                 #  sampled block passed without plan.transient_structures(), must not pay a plan build of milliseconds)
-                split_t = _xcd_split(plan.colptr, plan.rowind, grad_out, ctx.fp if (ctx.xcd is not None or plan.sightings > 1) else None)
+                split_t = _xcd_split(plan.colptr, plan.rowind, grad_out, ctx.fp if (ctx.xcd is not None or getattr(plan, "sightings", 1) > 1) else None)
                 if split_t is not None:
                     # (w stays in CSR order: the plan of the transpose maps its positions through the transpose's perm)
                     grad_feat = csr_spmm_xcd_raw(xcdplan.csc_plan(ctx.fp, plan, split_t), w, grad_out)

@@ -386,7 +386,7 @@ class PlanCache:
         if plan is not None:
             self.lru.move_to_end(key)
             self.hits += 1
-            plan.sightings += 1
+            plan.sightings = getattr(plan, "sightings", 1) + 1
             if VERIFY_HITS:
                 verify_plan(plan, rowptr, colind)
             return plan
