@@ -198,10 +198,11 @@ struct GatFwdOp {
     int heads, fdim;
     GatDrop drop;
     struct Ctx {
-        int col0, cc, hd, l;
+        int col0, cc, hd, l, sub;
         bool col_ok;
         float ar;
         ChunkScalars<ACH> cs;
+        DropLane<DROP> lv;
     };
     struct State {
         float acc[VEC];
@@ -211,7 +212,6 @@ struct GatFwdOp {
     struct Batch {
         float v[UNROLL][VEC];
         float ac[UNROLL];
-        float d[DROP ? UNROLL : 1];
     };
 
     __device__ __forceinline__ Ctx make_ctx(int l, int tile) const {
@@ -241,13 +241,14 @@ struct GatFwdOp {
                                           int jj) const {
         if constexpr (ACH == 0) b.ac[u] = *gather_row<A24>(attn_col, c.hd, col, (uint32_t)heads * 4u);
         load_vec<T, VEC>(gather_row<A24>(feat, c.cc, col, (uint32_t)(heads * fdim) * (uint32_t)sizeof(T)), b.v[u]);
-        if constexpr (DROP) b.d[u] = drop_factor<LPR>(drop, lv, sub, jj, c.hd, heads);
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
                                           int jpos) const {
         if constexpr (ACH > 0) {
             if (jpos == 0) chunk_scalars_park<ACH, LPR>(c.cs, c.l);
         }
+        float d_u = 1.f;
+        if constexpr (DROP) d_u = drop_factor<LPR>(drop, c.lv, c.sub, jpos & (LPR - 1), c.hd, heads);
         if (valid) {
             float ac_u;
             if constexpr (ACH > 0) ac_u = chunk_scalars_row<ACH, LPR>(c.cs, jpos)[ACH == 1 ? 0 : c.hd];
@@ -264,7 +265,7 @@ struct GatFwdOp {
             const bool up = dlt > 0.f;
             const float t = gat_exp(-fabsf(dlt));  // (|.| and the sign are operand modifiers of the multiply in front of v_exp)
             const float p = up ? 1.f : t;
-            const float pw = DROP ? p * b.d[DROP ? u : 0] : p;
+            const float pw = DROP ? p * d_u : p;
             if (__ballot(up) != 0ull) {
                 const float scale = up ? t : 1.f;
                 s.lsum *= scale;
@@ -278,8 +279,10 @@ struct GatFwdOp {
         }
     }
     __device__ __forceinline__ void chunk_begin(Ctx &c, State &, int, int, int my_c, int sub, int, float *lds,
-                                                const LaneVals &) const {
+                                                const LaneVals &lv) const {
         chunk_scalars_load<ACH, A24>(c.cs, attn_col, my_c, sub, lds);
+        c.lv = lv;
+        c.sub = sub;
     }
     __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
@@ -531,8 +534,9 @@ struct GatBwdRowOp {
         GatBwdLane m;
         float g[VEC];
         float d, ar, nml, inv, slope_v;
-        int l;
+        int l, sub;
         ChunkScalars<ACH> cs;
+        DropLane<DROP> lv;
     };
     // grad_attn_row[v,h] = sum_e c_e (d_e <g, feat[col_e]> - D) with c_e = a_e * LeakyReLU'(.)
     //                    = < g, sum_e c_e d_e feat[col_e] >  -  D * sum_e c_e :
@@ -546,7 +550,6 @@ struct GatBwdRowOp {
     struct Batch {
         float v[UNROLL][VEC];
         float ac[UNROLL];
-        float d[DROP ? UNROLL : 1];
     };
 
     __device__ __forceinline__ Ctx make_ctx(int l, int tile) const {
@@ -591,13 +594,14 @@ struct GatBwdRowOp {
                                           int jj) const {
         if constexpr (ACH == 0) b.ac[u] = *gather_row<A24>(attn_col, c.m.hd, col, (uint32_t)heads * 4u);
         load_vec<T, VEC>(gather_row<A24>(feat, c.m.cc, col, (uint32_t)(heads * fdim) * (uint32_t)sizeof(T)), b.v[u]);
-        if constexpr (DROP) b.d[u] = drop_factor<LPR>(drop, lv, sub, jj, c.m.hd, heads);
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
                                           int jpos) const {
         if constexpr (ACH > 0) {
             if (jpos == 0) chunk_scalars_park<ACH, LPR>(c.cs, c.l);
         }
+        float d_u = 1.f;
+        if constexpr (DROP) d_u = drop_factor<LPR>(drop, c.lv, c.sub, jpos & (LPR - 1), c.m.hd, heads);
         if (valid) {
             float ac_u;
             if constexpr (ACH > 0) ac_u = chunk_scalars_row<ACH, LPR>(c.cs, jpos)[ACH == 1 ? 0 : c.m.hd];
@@ -606,15 +610,17 @@ struct GatBwdRowOp {
             float lg;
             const float lk = leaky_with_grad(pre, c.slope_v, lg);
             const float ce = gat_softmax_weight(lk, c.nml) * lg;
-            const float cw = DROP ? ce * b.d[DROP ? u : 0] : ce;
+            const float cw = DROP ? ce * d_u : ce;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) s.s[i] = fmaf(cw, b.v[u][i], s.s[i]);
             s.csum += ce;
         }
     }
     __device__ __forceinline__ void chunk_begin(Ctx &c, State &, int, int, int my_c, int sub, int, float *lds,
-                                                const LaneVals &) const {
+                                                const LaneVals &lv) const {
         chunk_scalars_load<ACH, A24>(c.cs, attn_col, my_c, sub, lds);
+        c.lv = lv;
+        c.sub = sub;
     }
     __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
@@ -681,8 +687,9 @@ struct GatBwdColOp {
         GatBwdLane m;
         float f[VEC];
         float ac, slope_v;
-        int l;
+        int l, sub;
         ChunkScalars<ACS> cs;
+        DropLane<DROP> lv;
     };
     // grad_attn_col[u,h] = sum_e c_e (d_e <feat[u], g[row_e]> - D[row_e])
     //                    = <feat[u], sum_e c_e d_e g[row_e]> - sum_e c_e D[row_e]:
@@ -697,7 +704,6 @@ struct GatBwdColOp {
     struct Batch {
         float g[UNROLL][VEC];
         float4 st[UNROLL];
-        float d[DROP ? UNROLL : 1];
     };
 
     __device__ __forceinline__ Ctx make_ctx(int l, int tile) const {
@@ -730,13 +736,14 @@ struct GatBwdColOp {
                                           int jj) const {
         if constexpr (ACS == 0) b.st[u] = *gather_row<A24>(stats, c.m.hd, r, (uint32_t)heads * 16u);
         load_vec<T, VEC>(gather_row<A24>(grad_out, c.m.cc, r, (uint32_t)(heads * fdim) * (uint32_t)sizeof(T)), b.g[u]);
-        if constexpr (DROP) b.d[u] = drop_factor<LPR>(drop, lv, sub, jj, c.m.hd, heads);
     }
     __device__ __forceinline__ void apply(const Ctx &c, State &s, const Batch &b, int u, bool valid, int64_t,
                                           int jpos) const {
         if constexpr (ACS > 0) {
             if (jpos == 0) chunk_scalars_park<ACS, LPR>(c.cs, c.l);
         }
+        float d_u = 1.f;
+        if constexpr (DROP) d_u = drop_factor<LPR>(drop, c.lv, c.sub, jpos & (LPR - 1), c.m.hd, heads);
         if (valid) {
             float4 st_u;
             if constexpr (ACS > 0) st_u = *reinterpret_cast<const float4 *>(chunk_scalars_row<ACS, LPR>(c.cs, jpos));
@@ -746,8 +753,8 @@ struct GatBwdColOp {
             const float lk = leaky_with_grad(pre, c.slope_v, lg);
             const float a = gat_softmax_weight(lk, st_u.y);
             const float ce = a * lg;
-            const float aw = DROP ? a * b.d[DROP ? u : 0] : a;
-            const float cw = DROP ? ce * b.d[DROP ? u : 0] : ce;
+            const float aw = DROP ? a * d_u : a;
+            const float cw = DROP ? ce * d_u : ce;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 s.acc[i] = fmaf(aw, b.g[u][i], s.acc[i]);
@@ -757,8 +764,10 @@ struct GatBwdColOp {
         }
     }
     __device__ __forceinline__ void chunk_begin(Ctx &c, State &, int, int, int my_c, int sub, int, float *lds,
-                                                const LaneVals &) const {
+                                                const LaneVals &lv) const {
         chunk_scalars_load<ACS, A24>(c.cs, reinterpret_cast<const float *>(stats), my_c, sub, lds);
+        c.lv = lv;
+        c.sub = sub;
     }
     __device__ __forceinline__ void batch_end(const Ctx &, State &, int, int, int) const {}
     __device__ __forceinline__ void chunk_end(const Ctx &, State &, int, int) const {}
