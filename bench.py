@@ -357,6 +357,25 @@ def bench_single(args):
     except Exception as e:  # a capture failure must not take the bench line down
         result["gnn_epoch"]["ms_hipgraph"] = None
         result["gnn_epoch"]["hipgraph_error"] = repr(e)[:300]
+    try:
+        # the same epoch on the REALISTIC topology (arxiv-sized R-MAT graph: the real ogbn-arxiv is power-law): eager, and
+        # captured -- where every csr_spmm launch runs over the length-ordered plan of the structure (the recorded run of
+        # graphs.capture waits for the key: plan.taped_choice) -- with the plans switched off beside it
+        from cogdl_amd import xcdplan
+
+        gr = synth.arxiv_like(seed=0, topology="rmat").to(dev)
+        r64r, c64r = gr.rowptr.long(), gr.colind.long()
+        rm = {"topology": "arxiv-sized R-MAT (roofline.rmat's graph)", "ms": gcn_epoch_ms(gr, r64r, c64r, x)["ms"],
+              "ms_hipgraph": gcn_epoch_ms(gr, r64r, c64r, x, captured=True)["ms"]}
+        mode, xcdplan.MODE = xcdplan.MODE, "off"
+        try:
+            rm["ms_hipgraph_plans_off"] = gcn_epoch_ms(gr, r64r, c64r, x, captured=True)["ms"]
+        finally:
+            xcdplan.MODE = mode
+        result["gnn_epoch"]["rmat"] = rm
+        del gr, r64r, c64r
+    except Exception as e:
+        result["gnn_epoch"]["rmat"] = {"error": repr(e)[:300]}
     if not args.no_pmc:
         # where the captured epoch goes: the library's kernels / torch's kernels (three largest named) / launch gaps, from one
         # rocprofv3 --kernel-trace of the hipGraph replay in a child interpreter (tools/epoch_account.py)

@@ -8,6 +8,9 @@ synchronises, so a whole step -- forward, backward, optimizer -- can be captured
 What the helper takes care of (torch.cuda.CUDAGraph does the capture itself):
   * the graph-plan lookups of the backward passes (cached transposes, keyed on a structure hash that has to be read on
     the host) are recorded during an eager run and replayed from that record while capturing (cogdl_amd.plan.PlanTape);
+    so are the launches' own decisions (plan.taped_choice): the recorded run waits for every structure's key, so skewed
+    structures run over their XCD-partitioned, length-ordered plans (cogdl_amd/xcdplan.py) in the captured step -- forward
+    calls too, which an eager call with its hash still in flight cannot;
   * warm-up runs on a side stream, as torch's capture rules ask, so that every lazily created piece of state
     (plans, memoised transposed weights, cuBLAS/hipBLASLt workspaces, optimizer state) exists before the capture.
 What the step must respect: static shapes and addresses (index with precomputed index tensors, not boolean masks), no
@@ -51,7 +54,7 @@ def capture(step, warmup=3, pool=None):
                 _plan.set_tape(None)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    tape.mode, tape.pos = "replay", 0
+    tape.mode, tape.pos, tape.cpos = "replay", 0, 0
     graph = torch.cuda.CUDAGraph()
     _plan.set_tape(tape)
     try:
@@ -62,7 +65,23 @@ def capture(step, warmup=3, pool=None):
     if tape.pos != len(tape.plans):
         raise RuntimeError("hipGraph capture: the captured step used %d of the %d recorded plan lookups"
                            % (tape.pos, len(tape.plans)))
+    if tape.cpos != len(tape.choices):
+        raise RuntimeError("hipGraph capture: the captured step took %d of the %d recorded launch decisions"
+                           % (tape.cpos, len(tape.choices)))
     keep = []
     for plan in tape.plans:
         keep.append((plan, plan.colptr, plan.rowind, plan.perm, plan._val_t, plan._val_src))
+
+    def xplans_of(value):  # the XCD-partitioned plans inside a recorded decision (None | plan | tuples of them)
+        if isinstance(value, (tuple, list)):
+            for v in value:
+                yield from xplans_of(v)
+        elif hasattr(value, "vrowptr"):
+            yield value
+
+    for _, value in tape.choices:
+        for xp in xplans_of(value):
+            # (the plan object owns its index tensors and the struct the launches pass by pointer; its memoised permuted weights
+            #  are replaced when another weight tensor comes by: the captured kernels read the ones of the capture)
+            keep.append((xp, xp._val_p, xp._val_src))
     return CapturedStep(graph, outputs, keep)

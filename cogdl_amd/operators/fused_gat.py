@@ -15,6 +15,7 @@ models/nn/gat.py:30; layers/gat_layer.py:72-77) inside the same kernels.
 import torch
 
 from .. import _lib, xcdplan
+from .. import plan as _plan
 from ..plan import PLANS, Fingerprint, fingerprint_of
 
 _lib.hip()
@@ -117,15 +118,21 @@ class FusedGATFunction(torch.autograd.Function):
         # XCD-partitioned plan (cogdl_amd/xcdplan.py): hub-heavy graphs over cache-sized tables (BASELINE configs[2])
         ok = feat.dim() == 3 and feat.dtype in _lib.DTYPE_CODE
         row_bytes = feat.shape[1] * fp * feat.element_size() if ok else 0
-        ctx.xcd = ok and xcdplan.wanted(row_ptr.numel() - 1, col_ind.numel(), feat.shape[0], row_bytes)
-        if ok and not ctx.xcd:
-            # a memoised fingerprint (install(structure_memo=True), or the identity memo of plan.fingerprint_of once a backward
-            # pass has asked for its key): skewed structures of any size (xcdplan.ordered_wanted)
-            if getattr(row_ptr, "_cogdl_amd_struct", None) is not None and ctx.fp.event is not None:
-                ctx.fp.key()
-            if ctx.fp._key is not None:
-                ctx.xcd = xcdplan.ordered_wanted(ctx.fp, row_ptr, row_ptr.numel() - 1, col_ind.numel(), feat.shape[0], row_bytes)
-        xplan = xcdplan.csr_plan(ctx.fp, row_ptr, col_ind) if ctx.xcd else None
+
+        def decide():
+            xcd = ok and xcdplan.wanted(row_ptr.numel() - 1, col_ind.numel(), feat.shape[0], row_bytes)
+            if ok and not xcd:
+                # a memoised fingerprint (install(structure_memo=True), or the identity memo of plan.fingerprint_of once a backward
+                # pass has asked for its key), or the recorded eager run of cogdl_amd.graphs.capture (which may wait for the
+                # hash): skewed structures of any size (xcdplan.ordered_wanted)
+                if (getattr(row_ptr, "_cogdl_amd_struct", None) is not None or _plan.recording()) and ctx.fp.event is not None:
+                    ctx.fp.key()
+                if ctx.fp._key is not None:
+                    xcd = xcdplan.ordered_wanted(ctx.fp, row_ptr, row_ptr.numel() - 1, col_ind.numel(), feat.shape[0], row_bytes)
+            return xcdplan.csr_plan(ctx.fp, row_ptr, col_ind) if xcd else None
+
+        xplan = _plan.taped_choice("fused_gat.forward", decide)  # (a capture replays the recorded run's plans: plan.PlanTape)
+        ctx.xcd = xplan is not None
         # (a shape the plan's forward declines -- column tiles -- keeps the ordinary backward too)
         if xplan is not None:
             out, edge_max, edge_sum, ctx.xcd = _gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, feat, p,
@@ -158,9 +165,16 @@ class FusedGATFunction(torch.autograd.Function):
         # (the structure's key is known by now -- PLANS.get has waited for the hash: a skewed structure takes the plans in
         #  backward whether or not its forward call could)
         #  -- from the structure's second sighting on: a one-off structure must not pay the plan builds)
-        if ctx.xcd or (getattr(plan, "sightings", 1) > 1 and
-                       xcdplan.ordered_wanted(ctx.fp, row_ptr, v, col_ind.numel(), n_src, h * fp * feat.element_size())):
-            xr, xc = xcdplan.csr_plan(ctx.fp, row_ptr, col_ind), xcdplan.csc_plan(ctx.fp, plan)
+
+        def decide():
+            if ctx.xcd or (getattr(plan, "sightings", 1) > 1 and
+                           xcdplan.ordered_wanted(ctx.fp, row_ptr, v, col_ind.numel(), n_src, h * fp * feat.element_size())):
+                return xcdplan.csr_plan(ctx.fp, row_ptr, col_ind), xcdplan.csc_plan(ctx.fp, plan)
+            return None
+
+        xplans = _plan.taped_choice("fused_gat.backward", decide)
+        if xplans is not None:
+            xr, xc = xplans
             ws, ws_bytes = _lib.workspace("cogdl_hip_gat_bwd_xcd_workspace_bytes", dev, v, h, fp, xr.n_parts, xc.n_parts, code)
             with _lib.on_device(dev):
                 rc = lib.cogdl_hip_gat_bwd_xcd(xr.ref(), xc.ref(), _lib.ptr(ar), _lib.ptr(ac), _lib.ptr(feat),

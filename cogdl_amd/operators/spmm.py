@@ -170,15 +170,26 @@ class SPMMFunction(torch.autograd.Function):
         # kernel, not behind the SpMM).
         rowptr, colind = _lib.csr_structure(rowptr, colind)  # validated + contiguous before anything reads raw pointers
         ctx.transient = _plan.transient()  # (the dense operand is checked by csr_spmm_raw)
-        ctx.xcd = _xcd_split(rowptr, colind, feat)
+        taped = _plan._TAPE is not None and not ctx.transient
+        ctx.xcd = None if taped else _xcd_split(rowptr, colind, feat)
         memo = getattr(rowptr, "_cogdl_amd_struct", None) is not None
         if ctx.transient:
             ctx.fp = None
-        elif ctx.needs_input_grad[2] or ctx.xcd is not None or memo:
+        elif ctx.needs_input_grad[2] or ctx.xcd is not None or memo or taped:
             ctx.fp = fingerprint_of(rowptr, colind, feat.shape[0])
         else:
             ctx.fp = _plan.known_fingerprint(rowptr, colind, feat.shape[0])  # (never hashes: inference calls stay as they were)
-        if ctx.xcd is None and ctx.fp is not None:
+        xplan = None
+        if taped:
+            # cogdl_amd.graphs.capture: the recorded eager run waits for the structure's key and decides as a call with a known
+            # fingerprint would; the capture takes the recorded decision (nothing is hashed or read back while capturing)
+            def decide():
+                ctx.fp.key()
+                split = _xcd_split(rowptr, colind, feat, ctx.fp)
+                return split, (xcdplan.csr_plan(ctx.fp, rowptr, colind, split) if split is not None else None)
+
+            ctx.xcd, xplan = _plan.taped_choice("csr_spmm.forward", decide)
+        elif ctx.xcd is None and ctx.fp is not None:
             # a memoised fingerprint (install(structure_memo=True)): its key costs ONE wait per structure, after which skewed
             # structures of any size take a plan -- deterministically, from the first call on.  The identity memo (the same
             # index tensor objects as an earlier call, plan.fingerprint_of) has its key once a backward pass has asked for it.
@@ -187,7 +198,9 @@ class SPMMFunction(torch.autograd.Function):
             if ctx.fp._key is not None:
                 ctx.xcd = _xcd_split(rowptr, colind, feat, ctx.fp)
         if ctx.xcd is not None:
-            out = csr_spmm_xcd_raw(xcdplan.csr_plan(ctx.fp, rowptr, colind, ctx.xcd), edge_weight_csr, feat)
+            if xplan is None:
+                xplan = xcdplan.csr_plan(ctx.fp, rowptr, colind, ctx.xcd)
+            out = csr_spmm_xcd_raw(xplan, edge_weight_csr, feat)
         else:
             out = csr_spmm_raw(rowptr, colind, edge_weight_csr, feat)
         need_w = edge_weight_csr is not None and ctx.needs_input_grad[3]
@@ -211,10 +224,15 @@ class SPMMFunction(torch.autograd.Function):
                 # (the key is known here -- PLANS.get has waited for the hash: the transpose of a skewed structure takes a plan
                 #  whether or not the forward call could -- from its SECOND sighting on: a structure that never comes back, a
                 #  sampled block passed without plan.transient_structures(), must not pay a plan build of milliseconds)
-                split_t = _xcd_split(plan.colptr, plan.rowind, grad_out, ctx.fp if (ctx.xcd is not None or getattr(plan, "sightings", 1) > 1) else None)
+
+                def decide():
+                    split_t = _xcd_split(plan.colptr, plan.rowind, grad_out, ctx.fp if (ctx.xcd is not None or getattr(plan, "sightings", 1) > 1) else None)
+                    return split_t, (xcdplan.csc_plan(ctx.fp, plan, split_t) if split_t is not None else None)
+
+                split_t, xplan_t = _plan.taped_choice("csr_spmm.backward", decide)
                 if split_t is not None:
                     # (w stays in CSR order: the plan of the transpose maps its positions through the transpose's perm)
-                    grad_feat = csr_spmm_xcd_raw(xcdplan.csc_plan(ctx.fp, plan, split_t), w, grad_out)
+                    grad_feat = csr_spmm_xcd_raw(xplan_t, w, grad_out)
                 else:
                     w_t = plan.transposed_values(w) if w is not None else None
                     grad_feat = csr_spmm_raw(plan.colptr, plan.rowind, w_t, grad_out, split_long_rows=plan.has_hub_columns())

@@ -159,6 +159,9 @@ class PlanTape:
 
     def __init__(self):
         self.plans, self.pos, self.mode = [], 0, "record"
+        # the launches' own decisions (which of them take an XCD-partitioned plan, cogdl_amd/xcdplan.py, and which plan), in call
+        # order: (kind, value) pairs written by taped_choice()
+        self.choices, self.cpos = [], 0
 
 
 _TAPE = None
@@ -167,6 +170,38 @@ _TAPE = None
 def set_tape(tape):
     global _TAPE
     _TAPE = tape
+
+
+def recording():
+    """Is this the eager run whose lookups cogdl_amd.graphs.capture() records?  (It may wait for a structure hash: the run is
+    not captured -- so every launch of a captured step can be given the plan a call with a known fingerprint would take.)"""
+    return _TAPE is not None and _TAPE.mode == "record"
+
+
+def replaying():
+    return _TAPE is not None and _TAPE.mode == "replay"
+
+
+def taped_choice(kind, decide):
+    """A decision of an operator call that needs the structure's key (does the launch take an XCD-partitioned plan, and which):
+    without a tape decide() is called; while recording it is called and its value appended to the tape; while a capture replays
+    the tape the recorded value comes back (nothing may be hashed or read back then) -- `kind` names the call site, a captured
+    step that asks in another order than the recorded one is refused."""
+    tape = _TAPE
+    if tape is None:
+        return decide()
+    if tape.mode == "replay":
+        if tape.cpos >= len(tape.choices):
+            raise _lib.BackendError("hipGraph capture: the captured step takes more launch decisions than the recorded one")
+        k, value = tape.choices[tape.cpos]
+        tape.cpos += 1
+        if k != kind:
+            raise _lib.BackendError("hipGraph capture: the captured step's operator sequence differs from the recorded one "
+                                    "(decision %d: %s vs %s)" % (tape.cpos - 1, kind, k))
+        return value
+    value = decide()
+    tape.choices.append((kind, value))
+    return value
 
 
 _TRANSIENT = 0

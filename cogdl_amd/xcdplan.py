@@ -172,7 +172,7 @@ def wanted(m, nnz, n_src, row_bytes):
     F = 48 bf16 (96-byte rows, 22 MB: one head per lane group, bound by instruction issue, not by the gathers) 6.07 -> 5.97 ms
     without and 6.56 -> 6.93 ms with dropout -- not taken (the operator pads such rows to 128 bytes: fused_gat._padded_width).
     Which operators ask: the fused GAT operator, and csr_spmm in fp32 (cut at its exact-row bound: operators/spmm.py)."""
-    if MODE == "off" or _plan.transient() or _plan._TAPE is not None:
+    if MODE == "off" or _plan.transient():
         return False
     if n_src >= (1 << 24) or n_src * row_bytes >= (1 << 32):  # (the plan kernels address the table with 24 x 24 -> 32-bit offsets)
         return False
@@ -197,8 +197,11 @@ def ordered_wanted(fp, rowptr, m, nnz, n_src, row_bytes):
     bound: fp32 F = 128 183 -> 144 us, F = 64 100 -> 63 us, F = 40 103 -> 60 us; bf16 134 -> 68, 96 -> 44, 95 -> 47 us; on
     the uniform graph of the same size +-3 % -- hence the skew test (one pass over the degrees per structure, cached): the
     share of lane-slots that eight consecutive rows fill, 0.73 on the uniform graph, 0.32 on the R-MAT one.
-    A forward call whose hash is still in flight keeps the ordinary launch: waiting would drain the stream."""
-    if MODE == "off" or _plan.transient() or _plan._TAPE is not None or fp is None or getattr(fp, "_key", None) is None:
+    A forward call whose hash is still in flight keeps the ordinary launch: waiting would drain the stream.
+    Under cogdl_amd.graphs.capture the operators ask through plan.taped_choice: the recorded eager run waits for the key (it is
+    not captured), the capture replays its decisions -- every launch of a captured step runs over the plan a known structure
+    takes, forward calls included."""
+    if MODE == "off" or _plan.transient() or fp is None or getattr(fp, "_key", None) is None:
         return False
     if nnz < ORDERED_MIN_EDGES or n_src >= (1 << 24) or n_src * row_bytes >= (1 << 32) or row_bytes >= (1 << 22):
         return False

@@ -178,3 +178,44 @@ def test_captured_step_owns_its_plans_cache_eviction_and_new_weights_do_not_corr
     np.testing.assert_allclose(losses_c, losses_e[3:], rtol=1e-5)
     for a, b in zip(params_c, params_e):
         np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_captured_step_on_a_skewed_graph_runs_over_the_recorded_xcd_plans():
+    """Round 6: the recorded eager run of graphs.capture waits for the structure's key, so every csr_spmm launch of the captured
+    step -- forward calls too -- takes the length-ordered plan a known skewed structure takes (cogdl_amd/xcdplan.py:
+    ordered_wanted; an eager forward call whose hash is in flight cannot).  The tape holds the decisions, the captured step
+    owns the plans: the plan caches are emptied and the freed memory overwritten before the replays, which must equal the
+    eager steps up to the re-association of the rows beyond the exact-row bound."""
+    import gc
+
+    from cogdl_amd import plan as plan_mod, xcdplan
+
+    step_e, _ = _gcn_step_factory(2, n=60000)
+    losses_e = [float(step_e()) for _ in range(3 + 3)]
+    step_c, _ = _gcn_step_factory(2, n=60000)
+    tapes, set_tape = [], plan_mod.set_tape
+
+    def spy(tape):
+        if tape is not None and tape not in tapes:
+            tapes.append(tape)
+        set_tape(tape)
+
+    plan_mod.set_tape = spy
+    try:
+        captured = graphs.capture(step_c, warmup=3)
+    finally:
+        plan_mod.set_tape = set_tape
+    (tape,) = tapes
+    assert [k for k, _ in tape.choices] == ["csr_spmm.forward"] * 2 + ["csr_spmm.backward"] * 2
+    for _, (split, xplan) in tape.choices:
+        assert split is not None and isinstance(xplan, xcdplan.XcdPlan), "a skewed structure's launch recorded without a plan"
+    assert tape.cpos == len(tape.choices) and tape.pos == len(tape.plans)
+    xcdplan.XPLANS.clear()
+    plan_mod.PLANS.clear()
+    del tape, tapes
+    gc.collect()
+    poison = [torch.full((48 << 20,), 0x7F, dtype=torch.uint8, device=DEV) for _ in range(4)]
+    torch.cuda.synchronize()
+    del poison
+    losses_c = [float(captured()) for _ in range(3)]
+    np.testing.assert_allclose(losses_c, losses_e[3:], rtol=1e-4)

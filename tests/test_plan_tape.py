@@ -62,6 +62,41 @@ def test_record_then_replay_in_order(monkeypatch):
         plan.set_tape(None)
 
 
+def test_launch_decisions_are_recorded_and_replayed_by_call_site():
+    """plan.taped_choice: without a tape the decision is taken; while recording it is taken and kept; while replaying the
+    kept value comes back without deciding again -- and a step that asks from another call site, or more often, is refused."""
+    calls = []
+
+    def decide(v):
+        def f():
+            calls.append(v)
+            return v
+        return f
+
+    assert plan.taped_choice("a", decide(1)) == 1 and calls == [1]
+    tape = plan.PlanTape()
+    plan.set_tape(tape)
+    try:
+        assert plan.recording() and not plan.replaying()
+        assert plan.taped_choice("csr_spmm.forward", decide((7, "planA"))) == (7, "planA")
+        assert plan.taped_choice("csr_spmm.backward", decide(None)) is None
+    finally:
+        plan.set_tape(None)
+    assert tape.choices == [("csr_spmm.forward", (7, "planA")), ("csr_spmm.backward", None)] and calls == [1, (7, "planA"), None]
+    tape.mode = "replay"
+    plan.set_tape(tape)
+    try:
+        assert plan.replaying() and not plan.recording()
+        assert plan.taped_choice("csr_spmm.forward", decide("never")) == (7, "planA")
+        with pytest.raises(_lib.BackendError):  # another call site than the recorded one
+            plan.taped_choice("fused_gat.backward", decide("never"))
+        with pytest.raises(_lib.BackendError):  # more decisions than recorded
+            plan.taped_choice("csr_spmm.forward", decide("never"))
+    finally:
+        plan.set_tape(None)
+    assert "never" not in calls
+
+
 def test_transient_structures_context_nests_and_resets():
     from cogdl_amd import plan, transient_structures
 

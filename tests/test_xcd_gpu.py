@@ -241,6 +241,71 @@ def test_fused_gat_xcd_kernels_are_the_ones_that_ran(monkeypatch):
     torch.cuda.synchronize()
 
 
+def test_fused_gat_under_hipgraph_capture_replays_the_recorded_plans():
+    """cogdl_amd.graphs.capture: the recorded eager run decides (plan.taped_choice) and builds the plans, the capture takes them
+    from the tape -- nothing is hashed or read back while capturing -- and the captured step keeps them alive.  The replays
+    (also on new inputs written into the static tensors) equal the eager operator bit for bit: same plans, same kernels."""
+    from cogdl_amd import graphs, plan as plan_mod
+
+    g = synth.hub_csr(400, 400, base_deg=6, hubs=((3, 129), (17, 5000), (100, 20000), (399, 700)), seed=11)
+    n, h, f = 400, 8, 8
+    rowptr, colind = g.rowptr.to(DEV), g.colind.to(DEV)
+    gen = torch.Generator().manual_seed(3)
+    ar, ac = (torch.randn(n, h, generator=gen).to(DEV).requires_grad_() for _ in range(2))
+    ft = torch.randn(n, h, f, generator=gen).bfloat16().to(DEV).requires_grad_()
+    gout = torch.randn(n, h, f, generator=gen).bfloat16().to(DEV)
+    res = [torch.zeros(n, h, f, device=DEV), torch.zeros(n, h, f, device=DEV), torch.zeros(n, h, device=DEV), torch.zeros(n, h, device=DEV)]
+
+    def step():
+        for t in (ar, ac, ft):
+            t.grad = None
+        out = fused_gat_dropout_func(ar, ac, rowptr, colind, 0.2, ft, 0.0, 0)
+        out.backward(gout)
+        for r, t in zip(res, (out.detach(), ft.grad, ar.grad, ac.grad)):
+            r.copy_(t)
+        return res
+
+    def eager():
+        step()
+        torch.cuda.synchronize()
+        return [r.clone() for r in res]
+
+    want0 = eager()
+    tapes, set_tape = [], plan_mod.set_tape
+
+    def spy(tape):
+        if tape is not None and tape not in tapes:
+            tapes.append(tape)
+        set_tape(tape)
+
+    plan_mod.set_tape = spy
+    try:
+        captured = graphs.capture(step, warmup=2)
+    finally:
+        plan_mod.set_tape = set_tape
+    (tape,) = tapes
+    assert [k for k, _ in tape.choices] == ["fused_gat.forward", "fused_gat.backward"]
+    assert isinstance(tape.choices[0][1], xcdplan.XcdPlan) and all(isinstance(p, xcdplan.XcdPlan) for p in tape.choices[1][1])
+    xcdplan.XPLANS.clear()
+    plan_mod.PLANS.clear()
+    del tape, tapes
+    for r in res:
+        r.zero_()
+    captured()
+    torch.cuda.synchronize()
+    for got, want in zip(res, want0):
+        assert torch.equal(got, want)
+    with torch.no_grad():  # new inputs in the static tensors
+        ft.copy_(torch.randn(n, h, f, generator=gen).bfloat16())
+        ar.copy_(torch.randn(n, h, generator=gen))
+    captured()
+    torch.cuda.synchronize()
+    got1 = [r.clone() for r in res]
+    want1 = eager()
+    for got, want in zip(got1, want1):
+        assert torch.equal(got, want)
+
+
 def test_csrspmm_fp32_on_the_reddit_shaped_graph_takes_the_plan_and_keeps_its_exact_rows(oracle, monkeypatch):
     """fp32 csr_spmm over a hub-heavy structure and a cache-sized table (auto mode): the plan is cut at the exact-row bound of
     the ordinary path, so every row of at most cogdl_hip_exact_row_edges(nnz) edges is still BIT-identical to the reference loop
