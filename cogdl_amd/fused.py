@@ -12,6 +12,7 @@ import sys
 
 import torch
 
+from . import linear as _linear
 from .operators.spmm import csrspmm_fused
 
 _orig = {}  # module name -> the reference's spmm
@@ -167,7 +168,8 @@ def _gat_forward_fused_dropout(self, graph, x):
         return _orig_gat_forward[type(self)](self, graph, x)
     from .operators.fused_gat import fused_gat_dropout_func
 
-    h = torch.matmul(x, self.W).view(-1, self.nhead, self.out_features)
+    # (bf16 autocast, tall x: the hand-written MFMA product that reads x once, cogdl_amd/linear.py: matmul; else torch.matmul)
+    h = _linear.matmul(x, self.W).view(-1, self.nhead, self.out_features)
     h[torch.isnan(h)] = 0.0
     h_l = _HeadProjection.apply(self.a_l, h)
     h_r = _HeadProjection.apply(self.a_r, h)

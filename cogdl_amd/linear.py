@@ -83,6 +83,70 @@ class LinearFunction(torch.autograd.Function):
         return grad_x, grad_w, grad_b
 
 
+def tall_skinny_matmul_bf16(x, w, bias, w_is_n_by_k):
+    """bf16(x[R, K]) . bf16(B) (+ bias) -> bf16 [R, N] through cogdl_hip_linear_fwd_bf16 (x, w: fp32 or bf16; B = w^T for
+    w [N, K], w for w [K, N]); None if the kernel declines the shape."""
+    dev = x.device
+    x, w = x.contiguous(), w.contiguous()
+    rows, k = x.shape
+    n = w.shape[0] if w_is_n_by_k else w.shape[1]
+    out = torch.empty((rows, n), dtype=torch.bfloat16, device=dev)
+    with _lib.on_device(dev):
+        rc = _lib.hip().cogdl_hip_linear_fwd_bf16(_lib.ptr(x), _lib.DTYPE_CODE[x.dtype], _lib.ptr(w), _lib.DTYPE_CODE[w.dtype],
+                                                  _lib.ptr(bias), _lib.ptr(out), rows, k, n, 1 if w_is_n_by_k else 0,
+                                                  _lib.stream_of(x))
+    if rc == EUNSUPPORTED:
+        return None
+    _lib.check(rc, "linear_fwd_bf16")
+    return out
+
+
+class MatmulBf16Function(torch.autograd.Function):
+    """torch.matmul(x, W) of a layer under bf16 autocast (x [R, K] tall, W [K, N] with N <= 64), round 6.
+    forward: cogdl_hip_linear_fwd_bf16 -- x is read ONCE, in the dtype the model holds it (fp32 x is rounded to bf16 in
+        registers: autocast's cast kernel and its bf16 copy of x do not exist), bf16 result like autocast's;
+    grad_W:  the fp32 split-K MFMA reduction of linear_wgrad over the SAVED INPUT ITSELF (autocast saves the bf16 copy and
+        sends hipBLASLt a [N, R] x [R, K] bf16 product it runs at 0.5 TB/s): x^T . fp32(grad_out), fp32 accumulation of
+        un-rounded x -- at least as accurate as autocast's product;
+    grad_x:  grad_out . W^T in grad_out's dtype (torch; only layers behind the first need it, where x is narrow)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        out = tall_skinny_matmul_bf16(x, w, None, False)
+        if out is None:  # (a shape the kernel declines: the same product by torch, same backward)
+            out = torch.mm(x.to(torch.bfloat16), w.to(torch.bfloat16))
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, w = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        grad_x = grad_w = None
+        if ctx.needs_input_grad[0]:
+            grad_x = torch.mm(grad_out, w.to(grad_out.dtype).t()).to(x.dtype)
+        if ctx.needs_input_grad[1]:
+            gw, _ = linear_wgrad(x.float(), grad_out.float(), want_bias=False)  # [N, K] = grad_out^T . x
+            grad_w = gw.t().to(w.dtype)
+        return grad_x, grad_w
+
+
+def matmul_covers(x, w):
+    return (torch.is_tensor(x) and torch.is_tensor(w) and x.is_cuda and w.is_cuda and w.device == x.device
+            and x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[0] and x.shape[0] >= MIN_ROWS
+            and w.shape[1] <= 64 and w.shape[0] <= MAX_FEATURES
+            and x.dtype in (torch.float32, torch.bfloat16) and w.dtype in (torch.float32, torch.bfloat16)
+            and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
+
+def matmul(x, w):
+    """Drop-in for `torch.matmul(x, self.W)` in a layer's forward (cogdl/layers/gat_layer.py:59): under bf16 autocast and for
+    the tall-skinny shapes of full-graph training MatmulBf16Function, else torch's own product."""
+    if matmul_covers(x, w):
+        return MatmulBf16Function.apply(x, w)
+    return torch.matmul(x, w)
+
+
 def covers(x, weight, bias):
     return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
             and x.shape[0] >= MIN_ROWS and weight.dim() == 2 and max(weight.shape) <= MAX_FEATURES

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define COGDL_HIP_ABI_VERSION 8
+#define COGDL_HIP_ABI_VERSION 9
 
 /* Exported with default visibility (the library is built -fvisibility=hidden). */
 #if defined(COGDL_HIP_BUILD)
@@ -610,6 +610,16 @@ COGDL_API int cogdl_hip_linear_wgrad_f32(const float *x, const float *grad_out, 
  * the caller then keeps its BLAS call.  x 16-byte aligned. */
 COGDL_API int cogdl_hip_linear_fwd_f32(const float *x, const float *w, const float *bias, float *out, int64_t rows,
                              int64_t k_dim, int64_t n_dim, int w_is_n_by_k, void *stream);
+
+/* linear_fwd_bf16 (ABI v9): out[rows, n] (bf16) = bf16(x[rows, k]) . bf16(B) (+ bias[n], fp32 added before the final
+ * rounding) -- the same product under bf16 autocast, as torch computes `torch.matmul(x, self.W)` / nn.Linear there
+ * (cogdl/layers/gat_layer.py:59 on BASELINE configs[2]: 232,965 x 602 -> 64).  x_dtype / w_dtype: COGDL_HIP_F32 (rounded
+ * to bf16 in registers, to nearest even: no bf16 copy of x is made) or COGDL_HIP_BF16; fp32 accumulation in
+ * v_mfma_f32_32x32x16_bf16, whose operands are eight CONSECUTIVE k per lane: rows of x are read straight from global
+ * memory, B sits in LDS in operand order (csrc/linear_fwd16.hip).  w_is_n_by_k as above.  COGDL_HIP_EUNSUPPORTED: n > 64,
+ * more than 128 KB of bf16 B operands, bf16 rows of odd length.  x 16-byte aligned. */
+COGDL_API int cogdl_hip_linear_fwd_bf16(const void *x, int x_dtype, const void *w, int w_dtype, const float *bias, void *out,
+                              int64_t rows, int64_t k_dim, int64_t n_dim, int w_is_n_by_k, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Vertex-sharded graphs (BASELINE.json configs[4]; no reference counterpart -- CogDL only partitions on the host, with

@@ -22,7 +22,7 @@ def test_hip_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.HIP_SIGNATURES) == names
-    assert _lib.hip().cogdl_hip_abi_version() == 8
+    assert _lib.hip().cogdl_hip_abi_version() == 9
     assert _lib.hip().cogdl_hip_strerror(3) == b"misaligned pointer"
 
 

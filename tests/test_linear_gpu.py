@@ -99,3 +99,115 @@ def test_tall_skinny_matmul_declines_big_weights():
     x = torch.randn(100, 1024, device=DEV)
     assert tall_skinny_matmul(x, torch.randn(64, 1024, device=DEV), None, True) is None   # 1024 x 64 x 4 B > 96 KB
     assert tall_skinny_matmul(x, torch.randn(65, 1024, device=DEV), None, True) is None   # > 64 columns
+
+
+# ---- bf16 autocast product (csrc/linear_fwd16.hip, ABI v9) ---------------------------------------------------------------
+def _bf16_round(t):
+    return t.to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("x_dtype", [torch.float32, torch.bfloat16], ids=["x-f32", "x-bf16"])
+@pytest.mark.parametrize("rows,k,n,transposed_w", [
+    (5000, 602, 64, False),   # configs[2], first layer: 2408-byte fp32 rows (8-byte loads), ragged last macro-step
+    (5000, 64, 41, False),    # its second layer
+    (4097, 128, 64, True), (1000, 33, 7, False), (1000, 40, 32, True), (33, 34, 1, False), (31, 16, 64, False),
+    (1, 8, 3, True), (300, 1000, 33, False), (2049, 96, 48, True), (64, 2, 2, False)])
+def test_bf16_matmul_matches_the_rounded_operands_in_float64(rows, k, n, transposed_w, x_dtype):
+    """out = bf16( sum_k bf16(x)[r, k] * bf16(B)[k, c] + bias ): fp32 accumulation of exact bf16 x bf16 products, so the
+    float64 product of the ROUNDED operands is matched to fp32-accumulation accuracy before the final rounding -- checked
+    as: |got - want| <= one bf16 ulp of want + 2e-6 of the sum of magnitudes.  One-hot / asymmetric columns catch operand
+    permutations (k order inside a macro-step, C/D register map)."""
+    from cogdl_amd.linear import tall_skinny_matmul_bf16
+
+    gen = torch.Generator().manual_seed(rows + 7 * k + n)
+    x = torch.randn(rows, k, generator=gen)
+    w = torch.randn((n, k) if transposed_w else (k, n), generator=gen)
+    x[:, 0] += 3.0
+    x[:, -1] -= 1.5
+    bias = torch.randn(n, generator=gen)
+    if x_dtype == torch.bfloat16 and k % 2:
+        got = tall_skinny_matmul_bf16(x.to(DEV).to(x_dtype), w.to(DEV), bias.to(DEV), transposed_w)
+        assert got is None  # (bf16 rows of odd length: declined, the caller keeps torch's product)
+        return
+    xd = x.to(DEV).to(x_dtype)
+    got = tall_skinny_matmul_bf16(xd, w.to(DEV), bias.to(DEV), transposed_w)
+    assert got is not None and got.dtype == torch.bfloat16 and got.shape == (rows, n)
+    b = _bf16_round(w).t() if transposed_w else _bf16_round(w)
+    want = _bf16_round(x) @ b + bias.double()
+    scale = _bf16_round(x).abs() @ b.abs() + bias.double().abs()
+    err = (got.cpu().double() - want).abs()
+    bound = want.abs() * 2.0 ** -8 + 2e-6 * scale + 1e-30
+    assert bool((err <= bound).all()), "max err/bound %.3f" % float((err / bound).max())
+    # weights already in bf16 (autocast's cached cast): same result
+    again = tall_skinny_matmul_bf16(xd, w.to(DEV).bfloat16(), bias.to(DEV), transposed_w)
+    assert torch.equal(again, got)
+
+
+def test_bf16_matmul_places_every_element_exactly():
+    """x = one-hot rows (column r % K), W = distinct small integers: out[r, c] = W[r % K, c] exactly -- any mix-up of the
+    k order inside a macro-step, of the half-waves or of the C/D register map shows as a wrong integer."""
+    from cogdl_amd.linear import tall_skinny_matmul_bf16
+
+    for rows, k, n in ((4096, 602, 64), (1000, 70, 33), (999, 32, 32)):
+        cols = torch.arange(rows) % k
+        x = torch.zeros(rows, k)
+        x[torch.arange(rows), cols] = 1.0
+        w = ((torch.arange(k * n, dtype=torch.float32).view(k, n) * 7) % 251) - 125.0  # exactly representable in bf16
+        got = tall_skinny_matmul_bf16(x.to(DEV), w.to(DEV), None, False)
+        assert torch.equal(got.cpu().float(), w[cols])
+
+
+def test_bf16_matmul_does_not_leak_a_neighbouring_row_through_the_ragged_tail():
+    """K = 602: the last macro-step of a row reads 22 elements of the NEXT row (B is zero there, but 0 * NaN is NaN)."""
+    from cogdl_amd.linear import tall_skinny_matmul_bf16
+
+    rows, k, n = 200, 602, 64
+    x = torch.randn(rows, k)
+    x[101, :30] = float("nan")
+    x[150, 0] = float("inf")
+    got = tall_skinny_matmul_bf16(x.to(DEV), torch.randn(k, n).to(DEV), None, False).cpu().float()
+    bad = ~torch.isfinite(got).all(1)
+    assert bad.nonzero().flatten().tolist() == [101, 150]
+
+
+def test_matmul_under_bf16_autocast_matches_torch_autocast():
+    """cogdl_amd.linear.matmul vs torch.matmul under the same autocast context: forward within a bf16 ulp, grad_W against
+    the float64 product of the operands torch's autocast backward sees (bf16 x, bf16 grad)."""
+    from cogdl_amd import linear as cl
+
+    torch.manual_seed(1)
+    rows, k, n = 20000, 602, 64
+    x = torch.randn(rows, k, device=DEV)
+    w0 = (torch.randn(k, n, device=DEV) * 0.05)
+    gout = torch.randn(rows, n, device=DEV).bfloat16()
+    outs = []
+    for fn in (torch.matmul, cl.matmul):
+        w = w0.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = fn(x, w)
+        assert y.dtype == torch.bfloat16
+        y.backward(gout)
+        outs.append((y.detach().float(), w.grad.clone()))
+    (y_t, gw_t), (y_c, gw_c) = outs
+    assert gw_c.dtype == torch.float32 and gw_c.shape == (k, n)
+    assert bool(((y_c - y_t).abs() <= y_t.abs() * 2.0 ** -7 + 1e-3).all())
+    want = x.double().t() @ gout.double()
+    scale = x.double().abs().t() @ gout.double().abs()
+    assert bool(((gw_c.double() - want).abs() <= 1e-5 * scale + 1e-6).all())       # fp32 reduction of un-rounded x
+    assert bool(((gw_t.double() - want).abs() <= 2.0 ** -7 * scale + 1e-6).all())  # (torch's own: bf16 operands, bf16 result)
+    # outside autocast, or for shapes it does not cover, it IS torch.matmul
+    w = w0.clone().requires_grad_()
+    assert torch.equal(cl.matmul(x, w), torch.matmul(x, w))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert not cl.matmul_covers(x[:100], w) and not cl.matmul_covers(x, torch.randn(k, 128, device=DEV))
+    # second-layer shape: bf16 x that requires grad
+    xb = torch.randn(rows, 64, device=DEV).bfloat16().requires_grad_()
+    w2 = (torch.randn(64, 41, device=DEV) * 0.1).requires_grad_()
+    g2 = torch.randn(rows, 41, device=DEV).bfloat16()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y2 = cl.matmul(xb, w2)
+    y2.backward(g2)
+    want_x = g2.double() @ w2.detach().bfloat16().double().t()
+    assert xb.grad.dtype == torch.bfloat16 and bool(((xb.grad.double() - want_x).abs() <= want_x.abs() * 2.0 ** -7 + 1e-2).all())
+    want_w = xb.detach().double().t() @ g2.double()
+    assert bool(((w2.grad.double() - want_w).abs() <= 1e-5 * (xb.detach().double().abs().t() @ g2.double().abs()) + 1e-6).all())

@@ -46,9 +46,14 @@ class GatLayer(torch.nn.Module):
 
     def forward(self, g, x):
         rowptr, colind, row = g
-        h = torch.matmul(x, self.W).view(-1, self.nhead, self.out_feats)
         if self.mode == "fused-dropout":  # (what install(fused_gat_dropout=True) rebinds GATLayer.forward to: cogdl_amd/fused.py)
+            from cogdl_amd import linear as cogdl_linear
             from cogdl_amd.fused import _HeadProjection
+
+            h = cogdl_linear.matmul(x, self.W).view(-1, self.nhead, self.out_feats)
+        else:
+            h = torch.matmul(x, self.W).view(-1, self.nhead, self.out_feats)
+        if self.mode == "fused-dropout":
 
             h_l, h_r = _HeadProjection.apply(self.a_l, h), _HeadProjection.apply(self.a_r, h)
         else:
