@@ -143,24 +143,39 @@ def _column_sum(t, block=512):
     return out + t[main:].sum(0) if main < n else out
 
 
-class _HeadProjection(torch.autograd.Function):
-    """h_x[v, h] = sum_f a[0, h, f] * feat[v, h, f]  -- `(self.a_l * h).sum(dim=-1)` of GATLayer.forward
-    (cogdl/layers/gat_layer.py:65-66) with a backward whose parameter gradient is a two-stage column sum."""
+class _HeadProjections(torch.autograd.Function):
+    """Both projections of GATLayer.forward at once: (h_l, h_r) = ((a_l * h).sum(-1), (a_r * h).sum(-1))
+    (cogdl/layers/gat_layer.py:65-66), same forward arithmetic as the layer's.  The backward is where the time was (Reddit-
+    shaped graph, bf16 step: ten column-sum launches, eight bf16 -> fp32 copies and the [N, H, F] products between them, 0.5 ms
+    of an 11.6 ms step): the parameter gradients  grad_a[h, f] = sum_v g[v, h] feat[v, h, f]  are the diagonal blocks of the
+    tall-skinny product  [g_l | g_r]^T . feat  -- ONE launch of the fp32 split-K MFMA reduction (cogdl_hip_linear_wgrad_f32,
+    fixed order) -- and grad_feat = g_l a_l + g_r a_r is one fp32 expression rounded once, instead of two rounded halves
+    summed by autograd."""
 
     @staticmethod
-    def forward(ctx, a, feat):
-        ctx.save_for_backward(a, feat)
-        return (a * feat).sum(dim=-1)
+    def forward(ctx, a_l, a_r, feat):
+        ctx.save_for_backward(a_l, a_r, feat)
+        return (a_l * feat).sum(dim=-1), (a_r * feat).sum(dim=-1)
 
     @staticmethod
-    def backward(ctx, g):
-        a, feat = ctx.saved_tensors
-        g3 = g.unsqueeze(-1)
-        grad_feat = (g3 * a).to(feat.dtype) if ctx.needs_input_grad[1] else None
-        grad_a = None
-        if ctx.needs_input_grad[0]:
-            grad_a = _column_sum((g3.float() * feat.float()).view(feat.shape[0], -1)).view(1, *feat.shape[1:]).to(a.dtype)
-        return grad_a, grad_feat
+    def backward(ctx, g_l, g_r):
+        a_l, a_r, feat = ctx.saved_tensors
+        n, h, f = feat.shape
+        grad_feat = grad_al = grad_ar = None
+        if ctx.needs_input_grad[2]:
+            grad_feat = (g_l.unsqueeze(-1) * a_l + g_r.unsqueeze(-1) * a_r).to(feat.dtype)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            if feat.is_cuda and n >= _linear.MIN_ROWS and h * f <= _linear.MAX_FEATURES:
+                g_cat = torch.cat([g_l.float(), g_r.float()], 1)                                # [N, 2 H]
+                gw, _ = _linear.linear_wgrad(feat.reshape(n, h * f).float(), g_cat, want_bias=False)  # [2 H, H F]
+                idx = torch.arange(h, device=feat.device)
+                blocks = gw.view(2, h, h, f)[:, idx, idx]                                       # [2, H, F]: the diagonal blocks
+                grad_al, grad_ar = blocks[0].unsqueeze(0).to(a_l.dtype), blocks[1].unsqueeze(0).to(a_r.dtype)
+            else:
+                ff = feat.float()
+                grad_al = _column_sum((g_l.unsqueeze(-1).float() * ff).view(n, -1)).view(1, h, f).to(a_l.dtype)
+                grad_ar = _column_sum((g_r.unsqueeze(-1).float() * ff).view(n, -1)).view(1, h, f).to(a_r.dtype)
+        return grad_al, grad_ar, grad_feat
 
 
 def _gat_forward_fused_dropout(self, graph, x):
@@ -171,8 +186,7 @@ def _gat_forward_fused_dropout(self, graph, x):
     # (bf16 autocast, tall x: the hand-written MFMA product that reads x once, cogdl_amd/linear.py: matmul; else torch.matmul)
     h = _linear.matmul(x, self.W).view(-1, self.nhead, self.out_features)
     h[torch.isnan(h)] = 0.0
-    h_l = _HeadProjection.apply(self.a_l, h)
-    h_r = _HeadProjection.apply(self.a_r, h)
+    h_l, h_r = _HeadProjections.apply(self.a_l, self.a_r, h)
     p = float(self.dropout.p) if self.training else 0.0
     out = fused_gat_dropout_func(h_l, h_r, graph.row_indptr.int(), graph.col_indices.int(), self.alpha, h, p)
     out = out.view(out.shape[0], -1)

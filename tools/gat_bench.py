@@ -48,14 +48,14 @@ class GatLayer(torch.nn.Module):
         rowptr, colind, row = g
         if self.mode == "fused-dropout":  # (what install(fused_gat_dropout=True) rebinds GATLayer.forward to: cogdl_amd/fused.py)
             from cogdl_amd import linear as cogdl_linear
-            from cogdl_amd.fused import _HeadProjection
+            from cogdl_amd.fused import _HeadProjections
 
             h = cogdl_linear.matmul(x, self.W).view(-1, self.nhead, self.out_feats)
         else:
             h = torch.matmul(x, self.W).view(-1, self.nhead, self.out_feats)
         if self.mode == "fused-dropout":
 
-            h_l, h_r = _HeadProjection.apply(self.a_l, h), _HeadProjection.apply(self.a_r, h)
+            h_l, h_r = _HeadProjections.apply(self.a_l, self.a_r, h)
         else:
             h_l, h_r = (self.a_l * h).sum(dim=-1), (self.a_r * h).sum(dim=-1)
         if self.mode == "fused-dropout":
