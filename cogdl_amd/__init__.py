@@ -6,7 +6,7 @@ vertex-sharded SpMM over RCCL; graphs of 2^31 edges and more run on one GPU thro
 pointers (cogdl_amd/bigcsr.py).  Everything else in CogDL is used as-is; `install()` slots these
 operators underneath CogDL's unchanged dispatcher (cogdl/utils/spmm_utils.py) and Graph class.
 """
-__version__ = "0.6.0"
+__version__ = "0.6.1"
 
 from .install import install, uninstall  # noqa: F401
 from .plan import transient_structures  # noqa: F401

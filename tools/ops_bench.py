@@ -265,6 +265,22 @@ def linear():
                 print("    torch g @ w: %.1f us" % (ms_t * 1e3), flush=True)
 
 
+def linear_bf16():
+    """The same product under bf16 autocast (csrc/linear_fwd16.hip): bytes = x as the model holds it + the bf16 result."""
+    from cogdl_amd.linear import tall_skinny_matmul_bf16
+
+    for k, i, o, xdt in ((232_965, 602, 64, torch.float32), (232_965, 64, 41, torch.bfloat16), (169_343, 128, 64, torch.float32),
+                         (2_449_029, 100, 47, torch.float32)):
+        x, w = torch.randn(k, i, device=DEV).to(xdt), torch.randn(i, o, device=DEV)
+        ms = timeit(lambda: tall_skinny_matmul_bf16(x, w, None, False), 20)
+        xb, wb = x.bfloat16(), w.bfloat16()
+        ms_t = timeit(lambda: torch.mm(xb, wb), 10)
+        ms_c = timeit(lambda: x.bfloat16(), 10) if xdt == torch.float32 else 0.0
+        report("linear_fwd_bf16 (MFMA)", "K=%d in=%d out=%d x=%s" % (k, i, o, str(xdt).split(".")[1]), ms,
+               k * i * x.element_size() + k * o * 2, k)
+        print("    torch (autocast): cast of x %.1f us + bf16 mm %.1f us" % (ms_c * 1e3, ms_t * 1e3), flush=True)
+
+
 def main():
     argv = sys.argv[1:]
     json_path = None
@@ -283,6 +299,7 @@ def main():
         reddit()
     if not args or "linear" in args:
         linear()
+        linear_bf16()
     if json_path:
         json.dump(ROWS, open(json_path, "w"), indent=1)
 
