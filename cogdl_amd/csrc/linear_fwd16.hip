@@ -82,6 +82,44 @@ __device__ __forceinline__ void fwd16_operands(const Fwd16Elems<XT> &e, int n_ok
     }
 }
 
+// B into LDS: entry e = ((ms * 2 + sub) * NT + nt) * 64 + lane holds B[32 ms + 16 h + 8 sub .. + 7][32 nt + j] as 8 bf16.  Every
+// load is unconditional (an element outside B reads w[0] and is replaced by zero afterwards): no branch per element, so the
+// 32 loads of a thread's four entries are all in flight before the first is used -- with a branch (and its s_waitcnt
+// vmcnt(0)) per element the prologue of a 602 x 64 weight took ~100 us, two thirds of the whole kernel.
+template <typename WT, bool N_BY_K, int NT>
+__device__ __forceinline__ void fwd16_fill_b(uint4 *bs, const WT *__restrict__ w, int k_dim, int n_dim, int n_ms) {
+    const int n_entries = n_ms * 2 * NT * 64;
+    for (int e0 = threadIdx.x; e0 < n_entries; e0 += 256 * 4) {
+        WT raw[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = min(e0 + 256 * u, n_entries - 1);
+            const int el = e & 63, nt = (e >> 6) % NT, sub = ((e >> 6) / NT) & 1, ms = (e >> 6) / (2 * NT);
+            const int n = 32 * nt + (el & 31), k0 = 32 * ms + 16 * (el >> 5) + 8 * sub;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = k0 + q;
+                const bool ok = k < k_dim && n < n_dim;
+                const int idx = N_BY_K ? n * k_dim + k : k * n_dim + n;  // (B of at most 64 x 4096 elements: int)
+                raw[u][q] = w[ok ? idx : 0];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u;
+            const int ec = min(e, n_entries - 1);
+            const int el = ec & 63, nt = (ec >> 6) % NT, sub = ((ec >> 6) / NT) & 1, ms = (ec >> 6) / (2 * NT);
+            const int n = 32 * nt + (el & 31), k0 = 32 * ms + 16 * (el >> 5) + 8 * sub;
+            f32x8 f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) f[q] = (k0 + q < k_dim && n < n_dim) ? to_f32<WT>(raw[u][q]) : 0.f;
+            union { bf16x8 b; uint4 r; } t;
+            t.b = __builtin_convertvector(f, bf16x8);
+            if (e < n_entries) bs[e] = t.r;
+        }
+    }
+}
+
 template <typename XT, int NT, int LB>
 __global__ __launch_bounds__(256) void linear_fwd16_kernel(const XT *__restrict__ x, const void *__restrict__ w, int w_is_f32,
                                                            const float *__restrict__ bias, __hip_bfloat16 *__restrict__ out,
@@ -90,38 +128,13 @@ __global__ __launch_bounds__(256) void linear_fwd16_kernel(const XT *__restrict_
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
-    // ---- prologue: B into LDS, converted and in operand order; four entries (32 loads) in flight per thread
-    const int n_entries = n_ms * 2 * NT * 64;
-    for (int e0 = threadIdx.x; e0 < n_entries; e0 += 256 * 4) {
-        float v[4][8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + 256 * u;
-            const int el = e & 63, nt = (e >> 6) % NT, sub = ((e >> 6) / NT) & 1, ms = (e >> 6) / (2 * NT);
-            const int n = 32 * nt + (el & 31), k0 = 32 * ms + 16 * (el >> 5) + 8 * sub;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int k = k0 + q;
-                float t = 0.f;
-                if (e < n_entries && k < k_dim && n < n_dim) {
-                    const int64_t idx = w_is_n_by_k ? (int64_t)n * k_dim + k : (int64_t)k * n_dim + n;
-                    t = w_is_f32 ? reinterpret_cast<const float *>(w)[idx] : to_f32(reinterpret_cast<const __hip_bfloat16 *>(w)[idx]);
-                }
-                v[u][q] = t;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + 256 * u;
-            if (e < n_entries) {
-                f32x8 f;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) f[q] = v[u][q];
-                union { bf16x8 b; uint4 r; } t;
-                t.b = __builtin_convertvector(f, bf16x8);
-                bs[e] = t.r;
-            }
-        }
+    // ---- prologue: B into LDS, converted and in operand order (fwd16_fill_b: branch-free, 32 loads in flight per thread)
+    if (w_is_f32) {
+        if (w_is_n_by_k) fwd16_fill_b<float, true, NT>(bs, reinterpret_cast<const float *>(w), k_dim, n_dim, n_ms);
+        else fwd16_fill_b<float, false, NT>(bs, reinterpret_cast<const float *>(w), k_dim, n_dim, n_ms);
+    } else {
+        if (w_is_n_by_k) fwd16_fill_b<__hip_bfloat16, true, NT>(bs, reinterpret_cast<const __hip_bfloat16 *>(w), k_dim, n_dim, n_ms);
+        else fwd16_fill_b<__hip_bfloat16, false, NT>(bs, reinterpret_cast<const __hip_bfloat16 *>(w), k_dim, n_dim, n_ms);
     }
     __syncthreads();
     // ---- main loop: every wave walks 32-row tiles on its own (no barrier), the flattened (tile, macro-step) sequence with
@@ -188,8 +201,8 @@ __global__ __launch_bounds__(256) void linear_fwd16_kernel(const XT *__restrict_
                     acc[a][q] = 0.f;
                 }
         }
-        cur = nxt;
-        tile = next_tile;
+        cur = nxt;  // (the compiler renames the two sets across the unrolled loop: no wait for `nxt` here -- the ISA waits with
+        tile = next_tile;  //  vmcnt(6) / vmcnt(4) in front of the operand conversion, i.e. for `cur` only)
         ms = next_ms;
     }
 }
