@@ -6,8 +6,11 @@ fp32 MFMA instead.
 
     linear(x, weight, bias)        functional form with the hand-written weight/bias gradient
     install() / uninstall()        make torch.nn.functional.linear -- hence every unchanged nn.Linear inside CogDL's
-                                   layers -- take it for the shapes it covers (2-D fp32 GPU input with many rows);
+                                   layers -- take it for the shapes it covers (2-D fp32 GPU input with many rows; under
+                                   bf16 autocast: LinearBf16Function, <= 64 output features);
                                    everything else goes to torch's own implementation, as before.
+    matmul(x, W)                   `torch.matmul(x, self.W)` of a layer (gat_layer.py:59) under bf16 autocast: the bf16 MFMA
+                                   product that reads x once in the dtype the model holds it (csrc/linear_fwd16.hip)
 The forward product and grad_input go through `cogdl_hip_linear_fwd_f32` (LDS-staged MFMA, weights resident in LDS)
 where that kernel is the faster one (<= 64 output columns, weight <= 96 KB), else stay torch.addmm / torch.mm.
 """
@@ -147,6 +150,50 @@ def matmul(x, w):
     return torch.matmul(x, w)
 
 
+class LinearBf16Function(torch.autograd.Function):
+    """torch.nn.functional.linear(x, W, b) under bf16 autocast for tall x and <= 64 output features: forward by
+    cogdl_hip_linear_fwd_bf16 (B = W^T; the bias rounded to bf16 like autocast's cast, added in fp32 before the result is
+    rounded), grad_W / grad_b by the fp32 split-K MFMA reduction over the saved input, grad_x by torch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        b = None if bias is None else bias.detach().to(torch.bfloat16).float()
+        out = tall_skinny_matmul_bf16(x, weight, b, True)
+        if out is None:
+            out = _orig_linear(x.to(torch.bfloat16), weight.to(torch.bfloat16), None if bias is None else bias.to(torch.bfloat16))
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        grad_x = grad_w = grad_b = None
+        if ctx.needs_input_grad[0]:
+            grad_x = torch.mm(grad_out, weight.to(grad_out.dtype)).to(x.dtype)
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            grad_w, grad_b = linear_wgrad(x.float(), grad_out.float(), want_bias=need_b)
+            grad_w = grad_w.to(weight.dtype)
+        elif need_b:
+            grad_b = grad_out.float().sum(0)
+        if grad_b is not None:
+            grad_b = grad_b.to(ctx.bias_dtype)
+        return grad_x, grad_w, grad_b
+
+
+def covers_bf16(x, weight, bias):
+    """nn.Linear under torch.autocast("cuda", bfloat16) on the tall-skinny shapes of full-graph training."""
+    return (torch.is_tensor(x) and x.is_cuda and x.dim() == 2 and weight.dim() == 2 and weight.is_cuda and weight.device == x.device
+            and x.shape[1] == weight.shape[1] and x.shape[0] >= MIN_ROWS and weight.shape[0] <= 64 and weight.shape[1] <= MAX_FEATURES
+            and x.dtype in (torch.float32, torch.bfloat16) and weight.dtype in (torch.float32, torch.bfloat16)
+            and (bias is None or (bias.is_cuda and bias.device == x.device and bias.dim() == 1 and bias.shape[0] == weight.shape[0]
+                                  and bias.dtype in (torch.float32, torch.bfloat16)))
+            and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
+
 def covers(x, weight, bias):
     return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
             and x.shape[0] >= MIN_ROWS and weight.dim() == 2 and max(weight.shape) <= MAX_FEATURES
@@ -154,13 +201,15 @@ def covers(x, weight, bias):
             and x.shape[1] == weight.shape[1] and weight.is_cuda and weight.device == x.device
             and (bias is None or (bias.dtype == torch.float32 and bias.is_cuda and bias.device == x.device
                                   and bias.dim() == 1 and bias.shape[0] == weight.shape[0]))
-            and torch.is_grad_enabled() and weight.requires_grad and not torch.is_autocast_enabled())
+            and torch.is_grad_enabled() and weight.requires_grad and not torch.is_autocast_enabled("cuda"))
 
 
 def linear(x, weight, bias=None):
     """Drop-in for torch.nn.functional.linear."""
     if covers(x, weight, bias):
         return LinearFunction.apply(x, weight, bias)
+    if covers_bf16(x, weight, bias):
+        return LinearBf16Function.apply(x, weight, bias)
     return _orig_linear(x, weight, bias)
 
 

@@ -211,3 +211,39 @@ def test_matmul_under_bf16_autocast_matches_torch_autocast():
     assert xb.grad.dtype == torch.bfloat16 and bool(((xb.grad.double() - want_x).abs() <= want_x.abs() * 2.0 ** -7 + 1e-2).all())
     want_w = xb.detach().double().t() @ g2.double()
     assert bool(((w2.grad.double() - want_w).abs() <= 1e-5 * (xb.detach().double().abs().t() @ g2.double().abs()) + 1e-6).all())
+
+
+def test_functional_linear_hook_under_bf16_autocast():
+    """install(): nn.Linear under torch.autocast(bfloat16) on a tall input takes LinearBf16Function -- forward within a bf16
+    ulp of torch's autocast product, grad_W / grad_b against float64 (fp32 reductions of the un-rounded input), grad_x against
+    the bf16 product torch forms; shapes outside the cover (wide outputs, few rows) stay torch's."""
+    from cogdl_amd import linear as cl
+
+    torch.manual_seed(2)
+    rows, k, n = 30000, 100, 47
+    lin = torch.nn.Linear(k, n).to(DEV)
+    x = torch.randn(rows, k, device=DEV, requires_grad=True)
+    gout = torch.randn(rows, n, device=DEV).bfloat16()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y_t = lin(x)
+    y_t.backward(gout)
+    ref = (y_t.detach().float(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x.grad = lin.weight.grad = lin.bias.grad = None
+    cl.install()
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert cl.covers_bf16(x, lin.weight, lin.bias)
+            y = lin(x)
+            wide = torch.nn.Linear(k, 128).to(DEV)
+            assert not cl.covers_bf16(x, wide.weight, wide.bias) and not cl.covers_bf16(x[:100], lin.weight, lin.bias)
+            assert wide(x).dtype == torch.bfloat16
+        assert y.dtype == torch.bfloat16
+        y.backward(gout)
+    finally:
+        cl.uninstall()
+    assert bool(((y.detach().float() - ref[0]).abs() <= ref[0].abs() * 2.0 ** -7 + 2e-3).all())
+    g64, x64 = gout.double(), x.detach().double()
+    want_w, scale_w = g64.t() @ x64, g64.abs().t() @ x64.abs()
+    assert lin.weight.grad.dtype == torch.float32 and bool(((lin.weight.grad.double() - want_w).abs() <= 1e-5 * scale_w + 1e-6).all())
+    assert bool(((lin.bias.grad.double() - g64.sum(0)).abs() <= 1e-5 * g64.abs().sum(0) + 1e-6).all())
+    assert x.grad.dtype == torch.float32 and bool(((x.grad - ref[1]).abs() <= ref[1].abs() * 2.0 ** -6 + 2e-2).all())
