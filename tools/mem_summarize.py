@@ -18,7 +18,7 @@ for root in sys.argv[1:]:
             d["c"][row["Counter_Name"]] += float(row["Counter_Value"])
         last = collections.OrderedDict()
         for did, d in by.items():
-            if "rowreduce_" in d["name"]:
+            if os.environ.get("MEM_SUMMARIZE_MATCH", "rowreduce_") in d["name"]:
                 last[d["name"]] = d
         for name, d in last.items():
             short = re.sub(r"\(.*", "", name).replace("void cogdl::", "").replace("cogdl::", "")
