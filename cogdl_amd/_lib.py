@@ -58,6 +58,8 @@ HIP_SIGNATURES = {
     "cogdl_hip_scatter_max_bwd_csc": ([_vp] * 5 + [_i64, _i64, _i64, _vp, _sz, _vp], _i32),
     "cogdl_hip_gspmm_workspace_bytes": ([_i64, _i64], _sz),
     "cogdl_hip_gspmm": ([_vp] * 5 + [_i32, _vp, _i32, _i32, _vp, _i64, _i64, _i64, _vp, _sz, _vp], _i32),
+    "cogdl_hip_gspmm_xcd_workspace_bytes": ([_i64, _i64], _sz),
+    "cogdl_hip_gspmm_xcd": ([_vp] * 4 + [_i32, _vp, _i32, _i32, _vp, _i64, _i64, _vp, _sz, _vp], _i32),
     "cogdl_hip_gspmm_edge_grad": ([_vp] * 7 + [_i32, _i32, _vp, _vp, _i64, _i64, _vp], _i32),
     "cogdl_hip_gat_fwd_workspace_bytes": ([_i64, _i64, _i64, _i32], _sz),
     "cogdl_hip_gat_fwd": ([_vp] * 5 + [_f32] + [_vp] * 3 + [_i64, _i64, _i64, _i64, _i32, _vp, _sz, _vp], _i32),

@@ -134,6 +134,7 @@ struct GspmmArgs {
     float *out;
     int64_t m, nnz;
     int k, op, ef_scalar, mean;
+    const cogdl_hip_vrows *vr = nullptr;  // XCD-partitioned, length-ordered plan of the destination-sorted view (rowreduce.h)
 };
 
 constexpr int kGspmmUnroll = 4;  // two gathers per edge: half of csr_spmm's unroll keeps the same loads in flight
@@ -142,6 +143,10 @@ template <int VEC, int LPR>
 static int launch_gspmm(const GspmmArgs &a, void *ws, size_t wsb, hipStream_t s) {
     GspmmOp<VEC, LPR, kGspmmUnroll> op{a.rowptr, a.eid, a.x, a.ef, a.w, a.out, a.k, a.op, a.ef_scalar, a.mean};
     const int64_t tiles = ((int64_t)a.k + (int64_t)LPR * VEC - 1) / ((int64_t)LPR * VEC);
+    if (a.vr) {  // plan position j -> edge id plan->eid[j] (the plan was built over the sorted view with the view's perm as base)
+        op.eid = a.vr->eid;
+        return launch_rowreduce_vrows(op, a.vr, tiles, ws, wsb, s);
+    }
     return launch_rowreduce(op, a.rowptr, a.colind, a.m, a.nnz, tiles, ws, wsb, s);
 }
 
@@ -188,6 +193,39 @@ extern "C" int cogdl_hip_gspmm(const int32_t *rowptr, const int32_t *colind, con
     if (!aligned_to(out, 4) || (x && !aligned_to(x, 4)) || (efeat && !aligned_to(efeat, 4))) return COGDL_HIP_EALIGN;
     const RowGeometry g = spmm_geometry(k, k, 4, gspmm_alignment(a));
     // The workspace was sized for the 16-byte-aligned geometry; a narrower one needs at most as many floats.
+    hipStream_t s = (hipStream_t)stream;
+    switch (g.vec) {
+        case 4: return gspmm_lpr<4>(a, g.lpr, workspace, workspace_bytes, s);
+        case 2: return gspmm_lpr<2>(a, g.lpr, workspace, workspace_bytes, s);
+        default: return gspmm_lpr<1>(a, g.lpr, workspace, workspace_bytes, s);
+    }
+}
+
+// The same operator over an XCD-partitioned plan of the destination-sorted view (cogdl_amd/xcdplan.py, cut at the exact-row
+// bound: rows up to it are one virtual row each, summed in the caller's edge order exactly as above; longer rows are summed in
+// pieces -- which the ordinary launch does too, rowreduce.h long-row path).  What the plan buys on skewed graphs is its slot
+// order (rows of one length per wave) and hub rows merged by whole workgroups.  rowptr: the view's row pointer (for `mean`).
+extern "C" size_t cogdl_hip_gspmm_xcd_workspace_bytes(int64_t n_parts, int64_t k) {
+    if (k <= 0) return 256;
+    const RowGeometry g = spmm_geometry(k, k, 4, 16);
+    return vrows_workspace_bytes(n_parts, g.tiles * g.vec * g.lpr);
+}
+
+extern "C" int cogdl_hip_gspmm_xcd(const cogdl_hip_vrows *plan, const int32_t *rowptr, const float *x, const float *efeat,
+                                   int efeat_is_scalar, const float *weight, int op, int mean, float *out, int64_t m, int64_t k,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = vrows_valid(plan);
+    if (rc != COGDL_HIP_OK) return rc;
+    if (m < 0 || k < 0) return COGDL_HIP_EINVAL;
+    if (m == 0 || k == 0) return COGDL_HIP_OK;
+    if (!rowptr || !out || (!x && !efeat)) return COGDL_HIP_EINVAL;
+    if (op < COGDL_HIP_GSPMM_ADD || op > COGDL_HIP_GSPMM_WMUL) return COGDL_HIP_EINVAL;
+    if (op == COGDL_HIP_GSPMM_WMUL && (!x || !efeat)) return COGDL_HIP_EINVAL;
+    if (!x && efeat_is_scalar) return COGDL_HIP_EINVAL;
+    if (k > 0x7fffffff) return COGDL_HIP_ERANGE;
+    GspmmArgs a{rowptr, nullptr, nullptr, x, efeat, weight, out, m, plan->nnz, (int)k, op, efeat_is_scalar ? 1 : 0, mean ? 1 : 0, plan};
+    if (!aligned_to(out, 4) || (x && !aligned_to(x, 4)) || (efeat && !aligned_to(efeat, 4))) return COGDL_HIP_EALIGN;
+    const RowGeometry g = spmm_geometry(k, k, 4, gspmm_alignment(a));
     hipStream_t s = (hipStream_t)stream;
     switch (g.vec) {
         case 4: return gspmm_lpr<4>(a, g.lpr, workspace, workspace_bytes, s);

@@ -31,7 +31,7 @@ _OPS_WMUL = 3  # COGDL_HIP_GSPMM_WMUL: (x * weight) * efeat, autograd's rounding
 class EdgePlan:
     """Destination-sorted view of an edge list: rowptr int32 [n+1], perm int32 [E] (sorted position -> edge id; stable),
     sorted (perm is the identity)."""
-    __slots__ = ("rowptr", "perm", "sorted", "n", "keep", "_col_key", "_col_src", "_colind")
+    __slots__ = ("rowptr", "perm", "sorted", "n", "keep", "_col_key", "_col_src", "_colind", "uses", "_skewed", "_xcd_key", "_xcd", "_xcd_builds")
 
     def __init__(self, dst, n):
         from ..graph_build import coo2csr_index
@@ -44,6 +44,43 @@ class EdgePlan:
         self.n = n
         self.keep = dst  # pins the key tensor: its data_ptr cannot be recycled while the plan lives
         self._col_key, self._col_src, self._colind = None, None, None
+        self.uses, self._skewed, self._xcd_key, self._xcd, self._xcd_builds = 0, None, None, None, 0
+
+    XCD_MIN_COLUMNS = 65  # (narrower rows: the plan's launch measured 8-15 % SLOWER than the ordinary one, below)
+
+    def xcd(self, colind, k):
+        """The XCD-partitioned, length-ordered plan of this view (cogdl_amd/xcdplan.py) for the launch that walks `colind` (int32,
+        sorted order), or None.  Taken by memoised edge lists of SKEWED graphs from their second use on (the plan build is a
+        few torch sorts: a one-off edge list must not pay it), cut at the exact-row bound of the ordinary launch -- rows up to it
+        are summed in the caller's edge order as before, longer rows in pieces as before.  Measured on the arxiv-sized R-MAT
+        graph, shuffled COO list, ordinary launch -> plan (profiles/r06_gspmm_plan_ab.txt): s_mul_e_sum F = 128 747 -> 460 us,
+        F = 96 497 -> 372, F = 256 1432 -> 917; scatter_add F = 128 622 -> 383; forward + backward 1554 -> 1010 us; but F = 64
+        327 -> 355 and F = 32 202 -> 231 us: rows of more than 64 columns only."""
+        from .. import xcdplan
+
+        nnz = self.perm.numel()
+        if xcdplan.MODE == "off" or nnz == 0:
+            return None
+        if xcdplan.MODE != "force":
+            if self.uses < 2 or nnz < xcdplan.ORDERED_MIN_EDGES or k < self.XCD_MIN_COLUMNS:
+                return None
+            if self._skewed is None:
+                if torch.cuda.is_current_stream_capturing():
+                    return None
+                self._skewed = xcdplan.skewed(self.rowptr)
+            if not self._skewed:
+                return None
+        key = tensor_key(colind)
+        if key != self._xcd_key or self._xcd is None:
+            if torch.cuda.is_current_stream_capturing():  # (the build reads sizes back: never inside a capture)
+                return None
+            if self._xcd_builds >= 4 and xcdplan.MODE != "force":
+                return None  # (a caller that pairs this index with ever new partner tensors: no plan build per call)
+            self._xcd_builds += 1
+            split = int(_lib.hip().cogdl_hip_exact_row_edges(nnz))
+            plan = xcdplan.build(self.rowptr, colind, eid_base=None if self.sorted else self.perm, split=split)
+            self._xcd_key, self._xcd = key, (plan, colind)  # (colind kept: pins the key's address)
+        return self._xcd[0]
 
     def colind(self, col):
         """The source ids in sorted order as int32, memoised on the identity (address, version, layout) of `col`; the
@@ -71,6 +108,7 @@ def edge_plan(dst, n):
             _PLANS.popitem(last=False)
     else:
         _PLANS.move_to_end(key)
+    plan.uses += 1
     return plan
 
 
@@ -83,6 +121,15 @@ def _gspmm(plan, colind, x, efeat, ef_scalar, weight, op, mean, k):
     dev = plan.rowptr.device
     nnz = plan.perm.numel()
     out = torch.empty((plan.n, k), dtype=torch.float32, device=dev)
+    xp = plan.xcd(colind, k)
+    if xp is not None:
+        ws, ws_bytes = _lib.workspace("cogdl_hip_gspmm_xcd_workspace_bytes", dev, xp.n_parts, k)
+        with _lib.on_device(dev):
+            rc = _lib.hip().cogdl_hip_gspmm_xcd(xp.ref(), _lib.ptr(plan.rowptr), _lib.ptr(x), _lib.ptr(efeat), int(ef_scalar),
+                                                _lib.ptr(weight), op, int(mean), _lib.ptr(out), plan.n, k, _lib.ptr(ws), ws_bytes,
+                                                _lib.stream_of(out))
+        _lib.check(rc, "gspmm_xcd")
+        return out
     ws, ws_bytes = _lib.workspace("cogdl_hip_gspmm_workspace_bytes", dev, nnz, k)
     eid = None if plan.sorted else plan.perm
     with _lib.on_device(dev):

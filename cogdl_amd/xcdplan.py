@@ -208,15 +208,21 @@ def ordered_wanted(fp, rowptr, m, nnz, n_src, row_bytes):
     key = fp.key()
     hit = _SKEW.get(key)
     if hit is None:
-        deg = (rowptr[1:] - rowptr[:-1]).float()
-        pad = (-deg.numel()) % 8
-        if pad:
-            deg = torch.cat([deg, deg.new_zeros(pad)])
-        fill = float(deg.sum() / (deg.view(-1, 8).max(1).values.sum() * 8).clamp(min=1.0))
         if len(_SKEW) > 256:
             _SKEW.clear()
-        hit = _SKEW[key] = fill < ORDERED_MAX_FILL
+        hit = _SKEW[key] = skewed(rowptr)
     return hit
+
+
+def skewed(rowptr):
+    """The skew test of ordered_wanted (one pass over the degrees + one host read): do eight consecutive rows fill less than
+    ORDERED_MAX_FILL of the lane-slots of their longest?"""
+    deg = (rowptr[1:] - rowptr[:-1]).float()
+    pad = (-deg.numel()) % 8
+    if pad:
+        deg = torch.cat([deg, deg.new_zeros(pad)])
+    fill = float(deg.sum() / (deg.view(-1, 8).max(1).values.sum() * 8).clamp(min=1.0))
+    return fill < ORDERED_MAX_FILL
 
 
 class _Cache:

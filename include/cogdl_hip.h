@@ -361,6 +361,17 @@ COGDL_API int cogdl_hip_gspmm(const int32_t *rowptr, const int32_t *colind, cons
                     const float *efeat, int efeat_is_scalar, const float *weight, int op, int mean, float *out,
                     int64_t m, int64_t k, int64_t nnz, void *workspace, size_t workspace_bytes, void *stream);
 
+/* gspmm over an XCD-partitioned plan of the destination-sorted view (round 6, ABI v9; cogdl_hip_vrows as built by
+ * cogdl_amd/xcdplan.py: build(rowptr, colind_sorted, eid_base = the view's perm, split = cogdl_hip_exact_row_edges(nnz))): the
+ * same sums -- rows up to the exact-row bound in the caller's edge order, longer rows in pieces like the ordinary launch's
+ * long-row path -- with rows of one length per wave.  rowptr: the view's row pointer (used by `mean`).  The Python front
+ * takes it for memoised edge lists of skewed graphs from their second use on (operators/ops.py: EdgePlan.xcd). */
+COGDL_API size_t cogdl_hip_gspmm_xcd_workspace_bytes(int64_t n_parts, int64_t k);
+COGDL_API int cogdl_hip_gspmm_xcd(const cogdl_hip_vrows *plan, const int32_t *rowptr, const float *x, const float *efeat,
+                        int efeat_is_scalar, const float *weight, int op, int mean, float *out, int64_t m, int64_t k,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+
 /* Per-edge gradients of the family (autograd of src_op_e_aggr_coo, ops.py:43-52) without [E, k] temporaries, over the
  * caller's COO list (row = destination, col = source, int64 as CogDL keeps them), from the upstream gradient grad [m, k]:
  *   g = grad[row[e], :] * scale[row[e]]            (scale [m]: 1 / deg for "mean", NULL for "sum")

@@ -261,3 +261,87 @@ def test_gpu_calls_outside_the_fused_kernel_take_the_torch_route_loudly():
         ops.src_op_e_aggr_coo("mul", "sum", x.to(DEV).half(), ef.to(DEV).half(), row.to(DEV), col.to(DEV))
     with pytest.warns(ops.TorchRouteWarning, match="scatter_add"):
         ops.scatter_add(ef.to(DEV).double(), row.to(DEV), n)
+
+
+@pytest.mark.parametrize("k", [16, 64, 100])
+@pytest.mark.parametrize("sort", [False, True], ids=["shuffled", "sorted"])
+def test_xcd_plan_of_the_sorted_view_keeps_the_exact_rows(oracle, k, sort, monkeypatch):
+    """cogdl_hip_gspmm_xcd (COGDL_AMD_XCD=force): the same sums over the length-ordered plan of the destination-sorted view --
+    rows up to the exact-row bound bit-exact against the oracle (caller's edge order), hub rows up to re-association; forward
+    AND the fused backward (the source-sorted view takes its own plan), scatter_add / op_aggr('mean') too."""
+    from cogdl_amd import xcdplan
+
+    monkeypatch.setattr(xcdplan, "MODE", "force")
+    ops.clear_plans()
+    n, e = 5000, 120000
+    row, col = _coo(n, e, seed=11, sort=sort, hub=((3, 129), (4, 20000), (17, 3000), (18, 700), (4999, 2)))
+    gen = torch.Generator().manual_seed(k)
+    x, ef, w = torch.randn(n, k, generator=gen), torch.randn(e, k, generator=gen), torch.rand(e, generator=gen)
+    g = _graph(row.to(DEV), col.to(DEV), w.to(DEV))
+    thresh = _lib.hip().cogdl_hip_exact_row_edges(e)
+    short = (torch.bincount(row, minlength=n) <= thresh).numpy()
+    for op1, op2 in (("mul", "sum"), ("add", "mean"), ("sub", "sum")):
+        xd, efd = x.to(DEV).requires_grad_(), ef.to(DEV).requires_grad_()
+        got = getattr(ops, "s_%s_e_%s" % (op1, op2))(g, xd, efd, weight=True)
+        plan = ops.edge_plan(g.edge_index[0], n)
+        assert plan._xcd is not None, "the forced plan was not taken"
+        want = oracle.src_op_e_aggr(op1, op2, x, ef, row, col, n, w=w)
+        gn = got.detach().cpu().numpy()
+        assert gn[short].tobytes() == want[short].tobytes()
+        # hub rows: against float64 (the oracle's own fp32 sequential sum of 20,000 terms is the less accurate of the two)
+        xs, es = x.double()[col], ef.double()
+        msg = {"mul": xs * es, "add": xs + es, "sub": xs - es}[op1] * w.double().view(-1, 1)
+        ref, scale = torch.zeros(n, k, dtype=torch.float64), torch.zeros(n, k, dtype=torch.float64)
+        ref.index_add_(0, row, msg)
+        scale.index_add_(0, row, msg.abs())
+        if op2 == "mean":
+            cnt = torch.bincount(row, minlength=n).clamp(min=1).double().view(-1, 1)
+            ref, scale = ref / cnt, scale / cnt
+        assert bool(((got.detach().cpu().double() - ref).abs() <= 1e-5 * scale + 1e-30).all())
+        # backward: against the same operator with the plans off
+        gout = torch.randn(n, k, generator=gen).to(DEV)
+        got.backward(gout)
+        gx, ge = xd.grad.clone(), efd.grad.clone()
+        monkeypatch.setattr(xcdplan, "MODE", "off")
+        xo, efo = x.to(DEV).requires_grad_(), ef.to(DEV).requires_grad_()
+        getattr(ops, "s_%s_e_%s" % (op1, op2))(g, xo, efo, weight=True).backward(gout)
+        monkeypatch.setattr(xcdplan, "MODE", "force")
+        assert torch.equal(ge, efo.grad)  # (per-edge kernel: no plan involved)
+        out_deg = torch.bincount(col, minlength=n)
+        short_src = (out_deg <= thresh).to(DEV)
+        assert torch.equal(gx[short_src], xo.grad[short_src])
+        torch.testing.assert_close(gx, xo.grad, rtol=1e-4, atol=1e-4)
+    data = torch.randn(e, k, generator=gen)
+    for mean in (False, True):
+        got = ops.op_aggr("mean" if mean else "sum", data.to(DEV), g.edge_index[0], n).cpu().numpy()
+        want, scale = np.zeros((n, k), dtype=np.float64), np.zeros((n, k), dtype=np.float64)
+        np.add.at(want, row.numpy(), data.numpy().astype(np.float64))
+        np.add.at(scale, row.numpy(), np.abs(data.numpy()).astype(np.float64))
+        if mean:
+            cnt = np.maximum(np.bincount(row.numpy(), minlength=n), 1)[:, None]
+            want, scale = want / cnt, scale / cnt
+        assert np.all(np.abs(got - want) <= 1e-5 * scale + 1e-30)
+
+
+def test_xcd_plan_is_taken_by_skewed_edge_lists_from_their_second_use_on(monkeypatch):
+    from cogdl_amd import synth, xcdplan
+
+    monkeypatch.setattr(xcdplan, "MODE", "auto")
+    ops.clear_plans()
+    for topo, expect in (("rmat", True), ("uniform", False)):
+        gr = synth.arxiv_like(seed=0, topology=topo)
+        deg = (gr.rowptr[1:] - gr.rowptr[:-1]).long()
+        row = torch.repeat_interleave(torch.arange(gr.num_nodes), deg)
+        shuffle = torch.randperm(row.numel(), generator=torch.Generator().manual_seed(1))
+        row, col = row[shuffle].to(DEV), gr.colind.long()[shuffle].to(DEV)
+        g = _graph(row, col, None)
+        x, ef = torch.randn(gr.num_nodes, 96, device=DEV), torch.randn(row.numel(), 96, device=DEV)
+        assert ops.s_mul_e_sum(g, x[:, :32].contiguous(), ef[:, :32].contiguous()).shape[1] == 32  # (narrow rows never take it)
+        ops.clear_plans()
+        first = ops.s_mul_e_sum(g, x, ef)
+        plan = ops.edge_plan(row, gr.num_nodes)
+        assert plan._xcd is None  # first use: the ordinary launch
+        second = ops.s_mul_e_sum(g, x, ef)
+        assert (plan._xcd is not None) == expect
+        torch.testing.assert_close(second, first, rtol=1e-3, atol=1e-3)  # (hub rows: re-association under cancellation)
+        ops.clear_plans()

@@ -112,10 +112,17 @@ def arxiv():
         shuffle = torch.randperm(nnz, device=DEV)  # an UNSORTED edge list, as Graph(edge_index=...) holds it
         coo = types.SimpleNamespace(edge_index=(rows[shuffle].contiguous(), g.colind.long()[shuffle].contiguous()),
                                     edge_weight=g.weight[shuffle].contiguous())
-        for f in (64,):
+        for f in (64, 128):
             x, ef = torch.randn(n, f, device=DEV), torch.randn(nnz, f, device=DEV)
             cfg = "arxiv-%s F=%d f32 COO" % (topo, f)
             mops.s_mul_e_sum(coo, x, ef, weight=True)  # builds and caches the destination plan
+            if f > 64:  # (a memoised edge list of a skewed graph takes the length-ordered plan from its second use on, rows of
+                from cogdl_amd import xcdplan  # more than 64 columns: the ordinary launch beside it)
+
+                mode, xcdplan.MODE = xcdplan.MODE, "off"
+                report("s_mul_e_sum(fused, ordinary launch)", cfg, timeit(lambda: mops.s_mul_e_sum(coo, x, ef, weight=True)),
+                       nnz * (4 + 4 + 4 + 2 * f * 4) + n * (4 + f * 4), nnz)
+                xcdplan.MODE = mode
             report("s_mul_e_sum(fused)", cfg, timeit(lambda: mops.s_mul_e_sum(coo, x, ef, weight=True)),
                    nnz * (4 + 4 + 4 + 2 * f * 4) + n * (4 + f * 4), nnz)
 
