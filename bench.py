@@ -312,13 +312,17 @@ def bench_single(args):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    spmm_mod.KERNEL_EVENTS = []
+    # HIP events around the csr_spmm launches of every 4th step (both launches of it; at least 5 steps): a timing-event record
+    # costs the host ~18 us, four per step would make the timed loop host-bound on a slow box (spmm.KernelEventLog)
+    spmm_mod.KERNEL_EVENTS = spmm_mod.KernelEventLog(every=1)
+    sample_every = max(1, min(4, args.steps // 5))
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        spmm_mod.KERNEL_EVENTS.enabled = i % sample_every == 0  # (this step's two launches, or none)
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    events, spmm_mod.KERNEL_EVENTS = spmm_mod.KERNEL_EVENTS, None
+    events, spmm_mod.KERNEL_EVENTS = list(spmm_mod.KERNEL_EVENTS), None
     kern_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
 
     fwd_ms = kernel_alone_ms(gd, x.detach())
@@ -343,7 +347,11 @@ def bench_single(args):
                      "traffic": traffic, "traffic_info": traffic_info,
                      "algorithmic_bytes_per_launch": bytes_alg,
                      "compulsory_bytes_per_launch": g.nnz * 8 + 4 * (g.num_nodes + 1) + 2 * g.num_nodes * f * 4,
-                     "kernel_ms_in_step": kern_ms, "kernel_ms_fwd_alone": fwd_ms,
+                     "kernel_ms_in_step": kern_ms, "kernel_launches_timed": len(events),
+                     "kernel_timing": "HIP events around both csr_spmm launches of every %d%s step of the timed region (a timing-event "
+                                      "record costs the host ~18 us: bracketing all %d launches would make the loop host-bound on a "
+                                      "slow box)" % (sample_every, {1: "st", 2: "nd", 3: "rd"}.get(sample_every, "th"), 2 * args.steps),
+                     "kernel_ms_fwd_alone": fwd_ms,
                      "GEdges_s_fwd_alone": g.nnz / (fwd_ms * 1e-3) / 1e9},
     }
     result["roofline"]["rmat"] = rmat_roofline(dev)

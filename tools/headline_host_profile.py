@@ -96,6 +96,17 @@ def main():
         small()
     torch.cuda.synchronize()
     print("2048-row graph: wall %.1f us/step (the host's own pace)" % ((time.perf_counter() - t0) / 200 * 1e6))
+    from cogdl_amd.operators import spmm as spmm_mod
+
+    for name, make in (("a plain list (events created per launch)", lambda: []), ("KernelEventLog(every = 8 launches)", lambda: spmm_mod.KernelEventLog(every=8))):
+        spmm_mod.KERNEL_EVENTS = make()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            small()
+        torch.cuda.synchronize()
+        print("2048-row graph with KERNEL_EVENTS = %s: wall %.1f us/step" % (name, (time.perf_counter() - t0) / 200 * 1e6))
+        spmm_mod.KERNEL_EVENTS = None
     import cProfile
     import pstats
 
