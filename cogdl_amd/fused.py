@@ -162,6 +162,10 @@ class _HeadProjections(torch.autograd.Function):
         a_l, a_r, feat = ctx.saved_tensors
         n, h, f = feat.shape
         grad_feat = grad_al = grad_ar = None
+        if g_l is None and g_r is None:
+            return None, None, None
+        g_l = torch.zeros_like(g_r) if g_l is None else g_l  # (an output the caller never used)
+        g_r = torch.zeros_like(g_l) if g_r is None else g_r
         if ctx.needs_input_grad[2]:
             grad_feat = (g_l.unsqueeze(-1) * a_l + g_r.unsqueeze(-1) * a_r).to(feat.dtype)
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:

@@ -39,3 +39,12 @@ def test_fallback_path_matches_float64_autograd(n, h, f):
 @pytest.mark.parametrize("n,h,f", [(232965, 8, 8), (50000, 1, 41), (5000, 4, 16), (4097, 3, 5), (300, 8, 8)])
 def test_mfma_path_matches_float64_autograd(n, h, f, dtype):
     _check(n, h, f, dtype, "cuda:0", 1e-6 if dtype == torch.float32 else 2.0 ** -8)
+
+
+def test_an_unused_projection_gets_a_zero_gradient():
+    feat = torch.randn(50, 2, 3, requires_grad=True)
+    a_l, a_r = torch.randn(1, 2, 3, requires_grad=True), torch.randn(1, 2, 3, requires_grad=True)
+    h_l, _ = _HeadProjections.apply(a_l, a_r, feat)
+    h_l.sum().backward()
+    assert torch.allclose(a_l.grad, feat.detach().sum(0, keepdim=True)) and bool((a_r.grad == 0).all())
+    assert torch.allclose(feat.grad, a_l.detach().expand_as(feat))
