@@ -216,6 +216,7 @@ def trainer_epoch(budget_s=240):
     # gnn.py:148-156), the configuration BASELINE.md section 3 timed at 5.94 s per training step on the CPU
     for key, argv in (("gpu", ["gpu", "30"]), ("gpu_mfma_linear", ["gpu", "30", "linear"]),
                       ("gpu_mfma_linear_structure_memo", ["gpu", "30", "linear", "memo"]), ("cpu_reference", ["cpu", "3"]),
+                      ("gpu_fp16", ["gpu", "30", "fp16"]), ("gpu_fp16_mfma_linear", ["gpu", "30", "linear", "fp16"]),
                       ("arxiv_example_gpu", ["gpu", "30", "example"]),
                       ("arxiv_example_gpu_mfma_linear", ["gpu", "30", "linear", "example"])):
         try:

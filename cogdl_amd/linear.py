@@ -86,22 +86,38 @@ class LinearFunction(torch.autograd.Function):
         return grad_x, grad_w, grad_b
 
 
-def tall_skinny_matmul_bf16(x, w, bias, w_is_n_by_k):
-    """bf16(x[R, K]) . bf16(B) (+ bias) -> bf16 [R, N] through cogdl_hip_linear_fwd_bf16 (x, w: fp32 or bf16; B = w^T for
-    w [N, K], w for w [K, N]); None if the kernel declines the shape."""
+_HALF_ENTRY = {torch.bfloat16: "cogdl_hip_linear_fwd_bf16", torch.float16: "cogdl_hip_linear_fwd_f16"}
+
+
+def tall_skinny_matmul_16(x, w, bias, w_is_n_by_k, out_dtype=torch.bfloat16):
+    """h(x[R, K]) . h(B) (+ bias) -> [R, N] in `out_dtype` (bfloat16 | float16; h = the rounding to it) through
+    cogdl_hip_linear_fwd_bf16 / _f16 (x, w: fp32 or `out_dtype`; B = w^T for w [N, K], w for w [K, N]); None if the kernel
+    declines the shape."""
     dev = x.device
     x, w = x.contiguous(), w.contiguous()
     rows, k = x.shape
     n = w.shape[0] if w_is_n_by_k else w.shape[1]
-    out = torch.empty((rows, n), dtype=torch.bfloat16, device=dev)
+    out = torch.empty((rows, n), dtype=out_dtype, device=dev)
     with _lib.on_device(dev):
-        rc = _lib.hip().cogdl_hip_linear_fwd_bf16(_lib.ptr(x), _lib.DTYPE_CODE[x.dtype], _lib.ptr(w), _lib.DTYPE_CODE[w.dtype],
-                                                  _lib.ptr(bias), _lib.ptr(out), rows, k, n, 1 if w_is_n_by_k else 0,
-                                                  _lib.stream_of(x))
+        rc = getattr(_lib.hip(), _HALF_ENTRY[out_dtype])(_lib.ptr(x), _lib.DTYPE_CODE[x.dtype], _lib.ptr(w), _lib.DTYPE_CODE[w.dtype],
+                                                         _lib.ptr(bias), _lib.ptr(out), rows, k, n, 1 if w_is_n_by_k else 0,
+                                                         _lib.stream_of(x))
     if rc == EUNSUPPORTED:
         return None
-    _lib.check(rc, "linear_fwd_bf16")
+    _lib.check(rc, "linear_fwd_16")
     return out
+
+
+def tall_skinny_matmul_bf16(x, w, bias, w_is_n_by_k):
+    return tall_skinny_matmul_16(x, w, bias, w_is_n_by_k, torch.bfloat16)
+
+
+def _autocast_half():
+    """The 16-bit dtype of the enclosing torch.autocast("cuda", ...) context (bfloat16 | float16), or None."""
+    if not torch.is_autocast_enabled("cuda"):
+        return None
+    dt = torch.get_autocast_dtype("cuda")
+    return dt if dt in _HALF_ENTRY else None
 
 
 class MatmulBf16Function(torch.autograd.Function):
@@ -114,10 +130,10 @@ class MatmulBf16Function(torch.autograd.Function):
     grad_x:  grad_out . W^T in grad_out's dtype (torch; only layers behind the first need it, where x is narrow)."""
 
     @staticmethod
-    def forward(ctx, x, w):
-        out = tall_skinny_matmul_bf16(x, w, None, False)
+    def forward(ctx, x, w, half=torch.bfloat16):
+        out = tall_skinny_matmul_16(x, w, None, False, half)
         if out is None:  # (a shape the kernel declines: the same product by torch, same backward)
-            out = torch.mm(x.to(torch.bfloat16), w.to(torch.bfloat16))
+            out = torch.mm(x.to(half), w.to(half))
         ctx.save_for_backward(x, w)
         return out
 
@@ -131,22 +147,22 @@ class MatmulBf16Function(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw, _ = linear_wgrad(x.float(), grad_out.float(), want_bias=False)  # [N, K] = grad_out^T . x
             grad_w = gw.t().to(w.dtype)
-        return grad_x, grad_w
+        return grad_x, grad_w, None
 
 
 def matmul_covers(x, w):
     return (torch.is_tensor(x) and torch.is_tensor(w) and x.is_cuda and w.is_cuda and w.device == x.device
             and x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[0] and x.shape[0] >= MIN_ROWS
             and w.shape[1] <= 64 and w.shape[0] <= MAX_FEATURES
-            and x.dtype in (torch.float32, torch.bfloat16) and w.dtype in (torch.float32, torch.bfloat16)
-            and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+            and _autocast_half() is not None
+            and x.dtype in (torch.float32, _autocast_half()) and w.dtype in (torch.float32, _autocast_half()))
 
 
 def matmul(x, w):
     """Drop-in for `torch.matmul(x, self.W)` in a layer's forward (cogdl/layers/gat_layer.py:59): under bf16 autocast and for
     the tall-skinny shapes of full-graph training MatmulBf16Function, else torch's own product."""
     if matmul_covers(x, w):
-        return MatmulBf16Function.apply(x, w)
+        return MatmulBf16Function.apply(x, w, _autocast_half())
     return torch.matmul(x, w)
 
 
@@ -156,11 +172,11 @@ class LinearBf16Function(torch.autograd.Function):
     rounded), grad_W / grad_b by the fp32 split-K MFMA reduction over the saved input, grad_x by torch."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        b = None if bias is None else bias.detach().to(torch.bfloat16).float()
-        out = tall_skinny_matmul_bf16(x, weight, b, True)
+    def forward(ctx, x, weight, bias, half=torch.bfloat16):
+        b = None if bias is None else bias.detach().to(half).float()
+        out = tall_skinny_matmul_16(x, weight, b, True, half)
         if out is None:
-            out = _orig_linear(x.to(torch.bfloat16), weight.to(torch.bfloat16), None if bias is None else bias.to(torch.bfloat16))
+            out = _orig_linear(x.to(half), weight.to(half), None if bias is None else bias.to(half))
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.bias_dtype = None if bias is None else bias.dtype
@@ -181,17 +197,18 @@ class LinearBf16Function(torch.autograd.Function):
             grad_b = grad_out.float().sum(0)
         if grad_b is not None:
             grad_b = grad_b.to(ctx.bias_dtype)
-        return grad_x, grad_w, grad_b
+        return grad_x, grad_w, grad_b, None
 
 
 def covers_bf16(x, weight, bias):
-    """nn.Linear under torch.autocast("cuda", bfloat16) on the tall-skinny shapes of full-graph training."""
+    """nn.Linear under torch.autocast("cuda", bfloat16 | float16 -- the latter is the reference's Trainer(fp16=True)) on the
+    tall-skinny shapes of full-graph training."""
     return (torch.is_tensor(x) and x.is_cuda and x.dim() == 2 and weight.dim() == 2 and weight.is_cuda and weight.device == x.device
             and x.shape[1] == weight.shape[1] and x.shape[0] >= MIN_ROWS and weight.shape[0] <= 64 and weight.shape[1] <= MAX_FEATURES
-            and x.dtype in (torch.float32, torch.bfloat16) and weight.dtype in (torch.float32, torch.bfloat16)
+            and _autocast_half() is not None
+            and x.dtype in (torch.float32, _autocast_half()) and weight.dtype in (torch.float32, _autocast_half())
             and (bias is None or (bias.is_cuda and bias.device == x.device and bias.dim() == 1 and bias.shape[0] == weight.shape[0]
-                                  and bias.dtype in (torch.float32, torch.bfloat16)))
-            and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+                                  and bias.dtype in (torch.float32, _autocast_half()))))
 
 
 def covers(x, weight, bias):
@@ -209,7 +226,7 @@ def linear(x, weight, bias=None):
     if covers(x, weight, bias):
         return LinearFunction.apply(x, weight, bias)
     if covers_bf16(x, weight, bias):
-        return LinearBf16Function.apply(x, weight, bias)
+        return LinearBf16Function.apply(x, weight, bias, _autocast_half())
     return _orig_linear(x, weight, bias)
 
 

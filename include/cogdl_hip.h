@@ -631,6 +631,10 @@ COGDL_API int cogdl_hip_linear_fwd_f32(const float *x, const float *w, const flo
  * more than 128 KB of bf16 B operands, bf16 rows of odd length.  x 16-byte aligned. */
 COGDL_API int cogdl_hip_linear_fwd_bf16(const void *x, int x_dtype, const void *w, int w_dtype, const float *bias, void *out,
                               int64_t rows, int64_t k_dim, int64_t n_dim, int w_is_n_by_k, void *stream);
+/* linear_fwd_f16: the same kernel on v_mfma_f32_32x32x16_f16 -- the autocast dtype of the reference's own Trainer(fp16=True)
+ * (cogdl/trainer/trainer.py: torch.cuda.amp.autocast); x_dtype / w_dtype: COGDL_HIP_F32 or COGDL_HIP_F16, out f16. */
+COGDL_API int cogdl_hip_linear_fwd_f16(const void *x, int x_dtype, const void *w, int w_dtype, const float *bias, void *out,
+                             int64_t rows, int64_t k_dim, int64_t n_dim, int w_is_n_by_k, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Vertex-sharded graphs (BASELINE.json configs[4]; no reference counterpart -- CogDL only partitions on the host, with

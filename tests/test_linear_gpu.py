@@ -102,44 +102,47 @@ def test_tall_skinny_matmul_declines_big_weights():
 
 
 # ---- bf16 autocast product (csrc/linear_fwd16.hip, ABI v9) ---------------------------------------------------------------
-def _bf16_round(t):
-    return t.to(torch.bfloat16).double()
+def _bf16_round(t, half=torch.bfloat16):
+    return t.to(half).double()
 
 
-@pytest.mark.parametrize("x_dtype", [torch.float32, torch.bfloat16], ids=["x-f32", "x-bf16"])
+@pytest.mark.parametrize("half", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("x_dtype", [torch.float32, "half"], ids=["x-f32", "x-16bit"])
 @pytest.mark.parametrize("rows,k,n,transposed_w", [
     (5000, 602, 64, False),   # configs[2], first layer: 2408-byte fp32 rows (8-byte loads), ragged last macro-step
     (5000, 64, 41, False),    # its second layer
     (4097, 128, 64, True), (1000, 33, 7, False), (1000, 40, 32, True), (33, 34, 1, False), (31, 16, 64, False),
     (1, 8, 3, True), (300, 1000, 33, False), (2049, 96, 48, True), (64, 2, 2, False)])
-def test_bf16_matmul_matches_the_rounded_operands_in_float64(rows, k, n, transposed_w, x_dtype):
+def test_bf16_matmul_matches_the_rounded_operands_in_float64(rows, k, n, transposed_w, x_dtype, half):
     """out = bf16( sum_k bf16(x)[r, k] * bf16(B)[k, c] + bias ): fp32 accumulation of exact bf16 x bf16 products, so the
     float64 product of the ROUNDED operands is matched to fp32-accumulation accuracy before the final rounding -- checked
     as: |got - want| <= one bf16 ulp of want + 2e-6 of the sum of magnitudes.  One-hot / asymmetric columns catch operand
     permutations (k order inside a macro-step, C/D register map)."""
-    from cogdl_amd.linear import tall_skinny_matmul_bf16
+    from cogdl_amd.linear import tall_skinny_matmul_16
 
+    x_dtype = half if x_dtype == "half" else x_dtype
+    ulp = 2.0 ** -8 if half == torch.bfloat16 else 2.0 ** -10  # (f16: 11 significant bits; one ulp of slack)
     gen = torch.Generator().manual_seed(rows + 7 * k + n)
     x = torch.randn(rows, k, generator=gen)
     w = torch.randn((n, k) if transposed_w else (k, n), generator=gen)
     x[:, 0] += 3.0
     x[:, -1] -= 1.5
     bias = torch.randn(n, generator=gen)
-    if x_dtype == torch.bfloat16 and k % 2:
-        got = tall_skinny_matmul_bf16(x.to(DEV).to(x_dtype), w.to(DEV), bias.to(DEV), transposed_w)
-        assert got is None  # (bf16 rows of odd length: declined, the caller keeps torch's product)
+    if x_dtype != torch.float32 and k % 2:
+        got = tall_skinny_matmul_16(x.to(DEV).to(x_dtype), w.to(DEV), bias.to(DEV), transposed_w, half)
+        assert got is None  # (16-bit rows of odd length: declined, the caller keeps torch's product)
         return
     xd = x.to(DEV).to(x_dtype)
-    got = tall_skinny_matmul_bf16(xd, w.to(DEV), bias.to(DEV), transposed_w)
-    assert got is not None and got.dtype == torch.bfloat16 and got.shape == (rows, n)
-    b = _bf16_round(w).t() if transposed_w else _bf16_round(w)
-    want = _bf16_round(x) @ b + bias.double()
-    scale = _bf16_round(x).abs() @ b.abs() + bias.double().abs()
+    got = tall_skinny_matmul_16(xd, w.to(DEV), bias.to(DEV), transposed_w, half)
+    assert got is not None and got.dtype == half and got.shape == (rows, n)
+    b = _bf16_round(w, half).t() if transposed_w else _bf16_round(w, half)
+    want = _bf16_round(x, half) @ b + bias.double()
+    scale = _bf16_round(x, half).abs() @ b.abs() + bias.double().abs()
     err = (got.cpu().double() - want).abs()
-    bound = want.abs() * 2.0 ** -8 + 2e-6 * scale + 1e-30
+    bound = want.abs() * ulp + 2e-6 * scale + 1e-7  # (+ f16's subnormal spacing near zero)
     assert bool((err <= bound).all()), "max err/bound %.3f" % float((err / bound).max())
-    # weights already in bf16 (autocast's cached cast): same result
-    again = tall_skinny_matmul_bf16(xd, w.to(DEV).bfloat16(), bias.to(DEV), transposed_w)
+    # weights already in the 16-bit type (autocast's cached cast): same result
+    again = tall_skinny_matmul_16(xd, w.to(DEV).to(half), bias.to(DEV), transposed_w, half)
     assert torch.equal(again, got)
 
 
@@ -247,3 +250,35 @@ def test_functional_linear_hook_under_bf16_autocast():
     assert lin.weight.grad.dtype == torch.float32 and bool(((lin.weight.grad.double() - want_w).abs() <= 1e-5 * scale_w + 1e-6).all())
     assert bool(((lin.bias.grad.double() - g64.sum(0)).abs() <= 1e-5 * g64.abs().sum(0) + 1e-6).all())
     assert x.grad.dtype == torch.float32 and bool(((x.grad - ref[1]).abs() <= ref[1].abs() * 2.0 ** -6 + 2e-2).all())
+
+
+def test_functional_linear_hook_under_fp16_autocast_with_a_grad_scaler():
+    """The reference's own mixed precision (Trainer(fp16=True): torch.cuda.amp.autocast + GradScaler, cogdl/trainer/trainer.py):
+    nn.Linear on a tall input under float16 autocast takes cogdl_hip_linear_fwd_f16; the scaled gradients come out as torch's."""
+    from cogdl_amd import linear as cl
+
+    torch.manual_seed(3)
+    rows, k, n = 20000, 128, 40
+    x = torch.randn(rows, k, device=DEV)
+    y = torch.randint(0, n, (rows,), device=DEV)
+    grads = []
+    for hooked in (False, True):
+        torch.manual_seed(4)
+        lin = torch.nn.Linear(k, n).to(DEV)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+        if hooked:
+            cl.install()
+        try:
+            with torch.autocast("cuda", dtype=torch.float16):
+                if hooked:
+                    assert cl.covers_bf16(x, lin.weight, lin.bias)
+                out = lin(x)
+                assert out.dtype == torch.float16
+                loss = torch.nn.functional.cross_entropy(out.float(), y)
+            scaler.scale(loss).backward()
+        finally:
+            cl.uninstall()
+        grads.append((lin.weight.grad.clone() / 1024.0, lin.bias.grad.clone() / 1024.0, out.detach().float()))
+    (gw_t, gb_t, o_t), (gw_c, gb_c, o_c) = grads
+    assert bool(((o_c - o_t).abs() <= o_t.abs() * 2.0 ** -9 + 1e-3).all())
+    assert bool(((gw_c - gw_t).abs() <= 2e-3 * gw_t.abs().max()).all()) and bool(((gb_c - gb_t).abs() <= 2e-3 * gb_t.abs().max()).all())

@@ -72,17 +72,19 @@ def main():
         torch.set_num_threads(min(32, os.cpu_count() or 1))
     ds = refpkg.arxiv_like(seed=0)
     example = "example" in sys.argv[3:]
+    fp16 = "fp16" in sys.argv[3:]  # the reference's own mixed precision: Trainer(fp16=True) = torch.cuda.amp.autocast + GradScaler
+    extra = {"fp16": True} if fp16 else {}
     if example:
         model = example_gcn(ds.num_features, ds.num_classes)
         res, ms = refpkg.run_experiment(ds, model=model, epochs=epochs, cpu=(mode == "cpu"), seed=0, lr=0.01, weight_decay=0.0)
     else:
-        res, ms = refpkg.run_experiment(ds, model="gcn", epochs=epochs, cpu=(mode == "cpu"), seed=0)
+        res, ms = refpkg.run_experiment(ds, model="gcn", epochs=epochs, cpu=(mode == "cpu"), seed=0, **extra)
     steady = sorted(ms[min(5, len(ms) - 1):])  # the first epochs pay the CSR build, plan cache and allocator warm-up
     out = {"mode": mode, "epochs": epochs, "train_step_ms_median": steady[len(steady) // 2], "train_step_ms_min": steady[0],
            "train_step_ms_first": ms[0], "final_train_loss": res["train_losses"][-1],
            "val_acc": float(res.get("val_acc", float("nan"))),
            "threads": torch.get_num_threads() if mode == "cpu" else None,
-           "linear": "cogdl_amd.linear" if linear else "torch", "structure_memo": bool(memo and mode == "gpu"),
+           "linear": "cogdl_amd.linear" if linear else "torch", "structure_memo": bool(memo and mode == "gpu"), "fp16": fp16,
            "model": "examples/ogb/arxiv/gnn.py GCN: 3 layers, hidden 256, batchnorm, dropout 0.5" if example else "gcn (2 layers, hidden 64)"}
     print("TRAINER " + json.dumps(out))
 
