@@ -112,6 +112,15 @@ def tall_skinny_matmul_bf16(x, w, bias, w_is_n_by_k):
     return tall_skinny_matmul_16(x, w, bias, w_is_n_by_k, torch.bfloat16)
 
 
+def _dgrad_16(grad_out, w, w_is_n_by_k):
+    """grad_input of the 16-bit products through the same kernel where it covers the shape (<= 64 input features, 16-bit rows
+    of even length), in grad_out's dtype like torch's product; else None."""
+    n = w.shape[0] if w_is_n_by_k else w.shape[1]
+    if grad_out.dtype not in _HALF_ENTRY or n > 64 or grad_out.shape[0] < MIN_ROWS or w.dtype not in (torch.float32, grad_out.dtype):
+        return None
+    return tall_skinny_matmul_16(grad_out, w, None, w_is_n_by_k, grad_out.dtype)
+
+
 def _autocast_half():
     """The 16-bit dtype of the enclosing torch.autocast("cuda", ...) context (bfloat16 | float16), or None."""
     if not torch.is_autocast_enabled("cuda"):
@@ -143,7 +152,10 @@ class MatmulBf16Function(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         grad_x = grad_w = None
         if ctx.needs_input_grad[0]:
-            grad_x = torch.mm(grad_out, w.to(grad_out.dtype).t()).to(x.dtype)
+            grad_x = _dgrad_16(grad_out, w, True)  # grad_out . W^T, W stored [K, N] = [n, k] of the product
+            if grad_x is None:
+                grad_x = torch.mm(grad_out, w.to(grad_out.dtype).t())
+            grad_x = grad_x.to(x.dtype)
         if ctx.needs_input_grad[1]:
             gw, _ = linear_wgrad(x.float(), grad_out.float(), want_bias=False)  # [N, K] = grad_out^T . x
             grad_w = gw.t().to(w.dtype)
@@ -188,7 +200,10 @@ class LinearBf16Function(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         grad_x = grad_w = grad_b = None
         if ctx.needs_input_grad[0]:
-            grad_x = torch.mm(grad_out, weight.to(grad_out.dtype)).to(x.dtype)
+            grad_x = _dgrad_16(grad_out, weight, False)  # grad_out . W, W stored [N, K] = [k, n] of the product
+            if grad_x is None:
+                grad_x = torch.mm(grad_out, weight.to(grad_out.dtype))
+            grad_x = grad_x.to(x.dtype)
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             grad_w, grad_b = linear_wgrad(x.float(), grad_out.float(), want_bias=need_b)
