@@ -74,6 +74,7 @@ HIP_SIGNATURES = {
     "cogdl_hip_csr_fingerprint": ([_vp, _vp, _i64, _i64, _vp, _vp], _i32),
     "cogdl_hip_linear_fwd_f32": ([_vp] * 4 + [_i64, _i64, _i64, _i32, _vp], _i32),
     "cogdl_hip_linear_fwd_bf16": ([_vp, _i32, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _vp], _i32),
+    "cogdl_hip_head_projection_fwd": ([_vp, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp], _i32),
     "cogdl_hip_linear_fwd_f16": ([_vp, _i32, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _vp], _i32),
     "cogdl_hip_linear_wgrad_workspace_bytes": ([_i64, _i64, _i64], _sz),
     "cogdl_hip_linear_wgrad_f32": ([_vp] * 4 + [_i64, _i64, _i64, _vp, _sz, _vp], _i32),

@@ -12,6 +12,7 @@ import sys
 
 import torch
 
+from . import _lib
 from . import linear as _linear
 from .operators.spmm import csrspmm_fused
 
@@ -155,6 +156,20 @@ class _HeadProjections(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a_l, a_r, feat):
         ctx.save_for_backward(a_l, a_r, feat)
+        if (feat.is_cuda and feat.dim() == 3 and feat.dtype in _lib.DTYPE_CODE and a_l.dtype == torch.float32
+                and a_r.dtype == torch.float32 and a_l.shape == (1,) + tuple(feat.shape[1:]) and a_r.shape == a_l.shape):
+            # both projections in one pass over feat (cogdl_hip_head_projection_fwd): torch's form is two broadcast products
+            # into [N, H, F] fp32 temporaries and two reductions -- 0.24 ms of an 11.2 ms GAT step on the Reddit-shaped graph
+            f3 = feat.contiguous()
+            n, h, f = f3.shape
+            h_l = torch.empty((n, h), dtype=torch.float32, device=feat.device)
+            h_r = torch.empty_like(h_l)
+            with _lib.on_device(feat.device):
+                rc = _lib.hip().cogdl_hip_head_projection_fwd(_lib.ptr(f3), _lib.DTYPE_CODE[f3.dtype], _lib.ptr(a_l.detach().contiguous()),
+                                                              _lib.ptr(a_r.detach().contiguous()), _lib.ptr(h_l), _lib.ptr(h_r), n, h, f,
+                                                              _lib.stream_of(f3))
+            _lib.check(rc, "head_projection_fwd")
+            return h_l, h_r
         return (a_l * feat).sum(dim=-1), (a_r * feat).sum(dim=-1)
 
     @staticmethod

@@ -631,6 +631,13 @@ COGDL_API int cogdl_hip_linear_fwd_f32(const float *x, const float *w, const flo
  * more than 128 KB of bf16 B operands, bf16 rows of odd length.  x 16-byte aligned. */
 COGDL_API int cogdl_hip_linear_fwd_bf16(const void *x, int x_dtype, const void *w, int w_dtype, const float *bias, void *out,
                               int64_t rows, int64_t k_dim, int64_t n_dim, int w_is_n_by_k, void *stream);
+/* head_projection_fwd (ABI v9): h_l[v, h] = sum_f a_l[h, f] * feat[v, h, f] and h_r likewise with a_r -- both attention
+ * projections of GATLayer.forward (cogdl/layers/gat_layer.py:65-66) in one pass over feat [n_rows, heads, f_dim] (f32 / f16 /
+ * bf16); a_l, a_r [heads, f_dim] fp32; h_l, h_r [n_rows, heads] fp32.  fp32 products summed left to right
+ * (csrc/head_proj.hip). */
+COGDL_API int cogdl_hip_head_projection_fwd(const void *feat, int dtype, const float *a_l, const float *a_r, float *h_l, float *h_r,
+                                  int64_t n_rows, int64_t heads, int64_t f_dim, void *stream);
+
 /* linear_fwd_f16: the same kernel on v_mfma_f32_32x32x16_f16 -- the autocast dtype of the reference's own Trainer(fp16=True)
  * (cogdl/trainer/trainer.py: torch.cuda.amp.autocast); x_dtype / w_dtype: COGDL_HIP_F32 or COGDL_HIP_F16, out f16. */
 COGDL_API int cogdl_hip_linear_fwd_f16(const void *x, int x_dtype, const void *w, int w_dtype, const float *bias, void *out,
